@@ -1,0 +1,419 @@
+"""TEST INFRASTRUCTURE ONLY -- CPU oracle for the VALL-E AR+NAR decode path.
+
+A functional (state_dict in, codes out) restatement, in plain fp32 torch-CPU tensor ops,
+of the algorithm the reference executes in ``VALLE.inference()`` / ``VALLE.continual()``.
+Every function cites the reference file:line it follows (paths relative to
+/root/reference).  It is the *checker* for the HIP engine: only ``tests/``,
+``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the
+product path (``vall-e_amd/``) never does.
+
+Parity status: PINNED.  ``oracle/make_golden.py`` runs the unmodified reference (imported
+through ``oracle/ref_import.py``) on the weights produced by ``make_state_dict`` here and
+commits the reference's outputs under ``tests/golden/``; ``tests/test_oracle_golden.py``
+checks this restatement against those vectors (token ids exact, logits to fp32 noise).
+The reference's own tests pin nothing numerically.
+
+Deliberately *literal*: like the reference there is no KV cache -- every AR step re-runs
+the whole [text; audio] sequence (valle/models/valle.py:1012-1057).  ``kv_cache=True``
+selects an incremental evaluation that is exact by the prefix-LM mask argument
+(valle.py:1019-1030) and is itself pinned against the literal path in the tests; it
+exists so GPU parity tests can use sizes the literal path cannot finish in seconds.
+"""
+from __future__ import annotations
+
+import hashlib
+import math
+from collections import OrderedDict
+from dataclasses import dataclass
+from typing import Dict, List, Optional
+
+import torch
+import torch.nn.functional as F
+
+NUM_TEXT_TOKENS = 512  # valle/models/macros.py:2
+NUM_AUDIO_TOKENS = 1024  # valle/models/macros.py:5
+LN_EPS = 1e-5  # valle/modules/transformer.py:27
+
+
+@dataclass
+class OracleConfig:
+    """Constructor surface of VALLE (valle/models/valle.py:727-760, 54-84)."""
+
+    d_model: int = 1024
+    nhead: int = 16
+    num_layers: int = 12
+    norm_first: bool = True
+    add_prenet: bool = False
+    prefix_mode: int = 0
+    share_embedding: bool = True
+    nar_scale_factor: float = 1.0
+    prepend_bos: bool = False
+    num_quantizers: int = 8
+
+    def check_supported(self):
+        # production shape only; the oracle mirrors what the engine runs natively
+        assert self.norm_first and not self.add_prenet and self.nar_scale_factor == 1.0
+
+
+# --------------------------------------------------------------------------------------
+# deterministic weights (same on every machine with this torch build; no reference needed)
+# --------------------------------------------------------------------------------------
+def state_dict_spec(cfg: OracleConfig) -> "OrderedDict[str, tuple]":
+    """Key -> shape, exactly the reference's ``state_dict()`` (valle.py:85-279)."""
+    d, L, Q = cfg.d_model, cfg.num_layers, cfg.num_quantizers
+    s: "OrderedDict[str, tuple]" = OrderedDict()
+    s["ar_text_embedding.word_embeddings.weight"] = (NUM_TEXT_TOKENS, d)
+    s["nar_text_embedding.word_embeddings.weight"] = (NUM_TEXT_TOKENS, d)
+    s["ar_audio_embedding.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1 + int(cfg.prepend_bos), d)
+    s["ar_text_position.alpha"] = (1,)
+    s["ar_audio_position.alpha"] = (1,)
+
+    def layer(prefix, adaptive):
+        s[f"{prefix}.self_attn.in_proj_weight"] = (3 * d, d)
+        s[f"{prefix}.self_attn.in_proj_bias"] = (3 * d,)
+        s[f"{prefix}.self_attn.out_proj.weight"] = (d, d)
+        s[f"{prefix}.self_attn.out_proj.bias"] = (d,)
+        s[f"{prefix}.linear1.weight"] = (4 * d, d)
+        s[f"{prefix}.linear1.bias"] = (4 * d,)
+        s[f"{prefix}.linear2.weight"] = (d, 4 * d)
+        s[f"{prefix}.linear2.bias"] = (d,)
+        for n in ("norm1", "norm2"):
+            if adaptive:
+                s[f"{prefix}.{n}.project_layer.weight"] = (2 * d, d)
+                s[f"{prefix}.{n}.project_layer.bias"] = (2 * d,)
+                s[f"{prefix}.{n}.norm.weight"] = (d,)
+                s[f"{prefix}.{n}.norm.bias"] = (d,)
+            else:
+                s[f"{prefix}.{n}.weight"] = (d,)
+                s[f"{prefix}.{n}.bias"] = (d,)
+
+    for l in range(L):
+        layer(f"ar_decoder.layers.{l}", False)
+    s["ar_decoder.norm.weight"] = (d,)
+    s["ar_decoder.norm.bias"] = (d,)
+    s["ar_predict_layer.weight"] = (NUM_AUDIO_TOKENS + 1, d)
+    if Q > 1:
+        s["nar_audio_embeddings.0.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1, d)
+        for j in range(1, Q):
+            s[f"nar_audio_embeddings.{j}.word_embeddings.weight"] = (NUM_AUDIO_TOKENS, d)
+        s["nar_text_position.alpha"] = (1,)
+        s["nar_audio_position.alpha"] = (1,)
+        for l in range(L):
+            layer(f"nar_decoder.layers.{l}", True)
+        s["nar_decoder.norm.project_layer.weight"] = (2 * d, d)
+        s["nar_decoder.norm.project_layer.bias"] = (2 * d,)
+        s["nar_decoder.norm.norm.weight"] = (d,)
+        s["nar_decoder.norm.norm.bias"] = (d,)
+        for i in range(Q - 1):
+            s[f"nar_predict_layers.{i}.weight"] = (NUM_AUDIO_TOKENS, d)
+        for i in range(Q - 1):
+            s[f"nar_stage_embeddings.{i}.word_embeddings.weight"] = (1, d)
+    return s
+
+
+def _key_seed(seed: int, key: str) -> int:
+    h = hashlib.sha256(f"{seed}:{key}".encode()).digest()
+    return int.from_bytes(h[:7], "little")
+
+
+def make_state_dict(cfg: OracleConfig, seed: int = 0) -> "OrderedDict[str, torch.Tensor]":
+    """Deterministic synthetic weights with the reference's init *distributions*
+    (xavier-uniform in_proj: valle/modules/activation.py:175-190; nn.Linear / nn.Embedding
+    defaults elsewhere), but every layer distinct and biases / LN affine / alpha perturbed so
+    that every term of the computation is exercised.  Weight tying as valle.py:261-271."""
+    cfg.check_supported()
+    spec = state_dict_spec(cfg)
+    sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
+    for key, shape in spec.items():
+        g = torch.Generator().manual_seed(_key_seed(seed, key))
+        if key.endswith("alpha"):
+            t = 1.0 + 0.25 * torch.rand(shape, generator=g) if key.startswith("ar_") else torch.ones(shape)
+        elif "word_embeddings" in key:
+            t = torch.randn(shape, generator=g)
+        elif key.endswith("in_proj_weight"):
+            a = math.sqrt(6.0 / (shape[0] + shape[1]))
+            t = (torch.rand(shape, generator=g) * 2 - 1) * a
+        elif ".norm" in key and "project_layer" not in key and key.endswith("weight") and len(shape) == 1:
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif ".norm" in key and "project_layer" not in key and key.endswith("bias"):
+            t = 0.05 * torch.randn(shape, generator=g)
+        elif key.endswith("weight"):
+            a = 1.0 / math.sqrt(shape[1])
+            t = (torch.rand(shape, generator=g) * 2 - 1) * a
+        elif key.endswith("bias"):
+            t = (torch.rand(shape, generator=g) * 2 - 1) * 0.02
+        else:
+            raise KeyError(key)
+        sd[key] = t.to(torch.float32).contiguous()
+    if cfg.share_embedding and cfg.num_quantizers > 1:
+        for j in range(0, cfg.num_quantizers - 2):  # valle.py:268-271
+            sd[f"nar_predict_layers.{j}.weight"] = sd[f"nar_audio_embeddings.{j + 2}.word_embeddings.weight"]
+    return sd
+
+
+def make_inputs(S: int, P: int, seed: int = 1234, Q: int = 8):
+    """Synthetic inputs of SURVEY.md 8(d): text ids uniform in [3,100) with BOS=1 / EOS=2
+    (valle/data/collation.py:49-57), prompt codes uniform in [0,1024)."""
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randint(3, 100, (1, S), generator=g, dtype=torch.int64)
+    x[0, 0] = 1
+    x[0, -1] = 2
+    x_lens = torch.tensor([S], dtype=torch.int32)
+    y = torch.randint(0, NUM_AUDIO_TOKENS, (1, P, 8), generator=g, dtype=torch.int64)
+    return x, x_lens, y[..., :Q].contiguous()
+
+
+# --------------------------------------------------------------------------------------
+# building blocks
+# --------------------------------------------------------------------------------------
+def sine_pe(T: int, d: int) -> torch.Tensor:
+    """valle/modules/embedding.py:75-91 (reverse=False); returns (T, d) fp32."""
+    pe = torch.zeros(T, d)
+    position = torch.arange(0, T, dtype=torch.float32).unsqueeze(1)
+    div_term = torch.exp(torch.arange(0, d, 2, dtype=torch.float32) * -(math.log(10000.0) / d))
+    pe[:, 0::2] = torch.sin(position * div_term)
+    pe[:, 1::2] = torch.cos(position * div_term)
+    return pe
+
+
+def sine_position(x: torch.Tensor, alpha: torch.Tensor, start: int = 0) -> torch.Tensor:
+    """SinePositionalEmbedding.forward, embedding.py:93-97 with x_scale = 1 (scale=False at
+    valle.py:131,137,221,227) and dropout = identity in eval.  ``start`` only for kv_cache mode."""
+    T, d = x.shape[-2], x.shape[-1]
+    pe = sine_pe(start + T, d)[start:]
+    return x * 1.0 + alpha * pe
+
+
+def token_embedding(sd, name: str, ids: torch.Tensor) -> torch.Tensor:
+    """TokenEmbedding.forward, embedding.py:43-47 (dropout p=0)."""
+    return F.embedding(ids, sd[f"{name}.word_embeddings.weight"])
+
+
+def layer_norm(x, w, b):
+    """LayerNorm.forward, valle/modules/transformer.py:57-74 -> F.layer_norm, eps 1e-5."""
+    return F.layer_norm(x, (x.shape[-1],), w, b, LN_EPS)
+
+
+def norm_site(sd, prefix: str, x, stage_emb):
+    """Plain LayerNorm (AR) or AdaptiveLayerNorm (NAR): transformer.py:93-108 --
+    [w, b] = split(project_layer(stage_emb)); w * norm(x) + b."""
+    if stage_emb is None:
+        return layer_norm(x, sd[f"{prefix}.weight"], sd[f"{prefix}.bias"])
+    wb = F.linear(stage_emb, sd[f"{prefix}.project_layer.weight"], sd[f"{prefix}.project_layer.bias"])
+    d = x.shape[-1]
+    w, b = wb[..., :d], wb[..., d:]
+    return w * layer_norm(x, sd[f"{prefix}.norm.weight"], sd[f"{prefix}.norm.bias"]) + b
+
+
+def mha(sd, prefix: str, x, nhead: int, attn_mask: Optional[torch.Tensor], kv_state=None):
+    """MultiheadAttention.forward (valle/modules/activation.py:199-431) ->
+    F.multi_head_attention_forward: packed in-proj rows [Q;K;V], heads = contiguous dh slices,
+    softmax(Q K^T / sqrt(dh) + mask) V, out_proj.  ``attn_mask``: bool (T,T), True = blocked
+    (valle.py:1019-1033).  x: (T, d)."""
+    T, d = x.shape
+    dh = d // nhead
+    qkv = F.linear(x, sd[f"{prefix}.in_proj_weight"], sd[f"{prefix}.in_proj_bias"])
+    q, k, v = qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :]
+    if kv_state is not None:  # incremental mode: append to cached keys/values
+        if kv_state.get("k") is not None:
+            k = torch.cat([kv_state["k"], k], 0)
+            v = torch.cat([kv_state["v"], v], 0)
+        kv_state["k"], kv_state["v"] = k, v
+    Tk = k.shape[0]
+    qh = q.view(T, nhead, dh).transpose(0, 1)  # (h, T, dh)
+    kh = k.view(Tk, nhead, dh).transpose(0, 1)
+    vh = v.view(Tk, nhead, dh).transpose(0, 1)
+    scores = torch.matmul(qh, kh.transpose(1, 2)) / math.sqrt(dh)
+    if attn_mask is not None:
+        scores = scores.masked_fill(attn_mask[None], float("-inf"))
+    p = torch.softmax(scores, dim=-1)
+    o = torch.matmul(p, vh).transpose(0, 1).reshape(T, d)
+    return F.linear(o, sd[f"{prefix}.out_proj.weight"], sd[f"{prefix}.out_proj.bias"])
+
+
+def encoder_layer(sd, prefix: str, x, nhead: int, attn_mask, stage_emb, kv_state=None):
+    """TransformerEncoderLayer.forward, pre-norm branch (transformer.py:296-302):
+    x += SA(norm1(x)); x += W2 relu(W1 norm2(x) + b1) + b2 (ReLU: transformer.py:187, :333)."""
+    x = x + mha(sd, f"{prefix}.self_attn", norm_site(sd, f"{prefix}.norm1", x, stage_emb), nhead, attn_mask, kv_state)
+    h = F.relu(F.linear(norm_site(sd, f"{prefix}.norm2", x, stage_emb), sd[f"{prefix}.linear1.weight"], sd[f"{prefix}.linear1.bias"]))
+    x = x + F.linear(h, sd[f"{prefix}.linear2.weight"], sd[f"{prefix}.linear2.bias"])
+    return x
+
+
+def encoder(sd, prefix: str, cfg: OracleConfig, x, attn_mask=None, stage_emb=None, kv_states=None, layer_states=None):
+    """TransformerEncoder.forward (transformer.py:363-406): L layers, then the final norm
+    (LayerNorm for AR, valle.py:151; AdaptiveLayerNorm(nn.LayerNorm) for NAR, valle.py:242-244)."""
+    for l in range(cfg.num_layers):
+        x = encoder_layer(
+            sd, f"{prefix}.layers.{l}", x, cfg.nhead, attn_mask, stage_emb,
+            None if kv_states is None else kv_states[l],
+        )
+        if layer_states is not None:
+            layer_states.append(x.clone())
+    return norm_site(sd, f"{prefix}.norm", x, stage_emb)
+
+
+def prefix_lm_mask(S: int, T: int) -> torch.Tensor:
+    """valle.py:1018-1033: [[0_{SxS} | 1_{SxT}], [0_{TxS} | triu(1)_{TxT}]], True = blocked."""
+    top = F.pad(torch.zeros(S, S, dtype=torch.bool), (0, T), value=True)
+    bot = F.pad(torch.triu(torch.ones(T, T, dtype=torch.bool), diagonal=1), (S, 0), value=False)
+    return torch.cat([top, bot], 0)
+
+
+def top_k_filtering(logits: torch.Tensor, top_k: int) -> torch.Tensor:
+    """top_k_top_p_filtering with top_p = 1.0 (valle.py:1242-1284; callers fix top_p, :1041)."""
+    if top_k > 0:
+        top_k = min(max(top_k, 1), logits.size(-1))
+        kth = torch.topk(logits, top_k)[0][..., -1, None]
+        logits = logits.masked_fill(logits < kth, float("-inf"))
+    return logits
+
+
+def topk_sampling(logits: torch.Tensor, top_k: int, temperature: float, generator=None) -> torch.Tensor:
+    """valle.py:1287-1302.  top_k == 1 is the reference's 'greedy' (SURVEY.md fact 4)."""
+    if temperature != 1.0:
+        logits = logits / temperature
+    logits = top_k_filtering(logits, top_k)
+    return torch.multinomial(F.softmax(logits, dim=-1), num_samples=1, generator=generator)
+
+
+# --------------------------------------------------------------------------------------
+# the path
+# --------------------------------------------------------------------------------------
+def ar_decode(
+    sd, cfg: OracleConfig, x_ids, x_lens, prompts, top_k=-100, temperature=1.0,
+    kv_cache=False, force_tokens: Optional[torch.Tensor] = None, max_new: Optional[int] = None,
+    trace: Optional[Dict[str, List]] = None, generator=None,
+):
+    """The AR ``while True`` loop, valle.py:993-1059.  Returns y (1, [bos+]P+G) int64.
+
+    ``force_tokens`` (G,) teacher-forces the token history (the sampled token is still traced);
+    ``max_new`` stops after that many tokens (emulates a trained model's EOS from outside,
+    SURVEY.md 8c G1).  ``trace['ar_logits']`` collects the (1025,) fp32 logits of every step."""
+    assert x_ids.ndim == 2 and x_lens.ndim == 1 and prompts.ndim == 3 and prompts.shape[0] == 1  # :986-989
+    assert torch.all(x_lens > 0)  # :991
+    S = int(x_lens.max())
+    x = token_embedding(sd, "ar_text_embedding", x_ids[0])  # :994
+    x = sine_position(x, sd["ar_text_position.alpha"])  # :997 (prenet = Identity, :124-126)
+    P = prompts.shape[1]
+    y = prompts[0, :, 0]  # :1005
+    if cfg.prepend_bos:
+        y = F.pad(y, (1, 0), value=NUM_AUDIO_TOKENS + 1)  # :1006-1007
+    bos = int(cfg.prepend_bos)
+    kv_states = [dict(k=None, v=None) for _ in range(cfg.num_layers)] if kv_cache else None
+    n_cached_audio = 0
+    while True:
+        if not kv_cache:
+            y_pos = sine_position(token_embedding(sd, "ar_audio_embedding", y), sd["ar_audio_position.alpha"])  # :1013-1015
+            xy_pos = torch.cat([x, y_pos], 0)  # :1016
+            mask = prefix_lm_mask(S, y.shape[0])  # :1018-1033
+            xy_dec = encoder(sd, "ar_decoder", cfg, xy_pos, attn_mask=mask)  # :1035-1038
+        else:
+            new = y[n_cached_audio:]
+            y_pos = sine_position(token_embedding(sd, "ar_audio_embedding", new), sd["ar_audio_position.alpha"], start=n_cached_audio)
+            if n_cached_audio == 0:
+                inp = torch.cat([x, y_pos], 0)
+                mask = prefix_lm_mask(S, y.shape[0])
+            else:
+                inp, mask = y_pos, None  # the new row sees every cached key (causal row = last)
+            xy_dec = encoder(sd, "ar_decoder", cfg, inp, attn_mask=mask, kv_states=kv_states)
+            n_cached_audio = y.shape[0]
+        logits = F.linear(xy_dec[-1:], sd["ar_predict_layer.weight"])  # :1039  (1, 1025)
+        if trace is not None:
+            trace.setdefault("ar_logits", []).append(logits[0].clone())
+        # topk_sampling filters in place when temperature == 1 (valle.py:1260,1296-1299); the
+        # argmax of filtered and unfiltered logits coincide, so a copy is equivalent.
+        samples = topk_sampling(logits.clone(), top_k, temperature, generator)  # :1040-1042
+        n_gen = y.shape[0] - bos - P
+        stop = (
+            int(torch.argmax(logits, dim=-1)[0]) == NUM_AUDIO_TOKENS
+            or int(samples[0, 0]) == NUM_AUDIO_TOKENS
+            or (y.shape[0] - P) > S * 16
+        )  # :1044-1048
+        if max_new is not None and n_gen >= max_new:
+            stop = True
+        if force_tokens is not None:  # instrumentation: the forced history alone decides the length
+            stop = n_gen >= force_tokens.shape[0]
+        if stop:
+            if P == y.shape[0]:
+                raise SyntaxError("well trained model shouldn't reach here.")  # :1049-1052
+            break
+        nxt = samples[0] if force_tokens is None else force_tokens[n_gen : n_gen + 1].to(torch.int64)
+        y = torch.cat([y, nxt], 0)  # :1057
+    return y[None]
+
+
+def nar_decode(sd, cfg: OracleConfig, text_ids, y0, prompts, prefix_len, enroll_x_lens=None, trace=None):
+    """The seven NAR stages, valle.py:1062-1137 (also the body of continual(), :1176-1238).
+
+    text_ids (S,) ; y0 (P+G,) first-codebook stream without BOS ; prompts (P,Q)."""
+    Q = cfg.num_quantizers
+    codes = [y0[prefix_len:]]  # :1059
+    if Q == 1:
+        return torch.stack(codes, dim=-1)[None]
+    y_emb = token_embedding(sd, "nar_audio_embeddings.0", y0).clone()  # :1064-1066
+    text = text_ids
+    if cfg.prefix_mode in (2, 4):  # :1068-1079 -- drop the enrolled phonemes
+        enrolled_len = int(enroll_x_lens.max())
+        text = torch.cat([text[:1], text[enrolled_len - 1 :]], 0)
+    S = text.shape[0]
+    x = sine_position(token_embedding(sd, "nar_text_embedding", text), sd["nar_text_position.alpha"])  # :1081-1083
+    if cfg.prefix_mode != 0:
+        for j in range(1, Q):  # :1110-1113
+            y_emb[:prefix_len] += token_embedding(sd, f"nar_audio_embeddings.{j}", prompts[:, j])
+    for i in range(Q - 1):  # :1085 / :1115
+        y_pos = sine_position(y_emb, sd["nar_audio_position.alpha"])  # :1121-1122
+        xy_pos = torch.cat([x, y_pos], 0)  # :1123
+        stage = sd[f"nar_stage_embeddings.{i}.word_embeddings.weight"]  # (1, d)  :1126
+        xy_dec = encoder(sd, "nar_decoder", cfg, xy_pos, attn_mask=None, stage_emb=stage)  # :1125-1127
+        logits = F.linear(xy_dec[S + prefix_len :], sd[f"nar_predict_layers.{i}.weight"])  # :1128
+        if trace is not None:
+            trace.setdefault("nar_logits", []).append(logits.clone())
+        samples = torch.argmax(logits, dim=-1)  # :1130
+        codes.append(samples)
+        if i < Q - 2:  # :1133 / :1103
+            if cfg.prefix_mode == 0:
+                y_emb[:prefix_len] += token_embedding(sd, f"nar_audio_embeddings.{i + 1}", prompts[:, i + 1])  # :1104-1107
+            y_emb[prefix_len:] += token_embedding(sd, f"nar_audio_embeddings.{i + 1}", samples)  # :1108 / :1134
+    assert len(codes) == Q
+    return torch.stack(codes, dim=-1)[None]  # :1136-1137
+
+
+@torch.no_grad()
+def inference(
+    sd, cfg: OracleConfig, x, x_lens, y, enroll_x_lens=None, top_k=-100, temperature=1.0,
+    kv_cache=False, force_tokens=None, max_new=None, trace=None, generator=None, quiet=True,
+):
+    """VALLE.inference, valle/models/valle.py:961-1137.  x (1,S) int64, x_lens (1,) int32,
+    y (1,P,Q) int64 -> (1,G,Q) int64."""
+    cfg.check_supported()
+    yy = ar_decode(sd, cfg, x, x_lens, y, top_k, temperature, kv_cache, force_tokens, max_new, trace, generator)
+    P = y.shape[1]
+    if not quiet:
+        print(f"VALL-E EOS [{P} -> {yy.shape[1]}]")  # :1054
+    y0 = yy[0, int(cfg.prepend_bos) :]
+    return nar_decode(sd, cfg, x[0], y0, y[0], P, enroll_x_lens, trace)
+
+
+@torch.no_grad()
+def continual(sd, cfg: OracleConfig, x, x_lens, y, trace=None):
+    """VALLE.continual, valle.py:1139-1238: NAR only; first codebook taken from y[...,0];
+    prefix = min(T/2, 225) (:1173)."""
+    cfg.check_supported()
+    assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3 and y.shape[0] == 1
+    assert torch.all(x_lens > 0)
+    assert cfg.num_quantizers == 8  # :1160
+    prefix_len = min(int(y.shape[1] * 0.5), 3 * 75)
+    prompts = y[0, :prefix_len]
+    c = OracleConfig(**{**cfg.__dict__})
+    if c.prefix_mode in (2, 4):
+        c.prefix_mode = 1  # continual() never slices the text (no :1068-1079 equivalent)
+    return nar_decode(sd, c, x[0], y[0, :, 0], prompts, prefix_len, None, trace)
+
+
+# --------------------------------------------------------------------------------------
+# algorithmic byte / flop model of SURVEY.md 8(d) (used by bench.py for `roofline.achieved`)
+# --------------------------------------------------------------------------------------
+def expected_gen_len(S: int, prepend_bos: bool = False) -> int:
+    """Length cap of the stop rule when EOS never fires (valle.py:1047): G = 16*S + 1 - bos."""
+    return 16 * S + 1 - int(prepend_bos)

@@ -1,0 +1,165 @@
+/*
+ * valle_engine.h -- C ABI of the MI355X-native VALL-E decode engine (libvalle_engine.so).
+ *
+ * The reference (lifeiteng/vall-e) has no FFI layer: its seam for this path is the Python
+ * method surface VALLE.inference()/continual() and the Transformer block modules under it.
+ * Each entry point below names the reference interface it replaces (paths relative to the
+ * reference root).  INTEGRATION.md shows the ctypes binding a maintainer adds on the
+ * reference side.
+ *
+ * Conventions
+ *   - plain C: pointers + sizes, no torch / C++ types; every function returns 0 on success or a
+ *     negative VLE_E* code; vle_last_error() returns the message of the last failing call.
+ *   - "DEVICE" pointers are HBM addresses owned by the caller (e.g. tensor.data_ptr());
+ *     "HOST" pointers are ordinary host memory.  `stream` is a hipStream_t passed as void*
+ *     (NULL = the default stream); the engine orders its work against it with events.
+ *   - the engine owns packed weights, the KV cache, workspaces, RNG state and captured
+ *     hipGraphs (all sized at vle_create); one engine per (GPU, caller thread).
+ *   - batch is an extension: the reference asserts batch == 1 (valle/models/valle.py:989);
+ *     a batch here is B independent utterances (the oracle for it is B reference calls).
+ */
+#ifndef VALLE_ENGINE_H_
+#define VALLE_ENGINE_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VLE_OK 0
+#define VLE_EINVAL (-1)   /* bad argument / unsupported configuration                     */
+#define VLE_ESTATE (-2)   /* call out of order (e.g. generate before prefill)             */
+#define VLE_EHIP (-3)     /* a HIP runtime call failed                                     */
+#define VLE_EKEY (-4)     /* unknown / mis-shaped state_dict key                           */
+#define VLE_ENOTOKEN (-5) /* EOS at the very first AR step: the reference raises SyntaxError
+                             ("well trained model shouldn't reach here", valle.py:1049-1052) */
+
+/* arithmetic mode of the whole path */
+#define VLE_DTYPE_F32 0  /* fp32 weights / KV / accumulate: token-id-exact vs the reference */
+#define VLE_DTYPE_BF16 1 /* bf16 weights + KV, fp32 residual stream and accumulators       */
+
+typedef struct vle_engine vle_engine;
+
+/* Constructor surface of VALLE(d_model, nhead, num_layers, norm_first, add_prenet, prefix_mode,
+ * share_embedding, nar_scale_factor, prepend_bos, num_quantizers) -- valle/models/valle.py:727-760
+ * / :54-84 -- plus capacity limits.  Only the production shape runs natively (norm_first = 1,
+ * add_prenet = 0, nar_scale_factor = 1); anything else returns VLE_EINVAL. */
+typedef struct vle_config {
+  int32_t d_model;
+  int32_t nhead;
+  int32_t num_layers;
+  int32_t num_quantizers; /* 1..8 */
+  int32_t prefix_mode;    /* 0, 1, 2, 4 (valle/models/__init__.py:64-69) */
+  int32_t prepend_bos;    /* 0 / 1 */
+  int32_t norm_first;     /* must be 1 */
+  int32_t add_prenet;     /* must be 0 */
+  int32_t dtype_mode;     /* VLE_DTYPE_* */
+  int32_t max_batch;      /* utterances decoded together */
+  int32_t max_text;       /* S_max  (text tokens incl. BOS/EOS) */
+  int32_t max_prompt;     /* P_max  (prompt frames) */
+  int32_t max_gen;        /* G_max  (generated frames); 0 => 16*max_text + 1 */
+  int32_t device;         /* HIP device ordinal */
+  int32_t use_graph;      /* 1: capture the AR step in a hipGraph (default), 0: eager launches */
+  int32_t steps_per_graph;/* AR steps per captured graph (0 => default 8) */
+  int32_t reserved[8];
+} vle_config;
+
+/* get_model(params) + VALLE.__init__  (valle/models/__init__.py:98-136) */
+int vle_create(const vle_config* cfg, vle_engine** out);
+void vle_destroy(vle_engine* e);
+const char* vle_last_error(const vle_engine* e); /* e may be NULL: last vle_create error */
+
+/* model.load_state_dict(ckpt["model"], strict=True)  (valle/bin/infer.py:135-138).
+ * `key` is exactly a reference state_dict key, `data` fp32, HOST memory,
+ * C-contiguous with `shape[ndim]`.  Extra key "position.pe" (max_pos, d_model): the sinusoid table
+ * SinePositionalEmbedding.extend_pe builds (valle/modules/embedding.py:75-91); optional -- the
+ * engine computes it itself when absent. */
+int vle_load_tensor(vle_engine* e, const char* key, const float* data, const int64_t* shape, int ndim);
+/* strict=True check (every key present), AdaLN folding in fp32 (gamma' = w*gamma,
+ * beta' = w*beta + b per stage and norm site, valle/modules/transformer.py:93-108), conversion to the
+ * compute dtype and upload. */
+int vle_finalize_weights(vle_engine* e);
+
+/* ---- VALLE.inference()  (valle/models/valle.py:961-1137), split in its three phases ---------- */
+
+/* valle.py:993-1038 for the first loop iteration: embed text + prompt (first codebook), run the
+ * prefix-LM masked decoder over [text; prompt], fill the KV cache, leave step-0 logits ready.
+ *   text          DEVICE int64 [B, s_stride]        (x;  ids in [0,512))
+ *   text_lens     HOST   int32 [B]                  (x_lens)
+ *   prompt_codes  DEVICE int64 [B, p_stride, Q]     (y;  codes in [0,1024))
+ *   prompt_lens   HOST   int32 [B]                                                        */
+int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, int64_t s_stride, const int32_t* text_lens,
+                   const int64_t* prompt_codes, int64_t p_stride, const int32_t* prompt_lens, int32_t B);
+
+/* The AR `while True` loop, valle.py:1012-1057, with the reference's stop rule (:1044-1055) evaluated
+ * per utterance on the device.  top_k / temperature as topk_sampling (:1287-1302); top_k == 1 is the
+ * reference's greedy (lowest index wins ties).  `seed` feeds the engine's counter-based RNG (the
+ * reference draws from torch's global generator; sampled streams are not comparable, logits are).
+ *   max_new       0 => reference rule only; >0 => additionally stop after max_new frames
+ *   forced        DEVICE int64 [B, forced_stride] or NULL: teacher-forced token history (parity hook;
+ *                 utterance b then runs exactly forced_lens[b] steps)
+ *   forced_lens   HOST int32 [B] or NULL
+ *   codes0        DEVICE int64 [B, g_stride] or NULL: first-codebook tokens
+ *   gen_lens      HOST int32 [B]: frames generated per utterance (G_b)
+ * Blocks the host until every utterance stopped.  Returns VLE_ENOTOKEN if some utterance produced
+ * no frame and prepend_bos == 0 (the reference's SyntaxError case). */
+int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float temperature, uint64_t seed, int32_t max_new,
+                    const int64_t* forced, int64_t forced_stride, const int32_t* forced_lens,
+                    int64_t* codes0, int64_t g_stride, int32_t* gen_lens);
+
+/* The 7 NAR stages, valle.py:1062-1137, on the utterances of the last prefill/generate.
+ *   enroll_lens   HOST int32 [B] or NULL (required for prefix_mode 2/4, valle.py:1068-1079)
+ *   codes         DEVICE int64 [B, g_stride, Q]: all Q codebooks, frames >= G_b untouched */
+int vle_nar_decode(vle_engine* e, void* stream, const int32_t* enroll_lens, int64_t* codes, int64_t g_stride);
+
+/* ---- VALLE.continual()  (valle/models/valle.py:1139-1238): NAR only ------------------------- */
+/*   y_codes DEVICE int64 [B, t_stride, 8], y_lens HOST int32 [B]; prefix_b = min(T_b/2, 225) (:1173);
+ *   codes DEVICE int64 [B, g_stride, 8] receives (T_b - prefix_b) frames; gen_lens HOST int32 [B]. */
+int vle_nar_continual(vle_engine* e, void* stream, const int64_t* text, int64_t s_stride, const int32_t* text_lens,
+                      const int64_t* y_codes, int64_t t_stride, const int32_t* y_lens, int32_t B,
+                      int64_t* codes, int64_t g_stride, int32_t* gen_lens);
+
+/* ---- parity / measurement hooks -------------------------------------------------------------- */
+/* options: "trace_ar_logits" (0/1: keep every AR step's fp32 logits), "trace_nar_logits" (0/1) */
+int vle_set_option(vle_engine* e, const char* name, int64_t value);
+/* what: "ar_logits"  -> fp32 [n_steps, B, 1025] (row t = logits of AR loop iteration t)
+ *       "nar_logits:<stage>" -> fp32 [sum_b G_b, 1024]
+ *       "ar_sampled" -> int64 [B, G_max] the engine's own samples (differs from codes0 only when forced)
+ *       "kv_len" -> int32 [B];   returns the number of bytes written (>= 0) or an error code */
+int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_dst, size_t bytes);
+/* phase timings of the last call, milliseconds measured with hipEvents on the engine's stream:
+ * out[0] prefill, out[1] AR steps, out[2] NAR, out[3] number of AR steps executed */
+int vle_last_timings(vle_engine* e, double* out4);
+/* algorithmic bytes moved per AR step for the current batch at context length ctx */
+int64_t vle_ar_step_bytes(const vle_engine* e, int32_t B, int64_t sum_ctx);
+
+/* ---- Transformer-block operator surface (valle/modules/transformer.py, activation.py) -------- */
+/* Stand-alone kernels behind the block API (B3 in SURVEY.md 8b); all pointers DEVICE, row-major.
+ * dtype = VLE_DTYPE_*: element type of `x`/`w`/`out` where marked T; fp32 where marked f32. */
+
+/* LayerNorm.forward (transformer.py:57-74): out[T] = LN(x[f32]) * gamma + beta, eps 1e-5 */
+int vle_op_layernorm(void* stream, int dtype, const float* x, const float* gamma, const float* beta, void* out,
+                     int64_t rows, int32_t d);
+/* nn.Linear / in_proj / out_proj (activation.py:414-421, transformer.py:333):
+ * out = epilogue(a[T, M x K] @ w[T, N x K]^T + bias[f32, N]);
+ * epilogue 0: store T; 1: ReLU, store T; 2: resid[f32, M x N] += (.) in place; 3: store f32 */
+int vle_op_linear(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
+                  int64_t M, int32_t N, int32_t K, int epilogue);
+/* Same contract on the skinny (M <= 8, fp32 activations) weight-streaming path of the AR step:
+ * x[f32, M x K]; optional fused LayerNorm prologue when gamma != NULL;
+ * epilogue 0: out f32 = (.); 1: ReLU -> out f32; 2: resid += (.) */
+int vle_op_linear_skinny(void* stream, int dtype, const float* x, const float* gamma, const float* beta, const void* w,
+                         const float* bias, float* out, float* resid, int32_t M, int32_t N, int32_t K, int epilogue);
+/* F.multi_head_attention_forward core (activation.py:408-427) on packed sequences:
+ * qkv[T, rows x 3d] (rows of utterance b = seq_off[b] .. seq_off[b+1]), out[T, rows x d];
+ * row i of an utterance attends keys j < max(text_len[b], causal ? i+1 : len_b)  -- the prefix-LM
+ * mask of valle.py:1019-1033 when causal = 1, no mask (NAR) when causal = 0. */
+int vle_op_attention(void* stream, int dtype, const void* qkv, void* out, const int32_t* seq_off_dev,
+                     const int32_t* text_len_dev, int32_t B, int32_t max_len, int32_t d, int32_t nhead, int causal);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VALLE_ENGINE_H_ */

@@ -1,0 +1,132 @@
+"""GPU: each stand-alone HIP operator against its plain PyTorch fp32 definition
+(the floating-point kernels' reference; tolerances stated per test)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+import valle_amd  # noqa: E402
+from valle_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _rand(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.randn(*shape, generator=g) * scale).to(DEV)
+
+
+@pytest.mark.parametrize("d", [64, 192, 1024, 1536])
+@pytest.mark.parametrize("rows", [1, 7, 300])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_layernorm(d, rows, dt):
+    x = _rand(rows, d, seed=1, scale=3.0) + 0.5
+    g = _rand(d, seed=2) * 0.2 + 1.0
+    b = _rand(d, seed=3) * 0.1
+    out = ops.layernorm(x, g, b, out_dtype=dt)
+    ref = F.layer_norm(x.double(), (d,), g.double(), b.double(), 1e-5)
+    if dt == torch.float32:
+        assert (out.double() - ref).abs().max().item() < 2e-5
+    else:
+        assert torch.equal(out, ref.float().to(torch.bfloat16)) or (out.double() - ref).abs().max().item() < 0.04
+
+
+GEMM_SHAPES = [(1, 64, 64), (37, 192, 64), (130, 256, 256), (272, 3072, 1024), (1025, 1024, 4096), (300, 1025, 1024), (64, 4096, 1024)]
+
+
+@pytest.mark.parametrize("M,N,K", GEMM_SHAPES)
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("epi", [ops.EPI_STORE, ops.EPI_RELU, ops.EPI_RESID, ops.EPI_F32])
+def test_linear_gemm(M, N, K, dt, epi):
+    a = _rand(M, K, seed=4).to(dt)
+    w = (_rand(N, K, seed=5) / math.sqrt(K)).to(dt)
+    bias = _rand(N, seed=6) * 0.1
+    ref = a.double() @ w.double().t() + bias.double()
+    if epi == ops.EPI_RELU:
+        ref = ref.clamp_min(0)
+    if epi == ops.EPI_RESID:
+        r0 = _rand(M, N, seed=7)
+        out = ops.linear(a, w, bias, epi, resid=r0.clone())
+        ref = ref + r0.double()
+    else:
+        out = ops.linear(a, w, bias, epi)
+    err = (out.double() - ref).abs().max().item()
+    # fp32 MFMA = exact fp32 FMA chain: error ~ K * eps * |a||w|; bf16 output rounding 2^-9 relative
+    tol = 3e-5 * math.sqrt(K / 64) if dt == torch.float32 or epi in (ops.EPI_RESID, ops.EPI_F32) and False else None
+    if dt == torch.float32:
+        assert err < 1e-4, err
+    elif epi in (ops.EPI_RESID, ops.EPI_F32):
+        assert err < 2e-3, err  # bf16 inputs are exact in fp32 accumulate
+    else:
+        assert err < 0.03 * max(1.0, ref.abs().max().item()), err
+
+
+SK_SHAPES = [(3072, 1024), (1024, 4096), (1025, 1024), (192, 64), (64, 256), (4096, 1024), (768, 192)]
+
+
+@pytest.mark.parametrize("N,K", SK_SHAPES)
+@pytest.mark.parametrize("M", [1, 2, 3, 5, 8])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_linear_skinny(N, K, M, dt):
+    x = _rand(M, K, seed=8) * 2 + 0.3
+    w = (_rand(N, K, seed=9) / math.sqrt(K)).to(dt)
+    bias = _rand(N, seed=10) * 0.1
+    g = _rand(K, seed=11) * 0.2 + 1.0
+    b = _rand(K, seed=12) * 0.1
+    wd = w.double()
+    tol = 1e-4 if dt == torch.float32 else 2e-4
+    # plain + store / relu / resid
+    out = ops.linear_skinny(x, w, bias, 0)
+    ref = x.double() @ wd.t() + bias.double()
+    assert (out.double() - ref).abs().max().item() < tol
+    out = ops.linear_skinny(x, w, bias, 1)
+    assert (out.double() - ref.clamp_min(0)).abs().max().item() < tol
+    r0 = _rand(M, N, seed=13)
+    out = ops.linear_skinny(x, w, bias, 2, resid=r0.clone())
+    assert (out.double() - (ref + r0.double())).abs().max().item() < tol
+    # fused LayerNorm prologue, no bias (the logits head)
+    out = ops.linear_skinny(x, w, None, 0, gamma=g, beta=b)
+    xn = F.layer_norm(x.double(), (K,), g.double(), b.double(), 1e-5)
+    assert (out.double() - xn @ wd.t()).abs().max().item() < tol * 3
+
+
+def _ref_attention(qkv, lens, text_lens, nhead, causal):
+    d = qkv.shape[1] // 3
+    dh = d // nhead
+    outs = []
+    off = 0
+    for L, S in zip(lens, text_lens):
+        q, k, v = qkv[off : off + L].double().split(d, dim=1)
+        q = q.view(L, nhead, dh).transpose(0, 1)
+        k = k.view(L, nhead, dh).transpose(0, 1)
+        v = v.view(L, nhead, dh).transpose(0, 1)
+        s = q @ k.transpose(1, 2) / math.sqrt(dh)
+        if causal:
+            i = torch.arange(L, device=qkv.device)[:, None]
+            j = torch.arange(L, device=qkv.device)[None, :]
+            blocked = j >= torch.maximum(torch.tensor(S, device=qkv.device), i + 1)
+            s = s.masked_fill(blocked[None], float("-inf"))
+        o = torch.softmax(s, -1) @ v
+        outs.append(o.transpose(0, 1).reshape(L, d))
+        off += L
+    return torch.cat(outs, 0)
+
+
+@pytest.mark.parametrize("nhead,dh", [(16, 4), (4, 16), (4, 32), (2, 64), (16, 64), (2, 96)])
+@pytest.mark.parametrize("causal", [True, False])
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+def test_attention_rows(nhead, dh, causal, dt):
+    d = nhead * dh
+    lens = [70, 1, 133, 64]
+    text_lens = [9, 1, 20, 64]
+    rows = sum(lens)
+    qkv = (_rand(rows, 3 * d, seed=14)).to(dt)
+    so = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    tl = torch.tensor(text_lens, dtype=torch.int32, device=DEV)
+    out = ops.attention(qkv, so, tl, nhead, causal)
+    ref = _ref_attention(qkv, lens, text_lens, nhead, causal)
+    err = (out.double() - ref).abs().max().item()
+    assert err < (2e-5 if dt == torch.float32 else 0.02), err

@@ -1,0 +1,90 @@
+"""ctypes binding of libvalle_engine.so (the C ABI declared in include/valle_engine.h).
+
+The library is the product: there is NO Python/PyTorch fallback.  If it is missing or does
+not export the expected symbols, loading fails loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libvalle_engine.so")
+
+VLE_OK = 0
+VLE_EINVAL, VLE_ESTATE, VLE_EHIP, VLE_EKEY, VLE_ENOTOKEN = -1, -2, -3, -4, -5
+DTYPE_F32, DTYPE_BF16 = 0, 1
+
+
+class VleConfig(C.Structure):
+    _fields_ = [
+        ("d_model", C.c_int32), ("nhead", C.c_int32), ("num_layers", C.c_int32), ("num_quantizers", C.c_int32),
+        ("prefix_mode", C.c_int32), ("prepend_bos", C.c_int32), ("norm_first", C.c_int32), ("add_prenet", C.c_int32),
+        ("dtype_mode", C.c_int32), ("max_batch", C.c_int32), ("max_text", C.c_int32), ("max_prompt", C.c_int32),
+        ("max_gen", C.c_int32), ("device", C.c_int32), ("use_graph", C.c_int32), ("steps_per_graph", C.c_int32),
+        ("reserved", C.c_int32 * 8),
+    ]
+
+
+_P = C.c_void_p
+_I32P = C.POINTER(C.c_int32)
+
+# name -> (restype, argtypes); must list every symbol include/valle_engine.h declares
+SIGNATURES = {
+    "vle_create": (C.c_int, [C.POINTER(VleConfig), C.POINTER(_P)]),
+    "vle_destroy": (None, [_P]),
+    "vle_last_error": (C.c_char_p, [_P]),
+    "vle_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),
+    "vle_finalize_weights": (C.c_int, [_P]),
+    "vle_ar_prefill": (C.c_int, [_P, _P, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P, C.c_int32]),
+    "vle_ar_generate": (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_uint64, C.c_int32, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P]),
+    "vle_nar_decode": (C.c_int, [_P, _P, _I32P, _P, C.c_int64]),
+    "vle_nar_continual": (C.c_int, [_P, _P, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P, C.c_int32, _P, C.c_int64, _I32P]),
+    "vle_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
+    "vle_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_size_t]),
+    "vle_last_timings": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "vle_ar_step_bytes": (C.c_int64, [_P, C.c_int32, C.c_int64]),
+    "vle_op_layernorm": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int32]),
+    "vle_op_linear": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int]),
+    "vle_op_linear_skinny": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
+    "vle_op_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (once).  Raises RuntimeError when it is absent or incomplete."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.isfile(LIB_PATH):
+        raise RuntimeError(
+            f"{LIB_PATH} not found: the HIP engine is not built. Run `python __graft_entry__.py build` "
+            "(hipcc --offload-arch=gfx950). There is no fallback path."
+        )
+    # torch ships its own libamdhip64.so (same SONAME): import it first so both share one HIP runtime
+    import torch  # noqa: F401
+
+    lib = C.CDLL(LIB_PATH, mode=C.RTLD_LOCAL)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name, None)
+        if fn is None:
+            raise RuntimeError(f"{LIB_PATH} does not export {name}")
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+class VleError(RuntimeError):
+    def __init__(self, code: int, msg: str):
+        super().__init__(f"valle_engine error {code}: {msg}")
+        self.code = code
+
+
+def check(code: int, handle=None):
+    if code == VLE_OK:
+        return
+    msg = load().vle_last_error(handle)
+    raise VleError(code, msg.decode() if msg else "?")

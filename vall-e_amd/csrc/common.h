@@ -1,0 +1,137 @@
+// Shared device helpers for the gfx950 (CDNA4, wave64) kernels of the VALL-E decode engine.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vle {
+
+constexpr int WAVE = 64;
+constexpr float LN_EPS = 1e-5f;  // valle/modules/transformer.py:27
+
+// ---- element types ------------------------------------------------------------------------
+struct bf16_t {
+  uint16_t v;
+};
+
+__host__ __device__ inline float bf16_to_f32(uint16_t v) {
+  union {
+    uint32_t u;
+    float f;
+  } c;
+  c.u = ((uint32_t)v) << 16;
+  return c.f;
+}
+// round-to-nearest-even, same as torch's float -> bfloat16
+__host__ __device__ inline uint16_t f32_to_bf16(float f) {
+  union {
+    uint32_t u;
+    float f;
+  } c;
+  c.f = f;
+  uint32_t u = c.u;
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);  // NaN
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+
+template <typename T>
+struct Elem;
+template <>
+struct Elem<float> {
+  static constexpr int VEC = 4;  // elements per 16-byte vector
+  __device__ static inline float to_f32(float v) { return v; }
+  __device__ static inline float from_f32(float v) { return v; }
+};
+template <>
+struct Elem<bf16_t> {
+  static constexpr int VEC = 8;
+  __device__ static inline float to_f32(bf16_t v) { return bf16_to_f32(v.v); }
+  __device__ static inline bf16_t from_f32(float v) {
+    bf16_t r;
+    r.v = f32_to_bf16(v);
+    return r;
+  }
+};
+
+// 16-byte vector load of VEC elements, widened to fp32
+template <typename T>
+__device__ inline void load_vec16(const T* p, float (&out)[Elem<T>::VEC]);
+template <>
+__device__ inline void load_vec16<float>(const float* p, float (&out)[4]) {
+  const float4 v = *reinterpret_cast<const float4*>(p);
+  out[0] = v.x;
+  out[1] = v.y;
+  out[2] = v.z;
+  out[3] = v.w;
+}
+template <>
+__device__ inline void load_vec16<bf16_t>(const bf16_t* p, float (&out)[8]) {
+  const uint4 v = *reinterpret_cast<const uint4*>(p);
+  out[0] = __uint_as_float(v.x << 16);
+  out[1] = __uint_as_float(v.x & 0xffff0000u);
+  out[2] = __uint_as_float(v.y << 16);
+  out[3] = __uint_as_float(v.y & 0xffff0000u);
+  out[4] = __uint_as_float(v.z << 16);
+  out[5] = __uint_as_float(v.z & 0xffff0000u);
+  out[6] = __uint_as_float(v.w << 16);
+  out[7] = __uint_as_float(v.w & 0xffff0000u);
+}
+
+template <typename T>
+__device__ inline void store_elem(T* p, float v);
+template <>
+__device__ inline void store_elem<float>(float* p, float v) {
+  *p = v;
+}
+template <>
+__device__ inline void store_elem<bf16_t>(bf16_t* p, float v) {
+  p->v = f32_to_bf16(v);
+}
+
+// ---- wave / block reductions (wave = 64 lanes) ----------------------------------------------
+__device__ inline float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+__device__ inline float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o, 64));
+  return v;
+}
+__device__ inline int wave_sum_i(int v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// Block-wide sum for blockDim.x == NW*64; `red` is NW floats of LDS; all threads get the result.
+template <int NW>
+__device__ inline float block_sum(float v, float* red) {
+  v = wave_sum(v);
+  const int w = threadIdx.x >> 6;
+  __syncthreads();  // protect `red` from a previous use
+  if ((threadIdx.x & 63) == 0) red[w] = v;
+  __syncthreads();
+  float t = 0.f;
+#pragma unroll
+  for (int i = 0; i < NW; ++i) t += red[i];
+  return t;
+}
+
+// order-preserving float <-> uint key (for arg-max with lowest-index tie-break and k-th largest)
+__device__ inline uint32_t float_key(float f) {
+  uint32_t u = __float_as_uint(f);
+  return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+#define VLE_HIP_CHECK(expr)                                                 \
+  do {                                                                      \
+    hipError_t _e = (expr);                                                 \
+    if (_e != hipSuccess) return vle::hip_fail(_e, #expr, __FILE__, __LINE__); \
+  } while (0)
+
+int hip_fail(hipError_t e, const char* expr, const char* file, int line);
+void set_global_error(const char* msg);
+
+}  // namespace vle

@@ -1,0 +1,1127 @@
+// Host side of libvalle_engine.so: weight packing, buffers, the prefill / AR-step / NAR schedules,
+// hipGraph capture of the AR step, and the C ABI of include/valle_engine.h.
+//
+// Reference being replaced: VALLE.inference() / continual() -- valle/models/valle.py:961-1238 -- and
+// the modules under it (valle/modules/{transformer,activation,embedding}.py).  The reference has no
+// KV cache (valle.py:1004 "TODO: Managing decoder steps avoid repetitive computation"); the cache
+// here is exact because of the prefix-LM mask (valle.py:1019-1033): text rows never see audio
+// columns and audio rows are causal, so the hidden state of a position never changes once computed.
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "common.h"
+#include "kernels.h"
+#include "valle_engine.h"
+
+namespace vle {
+
+static std::mutex g_err_mu;
+static std::string g_last_error;
+
+void set_global_error(const char* msg) {
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  g_last_error = msg;
+}
+int hip_fail(hipError_t e, const char* expr, const char* file, int line) {
+  char buf[512];
+  snprintf(buf, sizeof(buf), "HIP error %d (%s) at %s:%d: %s", (int)e, hipGetErrorString(e), file, line, expr);
+  set_global_error(buf);
+  return VLE_EHIP;
+}
+
+constexpr int NUM_TEXT_TOKENS = 512;    // valle/models/macros.py:2
+constexpr int NUM_AUDIO_TOKENS = 1024;  // valle/models/macros.py:5
+constexpr int V_AR = NUM_AUDIO_TOKENS + 1;
+constexpr int SKINNY_MAX_B = 8;
+
+struct LayerW {
+  void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;  // T
+  float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;  // AR LayerNorm affine
+};
+
+}  // namespace vle
+
+using namespace vle;
+
+struct vle_engine {
+  vle_config cfg{};
+  int d = 0, H = 0, dh = 0, L = 0, Q = 0, bos = 0, dtype = 0;
+  int max_B = 0, max_S = 0, max_P = 0, max_G = 0, ctx_max = 0, max_pos = 0;
+  int64_t max_rows = 0;  // packed rows of the biggest pass
+  std::string err;
+  hipStream_t st = nullptr;
+  hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+  std::vector<void*> allocs;
+  bool finalized = false;
+
+  // ---- host staging of the state dict --------------------------------------------------------
+  std::map<std::string, std::vector<float>> host_w;
+  std::map<std::string, std::vector<int64_t>> host_shape;
+
+  // ---- device weights ---------------------------------------------------------------------------
+  float *ar_text_emb = nullptr, *nar_text_emb = nullptr, *ar_audio_emb = nullptr;
+  float* nar_audio_emb[8] = {};
+  const float** nar_audio_emb_tab = nullptr;  // device array of the Q table pointers
+  float* alphas = nullptr;                    // [4]: ar_text, ar_audio, nar_text, nar_audio
+  float* pe = nullptr;
+  std::vector<LayerW> ar, nar;
+  float *ar_norm_g = nullptr, *ar_norm_b = nullptr;
+  void* ar_predict = nullptr;
+  void* nar_predict[7] = {};
+  // folded AdaLN affine, [stage][site] with site = 2*l (norm1), 2*l+1 (norm2), 2*L (final)
+  std::vector<std::vector<float*>> nar_gamma, nar_beta;
+
+  // ---- buffers ------------------------------------------------------------------------------------
+  void *kcache = nullptr, *vcache = nullptr;  // T [L][B][H][ctx_max][dh]
+  float *x_step = nullptr, *q_step = nullptr, *h_step = nullptr, *part_o = nullptr, *part_ml = nullptr, *logits = nullptr;
+  void *xn_step = nullptr, *qkv_step = nullptr, *att_step = nullptr, *hT_step = nullptr;  // batch > 8 path
+  int32_t* state_dev = nullptr;  // kv_len, audio_pos, n_gen, done, cap, iter [max_B] each, then done_count
+  ArState S{};
+  ArDyn* dyn_dev = nullptr;
+  int64_t *tokens = nullptr, *sampled = nullptr;  // [max_B][max_G]
+  int64_t *text_ids = nullptr, *prompt_codes = nullptr;  // [max_B][max_S], [max_B][max_P + max_G][Q]
+  int32_t* forced_len_dev = nullptr;
+  float *X = nullptr, *yemb = nullptr, *nar_logits = nullptr;
+  void *Xn = nullptr, *QKV = nullptr, *ATT = nullptr, *Hb = nullptr;
+  int32_t* tables_dev = nullptr;  // row tables
+  int32_t* tables_host = nullptr; // pinned mirror
+  int64_t tables_cap = 0;
+  int32_t* poll_host = nullptr;   // pinned [64]
+  float* trace_ar = nullptr; int64_t trace_ar_cap = 0;
+  float* trace_nar = nullptr;     // [Q-1][sumG_max][1024]
+  bool opt_trace_ar = false, opt_trace_nar = false;
+
+  // ---- per-call state -------------------------------------------------------------------------------
+  int B = 0;
+  bool have_prefill = false, have_gen = false;
+  std::vector<int32_t> S_len, P_len, G_len;
+  int64_t sumG_last = 0;
+  int nsplit = 1;
+  std::map<int, std::pair<hipGraphExec_t, hipGraphExec_t>> graphs;  // B -> (multi, single)
+  double t_prefill = 0, t_ar = 0, t_nar = 0, n_steps = 0;
+
+  int fail(int code, const std::string& m) {
+    err = m;
+    return code;
+  }
+};
+
+namespace {
+
+#define E_HIP(e, expr)                                                                           \
+  do {                                                                                           \
+    hipError_t _r = (expr);                                                                      \
+    if (_r != hipSuccess) {                                                                      \
+      char _b[512];                                                                              \
+      snprintf(_b, sizeof(_b), "HIP error %d (%s) at %s:%d: %s", (int)_r, hipGetErrorString(_r), __FILE__, __LINE__, #expr); \
+      return (e)->fail(VLE_EHIP, _b);                                                            \
+    }                                                                                            \
+  } while (0)
+
+#define E_LAUNCH(e, expr)                                                                        \
+  do {                                                                                           \
+    int _r = (expr);                                                                             \
+    if (_r != 0) {                                                                               \
+      char _b[512];                                                                              \
+      snprintf(_b, sizeof(_b), "kernel launch rejected (%d) at %s:%d: %s", _r, __FILE__, __LINE__, #expr); \
+      return (e)->fail(_r == -3 ? VLE_EHIP : VLE_EINVAL, _b);                                    \
+    }                                                                                            \
+  } while (0)
+
+template <typename T>
+int dev_alloc(vle_engine* e, T** p, size_t count) {
+  void* q = nullptr;
+  E_HIP(e, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  e->allocs.push_back(q);
+  *p = (T*)q;
+  return 0;
+}
+
+int upload_f32(vle_engine* e, float** dst, const float* src, size_t n) {
+  int r = dev_alloc(e, dst, n);
+  if (r) return r;
+  E_HIP(e, hipMemcpy(*dst, src, n * sizeof(float), hipMemcpyHostToDevice));
+  return 0;
+}
+
+// fp32 host tensor -> compute dtype on the device
+int upload_T(vle_engine* e, void** dst, const float* src, size_t n) {
+  if (e->dtype == DT_F32) return upload_f32(e, (float**)dst, src, n);
+  std::vector<uint16_t> tmp(n);
+  for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16(src[i]);
+  uint16_t* p = nullptr;
+  int r = dev_alloc(e, &p, n);
+  if (r) return r;
+  E_HIP(e, hipMemcpy(p, tmp.data(), n * 2, hipMemcpyHostToDevice));
+  *dst = p;
+  return 0;
+}
+
+const std::vector<float>* find_w(vle_engine* e, const std::string& key, std::initializer_list<int64_t> shape) {
+  auto it = e->host_w.find(key);
+  if (it == e->host_w.end()) {
+    e->err = "missing state_dict key: " + key;
+    return nullptr;
+  }
+  const auto& sh = e->host_shape[key];
+  if (sh.size() != shape.size() || !std::equal(sh.begin(), sh.end(), shape.begin())) {
+    e->err = "shape mismatch for state_dict key: " + key;
+    return nullptr;
+  }
+  return &it->second;
+}
+
+// SinePositionalEmbedding.extend_pe, valle/modules/embedding.py:75-91 (fallback when the host
+// wrapper did not pass the torch-built table as "position.pe")
+void build_pe(std::vector<float>& pe, int max_pos, int d) {
+  pe.assign((size_t)max_pos * d, 0.f);
+  for (int i = 0; i < d; i += 2) {
+    const float div = (float)std::exp((double)((float)i * (float)(-(std::log(10000.0) / d))));
+    for (int p = 0; p < max_pos; ++p) {
+      const float ang = (float)p * div;
+      pe[(size_t)p * d + i] = (float)std::sin((double)ang);
+      if (i + 1 < d) pe[(size_t)p * d + i + 1] = (float)std::cos((double)ang);
+    }
+  }
+}
+
+int choose_nsplit(int B, int H) {
+  // spread the KV stream of a small batch over >= ~128-256 blocks
+  int ns = 1;
+  while (ns < 16 && (int64_t)B * H * ns < 192) ns *= 2;
+  return ns;
+}
+
+}  // namespace
+
+// =================================================================================================
+// create / destroy / load
+// =================================================================================================
+extern "C" int vle_create(const vle_config* c, vle_engine** out) {
+  if (!c || !out) {
+    set_global_error("vle_create: null argument");
+    return VLE_EINVAL;
+  }
+  auto bad = [&](const char* m) {
+    set_global_error(m);
+    return VLE_EINVAL;
+  };
+  if (c->norm_first != 1 || c->add_prenet != 0) return bad("only norm_first=1, add_prenet=0 run natively");
+  if (c->d_model <= 0 || c->nhead <= 0 || c->d_model % c->nhead) return bad("bad d_model / nhead");
+  if (c->d_model % 32 != 0) return bad("d_model must be a multiple of 32");
+  const int dh = c->d_model / c->nhead;
+  if (!(dh == 4 || dh == 8 || dh == 16 || dh == 32 || dh == 64 || dh == 96 || dh == 128)) return bad("unsupported head size");
+  if (c->dtype_mode == VLE_DTYPE_BF16 && c->d_model % 64 != 0) return bad("bf16 mode needs d_model % 64 == 0");
+  if (c->num_quantizers < 1 || c->num_quantizers > 8) return bad("num_quantizers must be 1..8");
+  if (!(c->prefix_mode == 0 || c->prefix_mode == 1 || c->prefix_mode == 2 || c->prefix_mode == 4)) return bad("bad prefix_mode");
+  if (c->dtype_mode != VLE_DTYPE_F32 && c->dtype_mode != VLE_DTYPE_BF16) return bad("bad dtype_mode");
+  if (c->max_batch < 1 || c->max_text < 1 || c->max_prompt < 0) return bad("bad capacity");
+
+  vle_engine* e = new vle_engine();
+  e->cfg = *c;
+  e->d = c->d_model; e->H = c->nhead; e->dh = dh; e->L = c->num_layers; e->Q = c->num_quantizers;
+  e->bos = c->prepend_bos ? 1 : 0; e->dtype = c->dtype_mode;
+  e->max_B = c->max_batch; e->max_S = c->max_text; e->max_P = c->max_prompt;
+  e->max_G = c->max_gen > 0 ? c->max_gen : 16 * c->max_text + 1;
+  e->ctx_max = e->max_S + e->max_P + 1 + e->max_G;
+  e->max_pos = std::max(e->max_S, e->max_P + 1 + e->max_G) + 1;
+  e->max_rows = (int64_t)e->max_B * (e->max_S + e->max_P + 1 + e->max_G);
+  if (hipSetDevice(c->device) != hipSuccess) {
+    delete e;
+    return bad("hipSetDevice failed");
+  }
+  auto chk = [&](hipError_t r, const char* what) {
+    if (r != hipSuccess) {
+      std::string m = std::string(what) + ": " + hipGetErrorString(r);
+      set_global_error(m.c_str());
+      return false;
+    }
+    return true;
+  };
+  bool ok = chk(hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking), "hipStreamCreate");
+  ok = ok && chk(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming), "hipEventCreate");
+  ok = ok && chk(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming), "hipEventCreate");
+  for (int i = 0; i < 6 && ok; ++i) ok = chk(hipEventCreate(&e->ev_t[i]), "hipEventCreate");
+  if (!ok) {
+    vle_destroy(e);
+    return VLE_EHIP;
+  }
+  *out = e;
+  return VLE_OK;
+}
+
+extern "C" void vle_destroy(vle_engine* e) {
+  if (!e) return;
+  (void)hipSetDevice(e->cfg.device);
+  if (e->st) (void)hipStreamSynchronize(e->st);
+  for (auto& kv : e->graphs) {
+    if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
+    if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+  }
+  for (void* p : e->allocs) (void)hipFree(p);
+  if (e->tables_host) (void)hipHostFree(e->tables_host);
+  if (e->poll_host) (void)hipHostFree(e->poll_host);
+  for (int i = 0; i < 6; ++i)
+    if (e->ev_t[i]) (void)hipEventDestroy(e->ev_t[i]);
+  if (e->ev_in) (void)hipEventDestroy(e->ev_in);
+  if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+  if (e->st) (void)hipStreamDestroy(e->st);
+  delete e;
+}
+
+extern "C" const char* vle_last_error(const vle_engine* e) {
+  if (e) return e->err.c_str();
+  std::lock_guard<std::mutex> lk(g_err_mu);
+  static thread_local std::string copy;
+  copy = g_last_error;
+  return copy.c_str();
+}
+
+extern "C" int vle_load_tensor(vle_engine* e, const char* key, const float* data, const int64_t* shape, int ndim) {
+  if (!e || !key || !data || !shape || ndim < 1 || ndim > 4) return VLE_EINVAL;
+  if (e->finalized) return e->fail(VLE_ESTATE, "vle_load_tensor after vle_finalize_weights");
+  size_t n = 1;
+  for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
+  e->host_w[key].assign(data, data + n);
+  e->host_shape[key].assign(shape, shape + ndim);
+  return VLE_OK;
+}
+
+static int load_layer(vle_engine* e, const std::string& p, LayerW& w, bool adaptive) {
+  const int64_t d = e->d;
+  const std::vector<float>* t;
+#define GET(name, ...)                          \
+  t = find_w(e, p + name, {__VA_ARGS__});       \
+  if (!t) return VLE_EKEY
+  int r;
+  GET(".self_attn.in_proj_weight", 3 * d, d);
+  if ((r = upload_T(e, &w.wqkv, t->data(), t->size()))) return r;
+  GET(".self_attn.in_proj_bias", 3 * d);
+  if ((r = upload_f32(e, &w.bqkv, t->data(), t->size()))) return r;
+  GET(".self_attn.out_proj.weight", d, d);
+  if ((r = upload_T(e, &w.wo, t->data(), t->size()))) return r;
+  GET(".self_attn.out_proj.bias", d);
+  if ((r = upload_f32(e, &w.bo, t->data(), t->size()))) return r;
+  GET(".linear1.weight", 4 * d, d);
+  if ((r = upload_T(e, &w.w1, t->data(), t->size()))) return r;
+  GET(".linear1.bias", 4 * d);
+  if ((r = upload_f32(e, &w.b1, t->data(), t->size()))) return r;
+  GET(".linear2.weight", d, 4 * d);
+  if ((r = upload_T(e, &w.w2, t->data(), t->size()))) return r;
+  GET(".linear2.bias", d);
+  if ((r = upload_f32(e, &w.b2, t->data(), t->size()))) return r;
+  if (!adaptive) {
+    GET(".norm1.weight", d);
+    if ((r = upload_f32(e, &w.g1, t->data(), t->size()))) return r;
+    GET(".norm1.bias", d);
+    if ((r = upload_f32(e, &w.be1, t->data(), t->size()))) return r;
+    GET(".norm2.weight", d);
+    if ((r = upload_f32(e, &w.g2, t->data(), t->size()))) return r;
+    GET(".norm2.bias", d);
+    if ((r = upload_f32(e, &w.be2, t->data(), t->size()))) return r;
+  }
+#undef GET
+  return 0;
+}
+
+// AdaptiveLayerNorm (valle/modules/transformer.py:93-108): [w, b] = project_layer(stage_emb);
+// w * (xhat * gamma + beta) + b  ==  xhat * (w * gamma) + (w * beta + b).  project_layer(stage_emb)
+// does not depend on the input, so it is folded once per (stage, norm site), in fp32.
+static int fold_adaln(vle_engine* e, const std::string& site, const std::vector<float>& stage_emb, float** g_out,
+                      float** b_out) {
+  const int64_t d = e->d;
+  const auto* pw = find_w(e, site + ".project_layer.weight", {2 * d, d});
+  const auto* pb = find_w(e, site + ".project_layer.bias", {2 * d});
+  const auto* g = find_w(e, site + ".norm.weight", {d});
+  const auto* b = find_w(e, site + ".norm.bias", {d});
+  if (!pw || !pb || !g || !b) return VLE_EKEY;
+  std::vector<float> gg(d), bb(d);
+  for (int64_t o = 0; o < 2 * d; ++o) {
+    double acc = 0.0;
+    const float* row = pw->data() + o * d;
+    for (int64_t k = 0; k < d; ++k) acc += (double)row[k] * (double)stage_emb[k];
+    const float wb = (float)(acc + (double)(*pb)[o]);
+    if (o < d) {
+      gg[o] = wb * (*g)[o];
+      bb[o] = wb * (*b)[o];  // + b part added below
+    } else {
+      bb[o - d] += wb;
+    }
+  }
+  int r;
+  if ((r = upload_f32(e, g_out, gg.data(), d))) return r;
+  return upload_f32(e, b_out, bb.data(), d);
+}
+
+static int alloc_buffers(vle_engine* e);
+
+extern "C" int vle_finalize_weights(vle_engine* e) {
+  if (!e) return VLE_EINVAL;
+  if (e->finalized) return VLE_OK;
+  E_HIP(e, hipSetDevice(e->cfg.device));
+  const int64_t d = e->d;
+  const std::vector<float>* t;
+  int r;
+#define GETK(key, ...)                   \
+  t = find_w(e, key, {__VA_ARGS__});     \
+  if (!t) return VLE_EKEY
+  GETK("ar_text_embedding.word_embeddings.weight", NUM_TEXT_TOKENS, d);
+  if ((r = upload_f32(e, &e->ar_text_emb, t->data(), t->size()))) return r;
+  GETK("ar_audio_embedding.word_embeddings.weight", V_AR + e->bos, d);
+  if ((r = upload_f32(e, &e->ar_audio_emb, t->data(), t->size()))) return r;
+  float al[4] = {1.f, 1.f, 1.f, 1.f};
+  GETK("ar_text_position.alpha", 1);
+  al[0] = (*t)[0];
+  GETK("ar_audio_position.alpha", 1);
+  al[1] = (*t)[0];
+  e->ar.resize(e->L);
+  for (int l = 0; l < e->L; ++l)
+    if ((r = load_layer(e, "ar_decoder.layers." + std::to_string(l), e->ar[l], false))) return r;
+  GETK("ar_decoder.norm.weight", d);
+  if ((r = upload_f32(e, &e->ar_norm_g, t->data(), t->size()))) return r;
+  GETK("ar_decoder.norm.bias", d);
+  if ((r = upload_f32(e, &e->ar_norm_b, t->data(), t->size()))) return r;
+  GETK("ar_predict_layer.weight", V_AR, d);
+  if ((r = upload_T(e, &e->ar_predict, t->data(), t->size()))) return r;
+
+  if (e->Q > 1) {
+    GETK("nar_text_embedding.word_embeddings.weight", NUM_TEXT_TOKENS, d);
+    if ((r = upload_f32(e, &e->nar_text_emb, t->data(), t->size()))) return r;
+    for (int j = 0; j < e->Q; ++j) {
+      GETK("nar_audio_embeddings." + std::to_string(j) + ".word_embeddings.weight", j == 0 ? V_AR : NUM_AUDIO_TOKENS, d);
+      if ((r = upload_f32(e, &e->nar_audio_emb[j], t->data(), t->size()))) return r;
+    }
+    const float* tab[8];
+    for (int j = 0; j < 8; ++j) tab[j] = e->nar_audio_emb[j];
+    if ((r = dev_alloc(e, &e->nar_audio_emb_tab, 8))) return r;
+    E_HIP(e, hipMemcpy((void*)e->nar_audio_emb_tab, tab, sizeof(tab), hipMemcpyHostToDevice));
+    GETK("nar_text_position.alpha", 1);
+    al[2] = (*t)[0];
+    GETK("nar_audio_position.alpha", 1);
+    al[3] = (*t)[0];
+    e->nar.resize(e->L);
+    for (int l = 0; l < e->L; ++l)
+      if ((r = load_layer(e, "nar_decoder.layers." + std::to_string(l), e->nar[l], true))) return r;
+    e->nar_gamma.assign(e->Q - 1, std::vector<float*>(2 * e->L + 1, nullptr));
+    e->nar_beta.assign(e->Q - 1, std::vector<float*>(2 * e->L + 1, nullptr));
+    for (int i = 0; i < e->Q - 1; ++i) {
+      GETK("nar_stage_embeddings." + std::to_string(i) + ".word_embeddings.weight", 1, d);
+      const std::vector<float> stage = *t;
+      for (int l = 0; l < e->L; ++l) {
+        const std::string p = "nar_decoder.layers." + std::to_string(l);
+        if ((r = fold_adaln(e, p + ".norm1", stage, &e->nar_gamma[i][2 * l], &e->nar_beta[i][2 * l]))) return r;
+        if ((r = fold_adaln(e, p + ".norm2", stage, &e->nar_gamma[i][2 * l + 1], &e->nar_beta[i][2 * l + 1]))) return r;
+      }
+      if ((r = fold_adaln(e, "nar_decoder.norm", stage, &e->nar_gamma[i][2 * e->L], &e->nar_beta[i][2 * e->L]))) return r;
+      GETK("nar_predict_layers." + std::to_string(i) + ".weight", NUM_AUDIO_TOKENS, d);
+      if ((r = upload_T(e, &e->nar_predict[i], t->data(), t->size()))) return r;
+    }
+  }
+#undef GETK
+  if ((r = upload_f32(e, &e->alphas, al, 4))) return r;
+  {
+    auto it = e->host_w.find("position.pe");
+    std::vector<float> pe;
+    if (it != e->host_w.end() && e->host_shape["position.pe"].size() == 2 && e->host_shape["position.pe"][1] == d &&
+        e->host_shape["position.pe"][0] >= e->max_pos) {
+      pe.assign(it->second.begin(), it->second.begin() + (size_t)e->max_pos * d);
+    } else {
+      build_pe(pe, e->max_pos, e->d);
+    }
+    if ((r = upload_f32(e, &e->pe, pe.data(), pe.size()))) return r;
+  }
+  e->host_w.clear();
+  e->host_shape.clear();
+  if ((r = alloc_buffers(e))) return r;
+  e->finalized = true;
+  return VLE_OK;
+}
+
+static int alloc_buffers(vle_engine* e) {
+  const size_t es = dtype_size(e->dtype);
+  const int64_t d = e->d, B = e->max_B;
+  int r;
+  const size_t kv_elems = (size_t)e->L * B * e->H * e->ctx_max * e->dh;
+  char* p = nullptr;
+  if ((r = dev_alloc(e, &p, kv_elems * es))) return r;
+  e->kcache = p;
+  if ((r = dev_alloc(e, &p, kv_elems * es))) return r;
+  e->vcache = p;
+  if ((r = dev_alloc(e, &e->x_step, B * d))) return r;
+  if ((r = dev_alloc(e, &e->q_step, B * d))) return r;
+  if ((r = dev_alloc(e, &e->h_step, B * 4 * d))) return r;
+  if ((r = dev_alloc(e, &e->part_o, (size_t)B * e->H * 16 * e->dh))) return r;
+  if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
+  if ((r = dev_alloc(e, &e->logits, B * V_AR))) return r;
+  if (B > SKINNY_MAX_B || true) {  // GEMM-path step buffers (also used when the GEMV path cannot hold B rows in LDS)
+    if ((r = dev_alloc(e, &p, (size_t)B * d * es))) return r;
+    e->xn_step = p;
+    if ((r = dev_alloc(e, &p, (size_t)B * 3 * d * es))) return r;
+    e->qkv_step = p;
+    if ((r = dev_alloc(e, &p, (size_t)B * d * es))) return r;
+    e->att_step = p;
+    if ((r = dev_alloc(e, &p, (size_t)B * 4 * d * es))) return r;
+    e->hT_step = p;
+  }
+  if ((r = dev_alloc(e, &e->state_dev, 6 * B + 8))) return r;
+  e->S.kv_len = e->state_dev;
+  e->S.audio_pos = e->state_dev + B;
+  e->S.n_gen = e->state_dev + 2 * B;
+  e->S.done = e->state_dev + 3 * B;
+  e->S.cap = e->state_dev + 4 * B;
+  e->S.iter = e->state_dev + 5 * B;
+  e->S.done_count = e->state_dev + 6 * B;
+  if ((r = dev_alloc(e, &e->dyn_dev, 1))) return r;
+  if ((r = dev_alloc(e, &e->tokens, (size_t)B * e->max_G))) return r;
+  if ((r = dev_alloc(e, &e->sampled, (size_t)B * e->max_G))) return r;
+  if ((r = dev_alloc(e, &e->text_ids, (size_t)B * e->max_S))) return r;
+  if ((r = dev_alloc(e, &e->prompt_codes, (size_t)B * (e->max_P + e->max_G) * 8))) return r;
+  if ((r = dev_alloc(e, &e->forced_len_dev, B))) return r;
+  const int64_t R = e->max_rows;
+  if ((r = dev_alloc(e, &e->X, (size_t)R * d))) return r;
+  if ((r = dev_alloc(e, &p, (size_t)R * d * es))) return r;
+  e->Xn = p;
+  if ((r = dev_alloc(e, &p, (size_t)R * 3 * d * es))) return r;
+  e->QKV = p;
+  if ((r = dev_alloc(e, &p, (size_t)R * d * es))) return r;
+  e->ATT = p;
+  if ((r = dev_alloc(e, &p, (size_t)R * 4 * d * es))) return r;
+  e->Hb = p;
+  if (e->Q > 1) {
+    if ((r = dev_alloc(e, &e->yemb, (size_t)B * (e->max_P + e->max_G) * d))) return r;
+    if ((r = dev_alloc(e, &e->nar_logits, (size_t)B * e->max_G * NUM_AUDIO_TOKENS))) return r;
+  }
+  // row tables: generous upper bound (a handful of int32 per packed row)
+  e->tables_cap = 8 * R + 64 * B + 1024;
+  if ((r = dev_alloc(e, &e->tables_dev, e->tables_cap))) return r;
+  E_HIP(e, hipHostMalloc((void**)&e->tables_host, e->tables_cap * sizeof(int32_t), hipHostMallocDefault));
+  E_HIP(e, hipHostMalloc((void**)&e->poll_host, 64 * sizeof(int32_t), hipHostMallocDefault));
+  return 0;
+}
+
+// =================================================================================================
+// schedules
+// =================================================================================================
+namespace {
+
+struct TableBuilder {  // packs int32 tables into the pinned mirror, one H2D copy
+  vle_engine* e;
+  int64_t used = 0;
+  int32_t* take(int64_t n, int32_t** host) {
+    if (used + n > e->tables_cap) return nullptr;
+    *host = e->tables_host + used;
+    int32_t* dev = e->tables_dev + used;
+    used += (n + 3) & ~int64_t(3);
+    return dev;
+  }
+};
+
+int enter(vle_engine* e, void* caller_stream) {
+  E_HIP(e, hipSetDevice(e->cfg.device));
+  E_HIP(e, hipStreamSynchronize(e->st));  // the pinned table mirror is reused by every call
+  E_HIP(e, hipEventRecord(e->ev_in, (hipStream_t)caller_stream));
+  E_HIP(e, hipStreamWaitEvent(e->st, e->ev_in, 0));
+  return 0;
+}
+int leave(vle_engine* e, void* caller_stream) {
+  E_HIP(e, hipEventRecord(e->ev_out, e->st));
+  E_HIP(e, hipStreamWaitEvent((hipStream_t)caller_stream, e->ev_out, 0));
+  return 0;
+}
+
+inline void* cache_layer(vle_engine* e, void* base, int l) {
+  return (char*)base + (size_t)l * e->B * e->H * e->ctx_max * e->dh * dtype_size(e->dtype);
+}
+
+// one transformer layer over packed rows (prefill: AR weights + prefix-LM mask; NAR: no mask, folded AdaLN)
+int enqueue_layer_rows(vle_engine* e, const LayerW& w, const float* g1, const float* b1, const float* g2, const float* b2,
+                       int64_t rows, const int32_t* seq_off, const int32_t* text_len, int max_len, int causal,
+                       void* kc, void* vc, const int32_t* row_seq, const int32_t* row_pos) {
+  const int d = e->d;
+  hipStream_t st = e->st;
+  E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, nullptr, g1, b1, e->Xn, rows, d));
+  E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.wqkv, w.bqkv, e->QKV, nullptr, rows, 3 * d, d, EPI_STORE));
+  if (kc) E_LAUNCH(e, launch_kv_scatter(st, e->dtype, e->QKV, kc, vc, row_seq, row_pos, rows, d, e->H, e->ctx_max));
+  E_LAUNCH(e, launch_attention(st, e->dtype, e->QKV, e->ATT, seq_off, text_len, e->B, max_len, d, e->H, causal));
+  E_LAUNCH(e, launch_gemm(st, e->dtype, e->ATT, w.wo, w.bo, nullptr, e->X, rows, d, d, EPI_RESID));
+  E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, nullptr, g2, b2, e->Xn, rows, d));
+  E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.w1, w.b1, e->Hb, nullptr, rows, 4 * d, d, EPI_RELU));
+  E_LAUNCH(e, launch_gemm(st, e->dtype, e->Hb, w.w2, w.b2, nullptr, e->X, rows, d, 4 * d, EPI_RESID));
+  return 0;
+}
+
+bool use_skinny(const vle_engine* e) {
+  return e->B <= SKINNY_MAX_B && (size_t)(e->B <= 1 ? 1 : e->B <= 2 ? 2 : e->B <= 4 ? 4 : 8) * 4 * e->d * sizeof(float) <= 160 * 1024;
+}
+
+// logits of the current x_step rows: final LayerNorm (valle.py:151) + ar_predict_layer (valle.py:1039)
+int enqueue_ar_logits(vle_engine* e) {
+  hipStream_t st = e->st;
+  if (use_skinny(e)) {
+    SkinnyArgs a;
+    a.w = e->ar_predict; a.bias = nullptr; a.N = V_AR; a.K = e->d; a.B = e->B;
+    a.pro = PRO_LN; a.epi = SEPI_STORE; a.x = e->x_step; a.gamma = e->ar_norm_g; a.beta = e->ar_norm_b; a.out = e->logits;
+    E_LAUNCH(e, launch_skinny(st, e->dtype, a));
+  } else {
+    E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d));
+    E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
+  }
+  return 0;
+}
+
+int enqueue_ar_sample(vle_engine* e, int first) {
+  ArSampleArgs a{};
+  a.s = e->S; a.dyn = e->dyn_dev; a.logits = e->logits; a.V = V_AR; a.B = e->B; a.d = e->d; a.bos = e->bos; a.first = first;
+  a.tokens = e->tokens; a.g_stride = e->max_G; a.sampled = e->sampled;
+  a.audio_emb = e->ar_audio_emb; a.pe = e->pe; a.alpha_audio = e->alphas + 1; a.x = e->x_step; a.ctx_max = e->ctx_max;
+  E_LAUNCH(e, launch_ar_sample(e->st, a));
+  return 0;
+}
+
+// One AR step = one new token per utterance through the L layers + logits + sampling.
+int enqueue_ar_step(vle_engine* e) {
+  hipStream_t st = e->st;
+  const int d = e->d;
+  const bool sk = use_skinny(e);
+  for (int l = 0; l < e->L; ++l) {
+    const LayerW& w = e->ar[l];
+    void* kc = cache_layer(e, e->kcache, l);
+    void* vc = cache_layer(e, e->vcache, l);
+    if (sk) {
+      SkinnyArgs a;
+      a.w = w.wqkv; a.bias = w.bqkv; a.N = 3 * d; a.K = d; a.B = e->B; a.pro = PRO_LN; a.epi = SEPI_QKV;
+      a.x = e->x_step; a.gamma = w.g1; a.beta = w.be1; a.q_out = e->q_step; a.k_cache = kc; a.v_cache = vc;
+      a.kv_len = e->S.kv_len; a.ctx_max = e->ctx_max; a.nhead = e->H; a.dh = e->dh;
+      E_LAUNCH(e, launch_skinny(st, e->dtype, a));
+    } else {
+      E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
+      E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, w.wqkv, w.bqkv, e->qkv_step, nullptr, e->B, 3 * d, d, EPI_STORE));
+      E_LAUNCH(e, launch_qkv_split(st, e->dtype, e->qkv_step, e->q_step, kc, vc, e->S.kv_len, e->B, d, e->H, e->ctx_max));
+    }
+    E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
+                                        e->ctx_max, e->nsplit));
+    if (sk) {
+      SkinnyArgs a;
+      a.w = w.wo; a.bias = w.bo; a.N = d; a.K = d; a.B = e->B; a.pro = PRO_ATTN; a.epi = SEPI_RESID;
+      a.part_o = e->part_o; a.part_ml = e->part_ml; a.nsplit = e->nsplit; a.nhead = e->H; a.dh = e->dh; a.resid = e->x_step;
+      E_LAUNCH(e, launch_skinny(st, e->dtype, a));
+      SkinnyArgs f1;
+      f1.w = w.w1; f1.bias = w.b1; f1.N = 4 * d; f1.K = d; f1.B = e->B; f1.pro = PRO_LN; f1.epi = SEPI_RELU;
+      f1.x = e->x_step; f1.gamma = w.g2; f1.beta = w.be2; f1.out = e->h_step;
+      E_LAUNCH(e, launch_skinny(st, e->dtype, f1));
+      SkinnyArgs f2;
+      f2.w = w.w2; f2.bias = w.b2; f2.N = d; f2.K = 4 * d; f2.B = e->B; f2.pro = PRO_PLAIN; f2.epi = SEPI_RESID;
+      f2.x = e->h_step; f2.resid = e->x_step;
+      E_LAUNCH(e, launch_skinny(st, e->dtype, f2));
+    } else {
+      E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
+      E_LAUNCH(e, launch_gemm(st, e->dtype, e->att_step, w.wo, w.bo, nullptr, e->x_step, e->B, d, d, EPI_RESID));
+      E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
+      E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, w.w1, w.b1, e->hT_step, nullptr, e->B, 4 * d, d, EPI_RELU));
+      E_LAUNCH(e, launch_gemm(st, e->dtype, e->hT_step, w.w2, w.b2, nullptr, e->x_step, e->B, d, 4 * d, EPI_RESID));
+    }
+  }
+  int r;
+  if ((r = enqueue_ar_logits(e))) return r;
+  return enqueue_ar_sample(e, 0);
+}
+
+int capture_graph(vle_engine* e, int steps, hipGraphExec_t* out) {
+  hipGraph_t g = nullptr;
+  E_HIP(e, hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal));
+  int r = 0;
+  for (int i = 0; i < steps && r == 0; ++i) r = enqueue_ar_step(e);
+  hipError_t ce = hipStreamEndCapture(e->st, &g);
+  if (r) {
+    if (g) (void)hipGraphDestroy(g);
+    return r;
+  }
+  E_HIP(e, ce);
+  hipError_t ie = hipGraphInstantiate(out, g, nullptr, nullptr, 0);
+  (void)hipGraphDestroy(g);
+  E_HIP(e, ie);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, int64_t s_stride, const int32_t* text_lens,
+                              const int64_t* prompt_codes, int64_t p_stride, const int32_t* prompt_lens, int32_t B) {
+  if (!e) return VLE_EINVAL;
+  if (!e->finalized) return e->fail(VLE_ESTATE, "weights not finalized");
+  if (!text || !text_lens || !prompt_codes || !prompt_lens) return e->fail(VLE_EINVAL, "null argument");
+  if (B < 1 || B > e->max_B) return e->fail(VLE_EINVAL, "batch exceeds max_batch");
+  for (int b = 0; b < B; ++b) {
+    if (text_lens[b] < 1 || text_lens[b] > e->max_S || text_lens[b] > s_stride) return e->fail(VLE_EINVAL, "text_lens out of range");
+    if (prompt_lens[b] < 0 || prompt_lens[b] > e->max_P || prompt_lens[b] > p_stride) return e->fail(VLE_EINVAL, "prompt_lens out of range");
+    if (prompt_lens[b] + e->bos < 1) return e->fail(VLE_EINVAL, "empty prompt needs prepend_bos");
+  }
+  int r;
+  if ((r = enter(e, stream))) return r;
+  hipStream_t st = e->st;
+  e->B = B;
+  e->have_prefill = e->have_gen = false;
+  e->nsplit = choose_nsplit(B, e->H);
+  e->S_len.assign(text_lens, text_lens + B);
+  e->P_len.assign(prompt_lens, prompt_lens + B);
+  E_HIP(e, hipEventRecord(e->ev_t[0], st));
+
+  // engine-owned copies of the inputs (the NAR phase needs them again)
+  E_HIP(e, hipMemcpy2DAsync(e->text_ids, e->max_S * sizeof(int64_t), text, s_stride * sizeof(int64_t),
+                            std::min<int64_t>(s_stride, e->max_S) * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
+  const int64_t pp = (int64_t)(e->max_P + e->max_G) * e->Q;
+  if (p_stride > 0)
+    E_HIP(e, hipMemcpy2DAsync(e->prompt_codes, pp * sizeof(int64_t), prompt_codes, p_stride * e->Q * sizeof(int64_t),
+                              std::min<int64_t>(p_stride, e->max_P) * e->Q * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
+
+  // tables
+  TableBuilder tb{e};
+  int64_t rows = 0;
+  int max_len = 0;
+  for (int b = 0; b < B; ++b) {
+    const int n = text_lens[b] + e->bos + prompt_lens[b];
+    rows += n;
+    max_len = std::max(max_len, n);
+  }
+  int32_t *h_seq_off, *h_text_len, *h_row_seq, *h_row_pos, *h_last, *h_state;
+  int32_t* d_seq_off = tb.take(B + 1, &h_seq_off);
+  int32_t* d_text_len = tb.take(B, &h_text_len);
+  int32_t* d_row_seq = tb.take(rows, &h_row_seq);
+  int32_t* d_row_pos = tb.take(rows, &h_row_pos);
+  int32_t* d_last = tb.take(B, &h_last);
+  int32_t* d_state = tb.take(6 * e->max_B + 8, &h_state);
+  if (!d_seq_off || !d_text_len || !d_row_seq || !d_row_pos || !d_last || !d_state) return e->fail(VLE_EINVAL, "table overflow");
+  int64_t off = 0;
+  memset(h_state, 0, (6 * e->max_B + 8) * sizeof(int32_t));
+  for (int b = 0; b < B; ++b) {
+    const int n = text_lens[b] + e->bos + prompt_lens[b];
+    h_seq_off[b] = (int32_t)off;
+    h_text_len[b] = text_lens[b];
+    for (int p = 0; p < n; ++p) {
+      h_row_seq[off + p] = b;
+      h_row_pos[off + p] = p;
+    }
+    off += n;
+    h_last[b] = (int32_t)(off - 1);
+    h_state[0 * e->max_B + b] = n;                              // kv_len: next free slot
+    h_state[1 * e->max_B + b] = e->bos + prompt_lens[b];        // audio_pos of the next token
+    h_state[4 * e->max_B + b] = 16 * text_lens[b];              // cap (valle.py:1047)
+  }
+  h_seq_off[B] = (int32_t)off;
+  E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  E_HIP(e, hipMemcpyAsync(e->state_dev, d_state, (6 * e->max_B + 8) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+
+  PrefillEmbedArgs pa{};
+  pa.text = e->text_ids; pa.s_stride = e->max_S; pa.prompt = e->prompt_codes; pa.p_stride = e->max_P + e->max_G; pa.Q = e->Q;
+  pa.text_len = d_text_len; pa.row_seq = d_row_seq; pa.row_pos = d_row_pos;
+  pa.text_emb = e->ar_text_emb; pa.audio_emb = e->ar_audio_emb; pa.pe = e->pe;
+  pa.alpha_text = e->alphas + 0; pa.alpha_audio = e->alphas + 1; pa.bos = e->bos; pa.d = e->d; pa.rows = rows; pa.x = e->X;
+  E_LAUNCH(e, launch_prefill_embed(st, pa));
+  for (int l = 0; l < e->L; ++l) {
+    const LayerW& w = e->ar[l];
+    if ((r = enqueue_layer_rows(e, w, w.g1, w.be1, w.g2, w.be2, rows, d_seq_off, d_text_len, max_len, 1,
+                                cache_layer(e, e->kcache, l), cache_layer(e, e->vcache, l), d_row_seq, d_row_pos)))
+      return r;
+  }
+  E_LAUNCH(e, launch_gather_rows(st, e->X, d_last, e->x_step, B, e->d));
+  if ((r = enqueue_ar_logits(e))) return r;
+  E_HIP(e, hipEventRecord(e->ev_t[1], st));
+  e->have_prefill = true;
+  return leave(e, stream);
+}
+
+extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float temperature, uint64_t seed, int32_t max_new,
+                               const int64_t* forced, int64_t forced_stride, const int32_t* forced_lens, int64_t* codes0,
+                               int64_t g_stride, int32_t* gen_lens) {
+  if (!e) return VLE_EINVAL;
+  if (!e->have_prefill) return e->fail(VLE_ESTATE, "vle_ar_generate needs vle_ar_prefill first");
+  if (!gen_lens) return e->fail(VLE_EINVAL, "gen_lens is null");
+  if (!(temperature > 0.f)) return e->fail(VLE_EINVAL, "temperature must be > 0");
+  if ((forced != nullptr) != (forced_lens != nullptr)) return e->fail(VLE_EINVAL, "forced and forced_lens go together");
+  int r;
+  if ((r = enter(e, stream))) return r;
+  hipStream_t st = e->st;
+  const int B = e->B;
+
+  // upper bound on loop iterations (stop rule valle.py:1047): n + bos > 16 S  first holds at n = 16 S + 1 - bos
+  int bound = 0;
+  for (int b = 0; b < B; ++b) {
+    int nb = 16 * e->S_len[b] + 1 - e->bos;
+    if (max_new > 0) nb = std::min(nb, (int)max_new);
+    if (forced) {
+      if (forced_lens[b] < 0 || forced_lens[b] > forced_stride) return e->fail(VLE_EINVAL, "forced_lens out of range");
+      nb = forced_lens[b];
+    }
+    nb = std::min(nb, e->max_G);
+    nb = std::min(nb, e->ctx_max - (e->S_len[b] + e->bos + e->P_len[b]));
+    bound = std::max(bound, nb);
+  }
+  ArDyn dyn{};
+  dyn.top_k = top_k; dyn.temperature = temperature; dyn.seed = seed; dyn.max_new = max_new;
+  dyn.has_forced = forced ? 1 : 0; dyn.forced = forced; dyn.forced_stride = forced_stride; dyn.forced_len = e->forced_len_dev;
+  if (e->opt_trace_ar) {
+    const int64_t need = (int64_t)(bound + 1);
+    if (e->trace_ar_cap < need * B) {
+      float* p = nullptr;
+      if ((r = dev_alloc(e, &p, (size_t)need * e->max_B * V_AR))) return r;
+      e->trace_ar = p;
+      e->trace_ar_cap = need * e->max_B;
+    }
+    dyn.trace = e->trace_ar;
+    dyn.trace_cap = e->trace_ar_cap / B;
+  }
+  // dyn / forced_lens go through the pinned mirror (valid until the stream consumed them: we sync below)
+  static_assert(sizeof(ArDyn) % 4 == 0, "ArDyn packing");
+  int32_t* hp = e->tables_host + e->tables_cap - (int64_t)(sizeof(ArDyn) / 4 + e->max_B + 4);
+  memcpy(hp, &dyn, sizeof(ArDyn));
+  E_HIP(e, hipMemcpyAsync(e->dyn_dev, hp, sizeof(ArDyn), hipMemcpyHostToDevice, st));
+  if (forced) {
+    int32_t* hf = hp + sizeof(ArDyn) / 4;
+    memcpy(hf, forced_lens, B * sizeof(int32_t));
+    E_HIP(e, hipMemcpyAsync(e->forced_len_dev, hf, B * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  }
+  E_HIP(e, hipEventRecord(e->ev_t[2], st));
+
+  // iteration 0: sample from the prefill's logits
+  if ((r = enqueue_ar_sample(e, 1))) return r;
+  int steps_done = 0;
+  const int spg = e->cfg.steps_per_graph > 0 ? e->cfg.steps_per_graph : 8;
+  const bool use_graph = e->cfg.use_graph != 0;
+  hipGraphExec_t g_multi = nullptr, g_single = nullptr;
+  if (use_graph && bound > 0) {
+    auto it = e->graphs.find(B * 64 + e->nsplit);
+    if (it == e->graphs.end()) {
+      // first step runs eagerly (sets kernel attributes outside capture), then capture
+      if ((r = enqueue_ar_step(e))) return r;
+      steps_done = 1;
+      if ((r = capture_graph(e, spg, &g_multi))) return r;
+      if ((r = capture_graph(e, 1, &g_single))) return r;
+      e->graphs[B * 64 + e->nsplit] = {g_multi, g_single};
+    } else {
+      g_multi = it->second.first;
+      g_single = it->second.second;
+    }
+  }
+  // run; poll the device-side done counter with a lag so the host never stalls the stream
+  constexpr int RING = 8, LAG = 3;
+  hipEvent_t evs[RING];
+  for (int i = 0; i < RING; ++i) E_HIP(e, hipEventCreateWithFlags(&evs[i], hipEventDisableTiming));
+  int launches = 0;
+  bool all_done = false;
+  while (steps_done < bound && !all_done) {
+    if (use_graph) {
+      if (bound - steps_done >= spg) {
+        E_HIP(e, hipGraphLaunch(g_multi, st));
+        steps_done += spg;
+      } else {
+        E_HIP(e, hipGraphLaunch(g_single, st));
+        steps_done += 1;
+      }
+    } else {
+      if ((r = enqueue_ar_step(e))) return r;
+      steps_done += 1;
+    }
+    const int slot = launches % RING;
+    E_HIP(e, hipMemcpyAsync(e->poll_host + slot, e->S.done_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    E_HIP(e, hipEventRecord(evs[slot], st));
+    ++launches;
+    if (launches > LAG) {
+      const int old = (launches - 1 - LAG) % RING;
+      E_HIP(e, hipEventSynchronize(evs[old]));
+      if (e->poll_host[old] >= B) all_done = true;
+    }
+  }
+  E_HIP(e, hipEventRecord(e->ev_t[3], st));
+  // results
+  std::vector<int32_t> st_host(6 * e->max_B + 8);
+  E_HIP(e, hipMemcpyAsync(e->tables_host, e->state_dev, st_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (codes0)
+    E_HIP(e, hipMemcpy2DAsync(codes0, g_stride * sizeof(int64_t), e->tokens, e->max_G * sizeof(int64_t),
+                              std::min<int64_t>(g_stride, e->max_G) * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
+  E_HIP(e, hipStreamSynchronize(st));
+  for (int i = 0; i < RING; ++i) (void)hipEventDestroy(evs[i]);
+  memcpy(st_host.data(), e->tables_host, st_host.size() * sizeof(int32_t));
+  e->G_len.resize(B);
+  bool no_token = false, not_done = false;
+  for (int b = 0; b < B; ++b) {
+    e->G_len[b] = st_host[2 * e->max_B + b];
+    gen_lens[b] = e->G_len[b];
+    if (e->G_len[b] == 0 && !e->bos && !forced && max_new <= 0) no_token = true;
+    if (!st_host[3 * e->max_B + b]) not_done = true;
+  }
+  e->n_steps = steps_done;
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, e->ev_t[2], e->ev_t[3]) == hipSuccess) e->t_ar = ms;
+  if (hipEventElapsedTime(&ms, e->ev_t[0], e->ev_t[1]) == hipSuccess) e->t_prefill = ms;
+  e->have_gen = true;
+  if ((r = leave(e, stream))) return r;
+  if (not_done) return e->fail(VLE_ESTATE, "AR loop ended with unfinished utterances (capacity too small?)");
+  if (no_token) return e->fail(VLE_ENOTOKEN, "well trained model shouldn't reach here.");
+  return VLE_OK;
+}
+
+// The NAR stages on (text, prompt, first codebook).  `mode`: prefix mode to apply (continual() maps
+// 2/4 to 1); drop[b] = enrolled_len - 2 for prefix_mode 2/4 inference, else 0.
+static int run_nar(vle_engine* e, const std::vector<int32_t>& drop, int mode, int64_t* codes, int64_t g_stride) {
+  hipStream_t st = e->st;
+  const int B = e->B, Q = e->Q, d = e->d;
+  int r;
+  TableBuilder tb{e};
+  std::vector<int> Sn(B), N(B);
+  int64_t xrows = 0, arows = 0, grows = 0;
+  int max_len = 0;
+  for (int b = 0; b < B; ++b) {
+    Sn[b] = e->S_len[b] - drop[b];
+    N[b] = Sn[b] + e->P_len[b] + e->G_len[b];
+    xrows += N[b];
+    arows += e->P_len[b] + e->G_len[b];
+    grows += e->G_len[b];
+    max_len = std::max(max_len, N[b]);
+  }
+  e->sumG_last = grows;
+  E_HIP(e, hipEventRecord(e->ev_t[4], st));
+  if (grows == 0 || Q == 1) {
+    if (Q == 1 && grows > 0) {
+      // only the first codebook exists (valle.py:1060-1061)
+      int32_t *h_gs, *h_gp;
+      int32_t* d_gs = tb.take(grows, &h_gs);
+      int32_t* d_gp = tb.take(grows, &h_gp);
+      if (!d_gs || !d_gp) return e->fail(VLE_EINVAL, "table overflow");
+      int64_t o = 0;
+      for (int b = 0; b < B; ++b)
+        for (int g = 0; g < e->G_len[b]; ++g, ++o) {
+          h_gs[o] = b;
+          h_gp[o] = g;
+        }
+      E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
+      E_LAUNCH(e, launch_codes_set_first(st, e->tokens, e->max_G, d_gs, d_gp, grows, codes, g_stride, Q));
+    }
+    E_HIP(e, hipEventRecord(e->ev_t[5], st));
+    return 0;
+  }
+  int32_t *h_tl, *h_td, *h_pl, *h_gl, *h_aoff, *h_xoff, *h_as, *h_ap, *h_xs, *h_xp, *h_gs, *h_gp, *h_gmap, *h_tl_zero;
+  int32_t* d_tl = tb.take(B, &h_tl);
+  int32_t* d_td = tb.take(B, &h_td);
+  int32_t* d_pl = tb.take(B, &h_pl);
+  int32_t* d_gl = tb.take(B, &h_gl);
+  int32_t* d_aoff = tb.take(B + 1, &h_aoff);
+  int32_t* d_xoff = tb.take(B + 1, &h_xoff);
+  int32_t* d_as = tb.take(arows, &h_as);
+  int32_t* d_ap = tb.take(arows, &h_ap);
+  int32_t* d_xs = tb.take(xrows, &h_xs);
+  int32_t* d_xp = tb.take(xrows, &h_xp);
+  int32_t* d_gs = tb.take(grows, &h_gs);
+  int32_t* d_gp = tb.take(grows, &h_gp);
+  int32_t* d_gmap = tb.take(grows, &h_gmap);
+  int32_t* d_tl_zero = tb.take(B, &h_tl_zero);
+  if (!d_tl || !d_td || !d_pl || !d_gl || !d_aoff || !d_xoff || !d_as || !d_ap || !d_xs || !d_xp || !d_gs || !d_gp || !d_gmap ||
+      !d_tl_zero)
+    return e->fail(VLE_EINVAL, "table overflow");
+  int64_t xo = 0, ao = 0, go = 0;
+  for (int b = 0; b < B; ++b) {
+    h_tl[b] = Sn[b]; h_td[b] = drop[b]; h_pl[b] = e->P_len[b]; h_gl[b] = e->G_len[b]; h_tl_zero[b] = 0;
+    h_aoff[b] = (int32_t)ao; h_xoff[b] = (int32_t)xo;
+    for (int a = 0; a < e->P_len[b] + e->G_len[b]; ++a) {
+      h_as[ao + a] = b;
+      h_ap[ao + a] = a;
+    }
+    for (int p = 0; p < N[b]; ++p) {
+      h_xs[xo + p] = b;
+      h_xp[xo + p] = p;
+    }
+    for (int g = 0; g < e->G_len[b]; ++g) {
+      h_gs[go + g] = b;
+      h_gp[go + g] = g;
+      h_gmap[go + g] = (int32_t)(xo + Sn[b] + e->P_len[b] + g);  // xy_dec[:, text_len + prefix_len:] (valle.py:1128)
+    }
+    ao += e->P_len[b] + e->G_len[b]; xo += N[b]; go += e->G_len[b];
+  }
+  h_aoff[B] = (int32_t)ao; h_xoff[B] = (int32_t)xo;
+  E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
+
+  NarEmbedArgs na{};
+  na.t = NarSeqTables{d_tl, d_td, d_pl, d_gl, d_aoff, d_xoff};
+  na.text = e->text_ids; na.s_stride = e->max_S; na.prompt = e->prompt_codes; na.p_stride = e->max_P + e->max_G; na.Q = Q;
+  na.first_cb = e->tokens; na.g_stride = e->max_G;
+  na.arow_seq = d_as; na.arow_pos = d_ap; na.xrow_seq = d_xs; na.xrow_pos = d_xp;
+  na.audio_embs = e->nar_audio_emb_tab; na.text_emb = e->nar_text_emb; na.pe = e->pe;
+  na.alpha_text = e->alphas + 2; na.alpha_audio = e->alphas + 3; na.d = d; na.arows = arows; na.xrows = xrows;
+  na.y_emb = e->yemb; na.x = e->X;
+
+  E_LAUNCH(e, launch_codes_set_first(st, e->tokens, e->max_G, d_gs, d_gp, grows, codes, g_stride, Q));
+  E_LAUNCH(e, launch_nar_yemb_init(st, na, mode != 0 ? 1 : 0));
+  for (int i = 0; i < Q - 1; ++i) {
+    E_LAUNCH(e, launch_nar_assemble(st, na));
+    for (int l = 0; l < e->L; ++l) {
+      if ((r = enqueue_layer_rows(e, e->nar[l], e->nar_gamma[i][2 * l], e->nar_beta[i][2 * l], e->nar_gamma[i][2 * l + 1],
+                                  e->nar_beta[i][2 * l + 1], xrows, d_xoff, d_tl_zero, max_len, 0, nullptr, nullptr, nullptr, nullptr)))
+        return r;
+    }
+    // final AdaLN only on the generated rows, then nar_predict_layers[i] (valle.py:1128)
+    E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, d_gmap, e->nar_gamma[i][2 * e->L], e->nar_beta[i][2 * e->L], e->Xn, grows, d));
+    float* lg = e->nar_logits;
+    if (e->opt_trace_nar && e->trace_nar) lg = e->trace_nar + (size_t)i * e->max_B * e->max_G * NUM_AUDIO_TOKENS;
+    E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, e->nar_predict[i], nullptr, lg, nullptr, grows, NUM_AUDIO_TOKENS, d, EPI_F32));
+    NarArgmaxArgs aa{};
+    aa.logits = lg; aa.V = NUM_AUDIO_TOKENS; aa.rows = grows; aa.grow_seq = d_gs; aa.grow_pos = d_gp; aa.aoff = d_aoff;
+    aa.prompt_len = d_pl; aa.codes = codes; aa.g_stride = g_stride; aa.Q = Q; aa.col = i + 1;
+    aa.next_emb = i < Q - 2 ? e->nar_audio_emb[i + 1] : nullptr;  // valle.py:1133-1134
+    aa.y_emb = e->yemb; aa.d = d;
+    E_LAUNCH(e, launch_nar_argmax(st, aa));
+    if (mode == 0 && i < Q - 2) E_LAUNCH(e, launch_nar_yemb_add_prompt(st, na, i + 1));  // valle.py:1104-1107
+  }
+  E_HIP(e, hipEventRecord(e->ev_t[5], st));
+  return 0;
+}
+
+static int finish_nar_timing(vle_engine* e) {
+  E_HIP(e, hipStreamSynchronize(e->st));
+  float ms = 0.f;
+  if (hipEventElapsedTime(&ms, e->ev_t[4], e->ev_t[5]) == hipSuccess) e->t_nar = ms;
+  return 0;
+}
+
+extern "C" int vle_nar_decode(vle_engine* e, void* stream, const int32_t* enroll_lens, int64_t* codes, int64_t g_stride) {
+  if (!e) return VLE_EINVAL;
+  if (!e->have_gen) return e->fail(VLE_ESTATE, "vle_nar_decode needs vle_ar_generate first");
+  if (!codes) return e->fail(VLE_EINVAL, "codes is null");
+  const int mode = e->cfg.prefix_mode;
+  std::vector<int32_t> drop(e->B, 0);
+  if (mode == 2 || mode == 4) {
+    if (!enroll_lens) return e->fail(VLE_EINVAL, "prefix_mode 2/4 needs enroll_lens (valle.py:1068-1079)");
+    for (int b = 0; b < e->B; ++b) {
+      // text = cat(text[:, :1], text[:, enrolled_len-1:]); text_len -= enrolled_len - 2
+      if (enroll_lens[b] < 2 || enroll_lens[b] - 1 > e->S_len[b]) return e->fail(VLE_EINVAL, "enroll_lens out of range");
+      drop[b] = enroll_lens[b] - 2;
+    }
+  }
+  for (int b = 0; b < e->B; ++b)
+    if (e->G_len[b] > g_stride) return e->fail(VLE_EINVAL, "g_stride smaller than generated length");
+  int r;
+  if ((r = enter(e, stream))) return r;
+  if ((r = run_nar(e, drop, mode, codes, g_stride))) return r;
+  if ((r = finish_nar_timing(e))) return r;
+  return leave(e, stream);
+}
+
+extern "C" int vle_nar_continual(vle_engine* e, void* stream, const int64_t* text, int64_t s_stride, const int32_t* text_lens,
+                                 const int64_t* y_codes, int64_t t_stride, const int32_t* y_lens, int32_t B, int64_t* codes,
+                                 int64_t g_stride, int32_t* gen_lens) {
+  if (!e) return VLE_EINVAL;
+  if (!e->finalized) return e->fail(VLE_ESTATE, "weights not finalized");
+  if (e->Q != 8) return e->fail(VLE_EINVAL, "continual() asserts num_quantizers == 8 (valle.py:1160)");
+  if (!text || !text_lens || !y_codes || !y_lens || !codes || !gen_lens) return e->fail(VLE_EINVAL, "null argument");
+  if (B < 1 || B > e->max_B) return e->fail(VLE_EINVAL, "batch exceeds max_batch");
+  e->S_len.assign(B, 0); e->P_len.assign(B, 0); e->G_len.assign(B, 0);
+  for (int b = 0; b < B; ++b) {
+    if (text_lens[b] < 1 || text_lens[b] > e->max_S || text_lens[b] > s_stride) return e->fail(VLE_EINVAL, "text_lens out of range");
+    if (y_lens[b] < 1 || y_lens[b] > t_stride || y_lens[b] > e->max_P + e->max_G) return e->fail(VLE_EINVAL, "y_lens out of range");
+    const int prefix = std::min((int)(y_lens[b] * 0.5), 3 * 75);  // valle.py:1173
+    e->S_len[b] = text_lens[b]; e->P_len[b] = prefix; e->G_len[b] = y_lens[b] - prefix;
+    if (e->P_len[b] > e->max_P + e->max_G || e->G_len[b] > e->max_G || e->G_len[b] > g_stride) return e->fail(VLE_EINVAL, "capacity exceeded");
+    gen_lens[b] = e->G_len[b];
+  }
+  int r;
+  if ((r = enter(e, stream))) return r;
+  hipStream_t st = e->st;
+  e->B = B;
+  e->have_prefill = e->have_gen = false;
+  E_HIP(e, hipMemcpy2DAsync(e->text_ids, e->max_S * sizeof(int64_t), text, s_stride * sizeof(int64_t),
+                            std::min<int64_t>(s_stride, e->max_S) * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
+  const int64_t pp = (int64_t)(e->max_P + e->max_G) * 8;
+  E_HIP(e, hipMemcpy2DAsync(e->prompt_codes, pp * sizeof(int64_t), y_codes, t_stride * 8 * sizeof(int64_t),
+                            std::min<int64_t>(t_stride, e->max_P + e->max_G) * 8 * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
+  // first codebook of the continuation: codes = [y[:, prefix_len:, 0]] (valle.py:1178)
+  for (int b = 0; b < B; ++b)
+    if (e->G_len[b] > 0)
+      E_HIP(e, hipMemcpy2DAsync(e->tokens + (size_t)b * e->max_G, sizeof(int64_t),
+                                y_codes + ((size_t)b * t_stride + e->P_len[b]) * 8, 8 * sizeof(int64_t), sizeof(int64_t),
+                                e->G_len[b], hipMemcpyDeviceToDevice, st));
+  std::vector<int32_t> drop(B, 0);
+  const int mode = e->cfg.prefix_mode == 0 ? 0 : 1;
+  if ((r = run_nar(e, drop, mode, codes, g_stride))) return r;
+  if ((r = finish_nar_timing(e))) return r;
+  return leave(e, stream);
+}
+
+// =================================================================================================
+// hooks
+// =================================================================================================
+extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
+  if (!e || !name) return VLE_EINVAL;
+  const std::string n = name;
+  if (n == "trace_ar_logits") {
+    e->opt_trace_ar = value != 0;
+    return VLE_OK;
+  }
+  if (n == "trace_nar_logits") {
+    e->opt_trace_nar = value != 0;
+    if (e->opt_trace_nar && !e->trace_nar && e->finalized && e->Q > 1) {
+      float* p = nullptr;
+      int r = dev_alloc(e, &p, (size_t)(e->Q - 1) * e->max_B * e->max_G * NUM_AUDIO_TOKENS);
+      if (r) return r;
+      e->trace_nar = p;
+    }
+    return VLE_OK;
+  }
+  if (n == "nsplit") {
+    if (value < 1 || value > 16) return e->fail(VLE_EINVAL, "nsplit must be 1..16");
+    e->nsplit = (int)value;
+    return VLE_OK;
+  }
+  return e->fail(VLE_EINVAL, "unknown option: " + n);
+}
+
+extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_dst, size_t bytes) {
+  if (!e || !what || !host_dst) return VLE_EINVAL;
+  (void)hipSetDevice(e->cfg.device);
+  (void)hipStreamSynchronize(e->st);
+  const std::string w = what;
+  const void* src = nullptr;
+  size_t n = 0;
+  if (w == "ar_logits") {
+    if (!e->trace_ar) return e->fail(VLE_ESTATE, "trace_ar_logits was not enabled");
+    src = e->trace_ar;
+    n = (size_t)((int64_t)e->n_steps + 1) * e->B * V_AR * sizeof(float);
+  } else if (w.rfind("nar_logits:", 0) == 0) {
+    const int stage = atoi(w.c_str() + 11);
+    if (!e->trace_nar || stage < 0 || stage >= e->Q - 1) return e->fail(VLE_ESTATE, "trace_nar_logits not enabled / bad stage");
+    src = e->trace_nar + (size_t)stage * e->max_B * e->max_G * NUM_AUDIO_TOKENS;
+    n = (size_t)e->sumG_last * NUM_AUDIO_TOKENS * sizeof(float);
+  } else if (w == "ar_sampled") {
+    src = e->sampled;
+    n = (size_t)e->B * e->max_G * sizeof(int64_t);
+  } else if (w == "kv_len") {
+    src = e->S.kv_len;
+    n = (size_t)e->B * sizeof(int32_t);
+  } else if (w == "last_logits") {
+    src = e->logits;
+    n = (size_t)e->B * V_AR * sizeof(float);
+  } else {
+    return e->fail(VLE_EINVAL, "unknown debug item: " + w);
+  }
+  n = std::min(n, bytes);
+  if (hipMemcpy(host_dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return e->fail(VLE_EHIP, "debug copy failed");
+  return (int64_t)n;
+}
+
+extern "C" int vle_last_timings(vle_engine* e, double* out4) {
+  if (!e || !out4) return VLE_EINVAL;
+  out4[0] = e->t_prefill; out4[1] = e->t_ar; out4[2] = e->t_nar; out4[3] = e->n_steps;
+  return VLE_OK;
+}
+
+// bytes of one AR step = W_AR * w + sum_b (2 L c_b d a  +  2 L d a)
+extern "C" int64_t vle_ar_step_bytes(const vle_engine* e, int32_t B, int64_t sum_ctx) {
+  if (!e) return VLE_EINVAL;
+  const int64_t d = e->d, L = e->L, es = (int64_t)dtype_size(e->dtype);
+  const int64_t w_ar = L * (12 * d * d + 13 * d) + 2 * d + (int64_t)V_AR * d;
+  return w_ar * es + 2 * L * d * es * (sum_ctx + B);
+}

@@ -1,0 +1,153 @@
+// Host-side launchers of the gfx950 kernels (one .hip file per family).  All pointers are
+// device pointers; `dtype` is VLE_DTYPE_F32 (0) or VLE_DTYPE_BF16 (1) and selects the element
+// type T of every `void*` operand marked T.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace vle {
+
+constexpr int DT_F32 = 0;
+constexpr int DT_BF16 = 1;
+inline size_t dtype_size(int dtype) { return dtype == DT_F32 ? 4 : 2; }
+
+// ---- layernorm.hip ---------------------------------------------------------------------------
+// out[T][r] = LN(x[f32][row_map ? row_map[r] : r]) * gamma + beta
+int launch_layernorm(hipStream_t st, int dtype, const float* x, const int32_t* row_map, const float* gamma,
+                     const float* beta, void* out, int64_t rows, int d);
+// dst[f32][r] = src[f32][row_map[r]]
+int launch_gather_rows(hipStream_t st, const float* src, const int32_t* row_map, float* dst, int rows, int d);
+
+// ---- gemm.hip -------------------------------------------------------------------------------
+enum { EPI_STORE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_F32 = 3 };
+// out = epi(A[T, M x K] @ W[T, N x K]^T + bias)
+int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const float* bias, void* out, float* resid,
+                int64_t M, int N, int K, int epi);
+
+// ---- skinny.hip (AR-step weight-streaming GEMV, M = batch <= 8) --------------------------------
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2 };
+enum { SEPI_STORE = 0, SEPI_RELU = 1, SEPI_RESID = 2, SEPI_QKV = 3 };
+struct SkinnyArgs {
+  const void* w = nullptr;     // T [N][K]
+  const float* bias = nullptr; // f32 [N] or null
+  int N = 0, K = 0, B = 0;
+  int pro = PRO_PLAIN, epi = SEPI_STORE;
+  const float* x = nullptr;      // f32 [B][K]           (PRO_PLAIN / PRO_LN)
+  const float* gamma = nullptr;  // f32 [K]              (PRO_LN)
+  const float* beta = nullptr;
+  const float* part_o = nullptr; // f32 [B][H][nsplit][dh] (PRO_ATTN): un-normalised partial outputs
+  const float* part_ml = nullptr;// f32 [B][H][nsplit][2]  (running max, running sum)
+  int nsplit = 1, nhead = 1, dh = 1;
+  float* out = nullptr;          // f32 [B][N]           (SEPI_STORE / SEPI_RELU)
+  float* resid = nullptr;        // f32 [B][N] += (.)    (SEPI_RESID)
+  float* q_out = nullptr;        // f32 [B][d]           (SEPI_QKV)
+  void* k_cache = nullptr;       // T [B][H][ctx_max][dh] (this layer)
+  void* v_cache = nullptr;
+  const int32_t* kv_len = nullptr; // [B] slot the new token's K/V go to
+  int ctx_max = 0;
+};
+int launch_skinny(hipStream_t st, int dtype, const SkinnyArgs& a);
+
+// ---- attention.hip --------------------------------------------------------------------------
+// prefill (causal=1: prefix-LM mask) / NAR (causal=0) attention over packed sequences
+int launch_attention(hipStream_t st, int dtype, const void* qkv, void* out, const int32_t* seq_off,
+                     const int32_t* text_len, int B, int max_len, int d, int nhead, int causal);
+// copy K,V of packed prefill rows into the cache: cache[b][h][pos][e]
+int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache, void* v_cache, const int32_t* row_seq,
+                      const int32_t* row_pos, int64_t rows, int d, int nhead, int ctx_max);
+// one new query per utterance against the KV cache; writes split partials
+int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
+                            const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
+                            int nsplit);
+
+// ---- embed.hip ------------------------------------------------------------------------------
+struct PrefillEmbedArgs {
+  const int64_t* text; int64_t s_stride;          // [B][s_stride]
+  const int64_t* prompt; int64_t p_stride; int Q; // [B][p_stride][Q]
+  const int32_t* text_len; const int32_t* row_seq; const int32_t* row_pos;
+  const float* text_emb; const float* audio_emb; const float* pe;
+  const float* alpha_text; const float* alpha_audio; // device scalars
+  int bos; int d; int64_t rows; float* x;
+};
+int launch_prefill_embed(hipStream_t st, const PrefillEmbedArgs& a);
+
+struct NarSeqTables {                 // all device int32 [B] unless noted
+  const int32_t* text_len;   // S'_b  (after prefix_mode 2/4 slicing)
+  const int32_t* text_drop;  // source index shift for text positions >= 1
+  const int32_t* prompt_len; // P_b
+  const int32_t* gen_len;    // G_b
+  const int32_t* aoff;       // first row of utterance b in the packed audio rows   [B+1]
+  const int32_t* xoff;       // first row of utterance b in the packed NAR rows     [B+1]
+};
+struct NarEmbedArgs {
+  NarSeqTables t;
+  const int64_t* text; int64_t s_stride;
+  const int64_t* prompt; int64_t p_stride; int Q;   // prompt codes [B][p_stride][Q]
+  const int64_t* first_cb; int64_t g_stride;        // generated first codebook [B][g_stride]
+  const int32_t* arow_seq; const int32_t* arow_pos; // packed audio rows -> (b, a)
+  const int32_t* xrow_seq; const int32_t* xrow_pos; // packed NAR rows   -> (b, pos)
+  const float* const* audio_embs;                   // device array of Q table pointers
+  const float* text_emb; const float* pe; const float* alpha_text; const float* alpha_audio;
+  int d; int64_t arows; int64_t xrows;
+  float* y_emb;  // [arows][d]
+  float* x;      // [xrows][d]
+};
+int launch_nar_yemb_init(hipStream_t st, const NarEmbedArgs& a, int sum_all_prompt_codebooks);
+int launch_nar_yemb_add_prompt(hipStream_t st, const NarEmbedArgs& a, int j);
+int launch_nar_assemble(hipStream_t st, const NarEmbedArgs& a);
+
+// ---- sampling.hip ---------------------------------------------------------------------------
+struct ArState {           // device pointers
+  int32_t* kv_len;     // [B] KV slot of the token being fed this step
+  int32_t* audio_pos;  // [B] position (audio stream, incl. BOS) of that token
+  int32_t* n_gen;      // [B] frames appended so far
+  int32_t* done;       // [B]
+  int32_t* cap;        // [B] 16 * S_b   (valle.py:1047)
+  int32_t* iter;       // [B] AR loop iterations executed
+  int32_t* done_count; // [1]
+};
+// Per-call sampling parameters live in DEVICE memory (one struct per engine) so that a captured
+// hipGraph of the AR step does not bake them in.
+struct ArDyn {
+  int32_t top_k; float temperature; uint64_t seed;
+  int32_t max_new; int32_t has_forced;
+  const int64_t* forced; int64_t forced_stride; const int32_t* forced_len;
+  float* trace; int64_t trace_cap;         // [trace_cap][B][V] or null
+};
+struct ArSampleArgs {
+  ArState s;
+  const ArDyn* dyn;
+  const float* logits;  // [B][V]
+  int V; int B; int d;
+  int bos; int first;
+  int64_t* tokens; int64_t g_stride;       // [B][g_stride] token history actually fed
+  int64_t* sampled;                        // [B][g_stride] engine's own samples
+  const float* audio_emb; const float* pe; const float* alpha_audio;
+  float* x;                                // [B][d] next step's input
+  int ctx_max;
+};
+int launch_ar_sample(hipStream_t st, const ArSampleArgs& a);
+
+struct NarArgmaxArgs {
+  const float* logits; int V;          // [rows][V]
+  int64_t rows;
+  const int32_t* grow_seq; const int32_t* grow_pos; // generated rows -> (b, g)
+  const int32_t* aoff; const int32_t* prompt_len;
+  int64_t* codes; int64_t g_stride; int Q; int col;  // codes[b][g][col] = argmax
+  const float* next_emb;  // table added to y_emb rows (null at the last stage)
+  float* y_emb; int d;
+};
+int launch_nar_argmax(hipStream_t st, const NarArgmaxArgs& a);
+
+// ---- misc.hip (batch > 8 AR-step glue + output packing) ------------------------------------------
+// qkv[T][B][3d] -> q f32 [B][d], K/V -> cache slot kv_len[b]
+int launch_qkv_split(hipStream_t st, int dtype, const void* qkv, float* q, void* k_cache, void* v_cache,
+                     const int32_t* kv_len, int B, int d, int nhead, int ctx_max);
+// merge decode-attention partials -> out[T][B][d]
+int launch_attn_combine(hipStream_t st, int dtype, const float* part_o, const float* part_ml, void* out, int B, int nhead,
+                        int dh, int nsplit);
+// codes[b][g][0] = first_cb[b][g] for the generated rows
+int launch_codes_set_first(hipStream_t st, const int64_t* first_cb, int64_t fc_stride, const int32_t* grow_seq,
+                           const int32_t* grow_pos, int64_t rows, int64_t* codes, int64_t g_stride, int Q);
+
+}  // namespace vle

@@ -1,0 +1,83 @@
+// LayerNorm over packed rows (prefill / NAR passes): one wave64 per row, fp32 in, T out.
+// Replaces F.layer_norm as called from LayerNorm.forward (valle/modules/transformer.py:57-74) and,
+// with the per-stage folded gamma'/beta', AdaptiveLayerNorm.forward (:93-108).
+// HBM-bound: 4*d bytes read + sizeof(T)*d written per row; float4 loads, 16 B per lane.
+#include "common.h"
+#include "kernels.h"
+
+namespace vle {
+
+template <typename T, int NW>
+__global__ __launch_bounds__(NW * 64) void layernorm_rows_kernel(const float* __restrict__ x,
+                                                                 const int32_t* __restrict__ row_map,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, T* __restrict__ out,
+                                                                 int64_t rows, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * NW + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int64_t src = row_map ? (int64_t)row_map[r] : r;
+  const float* xr = x + src * d;
+  const int nv = d >> 2;  // d % 4 == 0
+  float s = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    const float4 v = reinterpret_cast<const float4*>(xr)[i];
+    s += (v.x + v.y) + (v.z + v.w);
+  }
+  const float mean = wave_sum(s) / (float)d;
+  float q = 0.f;
+  for (int i = lane; i < nv; i += 64) {
+    const float4 v = reinterpret_cast<const float4*>(xr)[i];
+    const float a = v.x - mean, b = v.y - mean, c = v.z - mean, e = v.w - mean;
+    q += (a * a + b * b) + (c * c + e * e);
+  }
+  const float var = wave_sum(q) / (float)d;
+  const float rstd = 1.0f / sqrtf(var + LN_EPS);
+  T* orow = out + r * d;
+  for (int i = lane; i < nv; i += 64) {
+    const float4 v = reinterpret_cast<const float4*>(xr)[i];
+    const float4 g = reinterpret_cast<const float4*>(gamma)[i];
+    const float4 bb = reinterpret_cast<const float4*>(beta)[i];
+    const float o0 = (v.x - mean) * rstd * g.x + bb.x;
+    const float o1 = (v.y - mean) * rstd * g.y + bb.y;
+    const float o2 = (v.z - mean) * rstd * g.z + bb.z;
+    const float o3 = (v.w - mean) * rstd * g.w + bb.w;
+    if constexpr (sizeof(T) == 4) {
+      reinterpret_cast<float4*>(orow)[i] = make_float4(o0, o1, o2, o3);
+    } else {
+      uint2 p;
+      p.x = (uint32_t)f32_to_bf16(o0) | ((uint32_t)f32_to_bf16(o1) << 16);
+      p.y = (uint32_t)f32_to_bf16(o2) | ((uint32_t)f32_to_bf16(o3) << 16);
+      reinterpret_cast<uint2*>(orow)[i] = p;
+    }
+  }
+}
+
+int launch_layernorm(hipStream_t st, int dtype, const float* x, const int32_t* row_map, const float* gamma,
+                     const float* beta, void* out, int64_t rows, int d) {
+  if (rows <= 0) return 0;
+  if (d % 4 != 0) return -1;
+  constexpr int NW = 4;
+  const dim3 grid((unsigned)((rows + NW - 1) / NW)), block(NW * 64);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((layernorm_rows_kernel<float, NW>), grid, block, 0, st, x, row_map, gamma, beta, (float*)out, rows, d);
+  else
+    hipLaunchKernelGGL((layernorm_rows_kernel<bf16_t, NW>), grid, block, 0, st, x, row_map, gamma, beta, (bf16_t*)out, rows, d);
+  return 0;
+}
+
+__global__ void gather_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ row_map,
+                                   float* __restrict__ dst, int rows, int d) {
+  const int r = blockIdx.x;
+  const float4* s = reinterpret_cast<const float4*>(src + (int64_t)row_map[r] * d);
+  float4* o = reinterpret_cast<float4*>(dst + (int64_t)r * d);
+  for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) o[i] = s[i];
+}
+
+int launch_gather_rows(hipStream_t st, const float* src, const int32_t* row_map, float* dst, int rows, int d) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(gather_rows_kernel, dim3(rows), dim3(256), 0, st, src, row_map, dst, rows, d);
+  return 0;
+}
+
+}  // namespace vle

@@ -1,0 +1,85 @@
+// Small glue kernels: the batch > 8 AR step (which runs its linears on the MFMA GEMM path instead of
+// the weight-streaming GEMV path) and packing of the result codes.
+#include "common.h"
+#include "kernels.h"
+
+namespace vle {
+
+template <typename T>
+__global__ __launch_bounds__(256) void qkv_split_kernel(const T* __restrict__ qkv, float* __restrict__ q, T* __restrict__ kc,
+                                                        T* __restrict__ vc, const int32_t* __restrict__ kv_len, int d, int nhead,
+                                                        int ctx_max) {
+  const int b = blockIdx.x;
+  const int dh = d / nhead;
+  const T* src = qkv + (int64_t)b * 3 * d;
+  const int slot = kv_len[b];
+  for (int j = threadIdx.x; j < d; j += 256) {
+    q[(int64_t)b * d + j] = Elem<T>::to_f32(src[j]);
+    const int h = j / dh, e = j - h * dh;
+    const int64_t o = (((int64_t)b * nhead + h) * ctx_max + slot) * dh + e;
+    kc[o] = src[d + j];
+    vc[o] = src[2 * d + j];
+  }
+}
+
+int launch_qkv_split(hipStream_t st, int dtype, const void* qkv, float* q, void* k_cache, void* v_cache, const int32_t* kv_len,
+                     int B, int d, int nhead, int ctx_max) {
+  if (B <= 0) return 0;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(qkv_split_kernel<float>, dim3(B), dim3(256), 0, st, (const float*)qkv, q, (float*)k_cache,
+                       (float*)v_cache, kv_len, d, nhead, ctx_max);
+  else
+    hipLaunchKernelGGL(qkv_split_kernel<bf16_t>, dim3(B), dim3(256), 0, st, (const bf16_t*)qkv, q, (bf16_t*)k_cache,
+                       (bf16_t*)v_cache, kv_len, d, nhead, ctx_max);
+  return 0;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restrict__ part_o, const float* __restrict__ part_ml,
+                                                           T* __restrict__ out, int nhead, int dh, int ns) {
+  const int b = blockIdx.x;
+  const int d = nhead * dh;
+  for (int i = threadIdx.x; i < d; i += 256) {
+    const int h = i / dh, e = i - h * dh;
+    const float* ml = part_ml + ((int64_t)(b * nhead + h) * ns) * 2;
+    const float* po = part_o + ((int64_t)(b * nhead + h) * ns) * dh + e;
+    float m = -1e30f;
+    for (int s = 0; s < ns; ++s) m = fmaxf(m, ml[2 * s]);
+    float l = 0.f, o = 0.f;
+    for (int s = 0; s < ns; ++s) {
+      const float f = expf(ml[2 * s] - m);
+      l += ml[2 * s + 1] * f;
+      o += po[(int64_t)s * dh] * f;
+    }
+    store_elem<T>(out + (int64_t)b * d + i, o / l);
+  }
+}
+
+int launch_attn_combine(hipStream_t st, int dtype, const float* part_o, const float* part_ml, void* out, int B, int nhead, int dh,
+                        int nsplit) {
+  if (B <= 0) return 0;
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL(attn_combine_kernel<float>, dim3(B), dim3(256), 0, st, part_o, part_ml, (float*)out, nhead, dh, nsplit);
+  else
+    hipLaunchKernelGGL(attn_combine_kernel<bf16_t>, dim3(B), dim3(256), 0, st, part_o, part_ml, (bf16_t*)out, nhead, dh, nsplit);
+  return 0;
+}
+
+__global__ void codes_set_first_kernel(const int64_t* __restrict__ first_cb, int64_t fc_stride,
+                                       const int32_t* __restrict__ grow_seq, const int32_t* __restrict__ grow_pos, int64_t rows,
+                                       int64_t* __restrict__ codes, int64_t g_stride, int Q) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r >= rows) return;
+  const int b = grow_seq[r], g = grow_pos[r];
+  codes[((int64_t)b * g_stride + g) * Q] = first_cb[(int64_t)b * fc_stride + g];
+}
+
+int launch_codes_set_first(hipStream_t st, const int64_t* first_cb, int64_t fc_stride, const int32_t* grow_seq,
+                           const int32_t* grow_pos, int64_t rows, int64_t* codes, int64_t g_stride, int Q) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(codes_set_first_kernel, dim3((unsigned)((rows + 255) / 256)), dim3(256), 0, st, first_cb, fc_stride,
+                     grow_seq, grow_pos, rows, codes, g_stride, Q);
+  return 0;
+}
+
+}  // namespace vle

@@ -1,0 +1,55 @@
+// C ABI of the stand-alone Transformer-block operators (valle_engine.h, "operator surface"):
+// thin argument checks around the kernel launchers, no engine instance needed.
+#include "common.h"
+#include "kernels.h"
+#include "valle_engine.h"
+
+using namespace vle;
+
+static int op_fail(const char* m) {
+  set_global_error(m);
+  return VLE_EINVAL;
+}
+static int op_done(int r, const char* what) {
+  if (r != 0) {
+    set_global_error(what);
+    return r == -3 ? VLE_EHIP : VLE_EINVAL;
+  }
+  const hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return hip_fail(e, what, __FILE__, __LINE__);
+  return VLE_OK;
+}
+
+extern "C" int vle_op_layernorm(void* stream, int dtype, const float* x, const float* gamma, const float* beta, void* out,
+                                int64_t rows, int32_t d) {
+  if (!x || !gamma || !beta || !out || d % 4) return op_fail("vle_op_layernorm: bad argument");
+  return op_done(launch_layernorm((hipStream_t)stream, dtype, x, nullptr, gamma, beta, out, rows, d), "vle_op_layernorm");
+}
+
+extern "C" int vle_op_linear(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
+                             int64_t M, int32_t N, int32_t K, int epilogue) {
+  if (!a || !w) return op_fail("vle_op_linear: null operand");
+  if (epilogue == EPI_RESID ? !resid : !out) return op_fail("vle_op_linear: missing output");
+  return op_done(launch_gemm((hipStream_t)stream, dtype, a, w, bias, out, resid, M, N, K, epilogue), "vle_op_linear");
+}
+
+extern "C" int vle_op_linear_skinny(void* stream, int dtype, const float* x, const float* gamma, const float* beta, const void* w,
+                                    const float* bias, float* out, float* resid, int32_t M, int32_t N, int32_t K, int epilogue) {
+  if (!x || !w || M < 1 || M > 8) return op_fail("vle_op_linear_skinny: bad argument (M must be 1..8)");
+  SkinnyArgs a;
+  a.w = w; a.bias = bias; a.N = N; a.K = K; a.B = M;
+  a.pro = gamma ? PRO_LN : PRO_PLAIN;
+  a.x = x; a.gamma = gamma; a.beta = beta;
+  a.epi = epilogue == 0 ? SEPI_STORE : epilogue == 1 ? SEPI_RELU : SEPI_RESID;
+  a.out = out; a.resid = resid;
+  if (a.epi == SEPI_RESID ? !resid : !out) return op_fail("vle_op_linear_skinny: missing output");
+  if (a.pro == PRO_LN && a.epi == SEPI_RESID) return op_fail("vle_op_linear_skinny: LN + residual is not instantiated");
+  return op_done(launch_skinny((hipStream_t)stream, dtype, a), "vle_op_linear_skinny");
+}
+
+extern "C" int vle_op_attention(void* stream, int dtype, const void* qkv, void* out, const int32_t* seq_off_dev,
+                                const int32_t* text_len_dev, int32_t B, int32_t max_len, int32_t d, int32_t nhead, int causal) {
+  if (!qkv || !out || !seq_off_dev || !text_len_dev || nhead < 1 || d % nhead) return op_fail("vle_op_attention: bad argument");
+  return op_done(launch_attention((hipStream_t)stream, dtype, qkv, out, seq_off_dev, text_len_dev, B, max_len, d, nhead, causal),
+                 "vle_op_attention");
+}

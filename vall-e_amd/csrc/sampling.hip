@@ -1,0 +1,253 @@
+// AR sampling + stop rule + next-token embedding, and the NAR arg-max / y_emb update.
+//   reference: topk_sampling valle/models/valle.py:1287-1302, top_k_top_p_filtering :1242-1284,
+//              stop rule :1044-1055, y = concat([y, samples]) :1057, NAR argmax/update :1128-1134.
+// Everything stays on the device: per-utterance done flags / lengths live in HBM so the AR step can
+// be replayed from a hipGraph with no host round trip (the reference syncs 2-3x per step).
+#include "common.h"
+#include "kernels.h"
+
+namespace vle {
+
+// ---- Philox4x32-10 counter-based RNG -----------------------------------------------------------
+__device__ inline void philox_round(uint32_t (&c)[4], uint32_t k0, uint32_t k1) {
+  const uint64_t p0 = (uint64_t)0xD2511F53u * c[0];
+  const uint64_t p1 = (uint64_t)0xCD9E8D57u * c[2];
+  const uint32_t n0 = (uint32_t)(p1 >> 32) ^ c[1] ^ k0;
+  const uint32_t n1 = (uint32_t)p1;
+  const uint32_t n2 = (uint32_t)(p0 >> 32) ^ c[3] ^ k1;
+  const uint32_t n3 = (uint32_t)p0;
+  c[0] = n0; c[1] = n1; c[2] = n2; c[3] = n3;
+}
+__device__ inline float philox_uniform(uint64_t seed, uint32_t ctr0, uint32_t ctr1) {
+  uint32_t c[4] = {ctr0, ctr1, 0x9E3779B9u, 0xBB67AE85u};
+  uint32_t k0 = (uint32_t)seed, k1 = (uint32_t)(seed >> 32);
+#pragma unroll
+  for (int i = 0; i < 10; ++i) {
+    philox_round(c, k0, k1);
+    k0 += 0x9E3779B9u;
+    k1 += 0xBB67AE85u;
+  }
+  return (float)(c[0] >> 8) * (1.0f / 16777216.0f);  // [0, 1)
+}
+
+constexpr int SAMP_T = 256;
+constexpr int SAMP_PER = 5;  // 256 * 5 >= 1026 logits
+
+__device__ inline unsigned long long block_max_u64(unsigned long long v, unsigned long long* red) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  unsigned long long r = red[0];
+#pragma unroll
+  for (int i = 1; i < SAMP_T / 64; ++i) r = red[i] > r ? red[i] : r;
+  return r;
+}
+__device__ inline int block_sum_i(int v, int* red) {
+  v = wave_sum_i(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  int r = 0;
+#pragma unroll
+  for (int i = 0; i < SAMP_T / 64; ++i) r += red[i];
+  return r;
+}
+
+__global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
+  __shared__ unsigned long long red64[SAMP_T / 64];
+  __shared__ int redi[SAMP_T / 64];
+  __shared__ float redf[SAMP_T / 64];
+  __shared__ float wave_tot[SAMP_T / 64];
+  __shared__ int sh_next, sh_stop, sh_pos;
+
+  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (a.s.done[b]) return;
+  const int it = a.s.iter[b];
+  const int V = a.V;
+  const ArDyn dyn = *a.dyn;
+  const float* lg = a.logits + (int64_t)b * V;
+
+  float raw[SAMP_PER];
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int j = 0; j < SAMP_PER; ++j) {
+    const int idx = tid * SAMP_PER + j;
+    raw[j] = idx < V ? lg[idx] : -INFINITY;
+    if (idx < V) {
+      // highest value wins; among equal values the LOWEST index wins (torch.argmax convention)
+      const unsigned long long key = ((unsigned long long)float_key(raw[j]) << 32) | (unsigned)(0x7fffffff - idx);
+      best = key > best ? key : best;
+    }
+  }
+  if (dyn.trace != nullptr && it < dyn.trace_cap) {
+    float* tr = dyn.trace + ((int64_t)it * a.B + b) * V;
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) {
+      const int idx = tid * SAMP_PER + j;
+      if (idx < V) tr[idx] = raw[j];
+    }
+  }
+  best = block_max_u64(best, red64);
+  const int argmax = 0x7fffffff - (int)(best & 0xffffffffu);
+
+  int sample = argmax;
+  if (dyn.top_k != 1) {
+    float sc[SAMP_PER];
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) sc[j] = dyn.temperature != 1.0f ? raw[j] / dyn.temperature : raw[j];
+    uint32_t thr_key = 0u;  // keep keys >= thr_key
+    if (dyn.top_k > 1 && dyn.top_k < V) {
+      // k-th largest via bitwise binary search on the order-preserving key:
+      // largest K with count(key >= K) >= top_k.  Ties at the k-th value are all kept, like
+      // `logits < topk(logits, k)[0][..., -1]` (valle.py:1259-1260).
+      uint32_t cur = 0u;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = cur | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < SAMP_PER; ++j) cnt += (tid * SAMP_PER + j < V) && (float_key(sc[j]) >= cand);
+        cnt = block_sum_i(cnt, redi);
+        if (cnt >= dyn.top_k) cur = cand;
+      }
+      thr_key = cur;
+    }
+    // softmax over kept entries (max = global max, always kept)
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    __syncthreads();
+    if (lane == 0) redf[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    float p[SAMP_PER];
+    float local = 0.f;
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) {
+      const int idx = tid * SAMP_PER + j;
+      const bool keep = idx < V && float_key(sc[j]) >= thr_key;
+      p[j] = keep ? expf(sc[j] - m) : 0.f;
+      local += p[j];
+    }
+    // block-wide exclusive prefix of `local` (inclusive wave scan + per-wave totals)
+    float incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    float base = 0.f, total = 0.f;
+#pragma unroll
+    for (int i = 0; i < SAMP_T / 64; ++i) {
+      if (i < w) base += wave_tot[i];
+      total += wave_tot[i];
+    }
+    const float excl = base + incl - local;
+    const float u = philox_uniform(dyn.seed, (uint32_t)it, (uint32_t)b);
+    const float target = u * total;
+    int cand = 0x7fffffff;
+    float run = excl;
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) {
+      const int idx = tid * SAMP_PER + j;
+      run += p[j];
+      if (p[j] > 0.f && run > target && cand == 0x7fffffff) cand = idx;
+    }
+    // first index whose inclusive cumulative mass exceeds the target
+    const unsigned long long ck = block_max_u64((unsigned long long)(0x7fffffff - cand), red64);
+    const int pick = 0x7fffffff - (int)ck;
+    sample = pick == 0x7fffffff ? argmax : pick;
+  }
+
+  if (tid == 0) {
+    const int n = a.s.n_gen[b];
+    const int kvl = a.s.kv_len[b] + (a.first ? 0 : 1);
+    const int ap = a.s.audio_pos[b] + (a.first ? 0 : 1);
+    // valle.py:1044-1048: argmax == EOS  or  sample == EOS  or  (y.shape[1] - P) > 16 * S
+    int stop = (argmax == 1024) || (sample == 1024) || (n + a.bos > a.s.cap[b]);
+    if (dyn.max_new > 0 && n >= dyn.max_new) stop = 1;
+    if (dyn.has_forced) stop = n >= dyn.forced_len[b];
+    if (n >= (int)a.g_stride || kvl >= a.ctx_max) stop = 1;  // capacity guard
+    int next = sample;
+    if (!stop) {
+      if (dyn.has_forced) next = (int)dyn.forced[(int64_t)b * dyn.forced_stride + n];
+      a.tokens[(int64_t)b * a.g_stride + n] = next;
+      a.sampled[(int64_t)b * a.g_stride + n] = sample;
+      a.s.n_gen[b] = n + 1;
+      a.s.kv_len[b] = kvl;
+      a.s.audio_pos[b] = ap;
+    } else {
+      a.s.done[b] = 1;
+      atomicAdd(a.s.done_count, 1);
+    }
+    a.s.iter[b] = it + 1;
+    sh_next = next;
+    sh_stop = stop;
+    sh_pos = ap;
+  }
+  __syncthreads();
+  if (sh_stop) return;
+  // next step's input: ar_audio_position(ar_audio_embedding(token))  (valle.py:1013-1015)
+  const float4* e = reinterpret_cast<const float4*>(a.audio_emb + (int64_t)sh_next * a.d);
+  const float4* pe = reinterpret_cast<const float4*>(a.pe + (int64_t)sh_pos * a.d);
+  const float alpha = *a.alpha_audio;
+  float4* xo = reinterpret_cast<float4*>(a.x + (int64_t)b * a.d);
+  for (int i = tid; i < (a.d >> 2); i += SAMP_T) {
+    const float4 ev = e[i], pv = pe[i];
+    xo[i] = make_float4(__fadd_rn(ev.x, __fmul_rn(alpha, pv.x)), __fadd_rn(ev.y, __fmul_rn(alpha, pv.y)),
+                        __fadd_rn(ev.z, __fmul_rn(alpha, pv.z)), __fadd_rn(ev.w, __fmul_rn(alpha, pv.w)));
+  }
+}
+
+int launch_ar_sample(hipStream_t st, const ArSampleArgs& a) {
+  if (a.V > SAMP_T * SAMP_PER) return -1;
+  hipLaunchKernelGGL(ar_sample_kernel, dim3(a.B), dim3(SAMP_T), 0, st, a);
+  return 0;
+}
+
+// samples = argmax(logits); codes.append(samples); y_emb[:, P:] += embedding(samples)
+// (valle.py:1130-1134).  One wave per generated frame.
+constexpr int NARG_NW = 4;
+__global__ __launch_bounds__(NARG_NW * 64) void nar_argmax_kernel(NarArgmaxArgs a) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * NARG_NW + (threadIdx.x >> 6);
+  if (r >= a.rows) return;
+  const float* lg = a.logits + r * a.V;
+  unsigned long long best = 0ull;
+  for (int idx = lane; idx < a.V; idx += 64) {
+    const unsigned long long key = ((unsigned long long)float_key(lg[idx]) << 32) | (unsigned)(0x7fffffff - idx);
+    best = key > best ? key : best;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    const unsigned long long t = __shfl_xor(best, o, 64);
+    best = t > best ? t : best;
+  }
+  const int code = 0x7fffffff - (int)(best & 0xffffffffu);
+  const int b = a.grow_seq[r], g = a.grow_pos[r];
+  if (lane == 0) a.codes[((int64_t)b * a.g_stride + g) * a.Q + a.col] = code;
+  if (a.next_emb != nullptr) {
+    const float4* e = reinterpret_cast<const float4*>(a.next_emb + (int64_t)code * a.d);
+    float4* y = reinterpret_cast<float4*>(a.y_emb + ((int64_t)a.aoff[b] + a.prompt_len[b] + g) * a.d);
+    for (int i = lane; i < (a.d >> 2); i += 64) {
+      const float4 yv = y[i], ev = e[i];
+      y[i] = make_float4(yv.x + ev.x, yv.y + ev.y, yv.z + ev.z, yv.w + ev.w);
+    }
+  }
+}
+
+int launch_nar_argmax(hipStream_t st, const NarArgmaxArgs& a) {
+  if (a.rows <= 0) return 0;
+  hipLaunchKernelGGL(nar_argmax_kernel, dim3((unsigned)((a.rows + NARG_NW - 1) / NARG_NW)), dim3(NARG_NW * 64), 0, st, a);
+  return 0;
+}
+
+}  // namespace vle

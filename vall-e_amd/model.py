@@ -1,0 +1,313 @@
+"""Drop-in model surface: ``get_model(params)`` / ``VALLE`` with the reference's constructor,
+state-dict layout and ``inference()`` / ``continual()`` signatures
+(valle/models/__init__.py:98-136, valle/models/valle.py:727-760, :961-985, :1139-1156),
+backed by the HIP engine.  ``bin/infer.py`` of the reference works unchanged when its
+``from valle.models import get_model`` resolves to this module.
+
+The parameter tree mirrors the reference's module names so that
+``load_state_dict(ckpt["model"], strict=True)`` (valle/bin/infer.py:135-138) accepts a
+reference checkpoint.  Only the production shape runs (norm_first, no prenet,
+nar_scale_factor = 1); other combinations raise -- there is no PyTorch fallback.
+"""
+from __future__ import annotations
+
+import argparse
+from typing import List, Optional, Sequence
+
+import torch
+import torch.nn as nn
+
+from .engine import Engine, EngineConfig
+from . import _lib
+
+NUM_TEXT_TOKENS = 512  # valle/models/macros.py:2
+NUM_AUDIO_TOKENS = 1024  # valle/models/macros.py:5
+
+
+# ---- parameter containers with the reference's attribute names --------------------------------
+class TokenEmbedding(nn.Module):
+    """valle/modules/embedding.py:21-47 (parameters only; the gather runs fused in embed.hip)."""
+
+    def __init__(self, dim_model: int, vocab_size: int):
+        super().__init__()
+        self.vocab_size, self.dim_model = vocab_size, dim_model
+        self.word_embeddings = nn.Embedding(vocab_size, dim_model)
+
+    @property
+    def weight(self) -> torch.Tensor:
+        return self.word_embeddings.weight
+
+
+class SinePositionalEmbedding(nn.Module):
+    """valle/modules/embedding.py:50-97: holds the learnable ``alpha``."""
+
+    def __init__(self, dim_model: int, alpha: bool = False):
+        super().__init__()
+        self.dim_model = dim_model
+        self.alpha = nn.Parameter(torch.ones(1), requires_grad=alpha)
+
+
+class _MHAParams(nn.Module):
+    """Packed in-proj [Q;K;V] + out_proj (valle/modules/activation.py:128-143)."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
+        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
+        self.out_proj = nn.Linear(d, d)
+        nn.init.xavier_uniform_(self.in_proj_weight)
+        nn.init.zeros_(self.out_proj.bias)
+
+
+class _AdaLNParams(nn.Module):
+    """valle/modules/transformer.py:83-108."""
+
+    def __init__(self, d: int):
+        super().__init__()
+        self.project_layer = nn.Linear(d, 2 * d)
+        self.norm = nn.LayerNorm(d)
+
+
+class _EncoderLayerParams(nn.Module):
+    """valle/modules/transformer.py:178-263."""
+
+    def __init__(self, d: int, adaptive: bool):
+        super().__init__()
+        self.self_attn = _MHAParams(d)
+        self.linear1 = nn.Linear(d, 4 * d)
+        self.linear2 = nn.Linear(4 * d, d)
+        self.norm1 = _AdaLNParams(d) if adaptive else nn.LayerNorm(d)
+        self.norm2 = _AdaLNParams(d) if adaptive else nn.LayerNorm(d)
+
+
+class _EncoderParams(nn.Module):
+    """valle/modules/transformer.py:337-361."""
+
+    def __init__(self, d: int, num_layers: int, adaptive: bool):
+        super().__init__()
+        self.layers = nn.ModuleList([_EncoderLayerParams(d, adaptive) for _ in range(num_layers)])
+        self.norm = _AdaLNParams(d) if adaptive else nn.LayerNorm(d)
+
+
+class VALLE(nn.Module):
+    """HIP-backed VALL-E (valle/models/valle.py:722-1238)."""
+
+    def __init__(
+        self,
+        d_model: int,
+        nhead: int,
+        num_layers: int,
+        norm_first: bool = True,
+        add_prenet: bool = False,
+        prefix_mode: int = 0,
+        share_embedding: bool = True,
+        nar_scale_factor: float = 1.0,
+        prepend_bos: bool = False,
+        num_quantizers: int = 8,
+        *,
+        engine_dtype: str = "fp32",
+        max_batch: int = 1,
+        max_text: int = 0,
+        max_prompt: int = 0,
+        max_gen: int = 0,
+        use_graph: bool = True,
+        **kwargs,
+    ):
+        super().__init__()
+        if not norm_first or add_prenet or nar_scale_factor != 1.0:
+            raise NotImplementedError(
+                "the HIP engine runs the production shape only (norm_first=True, add_prenet=False, "
+                "nar_scale_factor=1.0); there is no PyTorch fallback"
+            )
+        assert num_quantizers >= 1
+        d = d_model
+        self.d_model, self.num_heads, self.num_layers = d_model, nhead, num_layers
+        self.prefix_mode, self.num_quantizers = prefix_mode, num_quantizers
+        self.ar_audio_prepend_bos = prepend_bos
+        self.share_embedding = share_embedding
+        self.engine_dtype, self.max_batch = engine_dtype, max_batch
+        self.max_text, self.max_prompt, self.max_gen, self.use_graph = max_text, max_prompt, max_gen, use_graph
+
+        self.ar_text_embedding = TokenEmbedding(d, NUM_TEXT_TOKENS)
+        self.nar_text_embedding = TokenEmbedding(d, NUM_TEXT_TOKENS)
+        self.ar_audio_embedding = TokenEmbedding(d, NUM_AUDIO_TOKENS + 1 + int(prepend_bos))
+        self.ar_text_position = SinePositionalEmbedding(d, alpha=True)
+        self.ar_audio_position = SinePositionalEmbedding(d, alpha=True)
+        self.ar_decoder = _EncoderParams(d, num_layers, adaptive=False)
+        self.ar_predict_layer = nn.Linear(d, NUM_AUDIO_TOKENS + 1, bias=False)
+        if num_quantizers > 1:
+            self.nar_audio_embeddings = nn.ModuleList(
+                [TokenEmbedding(d, NUM_AUDIO_TOKENS + 1)] + [TokenEmbedding(d, NUM_AUDIO_TOKENS) for _ in range(num_quantizers - 1)]
+            )
+            self.nar_text_position = SinePositionalEmbedding(d, alpha=False)
+            self.nar_audio_position = SinePositionalEmbedding(d, alpha=False)
+            self.nar_decoder = _EncoderParams(d, num_layers, adaptive=True)
+            self.nar_predict_layers = nn.ModuleList([nn.Linear(d, NUM_AUDIO_TOKENS, bias=False) for _ in range(num_quantizers - 1)])
+            self.nar_stage_embeddings = nn.ModuleList([TokenEmbedding(d, 1) for _ in range(num_quantizers - 1)])
+            if share_embedding:
+                for j in range(0, num_quantizers - 2):  # valle.py:268-271
+                    self.nar_predict_layers[j].weight = self.nar_audio_embeddings[j + 2].weight
+        self.requires_grad_(False)
+        self._engine: Optional[Engine] = None
+        self._engine_key = None
+
+    # ---- engine life cycle --------------------------------------------------------------------
+    def _invalidate(self):
+        if self._engine is not None:
+            self._engine.close()
+        self._engine, self._engine_key = None, None
+
+    def load_state_dict(self, *a, **k):
+        r = super().load_state_dict(*a, **k)
+        self._invalidate()
+        return r
+
+    def _apply(self, fn, *a, **k):
+        r = super()._apply(fn, *a, **k)
+        self._invalidate()
+        return r
+
+    def engine_for(self, batch: int, text_len: int, prompt_len: int, gen_len: int = 0) -> Engine:
+        """Engine sized for the request (rebuilt only when a capacity grows)."""
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("the HIP engine needs the model on a ROCm device: call .to('cuda') first (no CPU path)")
+        need_gen = max(gen_len, 16 * text_len + 1)
+        if self._engine is not None:
+            c = self._engine.cfg
+            if (self._engine_key == (dev.index or 0, self.engine_dtype) and c.max_batch >= batch and c.max_text >= text_len
+                    and c.max_prompt >= prompt_len and c.max_gen_eff() >= need_gen):
+                return self._engine
+            self._invalidate()
+        max_text = max(self.max_text, text_len)
+        max_gen = max(self.max_gen, gen_len)
+        if max_gen and max_gen < 16 * max_text + 1:
+            max_gen = max(max_gen, need_gen)
+        cfg = EngineConfig(
+            d_model=self.d_model, nhead=self.num_heads, num_layers=self.num_layers, num_quantizers=self.num_quantizers,
+            prefix_mode=self.prefix_mode, prepend_bos=self.ar_audio_prepend_bos, dtype=self.engine_dtype,
+            max_batch=max(self.max_batch, batch), max_text=max_text, max_prompt=max(self.max_prompt, prompt_len),
+            max_gen=max_gen, device=dev.index or 0, use_graph=self.use_graph,
+        )
+        eng = Engine(cfg)
+        eng.load_state_dict(self.state_dict())
+        self._engine, self._engine_key = eng, (dev.index or 0, self.engine_dtype)
+        self.max_text, self.max_prompt, self.max_batch, self.max_gen = cfg.max_text, cfg.max_prompt, cfg.max_batch, max_gen
+        return eng
+
+    # ---- VALLE.inference (valle/models/valle.py:961-1137) ---------------------------------------
+    @torch.no_grad()
+    def inference(
+        self,
+        x: torch.Tensor,
+        x_lens: torch.Tensor,
+        y: torch.Tensor,
+        enroll_x_lens: Optional[torch.Tensor] = None,
+        top_k: int = -100,
+        temperature: float = 1.0,
+        seed: int = 0,
+    ) -> torch.Tensor:
+        assert x.ndim == 2, x.shape
+        assert x_lens.ndim == 1, x_lens.shape
+        assert y.ndim == 3, y.shape
+        assert y.shape[0] == 1, y.shape
+        assert torch.all(x_lens > 0)
+        out = self.inference_batch(x, x_lens, y, [y.shape[1]], enroll_x_lens, top_k, temperature, seed)
+        return out[0][None]
+
+    @torch.no_grad()
+    def inference_batch(
+        self,
+        x: torch.Tensor,
+        x_lens: torch.Tensor,
+        y: torch.Tensor,
+        y_lens: Sequence[int],
+        enroll_x_lens: Optional[torch.Tensor] = None,
+        top_k: int = -100,
+        temperature: float = 1.0,
+        seed: int = 0,
+        max_new: int = 0,
+    ) -> List[torch.Tensor]:
+        """B independent utterances (the reference is batch-1, valle.py:989): returns a list of
+        (G_b, Q) int64 tensors on the model's device."""
+        B = x.shape[0]
+        xl = [int(v) for v in x_lens.tolist()]
+        yl = [int(v) for v in y_lens]
+        eng = self.engine_for(B, max(xl), max(yl))
+        dev = eng.device
+        eng.prefill(x.to(dev, torch.int64), xl, y.to(dev, torch.int64)[..., : self.num_quantizers], yl)
+        try:
+            _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new)
+        except _lib.VleError as err:
+            if err.code == _lib.VLE_ENOTOKEN:
+                raise SyntaxError("well trained model shouldn't reach here.") from None  # valle.py:1049-1052
+            raise
+        for b in range(B):
+            print(f"VALL-E EOS [{yl[b]} -> {yl[b] + int(self.ar_audio_prepend_bos) + gl[b]}]")  # valle.py:1054
+        en = None
+        if self.prefix_mode in (2, 4):
+            assert enroll_x_lens is not None, "prefix_mode 2/4 needs enroll_x_lens (valle.py:1068-1079)"
+            en = [int(v) for v in enroll_x_lens.tolist()]
+            if len(en) == 1 and B > 1:
+                en = en * B
+        codes = eng.nar(en)
+        return [codes[b, : gl[b]] for b in range(B)]
+
+    # ---- VALLE.continual (valle/models/valle.py:1139-1238) --------------------------------------
+    @torch.no_grad()
+    def continual(self, x: torch.Tensor, x_lens: torch.Tensor, y: torch.Tensor) -> torch.Tensor:
+        assert x.ndim == 2, x.shape
+        assert x_lens.ndim == 1, x_lens.shape
+        assert y.ndim == 3, y.shape
+        assert y.shape[0] == 1, y.shape
+        assert torch.all(x_lens > 0)
+        assert self.num_quantizers == 8
+        T = y.shape[1]
+        eng = self.engine_for(1, int(x_lens.max()), T, T)
+        dev = eng.device
+        codes, gl = eng.continual(x.to(dev, torch.int64), [int(x_lens.max())], y.to(dev, torch.int64), [T])
+        return codes[:, : gl[0]]
+
+
+# ---- valle/models/__init__.py surface ---------------------------------------------------------------
+def _str2bool(v):
+    return str(v).lower() in ("1", "true", "yes", "y", "t")
+
+
+def add_model_arguments(parser: argparse.ArgumentParser):
+    """Same flags as valle/models/__init__.py:18-95, plus the engine's own."""
+    parser.add_argument("--model-name", type=str, default="VALL-E")
+    parser.add_argument("--decoder-dim", type=int, default=1024)
+    parser.add_argument("--nhead", type=int, default=16)
+    parser.add_argument("--num-decoder-layers", type=int, default=12)
+    parser.add_argument("--scale-factor", type=float, default=1.0)
+    parser.add_argument("--norm-first", type=_str2bool, default=True)
+    parser.add_argument("--add-prenet", type=_str2bool, default=False)
+    parser.add_argument("--prefix-mode", type=int, default=0)
+    parser.add_argument("--share-embedding", type=_str2bool, default=True)
+    parser.add_argument("--prepend-bos", type=_str2bool, default=False)
+    parser.add_argument("--num-quantizers", type=int, default=8)
+    parser.add_argument("--scaling-xformers", type=_str2bool, default=False)
+    parser.add_argument("--engine-dtype", type=str, default="fp32", help="HIP engine arithmetic: fp32 (token-exact) or bf16")
+
+
+def get_model(params) -> nn.Module:
+    """valle/models/__init__.py:98-136 for --model-name vall-e|valle.  VALL-F and the debug
+    Transformer-TTS are outside this engine's scope."""
+    name = str(params.model_name).lower()
+    if name not in ("vall-e", "valle"):
+        raise NotImplementedError(f"model_name={params.model_name!r}: only VALL-E is implemented by the HIP engine")
+    get = params.get if hasattr(params, "get") else lambda k, dflt=None: getattr(params, k, dflt)
+    return VALLE(
+        params.decoder_dim,
+        params.nhead,
+        params.num_decoder_layers,
+        norm_first=params.norm_first,
+        add_prenet=params.add_prenet,
+        prefix_mode=params.prefix_mode,
+        share_embedding=params.share_embedding,
+        nar_scale_factor=params.scale_factor,
+        prepend_bos=params.prepend_bos,
+        num_quantizers=params.num_quantizers,
+        engine_dtype=get("engine_dtype", "fp32") or "fp32",
+    )

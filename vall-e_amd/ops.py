@@ -1,0 +1,95 @@
+"""Tensor-level wrappers of the stand-alone HIP operators (``vle_op_*`` in valle_engine.h).
+
+These are the kernels behind the Transformer block modules (``modules.py``); they exist as an
+API so each kernel can be checked against its PyTorch fp32 definition in isolation.
+All tensors must live on a ROCm device; nothing here computes on the host.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import Optional
+
+import torch
+
+from . import _lib
+
+EPI_STORE, EPI_RELU, EPI_RESID, EPI_F32 = 0, 1, 2, 3
+
+
+def _dt(t: torch.Tensor) -> int:
+    if t.dtype == torch.float32:
+        return _lib.DTYPE_F32
+    if t.dtype == torch.bfloat16:
+        return _lib.DTYPE_BF16
+    raise TypeError(f"unsupported dtype {t.dtype}")
+
+
+def _p(t: Optional[torch.Tensor]):
+    return None if t is None else C.c_void_p(t.data_ptr())
+
+
+def _st(t: torch.Tensor):
+    assert t.is_cuda, "HIP operators need device tensors (no CPU fallback)"
+    return C.c_void_p(torch.cuda.current_stream(t.device).cuda_stream)
+
+
+def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtype=torch.float32) -> torch.Tensor:
+    """F.layer_norm(x, (d,), gamma, beta, 1e-5) with fp32 input and fp32/bf16 output."""
+    lib = _lib.load()
+    x = x.contiguous()
+    assert x.dtype == torch.float32 and gamma.dtype == torch.float32 and beta.dtype == torch.float32
+    d = x.shape[-1]
+    rows = x.numel() // d
+    out = torch.empty(x.shape, dtype=out_dtype, device=x.device)
+    _lib.check(lib.vle_op_layernorm(_st(x), _dt(out), _p(x), _p(gamma.contiguous()), _p(beta.contiguous()), _p(out), rows, d))
+    return out
+
+
+def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_STORE,
+           resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """epilogue(a @ w.T + bias) on the MFMA GEMM path. a (M,K), w (N,K) same dtype (fp32|bf16)."""
+    lib = _lib.load()
+    a, w = a.contiguous(), w.contiguous()
+    assert a.dtype == w.dtype and a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1]
+    M, K = a.shape
+    N = w.shape[0]
+    out = None
+    if epilogue == EPI_RESID:
+        assert resid is not None and resid.dtype == torch.float32 and resid.is_contiguous() and resid.shape == (M, N)
+    elif epilogue == EPI_F32:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    else:
+        out = torch.empty(M, N, dtype=a.dtype, device=a.device)
+    b = None if bias is None else bias.contiguous()
+    _lib.check(lib.vle_op_linear(_st(a), _dt(a), _p(a), _p(w), _p(b), _p(out), _p(resid), M, N, K, epilogue))
+    return resid if epilogue == EPI_RESID else out
+
+
+def linear_skinny(x: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
+                  resid: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None,
+                  beta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Weight-streaming path of the AR step: x fp32 (M<=8, K), w (N,K) fp32|bf16; optional fused LayerNorm."""
+    lib = _lib.load()
+    x, w = x.contiguous(), w.contiguous()
+    assert x.dtype == torch.float32
+    M, K = x.shape
+    N = w.shape[0]
+    out = None if epilogue == 2 else torch.empty(M, N, dtype=torch.float32, device=x.device)
+    b = None if bias is None else bias.contiguous()
+    _lib.check(lib.vle_op_linear_skinny(_st(x), _dt(w), _p(x), _p(gamma), _p(beta), _p(w), _p(b), _p(out), _p(resid), M, N, K, epilogue))
+    return resid if epilogue == 2 else out
+
+
+def attention(qkv: torch.Tensor, seq_off: torch.Tensor, text_len: torch.Tensor, nhead: int, causal: bool) -> torch.Tensor:
+    """Packed-sequence attention. qkv (rows, 3d); seq_off int32 (B+1,), text_len int32 (B,) on device."""
+    lib = _lib.load()
+    qkv = qkv.contiguous()
+    rows, d3 = qkv.shape
+    d = d3 // 3
+    B = seq_off.numel() - 1
+    so = seq_off.to(torch.int32).contiguous()
+    tl = text_len.to(torch.int32).contiguous()
+    lens = (so[1:] - so[:-1]).cpu()
+    out = torch.empty(rows, d, dtype=qkv.dtype, device=qkv.device)
+    _lib.check(lib.vle_op_attention(_st(qkv), _dt(qkv), _p(qkv), _p(out), _p(so), _p(tl), B, int(lens.max()), d, nhead, int(causal)))
+    return out

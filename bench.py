@@ -1,0 +1,210 @@
+#!/usr/bin/env python
+"""bench.py -- audio-tokens/s of the AR+NAR decode hot path on MI355X (BASELINE.json metric).
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--batch B]
+
+A "step" = one full pass of the hot path over one batch of synthetic utterances: prefill of
+[text; 3 s prompt], the AR loop to the reference's length cap (G = 16*S + 1 = 753 frames = 10.04 s
+at S = 47), and the 7 NAR stages.  Inputs are already resident in HBM when the timed region starts.
+N > 1: one process per GPU (torch.distributed, RCCL), the batch is sharded (weak scaling, B
+utterances per GPU); no collective on the decode path, one all_gather of the result codes per step.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (AR step =
+the HBM-bound dominant phase; algorithmic bytes of SURVEY.md 8d / measured hipEvent time) and
+`cpu_baseline` (the CPU oracle -- a restatement of the reference's no-KV-cache algorithm -- timed
+on the host cores on a bounded sample).
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
+S_TEXT, P_PROMPT = 47, 225  # 47 phonemes, 3 s x 75 Hz prompt
+
+
+def synth_inputs(index: int, S: int = S_TEXT, P: int = P_PROMPT):
+    """ids uniform in [3,100) with BOS=1 / EOS=2, codes uniform in [0,1024); seed 1234+index."""
+    g = torch.Generator().manual_seed(1234 + index)
+    x = torch.randint(3, 100, (S,), generator=g, dtype=torch.int64)
+    x[0], x[-1] = 1, 2
+    y = torch.randint(0, 1024, (P, 8), generator=g, dtype=torch.int64)
+    return x, y
+
+
+def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
+    """The CPU oracle (literal no-KV-cache restatement of valle/models/valle.py:961-1137), fp32, on
+    all host cores, on a bounded sample: the first `frames` frames of utterance 0 (+ the 7 NAR
+    stages over them).  Only this leg of bench.py touches oracle/."""
+    from oracle import valle_oracle as vo
+
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    cfg = vo.OracleConfig(d_model=d_model, nhead=nhead, num_layers=num_layers, prefix_mode=1)
+    x, y = synth_inputs(0)
+    t0 = time.perf_counter()
+    codes = vo.inference(sd_cpu, cfg, x[None], torch.tensor([S_TEXT], dtype=torch.int32), y[None], None, top_k=1,
+                         kv_cache=False, max_new=frames)
+    dt = time.perf_counter() - t0
+    n_tok = codes.shape[1] * codes.shape[2]
+    return dict(
+        value=round(n_tok / dt, 3), unit="audio-tokens/s", cores=cores, kind="port",
+        sample=f"first {codes.shape[1]} of 753 frames of utterance 0 (ctx {S_TEXT + P_PROMPT}..{S_TEXT + P_PROMPT + frames}) "
+               f"+ 7 NAR stages, fp32, {dt:.1f} s; the full-length run is slower per token (no KV cache: O(G*N))",
+    )
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU (configs[1]: 1; configs[2]: 64)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--d-model", type=int, default=1024)
+    ap.add_argument("--nhead", type=int, default=16)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--top-k", type=int, default=1, help="1 = the reference's greedy; -100 = pure multinomial")
+    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--profile-kernels", type=int, default=0, help="extra untimed pass: hipEvent time per AR-step kernel family over n steps")
+    args = ap.parse_args()
+
+    import valle_amd
+    from valle_amd import dist as vdist
+
+    rank, local_rank, world = vdist.init_process_group()
+    if world != args.gpus and world > 1:
+        args.gpus = world
+    assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    # random-init weights of the named architecture (no network for checkpoints), reference init distributions
+    torch.manual_seed(0)
+    model = valle_amd.VALLE(args.d_model, args.nhead, args.layers, prefix_mode=1, engine_dtype=args.dtype,
+                            max_batch=args.batch, use_graph=not args.no_graph)
+    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.gpus == 1 and args.cpu_frames > 0) else None
+    model = model.to(dev).eval()
+    B = args.batch
+    eng = model.engine_for(B, S_TEXT, P_PROMPT)
+
+    X = torch.zeros(B, S_TEXT, dtype=torch.int64)
+    Y = torch.zeros(B, P_PROMPT, 8, dtype=torch.int64)
+    for b in range(B):
+        X[b], Y[b] = synth_inputs(rank * B + b)
+    X, Y = X.to(dev), Y.to(dev)
+    s_lens, p_lens = [S_TEXT] * B, [P_PROMPT] * B
+
+    def step():
+        eng.prefill(X, s_lens, Y, p_lens)
+        _, gl = eng.generate(top_k=args.top_k, temperature=1.0, seed=0)
+        codes = eng.nar(None)
+        out = [codes[b, : gl[b]] for b in range(B)]
+        if world > 1:
+            vdist.gather_codes(out, world * B, 8, dev)
+        return gl
+
+    def barrier():
+        if world > 1:
+            torch.distributed.barrier()
+
+    for _ in range(args.warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    tokens = 0
+    ar_ms = nar_ms = pre_ms = 0.0
+    ar_steps = 0
+    ar_bytes = 0
+    for _ in range(args.steps):
+        gl = step()
+        tokens += sum(gl) * 8
+        tm = eng.timings()
+        pre_ms += tm["prefill_ms"]; ar_ms += tm["ar_ms"]; nar_ms += tm["nar_ms"]; ar_steps += int(tm["ar_steps"])
+        # algorithmic bytes of this utterance batch's AR loop: per step W_AR*w + sum_b 2*L*d*a*(c_b + 1)
+        for t in range(1, max(gl) + 1):
+            live = [b for b in range(B) if gl[b] >= t]
+            ar_bytes += eng.ar_step_bytes(len(live), sum(S_TEXT + P_PROMPT + t for _ in live))
+    torch.cuda.synchronize(dev)
+    barrier()
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+        tk = torch.tensor([tokens], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tk, op=torch.distributed.ReduceOp.SUM)
+        tokens = int(tk.item())
+
+    kernel_prof = None
+    if args.profile_kernels > 0 and rank == 0:
+        eng.set_option("profile_kernels", args.profile_kernels)
+        eng.prefill(X, s_lens, Y, p_lens)
+        eng.generate(top_k=args.top_k, max_new=args.profile_kernels)
+        kernel_prof = eng.kernel_times()
+        eng.set_option("profile_kernels", 0)
+
+    if rank == 0:
+        step_ms = ar_ms / max(ar_steps, 1)
+        achieved = (ar_bytes / 1e9) / (ar_ms / 1e3) if ar_ms > 0 else 0.0
+        out = {
+            "metric": "audio-tokens/sec (AR+NAR decode, 3 s prompt -> 10 s target)",
+            "value": round(tokens / elapsed, 1),
+            "unit": "audio-tokens/s",
+            "n_gpus": args.gpus,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": args.dtype,
+            "data": "synthetic",
+            "config": {
+                "workload": f"dim{args.d_model}-L{args.layers}-h{args.nhead} {args.dtype}, batch={B} per GPU, S={S_TEXT} text tokens, "
+                            f"P={P_PROMPT} prompt frames (3 s) -> G={gl[0]} frames ({gl[0] / 75:.2f} s), "
+                            f"{'greedy (top_k=1)' if args.top_k == 1 else f'top_k={args.top_k}'}, random-init weights",
+                "parallelism": f"batch-sharded x{args.gpus} (independent utterances, gather of codes only)",
+                "hip_graph": not args.no_graph,
+            },
+            "per_gpu_value": round(tokens / elapsed / args.gpus, 1),
+            "phase_ms": {"prefill": round(pre_ms / args.steps, 3), "ar": round(ar_ms / args.steps, 3), "nar": round(nar_ms / args.steps, 3)},
+            "roofline": {
+                "kernel": "AR decode step (hipGraph replay: 5 kernels/layer x L + logits + sample; weights + KV streamed once)",
+                "bound": "hbm",
+                "achieved": round(achieved, 1),
+                "peak": HBM_PEAK_GBS,
+                "unit": "GB/s",
+                "frac": round(achieved / HBM_PEAK_GBS, 4),
+                "traffic": None,
+                "launch_us": round(step_ms * 1e3, 2),
+                "bytes_per_launch": int(ar_bytes / max(ar_steps, 1)),
+                "launches": ar_steps,
+            },
+        }
+        if kernel_prof is not None:
+            out["roofline"]["kernel_us"] = kernel_prof
+        if sd_cpu is not None:
+            out["cpu_baseline"] = cpu_baseline(sd_cpu, args.d_model, args.nhead, args.layers, args.cpu_frames)
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -122,12 +122,18 @@ int vle_nar_continual(vle_engine* e, void* stream, const int64_t* text, int64_t 
                       int64_t* codes, int64_t g_stride, int32_t* gen_lens);
 
 /* ---- parity / measurement hooks -------------------------------------------------------------- */
-/* options: "trace_ar_logits" (0/1: keep every AR step's fp32 logits), "trace_nar_logits" (0/1) */
+/* options: "trace_ar_logits" (0/1: keep every AR step's fp32 logits), "trace_nar_logits" (0/1),
+ *          "nsplit" (1..16: KV split of the decode attention; default chosen from the batch size),
+ *          "profile_kernels" (n > 0: time each kernel of the next n AR steps with hipEvents on the
+ *           engine stream, launches become eager; 0: off) */
 int vle_set_option(vle_engine* e, const char* name, int64_t value);
 /* what: "ar_logits"  -> fp32 [n_steps, B, 1025] (row t = logits of AR loop iteration t)
  *       "nar_logits:<stage>" -> fp32 [sum_b G_b, 1024]
  *       "ar_sampled" -> int64 [B, G_max] the engine's own samples (differs from codes0 only when forced)
- *       "kv_len" -> int32 [B];   returns the number of bytes written (>= 0) or an error code */
+ *       "kv_len" -> int32 [B]
+ *       "kernel_times" -> double [16]: total ms then launch counts for the AR-step kernel families
+ *                         {qkv, decode-attention, out-proj, ffn1, ffn2, logits, sample, -}
+ *   returns the number of bytes written (>= 0) or an error code */
 int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_dst, size_t bytes);
 /* phase timings of the last call, milliseconds measured with hipEvents on the engine's stream:
  * out[0] prefill, out[1] AR steps, out[2] NAR, out[3] number of AR steps executed */

@@ -97,6 +97,14 @@ struct vle_engine {
   float* trace_ar = nullptr; int64_t trace_ar_cap = 0;
   float* trace_nar = nullptr;     // [Q-1][sumG_max][1024]
   bool opt_trace_ar = false, opt_trace_nar = false;
+  // per-kernel timing of the AR step with hipEvents on the engine stream (option "profile_kernels"):
+  // forces eager launches; tags: 0 qkv, 1 decode-attention, 2 out-proj, 3 ffn1, 4 ffn2, 5 logits, 6 sample
+  bool opt_profile = false;
+  std::vector<hipEvent_t> prof_pool;
+  size_t prof_used = 0;
+  std::vector<int> prof_tags;
+  double prof_ms[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+  double prof_calls[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 
   // ---- per-call state -------------------------------------------------------------------------------
   int B = 0;
@@ -265,6 +273,7 @@ extern "C" void vle_destroy(vle_engine* e) {
     if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
     if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
   }
+  for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->tables_host) (void)hipHostFree(e->tables_host);
   if (e->poll_host) (void)hipHostFree(e->poll_host);
@@ -557,6 +566,26 @@ int enqueue_layer_rows(vle_engine* e, const LayerW& w, const float* g1, const fl
   return 0;
 }
 
+// event pair around one launch when profiling (events come from a pool, resolved after the sync)
+struct ProfScope {
+  vle_engine* e;
+  bool on;
+  ProfScope(vle_engine* e_, int tag) : e(e_), on(e_->opt_profile) {
+    if (!on) return;
+    if (e->prof_used + 2 > e->prof_pool.size()) {
+      on = false;
+      return;
+    }
+    e->prof_tags.push_back(tag);
+    (void)hipEventRecord(e->prof_pool[e->prof_used], e->st);
+  }
+  ~ProfScope() {
+    if (!on) return;
+    (void)hipEventRecord(e->prof_pool[e->prof_used + 1], e->st);
+    e->prof_used += 2;
+  }
+};
+
 bool use_skinny(const vle_engine* e) {
   return e->B <= SKINNY_MAX_B && (size_t)(e->B <= 1 ? 1 : e->B <= 2 ? 2 : e->B <= 4 ? 4 : 8) * 4 * e->d * sizeof(float) <= 160 * 1024;
 }
@@ -564,6 +593,7 @@ bool use_skinny(const vle_engine* e) {
 // logits of the current x_step rows: final LayerNorm (valle.py:151) + ar_predict_layer (valle.py:1039)
 int enqueue_ar_logits(vle_engine* e) {
   hipStream_t st = e->st;
+  ProfScope ps(e, 5);
   if (use_skinny(e)) {
     SkinnyArgs a;
     a.w = e->ar_predict; a.bias = nullptr; a.N = V_AR; a.K = e->d; a.B = e->B;
@@ -577,6 +607,7 @@ int enqueue_ar_logits(vle_engine* e) {
 }
 
 int enqueue_ar_sample(vle_engine* e, int first) {
+  ProfScope ps(e, 6);
   ArSampleArgs a{};
   a.s = e->S; a.dyn = e->dyn_dev; a.logits = e->logits; a.V = V_AR; a.B = e->B; a.d = e->d; a.bos = e->bos; a.first = first;
   a.tokens = e->tokens; a.g_stride = e->max_G; a.sampled = e->sampled;
@@ -595,37 +626,60 @@ int enqueue_ar_step(vle_engine* e) {
     void* kc = cache_layer(e, e->kcache, l);
     void* vc = cache_layer(e, e->vcache, l);
     if (sk) {
+      ProfScope ps(e, 0);
       SkinnyArgs a;
       a.w = w.wqkv; a.bias = w.bqkv; a.N = 3 * d; a.K = d; a.B = e->B; a.pro = PRO_LN; a.epi = SEPI_QKV;
       a.x = e->x_step; a.gamma = w.g1; a.beta = w.be1; a.q_out = e->q_step; a.k_cache = kc; a.v_cache = vc;
       a.kv_len = e->S.kv_len; a.ctx_max = e->ctx_max; a.nhead = e->H; a.dh = e->dh;
       E_LAUNCH(e, launch_skinny(st, e->dtype, a));
     } else {
+      ProfScope ps(e, 0);
       E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
       E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, w.wqkv, w.bqkv, e->qkv_step, nullptr, e->B, 3 * d, d, EPI_STORE));
       E_LAUNCH(e, launch_qkv_split(st, e->dtype, e->qkv_step, e->q_step, kc, vc, e->S.kv_len, e->B, d, e->H, e->ctx_max));
     }
-    E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
-                                        e->ctx_max, e->nsplit));
+    {
+      ProfScope ps(e, 1);
+      E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
+                                          e->ctx_max, e->nsplit));
+    }
     if (sk) {
-      SkinnyArgs a;
-      a.w = w.wo; a.bias = w.bo; a.N = d; a.K = d; a.B = e->B; a.pro = PRO_ATTN; a.epi = SEPI_RESID;
-      a.part_o = e->part_o; a.part_ml = e->part_ml; a.nsplit = e->nsplit; a.nhead = e->H; a.dh = e->dh; a.resid = e->x_step;
-      E_LAUNCH(e, launch_skinny(st, e->dtype, a));
-      SkinnyArgs f1;
-      f1.w = w.w1; f1.bias = w.b1; f1.N = 4 * d; f1.K = d; f1.B = e->B; f1.pro = PRO_LN; f1.epi = SEPI_RELU;
-      f1.x = e->x_step; f1.gamma = w.g2; f1.beta = w.be2; f1.out = e->h_step;
-      E_LAUNCH(e, launch_skinny(st, e->dtype, f1));
-      SkinnyArgs f2;
-      f2.w = w.w2; f2.bias = w.b2; f2.N = d; f2.K = 4 * d; f2.B = e->B; f2.pro = PRO_PLAIN; f2.epi = SEPI_RESID;
-      f2.x = e->h_step; f2.resid = e->x_step;
-      E_LAUNCH(e, launch_skinny(st, e->dtype, f2));
+      {
+        ProfScope ps(e, 2);
+        SkinnyArgs a;
+        a.w = w.wo; a.bias = w.bo; a.N = d; a.K = d; a.B = e->B; a.pro = PRO_ATTN; a.epi = SEPI_RESID;
+        a.part_o = e->part_o; a.part_ml = e->part_ml; a.nsplit = e->nsplit; a.nhead = e->H; a.dh = e->dh; a.resid = e->x_step;
+        E_LAUNCH(e, launch_skinny(st, e->dtype, a));
+      }
+      {
+        ProfScope ps(e, 3);
+        SkinnyArgs f1;
+        f1.w = w.w1; f1.bias = w.b1; f1.N = 4 * d; f1.K = d; f1.B = e->B; f1.pro = PRO_LN; f1.epi = SEPI_RELU;
+        f1.x = e->x_step; f1.gamma = w.g2; f1.beta = w.be2; f1.out = e->h_step;
+        E_LAUNCH(e, launch_skinny(st, e->dtype, f1));
+      }
+      {
+        ProfScope ps(e, 4);
+        SkinnyArgs f2;
+        f2.w = w.w2; f2.bias = w.b2; f2.N = d; f2.K = 4 * d; f2.B = e->B; f2.pro = PRO_PLAIN; f2.epi = SEPI_RESID;
+        f2.x = e->h_step; f2.resid = e->x_step;
+        E_LAUNCH(e, launch_skinny(st, e->dtype, f2));
+      }
     } else {
-      E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
-      E_LAUNCH(e, launch_gemm(st, e->dtype, e->att_step, w.wo, w.bo, nullptr, e->x_step, e->B, d, d, EPI_RESID));
-      E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
-      E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, w.w1, w.b1, e->hT_step, nullptr, e->B, 4 * d, d, EPI_RELU));
-      E_LAUNCH(e, launch_gemm(st, e->dtype, e->hT_step, w.w2, w.b2, nullptr, e->x_step, e->B, d, 4 * d, EPI_RESID));
+      {
+        ProfScope ps(e, 2);
+        E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
+        E_LAUNCH(e, launch_gemm(st, e->dtype, e->att_step, w.wo, w.bo, nullptr, e->x_step, e->B, d, d, EPI_RESID));
+      }
+      {
+        ProfScope ps(e, 3);
+        E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
+        E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, w.w1, w.b1, e->hT_step, nullptr, e->B, 4 * d, d, EPI_RELU));
+      }
+      {
+        ProfScope ps(e, 4);
+        E_LAUNCH(e, launch_gemm(st, e->dtype, e->hT_step, w.w2, w.b2, nullptr, e->x_step, e->B, d, 4 * d, EPI_RESID));
+      }
     }
   }
   int r;
@@ -793,7 +847,12 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   if ((r = enqueue_ar_sample(e, 1))) return r;
   int steps_done = 0;
   const int spg = e->cfg.steps_per_graph > 0 ? e->cfg.steps_per_graph : 8;
-  const bool use_graph = e->cfg.use_graph != 0;
+  const bool use_graph = e->cfg.use_graph != 0 && !e->opt_profile;
+  if (e->opt_profile) {
+    e->prof_used = 0;
+    e->prof_tags.clear();
+    for (int i = 0; i < 8; ++i) e->prof_ms[i] = e->prof_calls[i] = 0;
+  }
   hipGraphExec_t g_multi = nullptr, g_single = nullptr;
   if (use_graph && bound > 0) {
     auto it = e->graphs.find(B * 64 + e->nsplit);
@@ -847,6 +906,15 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
                               std::min<int64_t>(g_stride, e->max_G) * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
   E_HIP(e, hipStreamSynchronize(st));
   for (int i = 0; i < RING; ++i) (void)hipEventDestroy(evs[i]);
+  if (e->opt_profile) {
+    for (size_t i = 0; i < e->prof_tags.size(); ++i) {
+      float pm = 0.f;
+      if (hipEventElapsedTime(&pm, e->prof_pool[2 * i], e->prof_pool[2 * i + 1]) == hipSuccess) {
+        e->prof_ms[e->prof_tags[i]] += pm;
+        e->prof_calls[e->prof_tags[i]] += 1;
+      }
+    }
+  }
   memcpy(st_host.data(), e->tables_host, st_host.size() * sizeof(int32_t));
   e->G_len.resize(B);
   bool no_token = false, not_done = false;
@@ -1071,6 +1139,16 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
+  if (n == "profile_kernels") {
+    e->opt_profile = value != 0;
+    const size_t want = value > 0 ? (size_t)value * 2 * (5 * e->L + 2) : 0;  // value = steps to cover
+    while (e->prof_pool.size() < want) {
+      hipEvent_t ev;
+      if (hipEventCreate(&ev) != hipSuccess) return e->fail(VLE_EHIP, "hipEventCreate failed");
+      e->prof_pool.push_back(ev);
+    }
+    return VLE_OK;
+  }
   if (n == "nsplit") {
     if (value < 1 || value > 16) return e->fail(VLE_EINVAL, "nsplit must be 1..16");
     e->nsplit = (int)value;
@@ -1101,6 +1179,15 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
   } else if (w == "kv_len") {
     src = e->S.kv_len;
     n = (size_t)e->B * sizeof(int32_t);
+  } else if (w == "kernel_times") {  // 8 x total ms, then 8 x calls (doubles)
+    double buf[16];
+    for (int i = 0; i < 8; ++i) {
+      buf[i] = e->prof_ms[i];
+      buf[8 + i] = e->prof_calls[i];
+    }
+    const size_t nb = std::min(bytes, sizeof(buf));
+    memcpy(host_dst, buf, nb);
+    return (int64_t)nb;
   } else if (w == "last_logits") {
     src = e->logits;
     n = (size_t)e->B * V_AR * sizeof(float);

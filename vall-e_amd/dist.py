@@ -1,0 +1,73 @@
+"""Multi-GPU batch split: one process per GPU (``torch.distributed``, backend "nccl" = RCCL over
+xGMI on ROCm; "gloo" in the CPU tests).  Utterances are independent, so the decode
+path itself needs NO collective: each rank decodes a contiguous slice of the batch with its own
+replica of the weights and its own KV cache.  The only exchange is the final gather of the result
+codes (B/n x G x 8 ids per rank, < 4 MB): one all_gather, latency-bound, off the critical path.
+"""
+from __future__ import annotations
+
+import os
+from typing import Callable, List, Sequence, Tuple
+
+import torch
+import torch.distributed as dist
+
+
+def env_rank_world() -> Tuple[int, int, int]:
+    return int(os.environ.get("RANK", 0)), int(os.environ.get("LOCAL_RANK", 0)), int(os.environ.get("WORLD_SIZE", 1))
+
+
+def init_process_group(backend: str | None = None):
+    """Initialises the default group from the torchrun environment (no-op for world size 1)."""
+    rank, local_rank, world = env_rank_world()
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local_rank)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, local_rank, world
+
+
+def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
+    """Contiguous split; the first (n_items % world) ranks take one extra item."""
+    base, rem = divmod(n_items, world)
+    lo = rank * base + min(rank, rem)
+    return lo, lo + base + (1 if rank < rem else 0)
+
+
+def gather_codes(local: Sequence[torch.Tensor], n_total: int, Q: int = 8, device=None) -> List[torch.Tensor] | None:
+    """All ranks contribute their utterances' (G_b, Q) code matrices; every rank gets the full list in
+    global order.  Codes travel as int16 (< 1025), padded to the longest utterance."""
+    rank, _, world = env_rank_world()
+    if world == 1 or not dist.is_initialized():
+        return list(local)
+    device = device if device is not None else (local[0].device if len(local) else torch.device("cpu"))
+    per_rank = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
+    gmax_local = torch.tensor([max([int(t.shape[0]) for t in local] + [0])], dtype=torch.int64, device=device)
+    dist.all_reduce(gmax_local, op=dist.ReduceOp.MAX)
+    gmax = int(gmax_local.item())
+    buf = torch.full((per_rank, gmax + 1, Q), -1, dtype=torch.int16, device=device)
+    for i, t in enumerate(local):
+        buf[i, 0, 0] = t.shape[0]  # header row: length
+        buf[i, 1 : 1 + t.shape[0]] = t.to(device=device, dtype=torch.int16)
+    out = torch.empty((world,) + tuple(buf.shape), dtype=torch.int16, device=device)
+    dist.all_gather_into_tensor(out.view(world * per_rank, gmax + 1, Q), buf)
+    res: List[torch.Tensor] = []
+    for r in range(world):
+        lo, hi = shard_range(n_total, r, world)
+        for i in range(hi - lo):
+            n = int(out[r, i, 0, 0].item())
+            res.append(out[r, i, 1 : 1 + n].to(torch.int64))
+    return res
+
+
+def decode_sharded(decode_fn: Callable[[int, int], List[torch.Tensor]], n_total: int, Q: int = 8, device=None):
+    """decode_fn(lo, hi) decodes global utterances [lo, hi) on this rank's GPU; returns the gathered list."""
+    rank, _, world = env_rank_world()
+    lo, hi = shard_range(n_total, rank, world)
+    local = decode_fn(lo, hi)
+    return gather_codes(local, n_total, Q, device)

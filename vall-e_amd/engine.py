@@ -192,6 +192,15 @@ class Engine:
             _lib.check(int(n), self.h)
         return out
 
+    def kernel_times(self) -> Dict[str, float]:
+        """Average microseconds per launch of each AR-step kernel family (after "profile_kernels")."""
+        buf = (C.c_double * 16)()
+        n = self.lib.vle_debug_fetch(self.h, b"kernel_times", buf, 16 * 8)
+        if n < 0:
+            _lib.check(int(n), self.h)
+        names = ["qkv", "decode_attention", "out_proj", "ffn1", "ffn2", "logits", "sample"]
+        return {nm: round(buf[i] * 1e3 / buf[8 + i], 3) for i, nm in enumerate(names) if buf[8 + i] > 0}
+
     def fetch_sampled(self) -> torch.Tensor:
         out = torch.empty(self._B, self.cfg.max_gen_eff(), dtype=torch.int64)
         n = self.lib.vle_debug_fetch(self.h, b"ar_sampled", C.c_void_p(out.data_ptr()), out.numel() * 8)

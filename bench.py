@@ -47,7 +47,9 @@ def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
     stages over them).  Only this leg of bench.py touches oracle/."""
     from oracle import valle_oracle as vo
 
-    cores = os.cpu_count() or 1
+    # intra-op threads actually used: the reference's per-step ops are small (one utterance), more
+    # than ~16 threads only adds synchronisation cost (256 threads ran this sample 50x slower)
+    cores = min(os.cpu_count() or 1, 16)
     torch.set_num_threads(cores)
     cfg = vo.OracleConfig(d_model=d_model, nhead=nhead, num_layers=num_layers, prefix_mode=1)
     x, y = synth_inputs(0)
@@ -74,7 +76,7 @@ def main():
     ap.add_argument("--nhead", type=int, default=16)
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--top-k", type=int, default=1, help="1 = the reference's greedy; -100 = pure multinomial")
-    ap.add_argument("--cpu-frames", type=int, default=16, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-kernels", type=int, default=0, help="extra untimed pass: hipEvent time per AR-step kernel family over n steps")
     args = ap.parse_args()

@@ -123,7 +123,8 @@ int vle_nar_continual(vle_engine* e, void* stream, const int64_t* text, int64_t 
 
 /* ---- parity / measurement hooks -------------------------------------------------------------- */
 /* options: "trace_ar_logits" (0/1: keep every AR step's fp32 logits), "trace_nar_logits" (0/1),
- *          "nsplit" (1..16: KV split of the decode attention; default chosen from the batch size),
+ *          "nsplit" (0 = auto, else 1|2|4|8|16: KV split of the decode attention),
+ *          "no_gemv1" (1: batch-1 AR step on the generic skinny kernel instead of gemv1.hip), "gemv1_rpw" (rows per wave, tuning),
  *          "profile_kernels" (n > 0: time each kernel of the next n AR steps with hipEvents on the
  *           engine stream, launches become eager; 0: off) */
 int vle_set_option(vle_engine* e, const char* name, int64_t value);
@@ -164,6 +165,23 @@ int vle_op_linear_skinny(void* stream, int dtype, const float* x, const float* g
  * mask of valle.py:1019-1033 when causal = 1, no mask (NAR) when causal = 0. */
 int vle_op_attention(void* stream, int dtype, const void* qkv, void* out, const int32_t* seq_off_dev,
                      const int32_t* text_len_dev, int32_t B, int32_t max_len, int32_t d, int32_t nhead, int causal);
+
+/* The same attention for ONE new query per utterance against the head-major KV cache
+ * [B][H][ctx_max][dh] (element type T): the last row of F.multi_head_attention_forward under the
+ * prefix-LM mask of valle.py:1019-1033 (the new token sees cache slots 0 .. kv_len[b]).  The reference
+ * recomputes every row each step (valle.py:1004 TODO); this is the KV-cache form of that row.
+ *   q f32 [B][d]; kv_len_dev int32 [B] (slot of the newest key); nsplit in {1,2,4,8,16}
+ *   workspace f32 [B * nsplit * (d + 2 * nhead)]: the split partials (part_o [B][nsplit][d] then
+ *   part_ml [B][nhead][nsplit][2]), left there for vle_op_attn_out_proj
+ *   out f32 [B][d] or NULL: merged, normalised attention output */
+int vle_op_decode_attention(void* stream, int dtype, const float* q, const void* k_cache, const void* v_cache,
+                            const int32_t* kv_len_dev, float* workspace, float* out, int32_t B, int32_t nhead, int32_t dh,
+                            int32_t ctx_max, int32_t nsplit);
+/* out_proj of the AR step with the split merge fused in front (activation.py:421 `linear(attn_output,
+ * out_proj_weight, out_proj_bias)` + the residual add of transformer.py:297): resid[f32, B x d] +=
+ * merge(workspace) @ w[T, d x d]^T + bias; B <= 8. */
+int vle_op_attn_out_proj(void* stream, int dtype, const float* workspace, const void* w, const float* bias, float* resid,
+                         int32_t B, int32_t nhead, int32_t dh, int32_t nsplit);
 
 #ifdef __cplusplus
 }

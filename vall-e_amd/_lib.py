@@ -48,6 +48,8 @@ SIGNATURES = {
     "vle_op_linear": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_linear_skinny": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
+    "vle_op_decode_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
+    "vle_op_attn_out_proj": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
 }
 
 _lib = None

@@ -105,6 +105,40 @@ __device__ inline int wave_sum_i(int v) {
   return v;
 }
 
+// ---- DPP wave reductions --------------------------------------------------------------------
+// __shfl_xor lowers to ds_bpermute (an LDS-crossbar round trip per step); the AR-step kernels are
+// latency-bound chains, so their reductions use DPP row operations (VALU rate) for the 16-lane rows
+// and v_readlane for the four row totals.  Every lane gets the result; the add order is fixed.
+template <int CTRL>
+__device__ inline float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xf, 0xf, true));
+}
+__device__ inline float row16_sum_dpp(float v) {  // total of each 16-lane row, in every lane of the row
+  v += dpp_f32<0xB1>(v);   // quad_perm [1,0,3,2]
+  v += dpp_f32<0x4E>(v);   // quad_perm [2,3,0,1]
+  v += dpp_f32<0x141>(v);  // row_half_mirror
+  v += dpp_f32<0x140>(v);  // row_mirror
+  return v;
+}
+__device__ inline float row16_max_dpp(float v) {
+  v = fmaxf(v, dpp_f32<0xB1>(v));
+  v = fmaxf(v, dpp_f32<0x4E>(v));
+  v = fmaxf(v, dpp_f32<0x141>(v));
+  v = fmaxf(v, dpp_f32<0x140>(v));
+  return v;
+}
+__device__ inline float readlane_f32(float v, int l) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
+}
+__device__ inline float wave_sum_dpp(float v) {
+  v = row16_sum_dpp(v);
+  return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));
+}
+__device__ inline float wave_max_dpp(float v) {
+  v = row16_max_dpp(v);
+  return fmaxf(fmaxf(readlane_f32(v, 0), readlane_f32(v, 16)), fmaxf(readlane_f32(v, 32), readlane_f32(v, 48)));
+}
+
 // Block-wide sum for blockDim.x == NW*64; `red` is NW floats of LDS; all threads get the result.
 template <int NW>
 __device__ inline float block_sum(float v, float* red) {

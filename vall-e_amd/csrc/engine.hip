@@ -100,6 +100,9 @@ struct vle_engine {
   // per-kernel timing of the AR step with hipEvents on the engine stream (option "profile_kernels"):
   // forces eager launches; tags: 0 qkv, 1 decode-attention, 2 out-proj, 3 ffn1, 4 ffn2, 5 logits, 6 sample
   bool opt_profile = false;
+  bool opt_no_gemv1 = false;  // option "no_gemv1": force the generic skinny kernel at batch 1 (A/B measurements)
+  int opt_nsplit = 0;         // option "nsplit": 0 = chosen per batch
+  int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
   std::vector<int> prof_tags;
@@ -200,11 +203,31 @@ void build_pe(std::vector<float>& pe, int max_pos, int d) {
   }
 }
 
-int choose_nsplit(int B, int H) {
-  // spread the KV stream of a small batch over >= ~128-256 blocks
+int choose_nsplit(const vle_engine* e, int B) {
+  // spread the KV stream of a small batch over >= ~128-256 blocks, but never over more blocks than
+  // the context has key chunks (decode_attn.hip: a block owns fixed chunks of 16 wave-loads)
   int ns = 1;
-  while (ns < 16 && (int64_t)B * H * ns < 192) ns *= 2;
-  return ns;
+  while (ns < 16 && (int64_t)B * e->H * ns < 192) ns *= 2;
+  const int vec = e->dtype == DT_F32 ? 4 : 8;
+  int lpk = 1;
+  if (e->dh % vec == 0) while (lpk * vec < e->dh) lpk *= 2;
+  else while (lpk < e->dh) lpk *= 2;
+  const int chunk = 16 * (64 / lpk);
+  const int chunks = (e->ctx_max + chunk - 1) / chunk;
+  int cap = 1;
+  while (cap * 2 <= chunks) cap *= 2;
+  return std::min(ns, cap);
+}
+
+// batch 1: the wave-autonomous GEMV (gemv1.hip) when it has the shape, else the generic skinny kernel
+int launch_ar_linear(vle_engine* e, const SkinnyArgs& a) {
+  if (a.B == 1 && !e->opt_no_gemv1) {
+    SkinnyArgs t = a;
+    t.rpw_override = e->opt_rpw;
+    const int r = launch_gemv1(e->st, e->dtype, t);
+    if (r <= 0) return r;
+  }
+  return launch_skinny(e->st, e->dtype, a);
 }
 
 }  // namespace
@@ -463,6 +486,9 @@ static int alloc_buffers(vle_engine* e) {
   e->kcache = p;
   if ((r = dev_alloc(e, &p, kv_elems * es))) return r;
   e->vcache = p;
+  // decode_attn.hip reads (and masks) cache slots beyond the context: they must hold finite values
+  E_HIP(e, hipMemset(e->kcache, 0, kv_elems * es));
+  E_HIP(e, hipMemset(e->vcache, 0, kv_elems * es));
   if ((r = dev_alloc(e, &e->x_step, B * d))) return r;
   if ((r = dev_alloc(e, &e->q_step, B * d))) return r;
   if ((r = dev_alloc(e, &e->h_step, B * 4 * d))) return r;
@@ -598,7 +624,7 @@ int enqueue_ar_logits(vle_engine* e) {
     SkinnyArgs a;
     a.w = e->ar_predict; a.bias = nullptr; a.N = V_AR; a.K = e->d; a.B = e->B;
     a.pro = PRO_LN; a.epi = SEPI_STORE; a.x = e->x_step; a.gamma = e->ar_norm_g; a.beta = e->ar_norm_b; a.out = e->logits;
-    E_LAUNCH(e, launch_skinny(st, e->dtype, a));
+    E_LAUNCH(e, launch_ar_linear(e, a));
   } else {
     E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d));
     E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
@@ -631,7 +657,7 @@ int enqueue_ar_step(vle_engine* e) {
       a.w = w.wqkv; a.bias = w.bqkv; a.N = 3 * d; a.K = d; a.B = e->B; a.pro = PRO_LN; a.epi = SEPI_QKV;
       a.x = e->x_step; a.gamma = w.g1; a.beta = w.be1; a.q_out = e->q_step; a.k_cache = kc; a.v_cache = vc;
       a.kv_len = e->S.kv_len; a.ctx_max = e->ctx_max; a.nhead = e->H; a.dh = e->dh;
-      E_LAUNCH(e, launch_skinny(st, e->dtype, a));
+      E_LAUNCH(e, launch_ar_linear(e, a));
     } else {
       ProfScope ps(e, 0);
       E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
@@ -649,21 +675,21 @@ int enqueue_ar_step(vle_engine* e) {
         SkinnyArgs a;
         a.w = w.wo; a.bias = w.bo; a.N = d; a.K = d; a.B = e->B; a.pro = PRO_ATTN; a.epi = SEPI_RESID;
         a.part_o = e->part_o; a.part_ml = e->part_ml; a.nsplit = e->nsplit; a.nhead = e->H; a.dh = e->dh; a.resid = e->x_step;
-        E_LAUNCH(e, launch_skinny(st, e->dtype, a));
+        E_LAUNCH(e, launch_ar_linear(e, a));
       }
       {
         ProfScope ps(e, 3);
         SkinnyArgs f1;
         f1.w = w.w1; f1.bias = w.b1; f1.N = 4 * d; f1.K = d; f1.B = e->B; f1.pro = PRO_LN; f1.epi = SEPI_RELU;
         f1.x = e->x_step; f1.gamma = w.g2; f1.beta = w.be2; f1.out = e->h_step;
-        E_LAUNCH(e, launch_skinny(st, e->dtype, f1));
+        E_LAUNCH(e, launch_ar_linear(e, f1));
       }
       {
         ProfScope ps(e, 4);
         SkinnyArgs f2;
         f2.w = w.w2; f2.bias = w.b2; f2.N = d; f2.K = 4 * d; f2.B = e->B; f2.pro = PRO_PLAIN; f2.epi = SEPI_RESID;
         f2.x = e->h_step; f2.resid = e->x_step;
-        E_LAUNCH(e, launch_skinny(st, e->dtype, f2));
+        E_LAUNCH(e, launch_ar_linear(e, f2));
       }
     } else {
       {
@@ -722,7 +748,7 @@ extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, 
   hipStream_t st = e->st;
   e->B = B;
   e->have_prefill = e->have_gen = false;
-  e->nsplit = choose_nsplit(B, e->H);
+  e->nsplit = e->opt_nsplit > 0 ? e->opt_nsplit : choose_nsplit(e, B);
   e->S_len.assign(text_lens, text_lens + B);
   e->P_len.assign(prompt_lens, prompt_lens + B);
   E_HIP(e, hipEventRecord(e->ev_t[0], st));
@@ -1149,9 +1175,21 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
+  if (n == "no_gemv1" || n == "gemv1_rpw") {  // both change the captured kernels: drop the graphs
+    if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
+    else e->opt_rpw = (int)value;
+    (void)hipStreamSynchronize(e->st);
+    for (auto& kv : e->graphs) {
+      if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
+      if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+    }
+    e->graphs.clear();
+    return VLE_OK;
+  }
   if (n == "nsplit") {
-    if (value < 1 || value > 16) return e->fail(VLE_EINVAL, "nsplit must be 1..16");
-    e->nsplit = (int)value;
+    if (value < 0 || value > 16 || (value & (value - 1))) return e->fail(VLE_EINVAL, "nsplit must be 0 (auto), 1, 2, 4, 8 or 16");
+    e->opt_nsplit = (int)value;
+    if (value > 0) e->nsplit = (int)value;
     return VLE_OK;
   }
   return e->fail(VLE_EINVAL, "unknown option: " + n);

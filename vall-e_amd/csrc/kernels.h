@@ -35,7 +35,7 @@ struct SkinnyArgs {
   const float* x = nullptr;      // f32 [B][K]           (PRO_PLAIN / PRO_LN)
   const float* gamma = nullptr;  // f32 [K]              (PRO_LN)
   const float* beta = nullptr;
-  const float* part_o = nullptr; // f32 [B][H][nsplit][dh] (PRO_ATTN): un-normalised partial outputs
+  const float* part_o = nullptr; // f32 [B][nsplit][d] (PRO_ATTN): un-normalised partial outputs
   const float* part_ml = nullptr;// f32 [B][H][nsplit][2]  (running max, running sum)
   int nsplit = 1, nhead = 1, dh = 1;
   float* out = nullptr;          // f32 [B][N]           (SEPI_STORE / SEPI_RELU)
@@ -45,8 +45,11 @@ struct SkinnyArgs {
   void* v_cache = nullptr;
   const int32_t* kv_len = nullptr; // [B] slot the new token's K/V go to
   int ctx_max = 0;
+  int rpw_override = 0;          // tuning hook of the batch-1 path (rows per wave), 0 = heuristic
 };
 int launch_skinny(hipStream_t st, int dtype, const SkinnyArgs& a);
+// gemv1.hip: batch-1 wave-autonomous variant; returns 1 when the shape is not instantiated (use launch_skinny)
+int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a);
 
 // ---- attention.hip --------------------------------------------------------------------------
 // prefill (causal=1: prefix-LM mask) / NAR (causal=0) attention over packed sequences
@@ -55,7 +58,8 @@ int launch_attention(hipStream_t st, int dtype, const void* qkv, void* out, cons
 // copy K,V of packed prefill rows into the cache: cache[b][h][pos][e]
 int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache, void* v_cache, const int32_t* row_seq,
                       const int32_t* row_pos, int64_t rows, int d, int nhead, int ctx_max);
-// one new query per utterance against the KV cache; writes split partials
+// decode_attn.hip: one new query per utterance against the KV cache; writes split partials
+// part_o [B][nsplit][d], part_ml [B][H][nsplit][2]
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
                             int nsplit);

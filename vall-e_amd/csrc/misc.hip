@@ -40,16 +40,16 @@ __global__ __launch_bounds__(256) void attn_combine_kernel(const float* __restri
   const int b = blockIdx.x;
   const int d = nhead * dh;
   for (int i = threadIdx.x; i < d; i += 256) {
-    const int h = i / dh, e = i - h * dh;
+    const int h = i / dh;
     const float* ml = part_ml + ((int64_t)(b * nhead + h) * ns) * 2;
-    const float* po = part_o + ((int64_t)(b * nhead + h) * ns) * dh + e;
+    const float* po = part_o + (int64_t)b * ns * d + i;  // [B][nsplit][d]
     float m = -1e30f;
     for (int s = 0; s < ns; ++s) m = fmaxf(m, ml[2 * s]);
     float l = 0.f, o = 0.f;
     for (int s = 0; s < ns; ++s) {
       const float f = expf(ml[2 * s] - m);
       l += ml[2 * s + 1] * f;
-      o += po[(int64_t)s * dh] * f;
+      o += po[(int64_t)s * d] * f;
     }
     store_elem<T>(out + (int64_t)b * d + i, o / l);
   }

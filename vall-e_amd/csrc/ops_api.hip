@@ -44,6 +44,10 @@ extern "C" int vle_op_linear_skinny(void* stream, int dtype, const float* x, con
   a.out = out; a.resid = resid;
   if (a.epi == SEPI_RESID ? !resid : !out) return op_fail("vle_op_linear_skinny: missing output");
   if (a.pro == PRO_LN && a.epi == SEPI_RESID) return op_fail("vle_op_linear_skinny: LN + residual is not instantiated");
+  if (M == 1) {  // batch 1 runs on the wave-autonomous GEMV when it has the shape (as the engine does)
+    const int r = launch_gemv1((hipStream_t)stream, dtype, a);
+    if (r <= 0) return op_done(r, "vle_op_linear_skinny");
+  }
   return op_done(launch_skinny((hipStream_t)stream, dtype, a), "vle_op_linear_skinny");
 }
 
@@ -52,4 +56,35 @@ extern "C" int vle_op_attention(void* stream, int dtype, const void* qkv, void* 
   if (!qkv || !out || !seq_off_dev || !text_len_dev || nhead < 1 || d % nhead) return op_fail("vle_op_attention: bad argument");
   return op_done(launch_attention((hipStream_t)stream, dtype, qkv, out, seq_off_dev, text_len_dev, B, max_len, d, nhead, causal),
                  "vle_op_attention");
+}
+
+extern "C" int vle_op_decode_attention(void* stream, int dtype, const float* q, const void* k_cache, const void* v_cache,
+                                       const int32_t* kv_len_dev, float* workspace, float* out, int32_t B, int32_t nhead,
+                                       int32_t dh, int32_t ctx_max, int32_t nsplit) {
+  if (!q || !k_cache || !v_cache || !kv_len_dev || !workspace || B < 1 || nhead < 1 || dh < 1 || ctx_max < 1)
+    return op_fail("vle_op_decode_attention: bad argument");
+  if (nsplit < 1 || nsplit > 16 || (nsplit & (nsplit - 1))) return op_fail("vle_op_decode_attention: nsplit must be 1, 2, 4, 8 or 16");
+  const int64_t d = (int64_t)nhead * dh;
+  float* part_o = workspace;
+  float* part_ml = workspace + (int64_t)B * nsplit * d;
+  int r = launch_decode_attention((hipStream_t)stream, dtype, q, k_cache, v_cache, kv_len_dev, part_o, part_ml, B, nhead, dh, ctx_max,
+                                  nsplit);
+  if (r == 0 && out) r = launch_attn_combine((hipStream_t)stream, DT_F32, part_o, part_ml, out, B, nhead, dh, nsplit);
+  return op_done(r, "vle_op_decode_attention");
+}
+
+extern "C" int vle_op_attn_out_proj(void* stream, int dtype, const float* workspace, const void* w, const float* bias,
+                                    float* resid, int32_t B, int32_t nhead, int32_t dh, int32_t nsplit) {
+  if (!workspace || !w || !resid || B < 1 || B > 8 || nhead < 1 || dh < 1) return op_fail("vle_op_attn_out_proj: bad argument");
+  if (nsplit < 1 || nsplit > 16 || (nsplit & (nsplit - 1))) return op_fail("vle_op_attn_out_proj: nsplit must be 1, 2, 4, 8 or 16");
+  const int d = nhead * dh;
+  SkinnyArgs a;
+  a.w = w; a.bias = bias; a.N = d; a.K = d; a.B = B; a.pro = PRO_ATTN; a.epi = SEPI_RESID;
+  a.part_o = workspace; a.part_ml = workspace + (int64_t)B * nsplit * d; a.nsplit = nsplit; a.nhead = nhead; a.dh = dh;
+  a.resid = resid;
+  if (B == 1) {
+    const int r = launch_gemv1((hipStream_t)stream, dtype, a);
+    if (r <= 0) return op_done(r, "vle_op_attn_out_proj");
+  }
+  return op_done(launch_skinny((hipStream_t)stream, dtype, a), "vle_op_attn_out_proj");
 }

@@ -93,16 +93,16 @@ __global__ __launch_bounds__(SK_T) void skinny_kernel(SkinnyArgs a) {
       for (int i = tid; i < K; i += SK_T) {
         float val = 0.f;
         if (b < a.B) {
-          const int h = i / dh, e = i - h * dh;
+          const int h = i / dh;
           const float* ml = a.part_ml + ((int64_t)(b * H + h) * ns) * 2;
-          const float* po = a.part_o + ((int64_t)(b * H + h) * ns) * dh + e;
+          const float* po = a.part_o + (int64_t)b * ns * K + i;  // [B][nsplit][d]
           float m = -1e30f;
           for (int s = 0; s < ns; ++s) m = fmaxf(m, ml[2 * s]);
           float l = 0.f, o = 0.f;
           for (int s = 0; s < ns; ++s) {
             const float f = expf(ml[2 * s] - m);
             l += ml[2 * s + 1] * f;
-            o += po[(int64_t)s * dh] * f;
+            o += po[(int64_t)s * K] * f;
           }
           val = o / l;
         }

@@ -93,3 +93,33 @@ def attention(qkv: torch.Tensor, seq_off: torch.Tensor, text_len: torch.Tensor, 
     out = torch.empty(rows, d, dtype=qkv.dtype, device=qkv.device)
     _lib.check(lib.vle_op_attention(_st(qkv), _dt(qkv), _p(qkv), _p(out), _p(so), _p(tl), B, int(lens.max()), d, nhead, int(causal)))
     return out
+
+
+def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: torch.Tensor, nsplit: int = 1,
+                     merged: bool = True):
+    """One new query per utterance against the head-major KV cache.
+    q fp32 (B, H*dh); k_cache/v_cache (B, H, ctx_max, dh) fp32|bf16; kv_len int32 (B,) = slot of the newest key.
+    Returns (out fp32 (B, d) or None, workspace) -- the workspace holds the split partials for attn_out_proj."""
+    lib = _lib.load()
+    q, k_cache, v_cache = q.contiguous(), k_cache.contiguous(), v_cache.contiguous()
+    assert q.dtype == torch.float32 and k_cache.dtype == v_cache.dtype and k_cache.shape == v_cache.shape
+    B, H, ctx_max, dh = k_cache.shape
+    d = H * dh
+    ws = torch.empty(B * nsplit * (d + 2 * H), dtype=torch.float32, device=q.device)
+    out = torch.empty(B, d, dtype=torch.float32, device=q.device) if merged else None
+    kl = kv_len.to(torch.int32).contiguous()
+    _lib.check(lib.vle_op_decode_attention(_st(q), _dt(k_cache), _p(q), _p(k_cache), _p(v_cache), _p(kl), _p(ws), _p(out), B, H, dh,
+                                           ctx_max, nsplit))
+    return out, ws
+
+
+def attn_out_proj(ws: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], resid: torch.Tensor, nhead: int,
+                  nsplit: int) -> torch.Tensor:
+    """resid (B, d) fp32 += merge(split partials in ws) @ w.T + bias  -- out_proj of the AR step."""
+    lib = _lib.load()
+    w = w.contiguous()
+    B, d = resid.shape
+    assert resid.dtype == torch.float32 and resid.is_contiguous() and w.shape == (d, d)
+    b = None if bias is None else bias.contiguous()
+    _lib.check(lib.vle_op_attn_out_proj(_st(resid), _dt(w), _p(ws), _p(w), _p(b), _p(resid), B, nhead, d // nhead, nsplit))
+    return resid

@@ -76,7 +76,7 @@ def main():
     ap.add_argument("--nhead", type=int, default=16)
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--top-k", type=int, default=1, help="1 = the reference's greedy; -100 = pure multinomial")
-    ap.add_argument("--cpu-frames", type=int, default=24, help="frames of the bounded CPU-baseline sample (0 = skip)")
+    ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--profile-kernels", type=int, default=0, help="extra untimed pass: hipEvent time per AR-step kernel family over n steps")
     args = ap.parse_args()

@@ -31,13 +31,12 @@ def main():
     Y = torch.stack([synth_inputs(b)[1] for b in range(B)]).to(dev)
     variants = [
         ("default", {}),
+        ("nsplit1", {"nsplit": 1}),
+        ("nsplit2", {"nsplit": 2}),
         ("nsplit4", {"nsplit": 4}),
         ("nsplit8", {"nsplit": 8}),
         ("nsplit16", {"nsplit": 16}),
-        ("rpw1", {"gemv1_rpw": 1}),
-        ("rpw2", {"gemv1_rpw": 2}),
-        ("rpw4", {"gemv1_rpw": 4}),
-        ("skinny_v0", {"no_gemv1": 1}),
+        ("ns4_rpw2", {"nsplit": 4, "gemv1_rpw": 2}),
     ]
     res = {name: [] for name, _ in variants}
     for r in range(args.rounds):

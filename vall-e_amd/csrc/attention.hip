@@ -125,6 +125,8 @@ int launch_attention(hipStream_t st, int dtype, const void* qkv, void* out, cons
                      int B, int max_len, int d, int nhead, int causal) {
   if (B <= 0 || max_len <= 0) return 0;
   if (dtype == DT_F32) return attention_dispatch<float>(st, qkv, out, seq_off, text_len, B, max_len, d, nhead, causal);
+  // bf16: the MFMA flash kernel (attn_mfma.hip) when it has the head size
+  if (launch_attention_mfma(st, qkv, out, seq_off, text_len, B, max_len, d, nhead, causal) == 0) return 0;
   return attention_dispatch<bf16_t>(st, qkv, out, seq_off, text_len, B, max_len, d, nhead, causal);
 }
 

@@ -207,7 +207,7 @@ int choose_nsplit(const vle_engine* e, int B) {
   // spread the KV stream of a small batch over >= ~128-256 blocks, but never over more blocks than
   // the context has key chunks (decode_attn.hip: a block owns fixed chunks of 16 wave-loads)
   int ns = 1;
-  while (ns < 16 && (int64_t)B * e->H * ns < 192) ns *= 2;
+  while (ns < 16 && (int64_t)B * e->H * ns < 64) ns *= 2;  // measured at B=1, H=16: 4 splits best (op_chain_bench)
   const int vec = e->dtype == DT_F32 ? 4 : 8;
   int lpk = 1;
   if (e->dh % vec == 0) while (lpk * vec < e->dh) lpk *= 2;

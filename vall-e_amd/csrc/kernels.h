@@ -55,6 +55,9 @@ int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a);
 // prefill (causal=1: prefix-LM mask) / NAR (causal=0) attention over packed sequences
 int launch_attention(hipStream_t st, int dtype, const void* qkv, void* out, const int32_t* seq_off,
                      const int32_t* text_len, int B, int max_len, int d, int nhead, int causal);
+// attn_mfma.hip: bf16 MFMA flash kernel, dh in {32,64,96,128}; returns 1 when the head size is not covered
+int launch_attention_mfma(hipStream_t st, const void* qkv, void* out, const int32_t* seq_off, const int32_t* text_len, int B,
+                          int max_len, int d, int nhead, int causal);
 // copy K,V of packed prefill rows into the cache: cache[b][h][pos][e]
 int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache, void* v_cache, const int32_t* row_seq,
                       const int32_t* row_pos, int64_t rows, int d, int nhead, int ctx_max);

@@ -183,6 +183,8 @@ int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const f
                 int64_t M, int N, int K, int epi) {
   if (M <= 0 || N <= 0) return 0;
   if (dtype == DT_F32) return gemm_dispatch<float>(st, A, W, bias, out, resid, M, N, K, epi);
+  // bf16: the LDS-DMA pipelined kernel (gemm_glds.hip) when it has the shape
+  if (launch_gemm_glds(st, A, W, bias, out, resid, M, N, K, epi) == 0) return 0;
   return gemm_dispatch<bf16_t>(st, A, W, bias, out, resid, M, N, K, epi);
 }
 

@@ -1,0 +1,265 @@
+// bf16 GEMM of the prefill and the 7 NAR passes on the LDS-DMA path:
+//   out = epi(A[M x K] @ W[N x K]^T + bias)      (same contract and epilogues as gemm.hip)
+//   reference ops: in-proj / out-proj `linear` (valle/modules/activation.py:414-421), FFN
+//   linear1/linear2 (valle/modules/transformer.py:332-334), nar_predict_layers (valle.py:1128).
+//
+// Why a second GEMM: at M ~ 1 k rows (one utterance: text + prompt + generated frames) a GEMM is
+// one tile per CU, i.e. one 4-wave workgroup per CU with nothing else to hide latency.  gemm.hip
+// keeps ONE k-step of global loads in flight through registers, so every 64-deep k-step pays a
+// full L2/HBM round trip (measured 60-140 TF).  Here the tiles go global -> LDS directly
+// (global_load_lds_dwordx4, no VGPR round trip) into a ring of STAGES buffers with STAGES-1
+// k-steps in flight; the wait is a counted s_waitcnt vmcnt(N) + raw s_barrier (a __syncthreads()
+// would drain the DMA queue), one barrier per k-step.
+//   * LDS image of a stage: rows x 128 B (64 bf16 of K), 16-byte slot c of row r holds global
+//     vector c ^ (r & 7): LDS-DMA writes lane-linearly (wave base + lane*16), so the swizzle is
+//     applied on the SOURCE address and again on the ds_read_b128 side (same involution);
+//   * v_mfma_f32_16x16x32_bf16, 4 waves as 2 x 2, wave tile (BM/2) x (BN/2);
+//   * 16-row fragments that lie entirely beyond M skip their MFMAs (M = 1025 leaves a 1-row tail tile);
+//   * XCD-aware tile order as in gemm.hip.
+#include "common.h"
+#include "kernels.h"
+
+namespace vle {
+
+typedef __bf16 gg_bf16x8 __attribute__((ext_vector_type(8)));
+typedef float gg_f32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 gg_bf16x4 __attribute__((ext_vector_type(4)));
+
+template <int N>
+__device__ inline void gg_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int BM, int BN, int EPI>
+__global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                        const float* __restrict__ bias, void* __restrict__ out_,
+                                                        float* __restrict__ resid, int64_t M, int N, int K) {
+  constexpr int STAGE_BYTES = (BM + BN) * 128;
+  constexpr int STAGES = (4 * STAGE_BYTES <= 144 * 1024) ? 4 : 3;
+  constexpr int D = STAGES - 1;                 // k-steps in flight
+  constexpr int NIA = BM / 32, NIB = BN / 32;   // LDS-DMA instructions per wave per stage (8 rows each)
+  constexpr int NI = NIA + NIB;
+  constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches / LDS bases
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int nbx = gridDim.x, nby = gridDim.y;
+  const int nblk = nbx * nby;
+  int bid = blockIdx.y * nbx + blockIdx.x;
+  {
+    // XCD-aware order over the full-height tiles (block b runs on XCD b % 8: give each XCD a contiguous
+    // run of tiles sharing W panels in its L2); the cheap tail-row tiles keep the highest ids so they
+    // are dispatched last, behind the first round of full tiles
+    const int nfull = (int)(M / BM) * nbx;
+    const int nr = bid < nfull ? nfull : nblk;
+    if (bid < nfull || nfull == 0) {
+      const int q = nr / 8, r = nr % 8, xcd = bid % 8, idx = bid / 8;
+      bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+  }
+  const int64_t m0 = (int64_t)(bid / nbx) * BM;
+  const int n0 = (bid % nbx) * BN;
+
+  // per-lane source of the DMA pieces: piece p of a wave covers tile rows (p*4 + wave)*8 .. +8;
+  // lane -> (row = lane>>3, slot = lane&7), source vector = slot ^ (row & 7)
+  const int prow = lane >> 3;
+  const int pvec = (lane & 7) ^ prow;  // (row0 + prow) & 7 == prow because row0 % 8 == 0
+  const unsigned char* srcA[NIA];
+  const unsigned char* srcB[NIB];
+#pragma unroll
+  for (int p = 0; p < NIA; ++p) {
+    int64_t gm = m0 + (p * 4 + wave) * 8 + prow;
+    gm = gm < M ? gm : M - 1;
+    srcA[p] = reinterpret_cast<const unsigned char*>(A + gm * K) + pvec * 16;
+  }
+#pragma unroll
+  for (int p = 0; p < NIB; ++p) {
+    int gn = n0 + (p * 4 + wave) * 8 + prow;
+    gn = gn < N ? gn : N - 1;
+    srcB[p] = reinterpret_cast<const unsigned char*>(W + (int64_t)gn * K) + pvec * 16;
+  }
+  auto issue = [&](int kt) {
+    unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
+#pragma unroll
+    for (int p = 0; p < NIA; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[p] + (int64_t)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(st + (p * 4 + wave) * 1024), 16, 0, 0);
+#pragma unroll
+    for (int p = 0; p < NIB; ++p)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[p] + (int64_t)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(st + BM * 128 + (p * 4 + wave) * 1024), 16, 0, 0);
+  };
+
+  const int fr = lane & 15, fg = lane >> 4;
+  // bias of this lane's 4 consecutive output columns per n-fragment: requested first (ahead of the
+  // DMA queue, so its wait never drains the pipeline), clamped address, consumed in the epilogue
+  gg_f32x4 bias4[FN];
+#pragma unroll
+  for (int j = 0; j < FN; ++j) {
+    const int n = min(n0 + wn0 + j * 16 + fg * 4, N - 4);
+    bias4[j] = bias != nullptr ? *reinterpret_cast<const gg_f32x4*>(bias + n) : gg_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  gg_f32x4 acc[FM][FN];
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) acc[i][j] = gg_f32x4{0.f, 0.f, 0.f, 0.f};
+  // 16-row fragments of this wave with at least one row < M (wave-uniform; < FM only in the tail tile)
+  int nlive = (int)((M - (m0 + wm0) + 15) / 16);
+  nlive = nlive < 0 ? 0 : (nlive > FM ? FM : nlive);
+
+  const int KT = K / 64;
+#pragma unroll
+  for (int s = 0; s < D; ++s)
+    if (s < KT) issue(s);
+
+  for (int kt = 0; kt < KT; ++kt) {
+    // tile kt has landed once at most min(D-1, KT-1-kt) younger tiles of this wave are outstanding
+    const int younger = KT - 1 - kt;
+    if (younger >= D - 1) gg_wait_vm<(D - 1) * NI>();
+    else if (D >= 3 && younger == 1) gg_wait_vm<NI>();
+    else gg_wait_vm<0>();
+    __builtin_amdgcn_s_barrier();  // every wave's pieces of tile kt landed; everyone finished reading tile kt-1
+    if (kt + D < KT) issue(kt + D);  // into the buffer of tile kt-1
+
+    const unsigned char* As = smem + (kt % STAGES) * STAGE_BYTES;
+    const unsigned char* Bs = As + BM * 128;
+    if (nlive == FM) {
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        gg_bf16x8 af[FM], bfr[FN];
+        const int c = ks * 4 + fg;
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          const int row = wm0 + i * 16 + fr;
+          af[i] = *reinterpret_cast<const gg_bf16x8*>(As + row * 128 + ((c ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int row = wn0 + j * 16 + fr;
+          bfr[j] = *reinterpret_cast<const gg_bf16x8*>(Bs + row * 128 + ((c ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i)
+#pragma unroll
+          for (int j = 0; j < FN; ++j)  // W fragment as the A operand: C^T, see the epilogue
+            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+      }
+    } else if (nlive > 0) {  // tail tile (rows beyond M): only fragment rows that exist
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) {
+        const int c = ks * 4 + fg;
+        gg_bf16x8 bfr[FN];
+#pragma unroll
+        for (int j = 0; j < FN; ++j) {
+          const int row = wn0 + j * 16 + fr;
+          bfr[j] = *reinterpret_cast<const gg_bf16x8*>(Bs + row * 128 + ((c ^ (row & 7)) << 4));
+        }
+#pragma unroll
+        for (int i = 0; i < FM; ++i) {
+          if (i < nlive) {
+            const int row = wm0 + i * 16 + fr;
+            const gg_bf16x8 a = *reinterpret_cast<const gg_bf16x8*>(As + row * 128 + ((c ^ (row & 7)) << 4));
+#pragma unroll
+            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], a, acc[i][j], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // epilogue.  The MFMAs above compute C^T (W fragment as the A operand), so lane (fg, fr) holds
+  // C[m = 16 i + fr][n = 16 j + 4 fg + r], r = 0..3: four CONSECUTIVE columns of one row -> one 8-byte
+  // (bf16) or 16-byte (fp32) access per fragment instead of four scattered 2-byte stores.  N % 4 == 0.
+  // Values are finished in one straight-line block (a single wait for the bias / residual loads);
+  // the conditional blocks contain only the memory instructions, so no store waits for another.
+  const bool full = m0 + BM <= M && n0 + BN <= N;  // block-uniform: no per-element bounds checks
+  if constexpr (EPI == EPI_RESID) {
+    gg_f32x4 old[FM][FN];
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int64_t m = m0 + wm0 + i * 16 + fr;
+        const int n = n0 + wn0 + j * 16 + fg * 4;
+        old[i][j] = gg_f32x4{0.f, 0.f, 0.f, 0.f};
+        if (full || (m < M && n < N)) old[i][j] = *reinterpret_cast<const gg_f32x4*>(resid + m * N + n);
+      }
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) acc[i][j] = old[i][j] + (acc[i][j] + bias4[j]);
+  } else {
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        acc[i][j] += bias4[j];
+        if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
+        }
+      }
+  }
+  // pin the finished values here: without this the compiler sinks the adds (and their vmcnt(0)) into
+  // every conditional store block, where each wait also drains the previous store
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) asm volatile("" : "+v"(acc[i][j]));
+#pragma unroll
+  for (int i = 0; i < FM; ++i)
+#pragma unroll
+    for (int j = 0; j < FN; ++j) {
+      const int64_t m = m0 + wm0 + i * 16 + fr;
+      const int n = n0 + wn0 + j * 16 + fg * 4;
+      if (full || (m < M && n < N)) {
+        if constexpr (EPI == EPI_RESID) {
+          *reinterpret_cast<gg_f32x4*>(resid + m * N + n) = acc[i][j];
+        } else if constexpr (EPI == EPI_F32) {
+          *reinterpret_cast<gg_f32x4*>(reinterpret_cast<float*>(out_) + m * N + n) = acc[i][j];
+        } else {
+          gg_bf16x4 o4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o4[r] = (__bf16)acc[i][j][r];  // v_cvt_pk_bf16_f32: round-to-nearest-even
+          *reinterpret_cast<gg_bf16x4*>(reinterpret_cast<bf16_t*>(out_) + m * N + n) = o4;
+        }
+      }
+    }
+}
+
+template <int BM, int BN>
+static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const float* bias, void* out, float* resid, int64_t M,
+                     int N, int K, int epi) {
+  const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM)), block(256);
+#define VLE_GG(E) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E>), grid, block, 0, st, A, W, bias, out, resid, M, N, K)
+  switch (epi) {
+    case EPI_STORE: VLE_GG(EPI_STORE); break;
+    case EPI_RELU: VLE_GG(EPI_RELU); break;
+    case EPI_RESID: VLE_GG(EPI_RESID); break;
+    case EPI_F32: VLE_GG(EPI_F32); break;
+    default: return -1;
+  }
+#undef VLE_GG
+  return 0;
+}
+
+// returns 0 = launched, 1 = shape not covered (caller uses gemm.hip)
+int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
+                     int K, int epi) {
+  if (K % 64 != 0 || K < 64 || M < 1 || N < 1 || N % 4 != 0) return 1;
+  if (M < 128) return 1;  // tiny-M launches (AR step at batch > 8) stay on gemm.hip for now
+  // tile choice: estimated time ~ rounds of full-cost tiles over 256 CUs x per-tile cost (~ BM*BN/eff)
+  const int64_t full128 = (M / 128) * ((N + 127) / 128) + ((M % 128) ? ((N + 127) / 128) : 0);
+  const int64_t t128x64 = ((M + 127) / 128) * ((N + 63) / 64);
+  const bf16_t* a = (const bf16_t*)A;
+  const bf16_t* w = (const bf16_t*)W;
+  if (full128 >= 160) return gg_launch<128, 128>(st, a, w, bias, out, resid, M, N, K, epi);
+  if (t128x64 >= 96) return gg_launch<128, 64>(st, a, w, bias, out, resid, M, N, K, epi);
+  return gg_launch<64, 64>(st, a, w, bias, out, resid, M, N, K, epi);
+}
+
+}  // namespace vle

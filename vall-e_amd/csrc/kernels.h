@@ -24,6 +24,10 @@ enum { EPI_STORE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_F32 = 3 };
 int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const float* bias, void* out, float* resid,
                 int64_t M, int N, int K, int epi);
 
+// gemm_glds.hip: bf16, M >= 128, K % 64 == 0: LDS-DMA multi-stage pipeline; returns 1 when the shape is not covered
+int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
+                     int K, int epi);
+
 // ---- skinny.hip (AR-step weight-streaming GEMV, M = batch <= 8) --------------------------------
 enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2 };
 enum { SEPI_STORE = 0, SEPI_RELU = 1, SEPI_RESID = 2, SEPI_QKV = 3 };

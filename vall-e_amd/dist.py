@@ -55,7 +55,8 @@ def gather_codes(local: Sequence[torch.Tensor], n_total: int, Q: int = 8, device
         buf[i, 0, 0] = t.shape[0]  # header row: length
         buf[i, 1 : 1 + t.shape[0]] = t.to(device=device, dtype=torch.int16)
     out = torch.empty((world,) + tuple(buf.shape), dtype=torch.int16, device=device)
-    dist.all_gather_into_tensor(out.view(world * per_rank, gmax + 1, Q), buf)
+    # neither NCCL/RCCL nor gloo has an int16 collective type: ship the same bytes as uint8
+    dist.all_gather_into_tensor(out.view(world * per_rank, gmax + 1, Q).view(torch.uint8), buf.view(torch.uint8))
     res: List[torch.Tensor] = []
     for r in range(world):
         lo, hi = shard_range(n_total, r, world)

@@ -205,7 +205,7 @@ class VALLE(nn.Module):
         enroll_x_lens: Optional[torch.Tensor] = None,
         top_k: int = -100,
         temperature: float = 1.0,
-        seed: int = 0,
+        seed: Optional[int] = None,
     ) -> torch.Tensor:
         assert x.ndim == 2, x.shape
         assert x_lens.ndim == 1, x_lens.shape
@@ -225,7 +225,7 @@ class VALLE(nn.Module):
         enroll_x_lens: Optional[torch.Tensor] = None,
         top_k: int = -100,
         temperature: float = 1.0,
-        seed: int = 0,
+        seed: Optional[int] = None,
         max_new: int = 0,
     ) -> List[torch.Tensor]:
         """B independent utterances (the reference is batch-1, valle.py:989): returns a list of
@@ -235,6 +235,10 @@ class VALLE(nn.Module):
         yl = [int(v) for v in y_lens]
         eng = self.engine_for(B, max(xl), max(yl))
         dev = eng.device
+        if seed is None:
+            # the reference samples from torch's global generator (valle.py:1301): draw the engine's RNG seed
+            # from it, so torch.manual_seed() makes sampled decodes reproducible and successive calls differ
+            seed = 0 if top_k == 1 else int(torch.randint(0, 2**62, (1,)).item())
         eng.prefill(x.to(dev, torch.int64), xl, y.to(dev, torch.int64)[..., : self.num_quantizers], yl)
         try:
             _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new)

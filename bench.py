@@ -30,6 +30,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 S_TEXT, P_PROMPT = 47, 225  # 47 phonemes, 3 s x 75 Hz prompt
+PMC_STEP_BYTES = 351_600_000  # (2 x FETCH_SIZE + WRITE_SIZE) KB summed over the 62 kernels of one AR step, mean context
 
 
 def synth_inputs(index: int, S: int = S_TEXT, P: int = P_PROMPT):
@@ -191,7 +192,10 @@ def main():
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                "traffic": None,
+                # HBM bytes per AR step from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
+                # FETCH_SIZE doubled per the gfx950 correction): profiles/r01_s2_pmc_*_by_kernel.csv, profiles/README.md.
+                # Measured for the default workload only (C2, batch 1, bf16).
+                "traffic": PMC_STEP_BYTES if (B == 1 and args.dtype == "bf16" and args.d_model == 1024 and args.layers == 12) else None,
                 "launch_us": round(step_ms * 1e3, 2),
                 "bytes_per_launch": int(ar_bytes / max(ar_steps, 1)),
                 "launches": ar_steps,

@@ -31,19 +31,18 @@ def main():
     Y = torch.stack([synth_inputs(b)[1] for b in range(B)]).to(dev)
     variants = [
         ("default", {}),
-        ("nsplit1", {"nsplit": 1}),
-        ("nsplit2", {"nsplit": 2}),
-        ("nsplit4", {"nsplit": 4}),
-        ("nsplit8", {"nsplit": 8}),
-        ("nsplit16", {"nsplit": 16}),
-        ("ns4_rpw2", {"nsplit": 4, "gemv1_rpw": 2}),
+        ("ns4_nk4", {"nsplit": 4, "attn_nk": 4}),
+        ("ns4_nk8", {"nsplit": 4, "attn_nk": 8}),
+        ("ns8_nk4", {"nsplit": 8, "attn_nk": 4}),
+        ("ns2_nk8", {"nsplit": 2, "attn_nk": 8}),
+        ("spg32", {"steps_per_graph": 32}),
+        ("spg2", {"steps_per_graph": 2}),
     ]
     res = {name: [] for name, _ in variants}
     for r in range(args.rounds):
         for name, opts in variants:
-            eng.set_option("nsplit", 0)
-            eng.set_option("gemv1_rpw", 0)
-            eng.set_option("no_gemv1", 0)
+            for k in ("nsplit", "gemv1_rpw", "no_gemv1", "attn_nk", "steps_per_graph"):
+                eng.set_option(k, 0)
             for k, v in opts.items():
                 eng.set_option(k, v)
             for rep in range(2):  # first pass (re)captures the graph
@@ -51,7 +50,6 @@ def main():
                 eng.generate(top_k=1, max_new=args.steps)
             tm = eng.timings()
             res[name].append(tm["ar_ms"] * 1e3 / max(tm["ar_steps"], 1))
-    eng.set_option("nsplit", 0); eng.set_option("gemv1_rpw", 0); eng.set_option("no_gemv1", 0)
     print(json.dumps({k: [round(x, 2) for x in v] for k, v in res.items()}))
 
 

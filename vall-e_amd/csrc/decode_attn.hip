@@ -54,22 +54,34 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   const T* Kb = kc + ((int64_t)b * nhead + h) * ctx_max * dh + (active ? part * VEC : 0);
   const T* Vb = vc + ((int64_t)b * nhead + h) * ctx_max * dh + (active ? part * VEC : 0);
 
-  float kf[NK][VEC], vf[NK][VEC];
+  constexpr bool kVec = VEC * sizeof(T) == 16;
+  uint4 kraw[kVec ? NK : 1], vraw[kVec ? NK : 1];  // 16-byte vectors stay raw until they are consumed
+  float kf1[kVec ? 1 : NK][VEC], vf1[kVec ? 1 : NK][VEC];
   auto issue = [&](int base) {  // loads of the NK keys base + w*WCH + i*KPW + slot (clamped into the cache)
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       int key = base + w * WCH + i * KPW + slot;
       key = key < ctx_max ? key : ctx_max - 1;
-      if constexpr (VEC * sizeof(T) == 16) {
-        load_vec16<T>(Kb + (int64_t)key * dh, kf[i]);
-        load_vec16<T>(Vb + (int64_t)key * dh, vf[i]);
+      if constexpr (kVec) {
+        kraw[i] = *reinterpret_cast<const uint4*>(Kb + (int64_t)key * dh);
+        vraw[i] = *reinterpret_cast<const uint4*>(Vb + (int64_t)key * dh);
       } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
-          kf[i][j] = Elem<T>::to_f32(Kb[(int64_t)key * dh + j]);
-          vf[i][j] = Elem<T>::to_f32(Vb[(int64_t)key * dh + j]);
+          kf1[i][j] = Elem<T>::to_f32(Kb[(int64_t)key * dh + j]);
+          vf1[i][j] = Elem<T>::to_f32(Vb[(int64_t)key * dh + j]);
         }
       }
+    }
+  };
+  auto widen = [&](const uint4& r, float (&f)[VEC]) {
+    if constexpr (sizeof(T) == 4) {
+      f[0] = __uint_as_float(r.x); f[1 % VEC] = __uint_as_float(r.y); f[2 % VEC] = __uint_as_float(r.z); f[3 % VEC] = __uint_as_float(r.w);
+    } else {
+      f[0] = __uint_as_float(r.x << 16); f[1 % VEC] = __uint_as_float(r.x & 0xffff0000u);
+      f[2 % VEC] = __uint_as_float(r.y << 16); f[3 % VEC] = __uint_as_float(r.y & 0xffff0000u);
+      f[4 % VEC] = __uint_as_float(r.z << 16); f[5 % VEC] = __uint_as_float(r.z & 0xffff0000u);
+      f[6 % VEC] = __uint_as_float(r.w << 16); f[7 % VEC] = __uint_as_float(r.w & 0xffff0000u);
     }
   };
 
@@ -91,9 +103,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
     float mx = DA_NEG;
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
+      float kf[VEC];
+      if constexpr (kVec) widen(kraw[i], kf);
+      else {
+#pragma unroll
+        for (int j = 0; j < VEC; ++j) kf[j] = kf1[i][j];
+      }
       float t = 0.f;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], kf[i][j], t);
+      for (int j = 0; j < VEC; ++j) t = fmaf(qv[j], kf[j], t);
       t = group_sum<LPK>(active ? t : 0.f) * scale;
       const int key = base + w * WCH + i * KPW + slot;
       sc[i] = key < ctx ? t : DA_NEG;
@@ -109,8 +127,14 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
       const int key = base + w * WCH + i * KPW + slot;
       const float p = key < ctx ? __expf(sc[i] - mn) : 0.f;
       l += p;
+      float vf[VEC];
+      if constexpr (kVec) widen(vraw[i], vf);
+      else {
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vf[i][j], acc[j]);
+        for (int j = 0; j < VEC; ++j) vf[j] = vf1[i][j];
+      }
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] = fmaf(p, vf[j], acc[j]);
     }
     m = mn;
     base += nsplit * CHUNK;
@@ -158,14 +182,26 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
 
 template <typename T>
 static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const void* vc, const int32_t* kv_len, float* part_o,
-                           float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit) {
+                           float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit, int nk_override) {
   constexpr int VFULL = Elem<T>::VEC;
-  constexpr int NK = 4;
   if (dh > 254) return -1;
   const dim3 grid(nhead, nsplit, B), block(256);
-#define VLE_DA(VEC, LPK)                                                                                                  \
-  hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, NK>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
-                     part_ml, nhead, dh, ctx_max, nsplit)
+  // keys per lane per round: 4 by default, 8 on request (option "attn_nk")
+  int lpk = 1;
+  if (dh % VFULL == 0) while (lpk * VFULL < dh) lpk *= 2;
+  else while (lpk < dh) lpk *= 2;
+  const int keys4 = nsplit * 16 * (64 / lpk);
+  (void)keys4;
+  const bool nk8 = nk_override == 8;  // measured (tools/ar_tune.py, C2 batch 1): 4 keys x 2 rounds beats 8 keys x 1 round
+#define VLE_DA(VEC, LPK)                                                                                                    \
+  do {                                                                                                                      \
+    if (nk8)                                                                                                                \
+      hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 8>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
+                         part_ml, nhead, dh, ctx_max, nsplit);                                                              \
+    else                                                                                                                    \
+      hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 4>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
+                         part_ml, nhead, dh, ctx_max, nsplit);                                                              \
+  } while (0)
   if (dh % VFULL == 0) {
     const int nv = dh / VFULL;
     if (nv <= 1) VLE_DA(VFULL, 1);
@@ -190,10 +226,11 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
 
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
-                            int nsplit) {
+                            int nsplit, int nk_override) {
   if (B <= 0) return 0;
-  if (dtype == DT_F32) return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit);
-  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit);
+  if (dtype == DT_F32)
+    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override);
+  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override);
 }
 
 }  // namespace vle

@@ -102,6 +102,8 @@ struct vle_engine {
   bool opt_profile = false;
   bool opt_no_gemv1 = false;  // option "no_gemv1": force the generic skinny kernel at batch 1 (A/B measurements)
   int opt_nsplit = 0;         // option "nsplit": 0 = chosen per batch
+  int opt_nk = 0;             // option "attn_nk": keys per lane per round of the decode attention (0 auto, 4, 8)
+  int opt_spg = 0;            // option "steps_per_graph": overrides cfg.steps_per_graph when > 0
   int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
@@ -667,7 +669,7 @@ int enqueue_ar_step(vle_engine* e) {
     {
       ProfScope ps(e, 1);
       E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
-                                          e->ctx_max, e->nsplit));
+                                          e->ctx_max, e->nsplit, e->opt_nk));
     }
     if (sk) {
       {
@@ -872,7 +874,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   // iteration 0: sample from the prefill's logits
   if ((r = enqueue_ar_sample(e, 1))) return r;
   int steps_done = 0;
-  const int spg = e->cfg.steps_per_graph > 0 ? e->cfg.steps_per_graph : 8;
+  const int spg = e->opt_spg > 0 ? e->opt_spg : (e->cfg.steps_per_graph > 0 ? e->cfg.steps_per_graph : 8);
   const bool use_graph = e->cfg.use_graph != 0 && !e->opt_profile;
   if (e->opt_profile) {
     e->prof_used = 0;
@@ -1175,8 +1177,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw") {  // both change the captured kernels: drop the graphs
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
+    else if (n == "attn_nk") e->opt_nk = (int)value;
+    else if (n == "steps_per_graph") e->opt_spg = (int)value;
     else e->opt_rpw = (int)value;
     (void)hipStreamSynchronize(e->st);
     for (auto& kv : e->graphs) {

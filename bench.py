@@ -100,6 +100,10 @@ def main():
     model = model.to(dev).eval()
     B = args.batch
     eng = model.engine_for(B, S_TEXT, P_PROMPT)
+    if B > 1:
+        # random-init weights emit EOS at arbitrary steps for some seeds (utterance 23 at step 0); the batched
+        # configs time every utterance to the reference's length cap, like the batch-1 run (which never hits EOS)
+        eng.set_option("ignore_eos", 1)
 
     X = torch.zeros(B, S_TEXT, dtype=torch.int64)
     Y = torch.zeros(B, P_PROMPT, 8, dtype=torch.int64)
@@ -110,7 +114,7 @@ def main():
 
     def step():
         eng.prefill(X, s_lens, Y, p_lens)
-        _, gl = eng.generate(top_k=args.top_k, temperature=1.0, seed=0)
+        _, gl = eng.generate(top_k=args.top_k, temperature=1.0, seed=0, allow_empty=B > 1)
         codes = eng.nar(None)
         out = [codes[b, : gl[b]] for b in range(B)]
         if world > 1:

@@ -125,6 +125,9 @@ int vle_nar_continual(vle_engine* e, void* stream, const int64_t* text, int64_t 
 /* options: "trace_ar_logits" (0/1: keep every AR step's fp32 logits), "trace_nar_logits" (0/1),
  *          "nsplit" (0 = auto, else 1|2|4|8|16: KV split of the decode attention),
  *          "no_gemv1" (1: batch-1 AR step on the generic skinny kernel instead of gemv1.hip), "gemv1_rpw" (rows per wave, tuning),
+ *          "no_gemm_skinny" (1: batch 2..64 AR step on the v0 kernels), "attn_nk" (0|4|8 keys per lane per round),
+ *          "steps_per_graph" (n > 0 overrides vle_config.steps_per_graph),
+ *          "ignore_eos" (1: benchmark hook for random-init weights -- only the 16*S length cap stops an utterance),
  *          "profile_kernels" (n > 0: time each kernel of the next n AR steps with hipEvents on the
  *           engine stream, launches become eager; 0: off) */
 int vle_set_option(vle_engine* e, const char* name, int64_t value);

@@ -128,6 +128,52 @@ def test_ragged_batch_equals_independent_oracle_calls(B, dtype):
         assert torch.equal(got[b].cpu(), want[b]), f"utterance {b} differs"
 
 
+@pytest.mark.parametrize("B", [2, 5, 20, 64])
+def test_bf16_batch_path_teacher_forced_against_batch1(B):
+    """bf16 AR step of 2..64 utterances (LayerNorm kernel + gemm_skinny.hip MFMA path, K/V written by the
+    QKV epilogue) against the batch-1 path (gemv1.hip) of the same engine: the batch is teacher-forced on each
+    utterance's own batch-1 greedy tokens; per-step logits within 3 % of sigma, final codes (AR + NAR) equal
+    wherever no argmax flips.  Ragged text / prompt lengths."""
+    cfg = vo.OracleConfig(d_model=256, nhead=4, num_layers=3, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 9)
+    g = torch.Generator().manual_seed(5)
+    S = torch.randint(3, 7, (B,), generator=g).tolist()
+    P = torch.randint(4, 40, (B,), generator=g).tolist()
+    m = build_model(cfg, sd, "bf16", max_batch=B)
+    X = torch.zeros(B, max(S), dtype=torch.int64)
+    Y = torch.zeros(B, max(P), 8, dtype=torch.int64)
+    inputs = []
+    for b in range(B):
+        x, xl, y = vo.make_inputs(S[b], P[b], seed=300 + b)
+        X[b, : S[b]] = x[0]; Y[b, : P[b]] = y[0]
+        inputs.append((x, y))
+    X, Y = X.to(DEV), Y.to(DEV)
+    eng = m.engine_for(B, max(S), max(P))
+    eng.set_option("trace_ar_logits", 1)
+    eng.set_option("ignore_eos", 1)
+    nsteps = 24
+    # batch-1 runs: tokens + logits
+    toks, lg1 = [], []
+    for b in range(min(B, 6)):
+        eng.prefill(X[b : b + 1, : S[b]].contiguous(), [S[b]], Y[b : b + 1, : P[b]].contiguous(), [P[b]])
+        c0, gl = eng.generate(top_k=1, max_new=nsteps)
+        toks.append(c0[0, : gl[0]].clone()); lg1.append(eng.fetch_ar_logits()[: gl[0], 0].clone())
+    # the batch, forced on those tokens (utterances >= 6 repeat utterance b % 6's tokens: only their shapes matter)
+    F = torch.zeros(B, nsteps, dtype=torch.int64)
+    for b in range(B):
+        F[b] = toks[b % len(toks)][:nsteps].cpu()
+    eng.prefill(X, S, Y, P)
+    _, gl = eng.generate(top_k=1, forced=F.to(DEV), forced_lens=[nsteps] * B)
+    assert gl == [nsteps] * B
+    lgB = eng.fetch_ar_logits()
+    for b in range(len(toks)):
+        sigma = lg1[b].std().item()
+        d = (lgB[:nsteps, b] - lg1[b][:nsteps]).abs().max().item()
+        assert d <= 0.03 * sigma, (b, d, sigma)
+    codes = eng.nar(None)
+    assert codes.shape[0] == B and torch.equal(codes[: len(toks), :nsteps, 0].cpu(), F[: len(toks)])
+
+
 def test_graph_and_eager_paths_agree():
     cfg = vo.OracleConfig(d_model=128, nhead=2, num_layers=2, prefix_mode=1)
     sd = vo.make_state_dict(cfg, 2)

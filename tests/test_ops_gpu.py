@@ -34,7 +34,9 @@ def test_layernorm(d, rows, dt):
         assert torch.equal(out, ref.float().to(torch.bfloat16)) or (out.double() - ref).abs().max().item() < 0.04
 
 
-GEMM_SHAPES = [(1, 64, 64), (37, 192, 64), (130, 256, 256), (272, 3072, 1024), (1025, 1024, 4096), (300, 1025, 1024), (64, 4096, 1024)]
+GEMM_SHAPES = [(1, 64, 64), (37, 192, 64), (130, 256, 256), (272, 3072, 1024), (1025, 1024, 4096), (300, 1025, 1024), (64, 4096, 1024),
+               (2, 3072, 1024), (17, 1025, 1024), (48, 1024, 4096), (64, 1024, 4096), (33, 768, 256), (9, 1536, 1536), (1041, 4096, 1024),
+               (17408, 1024, 1024)]
 
 
 @pytest.mark.parametrize("M,N,K", GEMM_SHAPES)

@@ -1,0 +1,7 @@
+cd $GRAFT_REPO_ROOT
+D=gpurun_out/$1; mkdir -p $D
+export TMPDIR=/tmp
+timeout 900 python -m pytest tests -m gpu -x -q > $D/tests.log 2>&1; echo "tests rc=$?"; tail -n 8 $D/tests.log
+timeout 600 python bench.py --batch 64 --steps 1 --warmup 1 --cpu-frames 0 > $D/bench_b64.log 2>&1; echo "b64 rc=$?"; tail -n 1 $D/bench_b64.log
+timeout 300 python bench.py --batch 8 --steps 1 --warmup 1 --cpu-frames 0 > $D/bench_b8.log 2>&1; echo "b8 rc=$?"; tail -n 1 $D/bench_b8.log
+timeout 300 python bench.py --steps 3 --warmup 1 --cpu-frames 0 > $D/bench_b1.log 2>&1; echo "b1 rc=$?"; tail -n 1 $D/bench_b1.log

@@ -100,6 +100,8 @@ struct vle_engine {
   // per-kernel timing of the AR step with hipEvents on the engine stream (option "profile_kernels"):
   // forces eager launches; tags: 0 qkv, 1 decode-attention, 2 out-proj, 3 ffn1, 4 ffn2, 5 logits, 6 sample
   bool opt_profile = false;
+  bool opt_no_gemm_skinny = false;  // option "no_gemm_skinny": batch 2..64 on the v0 kernels (A/B measurements)
+  bool opt_ignore_eos = false;  // option "ignore_eos": synthetic-weight benchmarks run every utterance to the length cap
   bool opt_no_gemv1 = false;  // option "no_gemv1": force the generic skinny kernel at batch 1 (A/B measurements)
   int opt_nsplit = 0;         // option "nsplit": 0 = chosen per batch
   int opt_nk = 0;             // option "attn_nk": keys per lane per round of the decode attention (0 auto, 4, 8)
@@ -614,7 +616,13 @@ struct ProfScope {
   }
 };
 
+// bf16, 2..64 utterances: LayerNorm kernel + weight-streaming MFMA GEMM (gemm_skinny.hip)
+bool use_mfma_skinny(const vle_engine* e) {
+  return e->dtype == DT_BF16 && e->B >= 2 && e->B <= 64 && !e->opt_no_gemm_skinny && e->d % 256 == 0 && e->dh % 4 == 0;
+}
+
 bool use_skinny(const vle_engine* e) {
+  if (use_mfma_skinny(e)) return false;
   return e->B <= SKINNY_MAX_B && (size_t)(e->B <= 1 ? 1 : e->B <= 2 ? 2 : e->B <= 4 ? 4 : 8) * 4 * e->d * sizeof(float) <= 160 * 1024;
 }
 
@@ -629,7 +637,13 @@ int enqueue_ar_logits(vle_engine* e) {
     E_LAUNCH(e, launch_ar_linear(e, a));
   } else {
     E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d));
-    E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
+    if (use_mfma_skinny(e)) {
+      GemmSkinnyArgs g;
+      g.x = e->xn_step; g.w = e->ar_predict; g.M = e->B; g.N = V_AR; g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
+      E_LAUNCH(e, launch_gemm_skinny(st, g));
+    } else {
+      E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
+    }
   }
   return 0;
 }
@@ -649,10 +663,45 @@ int enqueue_ar_step(vle_engine* e) {
   hipStream_t st = e->st;
   const int d = e->d;
   const bool sk = use_skinny(e);
+  const bool gs = use_mfma_skinny(e);
   for (int l = 0; l < e->L; ++l) {
     const LayerW& w = e->ar[l];
     void* kc = cache_layer(e, e->kcache, l);
     void* vc = cache_layer(e, e->vcache, l);
+    if (gs) {
+      GemmSkinnyArgs g;
+      g.M = e->B;
+      {
+        ProfScope ps(e, 0);
+        E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
+        g.x = e->xn_step; g.w = w.wqkv; g.bias = w.bqkv; g.N = 3 * d; g.K = d; g.epi = GS_EPI_QKV;
+        g.q_out = e->q_step; g.k_cache = kc; g.v_cache = vc; g.kv_len = e->S.kv_len; g.ctx_max = e->ctx_max; g.nhead = e->H; g.dh = e->dh;
+        E_LAUNCH(e, launch_gemm_skinny(st, g));
+      }
+      {
+        ProfScope ps(e, 1);
+        E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
+                                            e->ctx_max, e->nsplit, e->opt_nk));
+      }
+      {
+        ProfScope ps(e, 2);
+        E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
+        g.x = e->att_step; g.w = w.wo; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
+        E_LAUNCH(e, launch_gemm_skinny(st, g));
+      }
+      {
+        ProfScope ps(e, 3);
+        E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
+        g.x = e->xn_step; g.w = w.w1; g.bias = w.b1; g.N = 4 * d; g.K = d; g.epi = GS_EPI_RELU; g.out = e->hT_step;
+        E_LAUNCH(e, launch_gemm_skinny(st, g));
+      }
+      {
+        ProfScope ps(e, 4);
+        g.x = e->hT_step; g.w = w.w2; g.bias = w.b2; g.N = d; g.K = 4 * d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
+        E_LAUNCH(e, launch_gemm_skinny(st, g));
+      }
+      continue;
+    }
     if (sk) {
       ProfScope ps(e, 0);
       SkinnyArgs a;
@@ -846,7 +895,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
     bound = std::max(bound, nb);
   }
   ArDyn dyn{};
-  dyn.top_k = top_k; dyn.temperature = temperature; dyn.seed = seed; dyn.max_new = max_new;
+  dyn.top_k = top_k; dyn.temperature = temperature; dyn.seed = seed; dyn.max_new = max_new; dyn.ignore_eos = e->opt_ignore_eos ? 1 : 0;
   dyn.has_forced = forced ? 1 : 0; dyn.forced = forced; dyn.forced_stride = forced_stride; dyn.forced_len = e->forced_len_dev;
   if (e->opt_trace_ar) {
     const int64_t need = (int64_t)(bound + 1);
@@ -1177,8 +1226,9 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
+    else if (n == "no_gemm_skinny") e->opt_no_gemm_skinny = value != 0;
     else if (n == "attn_nk") e->opt_nk = (int)value;
     else if (n == "steps_per_graph") e->opt_spg = (int)value;
     else e->opt_rpw = (int)value;
@@ -1188,6 +1238,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
       if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
     }
     e->graphs.clear();
+    return VLE_OK;
+  }
+  if (n == "ignore_eos") {
+    e->opt_ignore_eos = value != 0;
     return VLE_OK;
   }
   if (n == "nsplit") {

@@ -28,6 +28,24 @@ int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const f
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
                      int K, int epi);
 
+// ---- gemm_skinny.hip (AR-step weight-streaming MFMA GEMM, bf16, 2 <= M = batch <= 64) ------------
+enum { GS_EPI_STORE = 0, GS_EPI_RELU = 1, GS_EPI_RESID = 2, GS_EPI_F32 = 3, GS_EPI_QKV = 4 };
+struct GemmSkinnyArgs {
+  const void* x = nullptr;     // bf16 [M][K]
+  const void* w = nullptr;     // bf16 [N][K]
+  const float* bias = nullptr; // f32 [N] or null
+  int M = 0, N = 0, K = 0, epi = GS_EPI_STORE;
+  void* out = nullptr;         // bf16 [M][N] (STORE / RELU) or f32 [M][N] (F32)
+  float* resid = nullptr;      // f32 [M][N] += (.)   (RESID)
+  float* q_out = nullptr;      // f32 [M][d]          (QKV)
+  void* k_cache = nullptr;     // bf16 [M][H][ctx_max][dh] (this layer)
+  void* v_cache = nullptr;
+  const int32_t* kv_len = nullptr;
+  int ctx_max = 0, nhead = 1, dh = 4;
+};
+bool gemm_skinny_supports(int M, int N, int K, int epi, int dh);
+int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a);  // 1 = shape not covered
+
 // ---- skinny.hip (AR-step weight-streaming GEMV, M = batch <= 8) --------------------------------
 enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2 };
 enum { SEPI_STORE = 0, SEPI_RELU = 1, SEPI_RESID = 2, SEPI_QKV = 3 };
@@ -122,6 +140,7 @@ struct ArState {           // device pointers
 struct ArDyn {
   int32_t top_k; float temperature; uint64_t seed;
   int32_t max_new; int32_t has_forced;
+  int32_t ignore_eos; int32_t pad0;        // benchmark hook: only the length cap stops an utterance
   const int64_t* forced; int64_t forced_stride; const int32_t* forced_len;
   float* trace; int64_t trace_cap;         // [trace_cap][B][V] or null
 };

@@ -30,6 +30,11 @@ extern "C" int vle_op_linear(void* stream, int dtype, const void* a, const void*
                              int64_t M, int32_t N, int32_t K, int epilogue) {
   if (!a || !w) return op_fail("vle_op_linear: null operand");
   if (epilogue == EPI_RESID ? !resid : !out) return op_fail("vle_op_linear: missing output");
+  if (dtype == DT_BF16 && M <= 64 && gemm_skinny_supports((int)M, N, K, epilogue, 4)) {  // the AR-step path of 2..64 utterances
+    GemmSkinnyArgs g;
+    g.x = a; g.w = w; g.bias = bias; g.M = (int)M; g.N = N; g.K = K; g.epi = epilogue; g.out = out; g.resid = resid;
+    return op_done(launch_gemm_skinny((hipStream_t)stream, g), "vle_op_linear");
+  }
   return op_done(launch_gemm((hipStream_t)stream, dtype, a, w, bias, out, resid, M, N, K, epilogue), "vle_op_linear");
 }
 

@@ -172,7 +172,7 @@ __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
     const int kvl = a.s.kv_len[b] + (a.first ? 0 : 1);
     const int ap = a.s.audio_pos[b] + (a.first ? 0 : 1);
     // valle.py:1044-1048: argmax == EOS  or  sample == EOS  or  (y.shape[1] - P) > 16 * S
-    int stop = (argmax == 1024) || (sample == 1024) || (n + a.bos > a.s.cap[b]);
+    int stop = (!dyn.ignore_eos && ((argmax == 1024) || (sample == 1024))) || (n + a.bos > a.s.cap[b]);
     if (dyn.max_new > 0 && n >= dyn.max_new) stop = 1;
     if (dyn.has_forced) stop = n >= dyn.forced_len[b];
     if (n >= (int)a.g_stride || kvl >= a.ctx_max) stop = 1;  // capacity guard

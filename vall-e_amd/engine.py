@@ -121,7 +121,8 @@ class Engine:
         self._B = B
 
     def generate(self, top_k: int = -100, temperature: float = 1.0, seed: int = 0, max_new: int = 0,
-                 forced: Optional[torch.Tensor] = None, forced_lens: Optional[Sequence[int]] = None):
+                 forced: Optional[torch.Tensor] = None, forced_lens: Optional[Sequence[int]] = None,
+                 allow_empty: bool = False):
         """Runs the AR loop; returns (codes0 int64 (B, max_gen) device tensor, gen_lens list)."""
         B = self._B
         G = self.cfg.max_gen_eff()
@@ -138,7 +139,8 @@ class Engine:
             f_ptr, f_stride, f_lens, C.c_void_p(codes0.data_ptr()), G, gl,
         )
         self._gen_lens = [int(v) for v in gl]
-        _lib.check(rc, self.h)
+        if not (allow_empty and rc == _lib.VLE_ENOTOKEN):  # batch: an utterance that stops at step 0 yields 0 frames
+            _lib.check(rc, self.h)
         return codes0, self._gen_lens
 
     def nar(self, enroll_lens: Optional[Sequence[int]] = None) -> torch.Tensor:

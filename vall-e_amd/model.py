@@ -241,7 +241,8 @@ class VALLE(nn.Module):
             seed = 0 if top_k == 1 else int(torch.randint(0, 2**62, (1,)).item())
         eng.prefill(x.to(dev, torch.int64), xl, y.to(dev, torch.int64)[..., : self.num_quantizers], yl)
         try:
-            _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new)
+            # batch 1 keeps the reference's SyntaxError; in a batch an utterance that hits EOS at step 0 returns 0 frames
+            _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
         except _lib.VleError as err:
             if err.code == _lib.VLE_ENOTOKEN:
                 raise SyntaxError("well trained model shouldn't reach here.") from None  # valle.py:1049-1052

@@ -39,7 +39,7 @@ template <typename T, int VEC, int LPK, int NK>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ q, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, const int32_t* __restrict__ kv_len,
                                                           float* __restrict__ part_o, float* __restrict__ part_ml, int nhead,
-                                                          int dh, int ctx_max, int nsplit) {
+                                                          int dh, int ctx_max, int nsplit, T* __restrict__ out_norm) {
   constexpr int KPW = 64 / LPK;         // keys per wave-load
   constexpr int WCH = NK * KPW;         // keys per wave per round
   constexpr int CHUNK = 4 * WCH;        // keys per block per round
@@ -168,8 +168,15 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
       float o = 0.f;
 #pragma unroll
       for (int ww = 0; ww < 4; ++ww) o = fmaf(sm_o[ww][tid], f[ww], o);
-      part_o[((int64_t)b * nsplit + s) * d + h * dh + tid] = o;
-    } else {
+      if (out_norm != nullptr) {  // nsplit == 1: this block holds the whole softmax -> normalised T output, no merge kernel
+        float L = 0.f;
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) L = fmaf(sm_l[ww], f[ww], L);
+        store_elem<T>(out_norm + (int64_t)b * d + h * dh + tid, o / L);
+      } else {
+        part_o[((int64_t)b * nsplit + s) * d + h * dh + tid] = o;
+      }
+    } else if (out_norm == nullptr) {
       float L = 0.f;
 #pragma unroll
       for (int ww = 0; ww < 4; ++ww) L = fmaf(sm_l[ww], f[ww], L);
@@ -182,7 +189,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
 
 template <typename T>
 static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const void* vc, const int32_t* kv_len, float* part_o,
-                           float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit, int nk_override) {
+                           float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit, int nk_override, void* out_norm) {
   constexpr int VFULL = Elem<T>::VEC;
   if (dh > 254) return -1;
   const dim3 grid(nhead, nsplit, B), block(256);
@@ -197,10 +204,10 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
   do {                                                                                                                      \
     if (nk8)                                                                                                                \
       hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 8>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
-                         part_ml, nhead, dh, ctx_max, nsplit);                                                              \
+                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm);                                                              \
     else                                                                                                                    \
       hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 4>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
-                         part_ml, nhead, dh, ctx_max, nsplit);                                                              \
+                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm);                                                              \
   } while (0)
   if (dh % VFULL == 0) {
     const int nv = dh / VFULL;
@@ -226,11 +233,12 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
 
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
-                            int nsplit, int nk_override) {
+                            int nsplit, int nk_override, void* out_norm) {
   if (B <= 0) return 0;
+  if (out_norm != nullptr && nsplit != 1) return -1;
   if (dtype == DT_F32)
-    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override);
-  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override);
+    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm);
+  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm);
 }
 
 }  // namespace vle

@@ -678,14 +678,15 @@ int enqueue_ar_step(vle_engine* e) {
         g.q_out = e->q_step; g.k_cache = kc; g.v_cache = vc; g.kv_len = e->S.kv_len; g.ctx_max = e->ctx_max; g.nhead = e->H; g.dh = e->dh;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
+      const bool direct = e->nsplit == 1;  // one block holds a whole (utterance, head): it normalises itself
       {
         ProfScope ps(e, 1);
         E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
-                                            e->ctx_max, e->nsplit, e->opt_nk));
+                                            e->ctx_max, e->nsplit, e->opt_nk, direct ? e->att_step : nullptr));
       }
       {
         ProfScope ps(e, 2);
-        E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
+        if (!direct) E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
         g.x = e->att_step; g.w = w.wo; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }

@@ -9,10 +9,9 @@
 // fragment of W:
 //   * a workgroup owns W rows n0..n0+15; its 4 waves split K in four and combine through LDS,
 //     so N/16 = 64..256 workgroups stream disjoint 32..128 KB slabs of W;
-//   * W goes global -> registers directly as the MFMA A operand (no LDS: nothing shares it), 32
-//     contiguous bytes per lane per 64-deep k-chunk (4 lanes cover a full 128-byte line of a row);
-//     the contraction index inside a chunk is permuted the same way for both operands, which an
-//     MFMA allows;
+//   * W goes global -> registers directly as the MFMA A operand (no LDS: nothing shares it): per
+//     64-deep k-chunk two 16-byte vectors per lane, the 4 lanes of a row covering one full 64-byte
+//     sector per instruction;
 //   * X (the M activation rows, bf16) is the B operand, read through L1/L2 in the same pattern;
 //     v_mfma_f32_16x16x32_bf16 computes C^T[n][m], so a lane ends up with 4 consecutive output
 //     columns of one utterance: vector epilogue, and K/V go straight into the cache slot (EPI QKV),
@@ -40,10 +39,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   const int K = a.K, N = a.N, M = a.M;
   const int Kw = K >> 2;  // this wave's share of K (multiple of 64)
   const int nrow = min(n0 + fr, N - 1);
-  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w) + (int64_t)nrow * K + wave * Kw + fg * 16;
+  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w) + (int64_t)nrow * K + wave * Kw + fg * 8;
   const bf16_t* xp[MF];
 #pragma unroll
-  for (int i = 0; i < MF; ++i) xp[i] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(i * 16 + fr, M - 1) * K + wave * Kw + fg * 16;
+  for (int i = 0; i < MF; ++i) xp[i] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(i * 16 + fr, M - 1) * K + wave * Kw + fg * 8;
 
   // epilogue operands requested up front
   const int ncol = n0 + fg * 4;  // first of this lane's 4 output columns
@@ -67,11 +66,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     for (int g = 0; g < G; ++g) {
       const int c = min(c0 + g, chunks - 1);  // clamped: a short last round re-reads its final chunk, unused below
       wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64));
-      wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64 + 8));
+      wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64 + 32));
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
         xv[g][i][0] = *reinterpret_cast<const gs_u32x4*>(xp[i] + c * 64);
-        xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xp[i] + c * 64 + 8);
+        xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xp[i] + c * 64 + 32);
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -87,7 +87,9 @@ int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache,
 // part_o [B][nsplit][d], part_ml [B][H][nsplit][2]
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
-                            int nsplit, int nk_override = 0);  // nk_override: keys per lane per round (0 = auto, 4, 8)
+                            int nsplit, int nk_override = 0, void* out_norm = nullptr);
+// nk_override: keys per lane per round (0 = auto, 4, 8); out_norm (T [B][d], nsplit == 1 only): write the
+// normalised attention output directly instead of partials
 
 // ---- embed.hip ------------------------------------------------------------------------------
 struct PrefillEmbedArgs {

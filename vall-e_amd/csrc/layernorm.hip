@@ -53,10 +53,80 @@ __global__ __launch_bounds__(NW * 64) void layernorm_rows_kernel(const float* __
   }
 }
 
+// Row held in registers (d = NV * 256): one read of x, gamma / beta requested in the same burst,
+// DPP reductions -- one memory round trip instead of three dependent passes.
+template <typename T, int NV>
+__global__ __launch_bounds__(256) void layernorm_rows_reg_kernel(const float* __restrict__ x,
+                                                                 const int32_t* __restrict__ row_map,
+                                                                 const float* __restrict__ gamma,
+                                                                 const float* __restrict__ beta, T* __restrict__ out,
+                                                                 int64_t rows) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  constexpr int d = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int64_t src = row_map ? (int64_t)row_map[r] : r;
+  const f4* xr = reinterpret_cast<const f4*>(x + src * d) + lane;
+  f4 v[NV], g[NV], bb[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = xr[i * 64];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    g[i] = reinterpret_cast<const f4*>(gamma)[i * 64 + lane];
+    bb[i] = reinterpret_cast<const f4*>(beta)[i * 64 + lane];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum_dpp(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + e * e);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)d + LN_EPS);
+  T* orow = out + r * d;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const f4 o = (v[i] - mean) * rstd * g[i] + bb[i];
+    if constexpr (sizeof(T) == 4) {
+      reinterpret_cast<f4*>(orow)[i * 64 + lane] = o;
+    } else {
+      typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+      b4 p;
+      p[0] = (__bf16)o.x; p[1] = (__bf16)o.y; p[2] = (__bf16)o.z; p[3] = (__bf16)o.w;  // round-to-nearest-even
+      reinterpret_cast<b4*>(orow)[i * 64 + lane] = p;
+    }
+  }
+}
+
+template <typename T>
+static bool layernorm_reg_dispatch(hipStream_t st, const float* x, const int32_t* row_map, const float* gamma, const float* beta,
+                                   T* out, int64_t rows, int d) {
+  if (d % 256 != 0) return false;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define VLE_LN(NV) hipLaunchKernelGGL((layernorm_rows_reg_kernel<T, NV>), grid, block, 0, st, x, row_map, gamma, beta, out, rows)
+  switch (d / 256) {
+    case 1: VLE_LN(1); return true;
+    case 2: VLE_LN(2); return true;
+    case 3: VLE_LN(3); return true;
+    case 4: VLE_LN(4); return true;
+    case 6: VLE_LN(6); return true;
+    case 8: VLE_LN(8); return true;
+    default: return false;
+  }
+#undef VLE_LN
+}
+
 int launch_layernorm(hipStream_t st, int dtype, const float* x, const int32_t* row_map, const float* gamma,
                      const float* beta, void* out, int64_t rows, int d) {
   if (rows <= 0) return 0;
   if (d % 4 != 0) return -1;
+  if (dtype == DT_F32 ? layernorm_reg_dispatch<float>(st, x, row_map, gamma, beta, (float*)out, rows, d)
+                      : layernorm_reg_dispatch<bf16_t>(st, x, row_map, gamma, beta, (bf16_t*)out, rows, d))
+    return 0;
   constexpr int NW = 4;
   const dim3 grid((unsigned)((rows + NW - 1) / NW)), block(NW * 64);
   if (dtype == DT_F32)

@@ -174,6 +174,59 @@ def test_bf16_batch_path_teacher_forced_against_batch1(B):
     assert codes.shape[0] == B and torch.equal(codes[: len(toks), :nsteps, 0].cpu(), F[: len(toks)])
 
 
+def _bench_inputs(i, S=47, P=225):
+    g = torch.Generator().manual_seed(1234 + i)
+    x = torch.randint(3, 100, (S,), generator=g, dtype=torch.int64)
+    x[0], x[-1] = 1, 2
+    y = torch.randint(0, 1024, (P, 8), generator=g, dtype=torch.int64)
+    return x, y
+
+
+def test_c2_full_size_properties_bf16():
+    """BASELINE.json configs[1] at FULL size (d1024-L12-h16 bf16, S=47, P=225 -> G=16*S+1=753): the oracle cannot
+    run this in seconds, so size-independent properties: length rule, id ranges, run-to-run determinism,
+    hipGraph == eager launches, and the first AR codes unchanged by the NAR phase."""
+    torch.manual_seed(0)
+    m = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()
+    x, y = _bench_inputs(0)
+    X, XL, Y = x[None].to(DEV), torch.tensor([47], dtype=torch.int32, device=DEV), y[None].to(DEV)
+    a = m.inference(X, XL, Y, None, top_k=1).cpu()
+    assert a.shape == (1, 753, 8) and a.dtype == torch.int64            # valle.py:1047 cap: 16 * 47 + 1 frames
+    assert int(a.min()) >= 0 and int(a[..., 1:].max()) < 1024 and int(a[..., 0].max()) <= 1024
+    b = m.inference(X, XL, Y, None, top_k=1).cpu()
+    assert torch.equal(a, b), "two identical greedy decodes differ"
+    eng = m.engine_for(1, 47, 225)
+    eng.set_option("steps_per_graph", 3)                                  # different graph partition of the same steps
+    c = m.inference(X, XL, Y, None, top_k=1).cpu()
+    assert torch.equal(a, c)
+    sd = m.state_dict()
+    m2 = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16", use_graph=False)
+    m2.load_state_dict(sd, strict=True)
+    d = m2.to(DEV).eval().inference(X, XL, Y, None, top_k=1).cpu()
+    assert torch.equal(a, d), "hipGraph replay and eager launches disagree"
+
+
+def test_c3_batch64_full_architecture_batch_invariance():
+    """BASELINE.json configs[2] shape (d1024-L12-h16 bf16, 64 utterances, KV cache 64 x 50 MB): utterance b is a copy
+    of utterance b % 4, so the 16 copies of each must come out bit-identical (rows of a batch are independent in
+    every kernel), ragged generation lengths are honoured, and ids stay in range."""
+    torch.manual_seed(0)
+    B = 64
+    m = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16", max_batch=B).to(DEV).eval()
+    S, P = 12, 60
+    X = torch.stack([_bench_inputs(b % 4, S, P)[0] for b in range(B)]).to(DEV)
+    Y = torch.stack([_bench_inputs(b % 4, S, P)[1] for b in range(B)]).to(DEV)
+    eng = m.engine_for(B, S, P)
+    eng.set_option("ignore_eos", 1)
+    out = m.inference_batch(X, torch.full((B,), S, dtype=torch.int32), Y, [P] * B, None, top_k=1, max_new=40)
+    assert len(out) == B
+    for b in range(B):
+        assert out[b].shape == (40, 8)
+        assert torch.equal(out[b], out[b % 4]), f"utterance {b} differs from its copy {b % 4}"
+        assert int(out[b].min()) >= 0 and int(out[b].max()) <= 1024
+    assert not torch.equal(out[0], out[1])
+
+
 def test_graph_and_eager_paths_agree():
     cfg = vo.OracleConfig(d_model=128, nhead=2, num_layers=2, prefix_mode=1)
     sd = vo.make_state_dict(cfg, 2)

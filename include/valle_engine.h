@@ -186,6 +186,19 @@ int vle_op_decode_attention(void* stream, int dtype, const float* q, const void*
 int vle_op_attn_out_proj(void* stream, int dtype, const float* workspace, const void* w, const float* bias, float* resid,
                          int32_t B, int32_t nhead, int32_t dh, int32_t nsplit);
 
+/* TokenEmbedding.forward (valle/modules/embedding.py:43-47): out[f32, n x d] = table[f32, V x d][ids[i64, n]].
+ * ids must lie in [0, V) (like nn.Embedding on a device, no range check on the hot path). */
+int vle_op_token_embedding(void* stream, const int64_t* ids, const float* table, float* out, int64_t n, int32_t d);
+/* SinePositionalEmbedding.forward (embedding.py:93-97): out[b][t] = x[b][t] * x_scale + alpha[0] * pe[t];
+ * x/out f32 [B x T x d], pe f32 [>= T x d] (built as embedding.py:75-91), alpha f32 DEVICE scalar. */
+int vle_op_sine_positional(void* stream, const float* x, const float* pe, const float* alpha_dev, float x_scale, float* out,
+                           int64_t B, int32_t T, int32_t d);
+/* AdaptiveLayerNorm.forward (transformer.py:93-108) as an affine fold: with wb = project_layer(stage_emb)
+ * [f32, 2d] = [w ; b] and the inner norm's (g, be): gamma_out = w * g, beta_out = w * be + b, so that
+ * vle_op_layernorm(x, gamma_out, beta_out) == w * LayerNorm(x) + b (the fold vle_finalize_weights applies). */
+int vle_op_adaln_fold(void* stream, const float* wb, const float* g, const float* be, float* gamma_out, float* beta_out,
+                      int32_t d);
+
 #ifdef __cplusplus
 }
 #endif

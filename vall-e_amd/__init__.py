@@ -1,12 +1,12 @@
 """MI355X-native VALL-E decode engine (AR + NAR hot path of lifeiteng/vall-e).
 
-    from valle_amd import get_model, VALLE, Engine, EngineConfig, ops
+    from valle_amd import get_model, VALLE, Engine, EngineConfig, ops, modules
 
 Everything numeric runs in ``libvalle_engine.so`` (hand-written HIP for gfx950); this package is
 the host-side mirror of the reference's Python interface for that path.
 """
-from . import _lib, ops  # noqa: F401
+from . import _lib, modules, ops  # noqa: F401
 from .engine import Engine, EngineConfig, sine_pe  # noqa: F401
 from .model import VALLE, add_model_arguments, get_model  # noqa: F401
 
-__all__ = ["VALLE", "get_model", "add_model_arguments", "Engine", "EngineConfig", "ops", "sine_pe"]
+__all__ = ["VALLE", "get_model", "add_model_arguments", "Engine", "EngineConfig", "ops", "modules", "sine_pe"]

@@ -1,0 +1,75 @@
+// Stand-alone kernels of the block API (seam B3) that the engine itself runs fused:
+//   TokenEmbedding.forward            valle/modules/embedding.py:43-47   (row gather)
+//   SinePositionalEmbedding.forward   valle/modules/embedding.py:93-97   (x * x_scale + alpha * pe[:, :T])
+//   AdaptiveLayerNorm.forward         valle/modules/transformer.py:93-108 (affine fold of [w, b] = Linear(stage_emb))
+// All HBM/L2-bound row kernels: one wave per row, float4 (16 B / lane) accesses.
+#include "common.h"
+#include "kernels.h"
+
+namespace vle {
+
+constexpr int BO_NW = 4;
+
+__global__ __launch_bounds__(BO_NW * 64) void token_embedding_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                                      float* __restrict__ out, int64_t n, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * BO_NW + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float4* src = reinterpret_cast<const float4*>(table + ids[r] * (int64_t)d);
+  float4* dst = reinterpret_cast<float4*>(out + r * (int64_t)d);
+  for (int i = lane; i < (d >> 2); i += 64) dst[i] = src[i];
+}
+
+int launch_token_embedding(hipStream_t st, const int64_t* ids, const float* table, float* out, int64_t n, int d) {
+  if (n <= 0) return 0;
+  if (d % 4) return -1;
+  hipLaunchKernelGGL(token_embedding_kernel, dim3((unsigned)((n + BO_NW - 1) / BO_NW)), dim3(BO_NW * 64), 0, st, ids, table, out, n, d);
+  return 0;
+}
+
+// out[b][t][:] = x[b][t][:] * x_scale + alpha * pe[t][:]   -- multiply, multiply, add: three roundings as in torch
+__global__ __launch_bounds__(BO_NW * 64) void sine_positional_kernel(const float* __restrict__ x, const float* __restrict__ pe,
+                                                                      const float* __restrict__ alpha, float x_scale,
+                                                                      float* __restrict__ out, int64_t rows, int T, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * BO_NW + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const int t = (int)(r % T);
+  const float a = *alpha;
+  const float4* xs = reinterpret_cast<const float4*>(x + r * (int64_t)d);
+  const float4* ps = reinterpret_cast<const float4*>(pe + (int64_t)t * d);
+  float4* dst = reinterpret_cast<float4*>(out + r * (int64_t)d);
+  for (int i = lane; i < (d >> 2); i += 64) {
+    const float4 v = xs[i], p = ps[i];
+    dst[i] = make_float4(__fadd_rn(__fmul_rn(v.x, x_scale), __fmul_rn(a, p.x)), __fadd_rn(__fmul_rn(v.y, x_scale), __fmul_rn(a, p.y)),
+                         __fadd_rn(__fmul_rn(v.z, x_scale), __fmul_rn(a, p.z)), __fadd_rn(__fmul_rn(v.w, x_scale), __fmul_rn(a, p.w)));
+  }
+}
+
+int launch_sine_positional(hipStream_t st, const float* x, const float* pe, const float* alpha, float x_scale, float* out,
+                           int64_t B, int T, int d) {
+  const int64_t rows = B * T;
+  if (rows <= 0) return 0;
+  if (d % 4) return -1;
+  hipLaunchKernelGGL(sine_positional_kernel, dim3((unsigned)((rows + BO_NW - 1) / BO_NW)), dim3(BO_NW * 64), 0, st, x, pe, alpha,
+                     x_scale, out, rows, T, d);
+  return 0;
+}
+
+// w * (n * g + be) + b  ==  n * (w * g) + (w * be + b): the fp32 fold the engine applies per (stage, norm site)
+__global__ void adaln_fold_kernel(const float* __restrict__ wb, const float* __restrict__ g, const float* __restrict__ be,
+                                  float* __restrict__ gamma_out, float* __restrict__ beta_out, int d) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= d) return;
+  const float w = wb[i], b = wb[d + i];
+  gamma_out[i] = __fmul_rn(w, g[i]);
+  beta_out[i] = __fadd_rn(__fmul_rn(w, be[i]), b);
+}
+
+int launch_adaln_fold(hipStream_t st, const float* wb, const float* g, const float* be, float* gamma_out, float* beta_out, int d) {
+  if (d <= 0) return -1;
+  hipLaunchKernelGGL(adaln_fold_kernel, dim3((d + 255) / 256), dim3(256), 0, st, wb, g, be, gamma_out, beta_out, d);
+  return 0;
+}
+
+}  // namespace vle

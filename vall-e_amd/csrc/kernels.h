@@ -17,6 +17,11 @@ int launch_layernorm(hipStream_t st, int dtype, const float* x, const int32_t* r
                      const float* beta, void* out, int64_t rows, int d);
 // dst[f32][r] = src[f32][row_map[r]]
 int launch_gather_rows(hipStream_t st, const float* src, const int32_t* row_map, float* dst, int rows, int d);
+// block_ops.hip: stand-alone forms of ops the engine runs fused (block API, SURVEY.md 8b seam B3)
+int launch_token_embedding(hipStream_t st, const int64_t* ids, const float* table, float* out, int64_t n, int d);
+int launch_sine_positional(hipStream_t st, const float* x, const float* pe, const float* alpha, float x_scale, float* out,
+                           int64_t B, int T, int d);
+int launch_adaln_fold(hipStream_t st, const float* wb, const float* g, const float* be, float* gamma_out, float* beta_out, int d);
 
 // ---- gemm.hip -------------------------------------------------------------------------------
 enum { EPI_STORE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_F32 = 3 };

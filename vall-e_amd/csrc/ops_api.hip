@@ -93,3 +93,20 @@ extern "C" int vle_op_attn_out_proj(void* stream, int dtype, const float* worksp
   }
   return op_done(launch_skinny((hipStream_t)stream, dtype, a), "vle_op_attn_out_proj");
 }
+
+extern "C" int vle_op_token_embedding(void* stream, const int64_t* ids, const float* table, float* out, int64_t n, int32_t d) {
+  if (!ids || !table || !out || n < 0 || d < 4 || d % 4) return op_fail("vle_op_token_embedding: bad argument");
+  return op_done(launch_token_embedding((hipStream_t)stream, ids, table, out, n, d), "vle_op_token_embedding");
+}
+
+extern "C" int vle_op_sine_positional(void* stream, const float* x, const float* pe, const float* alpha_dev, float x_scale, float* out,
+                                      int64_t B, int32_t T, int32_t d) {
+  if (!x || !pe || !alpha_dev || !out || B < 0 || T < 1 || d < 4 || d % 4) return op_fail("vle_op_sine_positional: bad argument");
+  return op_done(launch_sine_positional((hipStream_t)stream, x, pe, alpha_dev, x_scale, out, B, T, d), "vle_op_sine_positional");
+}
+
+extern "C" int vle_op_adaln_fold(void* stream, const float* wb, const float* g, const float* be, float* gamma_out, float* beta_out,
+                                 int32_t d) {
+  if (!wb || !g || !be || !gamma_out || !beta_out || d < 1) return op_fail("vle_op_adaln_fold: bad argument");
+  return op_done(launch_adaln_fold((hipStream_t)stream, wb, g, be, gamma_out, beta_out, d), "vle_op_adaln_fold");
+}

@@ -4,9 +4,10 @@ state-dict layout and ``inference()`` / ``continual()`` signatures
 backed by the HIP engine.  ``bin/infer.py`` of the reference works unchanged when its
 ``from valle.models import get_model`` resolves to this module.
 
-The parameter tree mirrors the reference's module names so that
-``load_state_dict(ckpt["model"], strict=True)`` (valle/bin/infer.py:135-138) accepts a
-reference checkpoint.  Only the production shape runs (norm_first, no prenet,
+The module tree is built from the HIP-backed block modules of ``modules.py`` under the reference's
+attribute names, so that ``load_state_dict(ckpt["model"], strict=True)`` (valle/bin/infer.py:135-138)
+accepts a reference checkpoint and ``model.ar_decoder(...)`` / ``model.nar_decoder(...)`` keep the
+reference's block-level call surface; ``inference()`` itself drives the fused engine.  Only the production shape runs (norm_first, no prenet,
 nar_scale_factor = 1); other combinations raise -- there is no PyTorch fallback.
 """
 from __future__ import annotations
@@ -24,69 +25,17 @@ NUM_TEXT_TOKENS = 512  # valle/models/macros.py:2
 NUM_AUDIO_TOKENS = 1024  # valle/models/macros.py:5
 
 
-# ---- parameter containers with the reference's attribute names --------------------------------
-class TokenEmbedding(nn.Module):
-    """valle/modules/embedding.py:21-47 (parameters only; the gather runs fused in embed.hip)."""
-
-    def __init__(self, dim_model: int, vocab_size: int):
-        super().__init__()
-        self.vocab_size, self.dim_model = vocab_size, dim_model
-        self.word_embeddings = nn.Embedding(vocab_size, dim_model)
-
-    @property
-    def weight(self) -> torch.Tensor:
-        return self.word_embeddings.weight
+# the block modules (reference names, reference state-dict keys, HIP forward): modules.py
+from .modules import (AdaptiveLayerNorm, LayerNorm, SinePositionalEmbedding, TokenEmbedding, TransformerEncoder,  # noqa: E402
+                      TransformerEncoderLayer, set_compute_dtype)
 
 
-class SinePositionalEmbedding(nn.Module):
-    """valle/modules/embedding.py:50-97: holds the learnable ``alpha``."""
-
-    def __init__(self, dim_model: int, alpha: bool = False):
-        super().__init__()
-        self.dim_model = dim_model
-        self.alpha = nn.Parameter(torch.ones(1), requires_grad=alpha)
-
-
-class _MHAParams(nn.Module):
-    """Packed in-proj [Q;K;V] + out_proj (valle/modules/activation.py:128-143)."""
-
-    def __init__(self, d: int):
-        super().__init__()
-        self.in_proj_weight = nn.Parameter(torch.empty(3 * d, d))
-        self.in_proj_bias = nn.Parameter(torch.zeros(3 * d))
-        self.out_proj = nn.Linear(d, d)
-        nn.init.xavier_uniform_(self.in_proj_weight)
-        nn.init.zeros_(self.out_proj.bias)
-
-
-class _AdaLNParams(nn.Module):
-    """valle/modules/transformer.py:83-108."""
-
-    def __init__(self, d: int):
-        super().__init__()
-        self.project_layer = nn.Linear(d, 2 * d)
-        self.norm = nn.LayerNorm(d)
-
-
-class _EncoderLayerParams(nn.Module):
-    """valle/modules/transformer.py:178-263."""
-
-    def __init__(self, d: int, adaptive: bool):
-        super().__init__()
-        self.self_attn = _MHAParams(d)
-        self.linear1 = nn.Linear(d, 4 * d)
-        self.linear2 = nn.Linear(4 * d, d)
-        self.norm1 = _AdaLNParams(d) if adaptive else nn.LayerNorm(d)
-        self.norm2 = _AdaLNParams(d) if adaptive else nn.LayerNorm(d)
-
-
-class _EncoderParams(nn.Module):
-    """valle/modules/transformer.py:337-361."""
-
-    def __init__(self, d: int, num_layers: int, adaptive: bool):
-        super().__init__()
-        self.layers = nn.ModuleList([_EncoderLayerParams(d, adaptive) for _ in range(num_layers)])
-        self.norm = _AdaLNParams(d) if adaptive else nn.LayerNorm(d)
+def _decoder(d: int, nhead: int, num_layers: int, adaptive: bool) -> TransformerEncoder:
+    """valle/models/valle.py:141-152 (AR) / :232-245 (NAR): pre-norm layers, FFN 4d, final (Adaptive)LayerNorm."""
+    layer = TransformerEncoderLayer(d, nhead, dim_feedforward=d * 4, dropout=0.1, batch_first=True, norm_first=True,
+                                    adaptive_layer_norm=adaptive)
+    norm = AdaptiveLayerNorm(d, norm=LayerNorm(d)) if adaptive else LayerNorm(d)
+    return TransformerEncoder(layer, num_layers=num_layers, norm=norm)
 
 
 class VALLE(nn.Module):
@@ -131,23 +80,24 @@ class VALLE(nn.Module):
         self.ar_text_embedding = TokenEmbedding(d, NUM_TEXT_TOKENS)
         self.nar_text_embedding = TokenEmbedding(d, NUM_TEXT_TOKENS)
         self.ar_audio_embedding = TokenEmbedding(d, NUM_AUDIO_TOKENS + 1 + int(prepend_bos))
-        self.ar_text_position = SinePositionalEmbedding(d, alpha=True)
-        self.ar_audio_position = SinePositionalEmbedding(d, alpha=True)
-        self.ar_decoder = _EncoderParams(d, num_layers, adaptive=False)
+        self.ar_text_position = SinePositionalEmbedding(d, dropout=0.1, scale=False, alpha=True)
+        self.ar_audio_position = SinePositionalEmbedding(d, dropout=0.1, scale=False, alpha=True)
+        self.ar_decoder = _decoder(d, nhead, num_layers, adaptive=False)
         self.ar_predict_layer = nn.Linear(d, NUM_AUDIO_TOKENS + 1, bias=False)
         if num_quantizers > 1:
             self.nar_audio_embeddings = nn.ModuleList(
                 [TokenEmbedding(d, NUM_AUDIO_TOKENS + 1)] + [TokenEmbedding(d, NUM_AUDIO_TOKENS) for _ in range(num_quantizers - 1)]
             )
-            self.nar_text_position = SinePositionalEmbedding(d, alpha=False)
-            self.nar_audio_position = SinePositionalEmbedding(d, alpha=False)
-            self.nar_decoder = _EncoderParams(d, num_layers, adaptive=True)
+            self.nar_text_position = SinePositionalEmbedding(d, dropout=0.0, scale=False, alpha=False)
+            self.nar_audio_position = SinePositionalEmbedding(d, dropout=0.1, scale=False, alpha=False)
+            self.nar_decoder = _decoder(d, nhead, num_layers, adaptive=True)
             self.nar_predict_layers = nn.ModuleList([nn.Linear(d, NUM_AUDIO_TOKENS, bias=False) for _ in range(num_quantizers - 1)])
             self.nar_stage_embeddings = nn.ModuleList([TokenEmbedding(d, 1) for _ in range(num_quantizers - 1)])
             if share_embedding:
                 for j in range(0, num_quantizers - 2):  # valle.py:268-271
                     self.nar_predict_layers[j].weight = self.nar_audio_embeddings[j + 2].weight
         self.requires_grad_(False)
+        set_compute_dtype(self, engine_dtype)  # the block modules run the same element type as the engine
         self._engine: Optional[Engine] = None
         self._engine_key = None
 

@@ -123,3 +123,37 @@ def attn_out_proj(ws: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor
     b = None if bias is None else bias.contiguous()
     _lib.check(lib.vle_op_attn_out_proj(_st(resid), _dt(w), _p(ws), _p(w), _p(b), _p(resid), B, nhead, d // nhead, nsplit))
     return resid
+
+
+def token_embedding(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """TokenEmbedding.forward (valle/modules/embedding.py:43-47): table[ids]; ids int64 (...), table fp32 (V, d)."""
+    lib = _lib.load()
+    assert ids.dtype == torch.int64 and table.dtype == torch.float32 and table.dim() == 2
+    ids, table = ids.contiguous(), table.contiguous()
+    d = table.shape[1]
+    out = torch.empty(*ids.shape, d, dtype=torch.float32, device=table.device)
+    _lib.check(lib.vle_op_token_embedding(_st(table), _p(ids), _p(table), _p(out), ids.numel(), d))
+    return out
+
+
+def sine_positional(x: torch.Tensor, pe: torch.Tensor, alpha: torch.Tensor, x_scale: float = 1.0) -> torch.Tensor:
+    """SinePositionalEmbedding.forward (embedding.py:93-97): x * x_scale + alpha * pe[:T]; x fp32 (B, T, d), pe (>=T, d)."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 3 and pe.dtype == torch.float32 and alpha.dtype == torch.float32
+    x, pe = x.contiguous(), pe.contiguous()
+    B, T, d = x.shape
+    assert pe.shape[-1] == d and pe.numel() // d >= T
+    out = torch.empty_like(x)
+    _lib.check(lib.vle_op_sine_positional(_st(x), _p(x), _p(pe), _p(alpha), float(x_scale), _p(out), B, T, d))
+    return out
+
+
+def adaln_fold(wb: torch.Tensor, g: torch.Tensor, be: torch.Tensor):
+    """[w ; b] = project_layer(stage_emb) (2d,) with the inner LayerNorm affine -> (w * g, w * be + b)
+    (AdaptiveLayerNorm.forward, transformer.py:93-108, as the affine of one LayerNorm call)."""
+    lib = _lib.load()
+    d = g.numel()
+    assert wb.dtype == g.dtype == be.dtype == torch.float32 and wb.numel() == 2 * d and be.numel() == d
+    out = torch.empty(2, d, dtype=torch.float32, device=g.device)
+    _lib.check(lib.vle_op_adaln_fold(_st(g), _p(wb.contiguous()), _p(g.contiguous()), _p(be.contiguous()), _p(out[0]), _p(out[1]), d))
+    return out[0], out[1]

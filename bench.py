@@ -79,6 +79,7 @@ def main():
     ap.add_argument("--top-k", type=int, default=1, help="1 = the reference's greedy; -100 = pure multinomial")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine tuning option (vle_set_option), repeatable")
     ap.add_argument("--profile-kernels", type=int, default=0, help="extra untimed pass: hipEvent time per AR-step kernel family over n steps")
     args = ap.parse_args()
 
@@ -100,6 +101,9 @@ def main():
     model = model.to(dev).eval()
     B = args.batch
     eng = model.engine_for(B, S_TEXT, P_PROMPT)
+    for kv in args.opt:
+        name, val = kv.split("=")
+        eng.set_option(name, int(val))
     if B > 1:
         # random-init weights emit EOS at arbitrary steps for some seeds (utterance 23 at step 0); the batched
         # configs time every utterance to the reference's length cap, like the batch-1 run (which never hits EOS)

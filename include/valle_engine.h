@@ -157,6 +157,14 @@ int vle_op_layernorm(void* stream, int dtype, const float* x, const float* gamma
  * epilogue 0: store T; 1: ReLU, store T; 2: resid[f32, M x N] += (.) in place; 3: store f32 */
 int vle_op_linear(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
                   int64_t M, int32_t N, int32_t K, int epilogue);
+/* vle_op_linear with a caller-owned DEVICE workspace for the split-K form of the M <= 64 weight-streaming
+ * GEMM (gemm_skinny.hip; N / 16 row fragments alone would leave CUs idle when N = d).  The workspace holds
+ * vle_op_linear_workspace_bytes() bytes, its first 4096 zeroed once by the caller (the tickets reset
+ * themselves); calls sharing a workspace must be ordered on one stream.  Deterministic: partials are
+ * summed in slice order.  ksplit: 0 = chosen from the shape; other shapes ignore the workspace. */
+int vle_op_linear_ws(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
+                     int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit);
+int64_t vle_op_linear_workspace_bytes(void);
 /* Same contract on the skinny (M <= 8, fp32 activations) weight-streaming path of the AR step:
  * x[f32, M x K]; optional fused LayerNorm prologue when gamma != NULL;
  * epilogue 0: out f32 = (.); 1: ReLU -> out f32; 2: resid += (.) */

@@ -44,8 +44,9 @@ def test_token_and_positional_embedding():
         fill_module_(pe, 12)
         pe = pe.cuda()
         got = pe(rand((2, 9, 64), 6).cuda())
-        # same fp32 table, same mul/mul/add order: bit-exact up to the host/device sin-cos table (built on the host)
-        assert torch.equal(got.cpu(), torch.from_numpy(z[f"pos_{tag}"])), tag
+        # same mul/mul/add order on the same kind of fp32 table; the table itself is built by the host's libm
+        # (sin/cos/exp differ in the last ulp between the golden's host and this one): 2 ulp of |x| ~ 8
+        assert (got.cpu() - torch.from_numpy(z[f"pos_{tag}"])).abs().max().item() <= 2e-6, tag
 
 
 def test_layernorm_and_adaptive_layernorm():

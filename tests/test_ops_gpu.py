@@ -201,3 +201,33 @@ def test_decode_attention(H, dh, ctx_max, kv, nsplit, dt):
     got = ops.attn_out_proj(ws, w, bias, r0.clone(), H, nsplit)
     want = r0.double() + ref @ w.double().t() + bias.double()
     assert (got.double() - want).abs().max().item() < 1e-4
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 4096), (64, 1024, 1024), (33, 1025, 1024), (5, 3072, 1024), (64, 1536, 1536)])
+@pytest.mark.parametrize("ksplit", [None, 1, 2, 4, 8])
+@pytest.mark.parametrize("epi", [ops.EPI_RESID, ops.EPI_F32, ops.EPI_RELU])
+def test_linear_split_k_tickets(M, N, K, ksplit, epi):
+    """gemm_skinny split-K: every slice count gives the fp64 product within bf16-input roundoff, the result
+    does not depend on arrival order (bit-identical across repeats) and the tickets reset themselves."""
+    if ksplit and K % (256 * ksplit):
+        pytest.skip("slice would be shorter than one wave chunk")
+    a = _rand(M, K, seed=40).to(torch.bfloat16)
+    w = (_rand(N, K, seed=41) / math.sqrt(K)).to(torch.bfloat16)
+    bias = _rand(N, seed=42) * 0.1
+    ref = a.double() @ w.double().t() + bias.double()
+    r0 = _rand(M, N, seed=43)
+    outs = []
+    for rep in range(3):
+        if epi == ops.EPI_RESID:
+            o = ops.linear(a, w, bias, epi, resid=r0.clone(), ksplit=ksplit)
+        else:
+            o = ops.linear(a, w, bias, epi, ksplit=ksplit)
+        outs.append(o.clone())
+    want = ref + r0.double() if epi == ops.EPI_RESID else ref.clamp_min(0) if epi == ops.EPI_RELU else ref
+    err = (outs[0].double() - want).abs().max().item()
+    tol = 2e-5 * math.sqrt(K / 64) if epi != ops.EPI_RELU else 0.02  # RELU stores bf16
+    assert err < tol, (err, tol)
+    assert torch.equal(outs[0], outs[1]) and torch.equal(outs[0], outs[2])
+    if ksplit is not None:
+        torch.cuda.synchronize()
+        assert int(ops.linear_workspace(a.device)[:4096].view(torch.int32).abs().sum()) == 0, "tickets not reset"

@@ -46,6 +46,8 @@ SIGNATURES = {
     "vle_ar_step_bytes": (C.c_int64, [_P, C.c_int32, C.c_int64]),
     "vle_op_layernorm": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int32]),
     "vle_op_linear": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int]),
+    "vle_op_linear_ws": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int, _P, C.c_int32]),
+    "vle_op_linear_workspace_bytes": (C.c_int64, []),
     "vle_op_linear_skinny": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_decode_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

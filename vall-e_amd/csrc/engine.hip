@@ -101,6 +101,8 @@ struct vle_engine {
   // forces eager launches; tags: 0 qkv, 1 decode-attention, 2 out-proj, 3 ffn1, 4 ffn2, 5 logits, 6 sample
   bool opt_profile = false;
   bool opt_no_gemm_skinny = false;  // option "no_gemm_skinny": batch 2..64 on the v0 kernels (A/B measurements)
+  int opt_gs_target = 0;            // option "gs_target_wgs": workgroups the split-K of gemm_skinny aims for (0 = 256)
+  void* gs_ws = nullptr;            // split-K tickets + partial tiles of gemm_skinny (zeroed once)
   bool opt_ignore_eos = false;  // option "ignore_eos": synthetic-weight benchmarks run every utterance to the length cap
   bool opt_no_gemv1 = false;  // option "no_gemv1": force the generic skinny kernel at batch 1 (A/B measurements)
   int opt_nsplit = 0;         // option "nsplit": 0 = chosen per batch
@@ -508,6 +510,9 @@ static int alloc_buffers(vle_engine* e) {
     e->att_step = p;
     if ((r = dev_alloc(e, &p, (size_t)B * 4 * d * es))) return r;
     e->hT_step = p;
+    if ((r = dev_alloc(e, &p, gemm_skinny_workspace_bytes()))) return r;
+    E_HIP(e, hipMemset(p, 0, gemm_skinny_workspace_bytes()));
+    e->gs_ws = p;
   }
   if ((r = dev_alloc(e, &e->state_dev, 6 * B + 8))) return r;
   e->S.kv_len = e->state_dev;
@@ -639,6 +644,7 @@ int enqueue_ar_logits(vle_engine* e) {
     E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d));
     if (use_mfma_skinny(e)) {
       GemmSkinnyArgs g;
+      g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target;
       g.x = e->xn_step; g.w = e->ar_predict; g.M = e->B; g.N = V_AR; g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
       E_LAUNCH(e, launch_gemm_skinny(st, g));
     } else {
@@ -671,6 +677,7 @@ int enqueue_ar_step(vle_engine* e) {
     if (gs) {
       GemmSkinnyArgs g;
       g.M = e->B;
+      g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target;
       {
         ProfScope ps(e, 0);
         E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
@@ -1227,8 +1234,9 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
+    else if (n == "gs_target_wgs") e->opt_gs_target = (int)value;  // 1 = no split-K
     else if (n == "no_gemm_skinny") e->opt_no_gemm_skinny = value != 0;
     else if (n == "attn_nk") e->opt_nk = (int)value;
     else if (n == "steps_per_graph") e->opt_spg = (int)value;

@@ -16,7 +16,12 @@
 //     v_mfma_f32_16x16x32_bf16 computes C^T[n][m], so a lane ends up with 4 consecutive output
 //     columns of one utterance: vector epilogue, and K/V go straight into the cache slot (EPI QKV),
 //     which removes the separate split kernel;
-//   * up to 4 k-chunks (40 x 16-byte loads per lane at M = 64) are requested before the first MFMA.
+//   * up to 4 k-chunks (40 x 16-byte loads per lane at M = 64) are requested before the first MFMA;
+//   * split-K across workgroups (gridDim.y = KS) when N/16 alone would leave most of the 256 CUs idle
+//     (N = d: out-proj, FFN2, logits -> 64 row fragments): every slice writes its fp32 partial tile
+//     (4 KB) to a workspace, takes a ticket on the fragment's counter, and the LAST arriver sums the
+//     KS partials in slice order (deterministic, independent of arrival order) and runs the epilogue;
+//     the counter resets itself, so a captured graph replays without a memset.
 #include "common.h"
 #include "kernels.h"
 
@@ -37,12 +42,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   const int fr = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.x * 16;
   const int K = a.K, N = a.N, M = a.M;
-  const int Kw = K >> 2;  // this wave's share of K (multiple of 64)
+  const int KS = gridDim.y, ks = blockIdx.y;
+  const int Kw = K / (4 * KS);  // this wave's share of K (multiple of 64)
+  const int kbeg = (ks * 4 + wave) * Kw;
   const int nrow = min(n0 + fr, N - 1);
-  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w) + (int64_t)nrow * K + wave * Kw + fg * 8;
+  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w) + (int64_t)nrow * K + kbeg + fg * 8;
   const bf16_t* xp[MF];
 #pragma unroll
-  for (int i = 0; i < MF; ++i) xp[i] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(i * 16 + fr, M - 1) * K + wave * Kw + fg * 8;
+  for (int i = 0; i < MF; ++i) xp[i] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(i * 16 + fr, M - 1) * K + kbeg + fg * 8;
 
   // epilogue operands requested up front
   const int ncol = n0 + fg * 4;  // first of this lane's 4 output columns
@@ -91,11 +98,45 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
 #pragma unroll
   for (int i = 0; i < MF; ++i) *reinterpret_cast<gs_f32x4*>(&red[wave][i][lane][0]) = acc[i];
   __syncthreads();
-  if (wave >= MF) return;
-  const int i = wave;
-  gs_f32x4 v = *reinterpret_cast<const gs_f32x4*>(&red[0][i][lane][0]);
+  const int i = wave;  // waves >= MF only take part in the barriers below
+  gs_f32x4 v = gs_f32x4{0.f, 0.f, 0.f, 0.f};
+  if (wave < MF) {
+    v = *reinterpret_cast<const gs_f32x4*>(&red[0][i][lane][0]);
 #pragma unroll
-  for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const gs_f32x4*>(&red[w][i][lane][0]);
+    for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const gs_f32x4*>(&red[w][i][lane][0]);
+  }
+  if (KS > 1) {  // uniform per launch
+    // Cross-workgroup hand-off WITHOUT fences: an agent-scope release fence writes the whole L2 back
+    // (measured: 30-70 us per kernel).  Partials go out as write-through (sc1) stores, the wave waits for
+    // their acknowledgement (vmcnt), then one lane takes the ticket; the last arriver reads with sc1 loads.
+    __shared__ int s_last;
+    float* part = a.ws_part + ((int64_t)blockIdx.x * KS * MF) * 256;  // tile (ks, i): [r][lane], 4 x 256-B rows
+    if (wave < MF) {
+      float* p = part + (ks * MF + i) * 256 + lane;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) __hip_atomic_store(p + r * 64, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (tid == 0) {
+      const int t = __hip_atomic_fetch_add(a.ws_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      s_last = t == KS - 1;
+      if (t == KS - 1) __hip_atomic_store(a.ws_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-reset
+    }
+    __syncthreads();
+    if (!s_last) return;
+    if (wave < MF) {
+      v = gs_f32x4{0.f, 0.f, 0.f, 0.f};
+      for (int q = 0; q < KS; ++q) {  // fixed slice order: the sum does not depend on who arrived last
+        const float* pq = part + (q * MF + i) * 256 + lane;
+        gs_f32x4 t;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) t[r] = __hip_atomic_load(pq + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        v += t;
+      }
+    }
+  }
+  if (wave >= MF) return;
   v += bias4;
   // lane (fg, fr) holds C[m = 16 i + fr][n = n0 + 4 fg + r]
   const int m = i * 16 + fr;
@@ -148,9 +189,23 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   }
 }
 
+// K slices across workgroups: enough to give every CU a workgroup (target), each wave keeping >= 64 of K
+// Measured at M = 64 (MI355X, per launch incl. the ticket hand-off): K = 4096, N = 1024 (FFN2) 23.4 -> 12.8 us
+// with 4 slices; at K = 1024 a slice is one 64-deep chunk per wave and the hand-off costs more than the idle
+// CUs did (out-proj 9.8 -> 12.2 us, QKV 14.6 -> 20.4 us): split only long K.
+int gemm_skinny_ksplit(int N, int K, int target_wgs) {
+  if (K < 2048) return 1;
+  const int nblk = (N + 15) / 16;
+  int ks = 1;
+  while (nblk * ks < target_wgs && ks < 16 && K % (4 * 64 * ks * 2) == 0) ks *= 2;
+  return ks;
+}
+
+size_t gemm_skinny_workspace_bytes() { return GS_WS_CNT_BYTES + (size_t)GS_WS_MAX_TILES * 64 * 16 * sizeof(float); }
+
 template <int MF>
-static int gs_launch(hipStream_t st, const GemmSkinnyArgs& a) {
-  const dim3 grid((a.N + 15) / 16), block(256);
+static int gs_launch(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
+  const dim3 grid((a.N + 15) / 16, KS), block(256);
   switch (a.epi) {
     case GS_EPI_STORE: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_STORE>), grid, block, 0, st, a); break;
     case GS_EPI_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RELU>), grid, block, 0, st, a); break;
@@ -171,10 +226,19 @@ bool gemm_skinny_supports(int M, int N, int K, int epi, int dh) {
 // returns 0 = launched, 1 = shape not covered
 int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a) {
   if (!gemm_skinny_supports(a.M, a.N, a.K, a.epi, a.dh)) return 1;
-  if (a.M <= 16) return gs_launch<1>(st, a);
-  if (a.M <= 32) return gs_launch<2>(st, a);
-  if (a.M <= 48) return gs_launch<3>(st, a);
-  return gs_launch<4>(st, a);
+  int KS = 1;
+  if (a.workspace != nullptr) {  // [GS_WS_CNT_BYTES of zeroed tickets][partial tiles]
+    KS = a.ksplit > 0 ? a.ksplit : gemm_skinny_ksplit(a.N, a.K, a.target_wgs > 0 ? a.target_wgs : 256);
+    const int nblk = (a.N + 15) / 16;
+    while (KS > 1 && (a.K % (256 * KS) != 0 || nblk * KS > GS_WS_MAX_TILES || nblk > GS_WS_CNT_BYTES / 4)) KS >>= 1;
+  }
+  GemmSkinnyArgs b = a;
+  b.ws_cnt = reinterpret_cast<int*>(a.workspace);
+  b.ws_part = a.workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.workspace) + GS_WS_CNT_BYTES) : nullptr;
+  if (a.M <= 16) return gs_launch<1>(st, b, KS);
+  if (a.M <= 32) return gs_launch<2>(st, b, KS);
+  if (a.M <= 48) return gs_launch<3>(st, b, KS);
+  return gs_launch<4>(st, b, KS);
 }
 
 }  // namespace vle

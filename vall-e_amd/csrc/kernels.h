@@ -47,7 +47,18 @@ struct GemmSkinnyArgs {
   void* v_cache = nullptr;
   const int32_t* kv_len = nullptr;
   int ctx_max = 0, nhead = 1, dh = 4;
+  // split-K across workgroups (N/16 < #CUs): caller-owned device workspace of gemm_skinny_workspace_bytes(),
+  // its first GS_WS_CNT_BYTES zeroed once (the tickets reset themselves); null = no split
+  void* workspace = nullptr;
+  int ksplit = 0;      // 0 = chosen from N, K and target_wgs
+  int target_wgs = 0;  // 0 = 256
+  int* ws_cnt = nullptr;   // (filled by the launcher)
+  float* ws_part = nullptr;
 };
+constexpr int GS_WS_CNT_BYTES = 4096;  // 1024 row-fragment tickets
+constexpr int GS_WS_MAX_TILES = 2048;  // partial 16 x 64 fp32 tiles (4 KB each)
+size_t gemm_skinny_workspace_bytes();
+int gemm_skinny_ksplit(int N, int K, int target_wgs);
 bool gemm_skinny_supports(int M, int N, int K, int epi, int dh);
 int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a);  // 1 = shape not covered
 

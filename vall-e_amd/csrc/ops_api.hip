@@ -26,17 +26,31 @@ extern "C" int vle_op_layernorm(void* stream, int dtype, const float* x, const f
   return op_done(launch_layernorm((hipStream_t)stream, dtype, x, nullptr, gamma, beta, out, rows, d), "vle_op_layernorm");
 }
 
-extern "C" int vle_op_linear(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
-                             int64_t M, int32_t N, int32_t K, int epilogue) {
+static int op_linear(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid, int64_t M,
+                     int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit, const char* who) {
   if (!a || !w) return op_fail("vle_op_linear: null operand");
   if (epilogue == EPI_RESID ? !resid : !out) return op_fail("vle_op_linear: missing output");
   if (dtype == DT_BF16 && M <= 64 && gemm_skinny_supports((int)M, N, K, epilogue, 4)) {  // the AR-step path of 2..64 utterances
     GemmSkinnyArgs g;
     g.x = a; g.w = w; g.bias = bias; g.M = (int)M; g.N = N; g.K = K; g.epi = epilogue; g.out = out; g.resid = resid;
-    return op_done(launch_gemm_skinny((hipStream_t)stream, g), "vle_op_linear");
+    g.workspace = workspace; g.ksplit = ksplit;
+    return op_done(launch_gemm_skinny((hipStream_t)stream, g), who);
   }
-  return op_done(launch_gemm((hipStream_t)stream, dtype, a, w, bias, out, resid, M, N, K, epilogue), "vle_op_linear");
+  return op_done(launch_gemm((hipStream_t)stream, dtype, a, w, bias, out, resid, M, N, K, epilogue), who);
 }
+
+extern "C" int vle_op_linear(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
+                             int64_t M, int32_t N, int32_t K, int epilogue) {
+  return op_linear(stream, dtype, a, w, bias, out, resid, M, N, K, epilogue, nullptr, 0, "vle_op_linear");
+}
+
+extern "C" int vle_op_linear_ws(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
+                                int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit) {
+  if (ksplit < 0 || ksplit > 16 || (ksplit & (ksplit - 1))) return op_fail("vle_op_linear_ws: ksplit must be 0, 1, 2, 4, 8 or 16");
+  return op_linear(stream, dtype, a, w, bias, out, resid, M, N, K, epilogue, workspace, ksplit, "vle_op_linear_ws");
+}
+
+extern "C" int64_t vle_op_linear_workspace_bytes(void) { return (int64_t)gemm_skinny_workspace_bytes(); }
 
 extern "C" int vle_op_linear_skinny(void* stream, int dtype, const float* x, const float* gamma, const float* beta, const void* w,
                                     const float* bias, float* out, float* resid, int32_t M, int32_t N, int32_t K, int epilogue) {

@@ -45,9 +45,24 @@ def layernorm(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, out_dtyp
     return out
 
 
+_WORKSPACES = {}
+
+
+def linear_workspace(device: torch.device) -> torch.Tensor:
+    """Per-device split-K workspace of the M <= 64 GEMM (tickets zeroed once; calls must share one stream)."""
+    key = (device.type, device.index or 0)
+    ws = _WORKSPACES.get(key)
+    if ws is None:
+        ws = torch.zeros(int(_lib.load().vle_op_linear_workspace_bytes()), dtype=torch.uint8, device=device)
+        _WORKSPACES[key] = ws
+    return ws
+
+
 def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_STORE,
-           resid: Optional[torch.Tensor] = None) -> torch.Tensor:
-    """epilogue(a @ w.T + bias) on the MFMA GEMM path. a (M,K), w (N,K) same dtype (fp32|bf16)."""
+           resid: Optional[torch.Tensor] = None, ksplit: Optional[int] = 0) -> torch.Tensor:
+    """epilogue(a @ w.T + bias) on the MFMA GEMM path. a (M,K), w (N,K) same dtype (fp32|bf16).
+    ksplit (bf16, M <= 64 only): 0 = split K across workgroups as the engine does, n = force n slices,
+    None = never split (vle_op_linear without a workspace)."""
     lib = _lib.load()
     a, w = a.contiguous(), w.contiguous()
     assert a.dtype == w.dtype and a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[1]
@@ -61,7 +76,11 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     else:
         out = torch.empty(M, N, dtype=a.dtype, device=a.device)
     b = None if bias is None else bias.contiguous()
-    _lib.check(lib.vle_op_linear(_st(a), _dt(a), _p(a), _p(w), _p(b), _p(out), _p(resid), M, N, K, epilogue))
+    if ksplit is None:
+        _lib.check(lib.vle_op_linear(_st(a), _dt(a), _p(a), _p(w), _p(b), _p(out), _p(resid), M, N, K, epilogue))
+    else:
+        ws = linear_workspace(a.device)
+        _lib.check(lib.vle_op_linear_ws(_st(a), _dt(a), _p(a), _p(w), _p(b), _p(out), _p(resid), M, N, K, epilogue, _p(ws), int(ksplit)))
     return resid if epilogue == EPI_RESID else out
 
 

@@ -165,15 +165,8 @@ int vle_op_linear(void* stream, int dtype, const void* a, const void* w, const f
 int vle_op_linear_ws(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
                      int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit);
 int64_t vle_op_linear_workspace_bytes(void);
-/* LayerNorm + Linear in ONE launch -- norm1 -> in-proj, norm2 -> linear1, final norm -> predict of the AR step
- * at 2..64 utterances (transformer.py:296-302 pre-norm branch; valle.py:1035-1039):
- * out = epilogue(LayerNorm(x[f32, M x K]; gamma, beta, eps 1e-5) @ w[bf16, N x K]^T + bias); the normalised rows are
- * rounded to bf16 exactly as vle_op_layernorm(dtype bf16) would.  M <= 64, K in {1024, 1536};
- * epilogue 0 / 1 (bf16 out) or 3 (f32 out).  workspace / ksplit as vle_op_linear_ws (may be NULL / 0). */
-int vle_op_ln_linear_ws(void* stream, const float* x, const float* gamma, const float* beta, const void* w, const float* bias,
-                        void* out, int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit);
 /* Kernel-selection knobs of the stand-alone operators, process-global (tests and microbenchmarks):
- * "gs_variant" 0 auto | 1 (X fragments -> VGPR) | 2 (X staged in LDS); "gs_wn" 0 auto | 1 | 2. */
+ * "glds_big" -1 default | 0 never | n: full-tile count from which the bf16 GEMM uses its 8-wave 256 x 128 tile. */
 int vle_op_tune(const char* name, int64_t value);
 /* Same contract on the skinny (M <= 8, fp32 activations) weight-streaming path of the AR step:
  * x[f32, M x K]; optional fused LayerNorm prologue when gamma != NULL;

@@ -101,9 +101,6 @@ struct vle_engine {
   // forces eager launches; tags: 0 qkv, 1 decode-attention, 2 out-proj, 3 ffn1, 4 ffn2, 5 logits, 6 sample
   bool opt_profile = false;
   bool opt_no_gemm_skinny = false;  // option "no_gemm_skinny": batch 2..64 on the v0 kernels (A/B measurements)
-  int opt_gs_variant = 0;           // option "gs_variant": 0 auto (v2: X staged in LDS), 1 = v1, 2 = v2 or fail
-  int opt_gs_wn = 0;                // option "gs_wn": v2 row fragments per workgroup (0 auto)
-  bool opt_gs_fuse_ln = true;       // option "gs_fuse_ln": LayerNorm in the v2 GEMM prologue (no LayerNorm launch)
   int opt_gs_target = 0;            // option "gs_target_wgs": workgroups the split-K of gemm_skinny aims for (0 = 256)
   void* gs_ws = nullptr;            // split-K tickets + partial tiles of gemm_skinny (zeroed once)
   bool opt_ignore_eos = false;  // option "ignore_eos": synthetic-weight benchmarks run every utterance to the length cap
@@ -629,11 +626,6 @@ bool use_mfma_skinny(const vle_engine* e) {
   return e->dtype == DT_BF16 && e->B >= 2 && e->B <= 64 && !e->opt_no_gemm_skinny && e->d % 256 == 0 && e->dh % 4 == 0;
 }
 
-// batch 2..64: LayerNorm runs in the prologue of the QKV / FFN1 / logits GEMM (gemm_skinny.hip v2)
-bool gs_fused_ln(const vle_engine* e, int N, int epi) {
-  return e->opt_gs_fuse_ln && e->opt_gs_variant != 1 && gemm_skinny_ln_supports(e->B, N, e->d, epi, e->dh);
-}
-
 bool use_skinny(const vle_engine* e) {
   if (use_mfma_skinny(e)) return false;
   return e->B <= SKINNY_MAX_B && (size_t)(e->B <= 1 ? 1 : e->B <= 2 ? 2 : e->B <= 4 ? 4 : 8) * 4 * e->d * sizeof(float) <= 160 * 1024;
@@ -649,13 +641,11 @@ int enqueue_ar_logits(vle_engine* e) {
     a.pro = PRO_LN; a.epi = SEPI_STORE; a.x = e->x_step; a.gamma = e->ar_norm_g; a.beta = e->ar_norm_b; a.out = e->logits;
     E_LAUNCH(e, launch_ar_linear(e, a));
   } else {
-    const bool fuse = use_mfma_skinny(e) && gs_fused_ln(e, V_AR, GS_EPI_F32);
-    if (!fuse) E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d));
+    E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d));
     if (use_mfma_skinny(e)) {
       GemmSkinnyArgs g;
-      g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target; g.variant = e->opt_gs_variant; g.wn = e->opt_gs_wn;
+      g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target;
       g.x = e->xn_step; g.w = e->ar_predict; g.M = e->B; g.N = V_AR; g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
-      if (fuse) { g.x32 = e->x_step; g.gamma = e->ar_norm_g; g.beta = e->ar_norm_b; }
       E_LAUNCH(e, launch_gemm_skinny(st, g));
     } else {
       E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
@@ -687,11 +677,10 @@ int enqueue_ar_step(vle_engine* e) {
     if (gs) {
       GemmSkinnyArgs g;
       g.M = e->B;
-      g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target; g.variant = e->opt_gs_variant; g.wn = e->opt_gs_wn;
+      g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target;
       {
         ProfScope ps(e, 0);
-        if (gs_fused_ln(e, 3 * d, GS_EPI_QKV)) { g.x32 = e->x_step; g.gamma = w.g1; g.beta = w.be1; }
-        else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
+        E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
         g.x = e->xn_step; g.w = w.wqkv; g.bias = w.bqkv; g.N = 3 * d; g.K = d; g.epi = GS_EPI_QKV;
         g.q_out = e->q_step; g.k_cache = kc; g.v_cache = vc; g.kv_len = e->S.kv_len; g.ctx_max = e->ctx_max; g.nhead = e->H; g.dh = e->dh;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
@@ -705,20 +694,17 @@ int enqueue_ar_step(vle_engine* e) {
       {
         ProfScope ps(e, 2);
         if (!direct) E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
-        g.x32 = nullptr; g.gamma = g.beta = nullptr;
         g.x = e->att_step; g.w = w.wo; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       {
         ProfScope ps(e, 3);
-        if (gs_fused_ln(e, 4 * d, GS_EPI_RELU)) { g.x32 = e->x_step; g.gamma = w.g2; g.beta = w.be2; }
-        else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
+        E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
         g.x = e->xn_step; g.w = w.w1; g.bias = w.b1; g.N = 4 * d; g.K = d; g.epi = GS_EPI_RELU; g.out = e->hT_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       {
         ProfScope ps(e, 4);
-        g.x32 = nullptr; g.gamma = g.beta = nullptr;
         g.x = e->hT_step; g.w = w.w2; g.bias = w.b2; g.N = d; g.K = 4 * d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
@@ -1248,12 +1234,8 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_variant" ||
-      n == "gs_wn" || n == "gs_fuse_ln") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
-    else if (n == "gs_variant") e->opt_gs_variant = (int)value;
-    else if (n == "gs_wn") e->opt_gs_wn = (int)value;
-    else if (n == "gs_fuse_ln") e->opt_gs_fuse_ln = value != 0;
     else if (n == "gs_target_wgs") e->opt_gs_target = (int)value;  // 1 = no split-K
     else if (n == "no_gemm_skinny") e->opt_no_gemm_skinny = value != 0;
     else if (n == "attn_nk") e->opt_nk = (int)value;
@@ -1265,6 +1247,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
       if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
     }
     e->graphs.clear();
+    return VLE_OK;
+  }
+  if (n == "glds_big") {  // process-global tile policy of gemm_glds.hip (same knob as vle_op_tune)
+    g_glds_big = (int)value;
     return VLE_OK;
   }
   if (n == "ignore_eos") {

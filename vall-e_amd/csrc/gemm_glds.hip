@@ -30,21 +30,22 @@ __device__ inline void gg_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int EPI>
-__global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+template <int BM, int BN, int EPI, int NW>
+__global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const float* __restrict__ bias, void* __restrict__ out_,
                                                         float* __restrict__ resid, int64_t M, int N, int K) {
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int STAGES = (4 * STAGE_BYTES <= 144 * 1024) ? 4 : 3;
   constexpr int D = STAGES - 1;                 // k-steps in flight
-  constexpr int NIA = BM / 32, NIB = BN / 32;   // LDS-DMA instructions per wave per stage (8 rows each)
+  constexpr int NIA = BM / (8 * NW), NIB = BN / (8 * NW);   // LDS-DMA instructions per wave per stage (8 rows each)
   constexpr int NI = NIA + NIB;
-  constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
+  constexpr int WMW = NW / 2;                   // waves along M (x 2 along N): 2 x 2, or 4 x 2 for the 8-wave 256-row tile
+  constexpr int WM = BM / WMW, WN = BN / 2, FM = WM / 16, FN = WN / 16;
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches / LDS bases
-  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;
+  const int wm0 = (wave >> 1) * WM, wn0 = (wave & 1) * WN;  // wave >> 1 in [0, WMW)
   const int nbx = gridDim.x, nby = gridDim.y;
   const int nblk = nbx * nby;
   int bid = blockIdx.y * nbx + blockIdx.x;
@@ -70,13 +71,13 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
   const unsigned char* srcB[NIB];
 #pragma unroll
   for (int p = 0; p < NIA; ++p) {
-    int64_t gm = m0 + (p * 4 + wave) * 8 + prow;
+    int64_t gm = m0 + (p * NW + wave) * 8 + prow;
     gm = gm < M ? gm : M - 1;
     srcA[p] = reinterpret_cast<const unsigned char*>(A + gm * K) + pvec * 16;
   }
 #pragma unroll
   for (int p = 0; p < NIB; ++p) {
-    int gn = n0 + (p * 4 + wave) * 8 + prow;
+    int gn = n0 + (p * NW + wave) * 8 + prow;
     gn = gn < N ? gn : N - 1;
     srcB[p] = reinterpret_cast<const unsigned char*>(W + (int64_t)gn * K) + pvec * 16;
   }
@@ -85,11 +86,11 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
 #pragma unroll
     for (int p = 0; p < NIA; ++p)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcA[p] + (int64_t)kt * 128),
-                                       (__attribute__((address_space(3))) void*)(st + (p * 4 + wave) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(st + (p * NW + wave) * 1024), 16, 0, 0);
 #pragma unroll
     for (int p = 0; p < NIB; ++p)
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(srcB[p] + (int64_t)kt * 128),
-                                       (__attribute__((address_space(3))) void*)(st + BM * 128 + (p * 4 + wave) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(st + BM * 128 + (p * NW + wave) * 1024), 16, 0, 0);
   };
 
   const int fr = lane & 15, fg = lane >> 4;
@@ -231,11 +232,15 @@ __global__ __launch_bounds__(256) void gemm_glds_kernel(const bf16_t* __restrict
     }
 }
 
-template <int BM, int BN>
+// tile policy knob (vle_op_tune "glds_big"): 0 = never use the 8-wave 256 x 128 tile, -1 = default threshold
+// (>= 512 full tiles), n > 0 = threshold n
+int g_glds_big = -1;
+
+template <int BM, int BN, int NW = 4>
 static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const float* bias, void* out, float* resid, int64_t M,
                      int N, int K, int epi) {
-  const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM)), block(256);
-#define VLE_GG(E) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E>), grid, block, 0, st, A, W, bias, out, resid, M, N, K)
+  const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM)), block(NW * 64);
+#define VLE_GG(E) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW>), grid, block, 0, st, A, W, bias, out, resid, M, N, K)
   switch (epi) {
     case EPI_STORE: VLE_GG(EPI_STORE); break;
     case EPI_RELU: VLE_GG(EPI_RELU); break;
@@ -257,6 +262,10 @@ int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* 
   const int64_t t128x64 = ((M + 127) / 128) * ((N + 63) / 64);
   const bf16_t* a = (const bf16_t*)A;
   const bf16_t* w = (const bf16_t*)W;
+  // many tiles (batched prefill / NAR rows): 256 x 128 with 8 waves -- two waves per SIMD cover each other's
+  // ds_read -> MFMA latency, and the W panel is re-read half as often
+  const int64_t t256 = (M / 256) * ((N + 127) / 128);
+  if (g_glds_big != 0 && t256 >= (g_glds_big > 0 ? g_glds_big : 512)) return gg_launch<256, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi);
   if (full128 >= 160) return gg_launch<128, 128>(st, a, w, bias, out, resid, M, N, K, epi);
   if (t128x64 >= 96) return gg_launch<128, 64>(st, a, w, bias, out, resid, M, N, K, epi);
   return gg_launch<64, 64>(st, a, w, bias, out, resid, M, N, K, epi);

@@ -22,6 +22,11 @@
 //     (4 KB) to a workspace, takes a ticket on the fragment's counter, and the LAST arriver sums the
 //     KS partials in slice order (deterministic, independent of arrival order) and runs the epilogue;
 //     the counter resets itself, so a captured graph replays without a memset.
+// Measured and rejected (round 1, MI355X, M = 64, per launch in a dependent graph chain): staging the X slice in
+// LDS once per workgroup (full-line loads, waves as 1-2 row fragments x k-ranges) 9.2-9.8 us vs 7.2-7.3 us here --
+// the load -> LDS -> barrier -> ds_read prologue serialises what this kernel requests as one burst; LayerNorm fused
+// into that prologue 13.1 us vs 1.9 (LayerNorm launch) + 7.2.  All four shapes cost ~7.2 us regardless of W size
+// (2-8 MB): the launch is latency-bound on the X fragments (4x the bytes of W through each CU's texture path).
 #include "common.h"
 #include "kernels.h"
 
@@ -195,214 +200,6 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   gs_epilogue<EPI>(a, v, i * 16 + fr, ncol);
 }
 
-// ---- v2: X through LDS in full lines, shared by the waves of a workgroup; optional fused LayerNorm ----------
-// v1 reads X fragment-shaped (16 rows x 64 B per instruction) straight into VGPRs, once per MFMA: at M = 64 that
-// is 4x the bytes of W through the texture path of every CU, with no reuse.  Here a workgroup stages its X slice
-// [16 MF rows][Ks] in LDS once (row stride Ks*2 + 16 B: the 16 rows of a ds_read_b128 phase fall into 16 distinct
-// 4-bank groups), its 4 waves are WN row-fragments x WK k-ranges, and W still goes global -> VGPR (nothing shares it).
-//   PRO_PLAIN: X is bf16 [M][K] (attention output, FFN hidden): 16-byte loads, ds_write_b128.
-//   PRO_LN:    X is the fp32 residual stream [M][K]: LayerNorm (valle/modules/transformer.py:57-74, eps 1e-5,
-//              biased variance, two-pass fp32 like layernorm.hip) is applied on the way into LDS, which removes the
-//              separate LayerNorm launch and the bf16 xn round trip.  Statistics run over the full row even when the
-//              workgroup keeps only a K slice.
-enum { GS_PRO_PLAIN = 0, GS_PRO_LN = 1 };
-
-template <int MF, int WN, int EPI, int PRO, int NV /* K / 256 for PRO_LN */>
-__global__ __launch_bounds__(256) void gemm_skinny_lds_kernel(GemmSkinnyArgs a, int Ks, int xstride) {
-  constexpr int WK = 4 / WN;
-  constexpr int G = 8;  // k-chunks of W (64 deep, 2 x 16 B per lane) in flight per wave
-  extern __shared__ __attribute__((aligned(16))) unsigned char gs_smem[];
-  unsigned char* xs = gs_smem;                                                                   // [16 MF][xstride]
-  gs_f32x4* red = reinterpret_cast<gs_f32x4*>(gs_smem + (size_t)16 * MF * xstride);               // [4 waves][MF][64]
-  int* s_last = reinterpret_cast<int*>(gs_smem + (size_t)16 * MF * xstride + 4 * MF * 64 * 16);  // one LDS object only
-
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wn = wave % WN, wk = wave / WN;
-  const int fr = lane & 15, fg = lane >> 4;
-  const int K = a.K, N = a.N, M = a.M;
-  const int KS = gridDim.y, ks = blockIdx.y;
-  const int kbeg = ks * Ks;      // this workgroup's K slice
-  const int Kw = Ks / WK;        // this wave's share of it (multiple of 64)
-  const int kw0 = wk * Kw;
-  const int n0 = (blockIdx.x * WN + wn) * 16;
-  const int nrow = min(n0 + fr, N - 1);
-  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w) + (int64_t)nrow * K + kbeg + kw0 + fg * 8;
-  const int chunks = Kw >> 6;
-
-  // Request order (vmcnt retires in issue order): epilogue operands, the first X batch (L2), then the first round
-  // of W (HBM), then the remaining X batches -- the first batch is consumed at L2 latency while W is still in
-  // flight, everything later lands together with W.
-  gs_u32x4 wv[G][2];
-  auto issue_w = [&](int c0) {
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      const int c = min(c0 + g, chunks - 1);  // clamped: a short round re-reads its final chunk, unused below
-      wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64));
-      wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64 + 32));
-    }
-  };
-  const int ncol = n0 + fg * 4;
-  gs_f32x4 bias4 = gs_f32x4{0.f, 0.f, 0.f, 0.f};
-  if (a.bias != nullptr) {
-    if (ncol + 3 < N) bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
-    else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bias4[r] = ncol + r < N ? a.bias[ncol + r] : 0.f;
-    }
-  }
-
-  // ---- prologue: the X slice -> LDS -------------------------------------------------------------------
-  if constexpr (PRO == GS_PRO_PLAIN) {
-    const bf16_t* X = reinterpret_cast<const bf16_t*>(a.x);
-    const int vpr = Ks >> 3;              // 16-byte vectors per row of the slice (power of two not required)
-    const int total = 16 * MF * vpr;      // multiple of 256: Ks % 256 == 0
-    constexpr int XB = 16;                // 16-byte vectors in flight per lane per batch
-    for (int v0 = tid; v0 < total; v0 += 256 * XB) {
-      gs_u32x4 t[XB];
-#pragma unroll
-      for (int j = 0; j < XB; ++j) {
-        const int v = v0 + j * 256;
-        const int row = v / vpr, col = v - row * vpr;
-        const int srow = min(row, M - 1);
-        t[j] = v < total ? *reinterpret_cast<const gs_u32x4*>(X + (int64_t)srow * K + kbeg + col * 8) : gs_u32x4{0u, 0u, 0u, 0u};
-      }
-      if (v0 == tid) issue_w(0);
-#pragma unroll
-      for (int j = 0; j < XB; ++j) {
-        const int v = v0 + j * 256;
-        const int row = v / vpr, col = v - row * vpr;
-        if (v < total) *reinterpret_cast<gs_u32x4*>(xs + (size_t)row * xstride + col * 16) = t[j];
-      }
-    }
-  } else {
-    // LayerNorm on the way in: wave w normalises rows w, w + 4, ...; a lane holds K / 64 values of the row
-    const float* X = a.x32;
-    gs_f32x4 gam[NV], bet[NV];
-#pragma unroll
-    for (int j = 0; j < NV; ++j) {
-      gam[j] = reinterpret_cast<const gs_f32x4*>(a.gamma)[j * 64 + lane];
-      bet[j] = reinterpret_cast<const gs_f32x4*>(a.beta)[j * 64 + lane];
-    }
-    constexpr int RB = NV <= 4 ? 8 : 4;  // rows in flight per wave (RB * NV float4 per lane)
-    for (int r0 = 0; r0 < 4 * MF; r0 += RB) {
-      gs_f32x4 xv[RB][NV];
-#pragma unroll
-      for (int q = 0; q < RB; ++q) {
-        const int row = min((r0 + q) * 4 + wave, M - 1);
-        const gs_f32x4* xr = reinterpret_cast<const gs_f32x4*>(X + (int64_t)row * K) + lane;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) xv[q][j] = xr[j * 64];
-      }
-      if (r0 == 0) issue_w(0);
-#pragma unroll
-      for (int q = 0; q < RB; ++q) {
-        const int row = (r0 + q) * 4 + wave;
-        if (r0 + q >= 4 * MF) continue;  // 4 MF = 8 rows per wave at MF = 2: nothing beyond the X image
-        float sum = 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) sum += (xv[q][j].x + xv[q][j].y) + (xv[q][j].z + xv[q][j].w);
-        const float mean = wave_sum_dpp(sum) / (float)(NV * 256);
-        float sq = 0.f;
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const gs_f32x4 c = xv[q][j] - mean;
-          sq += (c.x * c.x + c.y * c.y) + (c.z * c.z + c.w * c.w);
-        }
-        const float rstd = 1.0f / sqrtf(wave_sum_dpp(sq) / (float)(NV * 256) + LN_EPS);
-#pragma unroll
-        for (int j = 0; j < NV; ++j) {
-          const gs_f32x4 o = (xv[q][j] - mean) * rstd * gam[j] + bet[j];
-          const int k = (j * 64 + lane) * 4 - kbeg;  // position inside this workgroup's slice
-          if (k >= 0 && k < Ks) {
-            gs_bf16x4 o4;
-            o4[0] = (__bf16)o.x; o4[1] = (__bf16)o.y; o4[2] = (__bf16)o.z; o4[3] = (__bf16)o.w;  // RNE, as layernorm.hip
-            *reinterpret_cast<gs_bf16x4*>(xs + (size_t)row * xstride + k * 2) = o4;
-          }
-        }
-      }
-    }
-  }
-  __syncthreads();
-
-  // ---- main loop: A = W fragment (registers), B = X fragment (LDS) -------------------------------------
-  gs_f32x4 acc[MF];
-#pragma unroll
-  for (int i = 0; i < MF; ++i) acc[i] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
-  const unsigned char* xb = xs + (size_t)fr * xstride + (kw0 + fg * 8) * 2;
-  for (int c0 = 0; c0 < chunks; c0 += G) {
-    if (c0 > 0) issue_w(c0);
-#pragma unroll
-    for (int g = 0; g < G; ++g) {
-      if (c0 + g < chunks) {
-#pragma unroll
-        for (int s2 = 0; s2 < 2; ++s2)
-#pragma unroll
-          for (int i = 0; i < MF; ++i) {
-            const gs_bf16x8 b = *reinterpret_cast<const gs_bf16x8*>(xb + (size_t)(16 * i) * xstride + (c0 + g) * 128 + s2 * 64);
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gs_bf16x8, wv[g][s2]), b, acc[i], 0, 0, 0);
-          }
-      }
-    }
-  }
-
-  // ---- combine the WK k-ranges through LDS: wave (wn, wk) finishes the m-fragments i = wk, wk + WK, ... -----
-#pragma unroll
-  for (int i = 0; i < MF; ++i) red[(wave * MF + i) * 64 + lane] = acc[i];
-  __syncthreads();
-  constexpr int NF = (MF + WK - 1) / WK;  // m-fragments per wave
-  gs_f32x4 v[NF];
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    const int i = wk + f * WK;
-    v[f] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
-    if (i < MF) {
-#pragma unroll
-      for (int q = 0; q < WK; ++q) v[f] += red[((q * WN + wn) * MF + i) * 64 + lane];
-    }
-  }
-  if (KS > 1) {  // split-K across workgroups: same fence-free ticket hand-off as v1
-    float* part = a.ws_part + ((int64_t)blockIdx.x * KS * WN * MF) * 256;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const int i = wk + f * WK;
-      if (i < MF) {
-        float* p = part + ((ks * WN + wn) * MF + i) * 256 + lane;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) __hip_atomic_store(p + r * 64, v[f][r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    if (tid == 0) {
-      const int t = __hip_atomic_fetch_add(a.ws_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      *s_last = t == KS - 1;
-      if (t == KS - 1) __hip_atomic_store(a.ws_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
-    __syncthreads();
-    if (!*s_last) return;
-#pragma unroll
-    for (int f = 0; f < NF; ++f) {
-      const int i = wk + f * WK;
-      if (i < MF) {
-        v[f] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
-        for (int q = 0; q < KS; ++q) {
-          const float* pq = part + ((q * WN + wn) * MF + i) * 256 + lane;
-          gs_f32x4 t;
-#pragma unroll
-          for (int r = 0; r < 4; ++r) t[r] = __hip_atomic_load(pq + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-          v[f] += t;
-        }
-      }
-    }
-  }
-#pragma unroll
-  for (int f = 0; f < NF; ++f) {
-    const int i = wk + f * WK;
-    if (i < MF) gs_epilogue<EPI>(a, v[f] + bias4, i * 16 + fr, ncol);
-  }
-}
-
 // K slices across workgroups: enough to give every CU a workgroup (target), each wave keeping >= 64 of K
 // Measured at M = 64 (MI355X, per launch incl. the ticket hand-off): K = 4096, N = 1024 (FFN2) 23.4 -> 12.8 us
 // with 4 slices; at K = 1024 a slice is one 64-deep chunk per wave and the hand-off costs more than the idle
@@ -437,73 +234,9 @@ bool gemm_skinny_supports(int M, int N, int K, int epi, int dh) {
   return true;
 }
 
-// ---- v2 dispatch ------------------------------------------------------------------------------------------
-template <int MF, int WN, int EPI, int PRO, int NV>
-static int gs2_launch_one(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
-  const int Ks = a.K / KS, xstride = Ks * 2 + 16;
-  const size_t smem = (size_t)16 * MF * xstride + 4 * MF * 64 * 16 + 16;
-  if (smem > 160 * 1024) return 1;
-  auto kern = gemm_skinny_lds_kernel<MF, WN, EPI, PRO, NV>;
-  static size_t attr_bytes = 0;  // per instantiation; the attribute is idempotent, a race only repeats the call
-  if (smem > attr_bytes) {
-    if (hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem) != hipSuccess)
-      return -3;
-    attr_bytes = smem;
-  }
-  const dim3 grid((a.N + 16 * WN - 1) / (16 * WN), KS), block(256);
-  hipLaunchKernelGGL(kern, grid, block, smem, st, a, Ks, xstride);
-  return 0;
-}
-
-template <int MF, int WN, int PRO, int NV>
-static int gs2_launch_epi(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
-  switch (a.epi) {
-    case GS_EPI_STORE: return gs2_launch_one<MF, WN, GS_EPI_STORE, PRO, NV>(st, a, KS);
-    case GS_EPI_RELU: return gs2_launch_one<MF, WN, GS_EPI_RELU, PRO, NV>(st, a, KS);
-    case GS_EPI_F32: return gs2_launch_one<MF, WN, GS_EPI_F32, PRO, NV>(st, a, KS);
-    case GS_EPI_QKV: return gs2_launch_one<MF, WN, GS_EPI_QKV, PRO, NV>(st, a, KS);
-    case GS_EPI_RESID:
-      if constexpr (PRO == GS_PRO_PLAIN) return gs2_launch_one<MF, WN, GS_EPI_RESID, PRO, NV>(st, a, KS);
-      else return 1;  // LayerNorm feeds QKV / FFN1 / logits, never a residual add
-    default: return -1;
-  }
-}
-
-template <int MF, int WN>
-static int gs2_launch_pro(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
-  if (a.x32 == nullptr) return gs2_launch_epi<MF, WN, GS_PRO_PLAIN, 0>(st, a, KS);
-  if (a.K == 1024) return gs2_launch_epi<MF, WN, GS_PRO_LN, 4>(st, a, KS);
-  if (a.K == 1536) return gs2_launch_epi<MF, WN, GS_PRO_LN, 6>(st, a, KS);
-  return 1;
-}
-
-// the fused-LayerNorm form exists for the two model widths of BASELINE.json (d = 1024, 1536)
-bool gemm_skinny_ln_supports(int M, int N, int K, int epi, int dh) {
-  return (K == 1024 || K == 1536) && epi != GS_EPI_RESID && gemm_skinny_supports(M, N, K, epi, dh);
-}
-
-static int launch_gemm_skinny_v2(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
-  // the X slice of a workgroup must fit LDS next to the reduction buffer: 64 rows x Ks bf16 <= ~132 KB
-  const int MF = a.M <= 32 ? 2 : 4;
-  while ((size_t)16 * MF * (a.K / KS * 2 + 16) + 4 * MF * 64 * 16 + 16 > 160 * 1024) {
-    KS *= 2;
-    if (a.workspace == nullptr || a.K % (256 * KS) != 0 || KS > 16) return 1;
-  }
-  const int nfrag = (a.N + 15) / 16;
-  int WN = a.wn > 0 ? a.wn : (nfrag >= 192 ? 2 : 1);  // enough 16-row fragments: pair them so two waves share the X image
-  if (WN != 1 && WN != 2) return -1;
-  if ((a.K / KS) % (64 * (4 / WN)) != 0) WN = 1;
-  if ((a.K / KS) % 256 != 0) return 1;
-  const int nblk = (nfrag + WN - 1) / WN;
-  if (KS > 1 && (nblk * KS * WN > GS_WS_MAX_TILES || nblk > GS_WS_CNT_BYTES / 4)) return 1;
-  if (MF == 2) return WN == 2 ? gs2_launch_pro<2, 2>(st, a, KS) : gs2_launch_pro<2, 1>(st, a, KS);
-  return WN == 2 ? gs2_launch_pro<4, 2>(st, a, KS) : gs2_launch_pro<4, 1>(st, a, KS);
-}
-
 // returns 0 = launched, 1 = shape not covered
 int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a) {
   if (!gemm_skinny_supports(a.M, a.N, a.K, a.epi, a.dh)) return 1;
-  if (a.x32 != nullptr && (a.gamma == nullptr || a.beta == nullptr || !gemm_skinny_ln_supports(a.M, a.N, a.K, a.epi, a.dh))) return -1;
   int KS = 1;
   if (a.workspace != nullptr) {  // [GS_WS_CNT_BYTES of zeroed tickets][partial tiles]
     KS = a.ksplit > 0 ? a.ksplit : gemm_skinny_ksplit(a.N, a.K, a.target_wgs > 0 ? a.target_wgs : 256);
@@ -513,13 +246,6 @@ int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a) {
   GemmSkinnyArgs b = a;
   b.ws_cnt = reinterpret_cast<int*>(a.workspace);
   b.ws_part = a.workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.workspace) + GS_WS_CNT_BYTES) : nullptr;
-  if (a.variant != 1) {
-    const int r = launch_gemm_skinny_v2(st, b, KS);
-    if (r <= 0) return r;
-    if (a.variant == 2 || a.x32 != nullptr) return r;  // v2 demanded (or needed for the fused LayerNorm) but not available
-  } else if (a.x32 != nullptr) {
-    return -1;  // v1 has no LayerNorm prologue
-  }
   if (a.M <= 16) return gs_launch<1>(st, b, KS);
   if (a.M <= 32) return gs_launch<2>(st, b, KS);
   if (a.M <= 48) return gs_launch<3>(st, b, KS);

@@ -33,6 +33,8 @@ int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const f
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
                      int K, int epi);
 
+extern int g_glds_big;  // gemm_glds.hip tile policy: 0 never the 8-wave 256 x 128 tile, -1 default threshold, n > 0 threshold
+
 // ---- gemm_skinny.hip (AR-step weight-streaming MFMA GEMM, bf16, 2 <= M = batch <= 64) ------------
 enum { GS_EPI_STORE = 0, GS_EPI_RELU = 1, GS_EPI_RESID = 2, GS_EPI_F32 = 3, GS_EPI_QKV = 4 };
 struct GemmSkinnyArgs {
@@ -54,14 +56,7 @@ struct GemmSkinnyArgs {
   int target_wgs = 0;  // 0 = 256
   int* ws_cnt = nullptr;   // (filled by the launcher)
   float* ws_part = nullptr;
-  // v2 (X staged in LDS): fused LayerNorm prologue when x32 != null -- x32 f32 [M][K] replaces x, K in {1024, 1536}
-  const float* x32 = nullptr;
-  const float* gamma = nullptr;
-  const float* beta = nullptr;
-  int variant = 0;  // 0 = auto (v2 when it has the shape), 1 = v1 (X fragments straight to VGPRs), 2 = v2
-  int wn = 0;       // v2: 16-row W fragments per workgroup (1 or 2); 0 = chosen from N
 };
-bool gemm_skinny_ln_supports(int M, int N, int K, int epi, int dh);
 constexpr int GS_WS_CNT_BYTES = 4096;  // 1024 row-fragment tickets
 constexpr int GS_WS_MAX_TILES = 2048;  // partial 16 x 64 fp32 tiles (4 KB each)
 size_t gemm_skinny_workspace_bytes();

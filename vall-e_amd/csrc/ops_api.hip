@@ -28,13 +28,10 @@ extern "C" int vle_op_layernorm(void* stream, int dtype, const float* x, const f
   return op_done(launch_layernorm((hipStream_t)stream, dtype, x, nullptr, gamma, beta, out, rows, d), "vle_op_layernorm");
 }
 
-static int g_gs_variant = 0, g_gs_wn = 0;
-
 extern "C" int vle_op_tune(const char* name, int64_t value) {
   if (!name) return op_fail("vle_op_tune: null name");
   const std::string n = name;
-  if (n == "gs_variant" && value >= 0 && value <= 2) g_gs_variant = (int)value;
-  else if (n == "gs_wn" && value >= 0 && value <= 2) g_gs_wn = (int)value;
+  if (n == "glds_big" && value >= -1) vle::g_glds_big = (int)value;
   else return op_fail("vle_op_tune: unknown knob or value out of range");
   return VLE_OK;
 }
@@ -46,7 +43,7 @@ static int op_linear(void* stream, int dtype, const void* a, const void* w, cons
   if (dtype == DT_BF16 && M <= 64 && gemm_skinny_supports((int)M, N, K, epilogue, 4)) {  // the AR-step path of 2..64 utterances
     GemmSkinnyArgs g;
     g.x = a; g.w = w; g.bias = bias; g.M = (int)M; g.N = N; g.K = K; g.epi = epilogue; g.out = out; g.resid = resid;
-    g.workspace = workspace; g.ksplit = ksplit; g.variant = g_gs_variant; g.wn = g_gs_wn;
+    g.workspace = workspace; g.ksplit = ksplit;
     return op_done(launch_gemm_skinny((hipStream_t)stream, g), who);
   }
   return op_done(launch_gemm((hipStream_t)stream, dtype, a, w, bias, out, resid, M, N, K, epilogue), who);
@@ -61,20 +58,6 @@ extern "C" int vle_op_linear_ws(void* stream, int dtype, const void* a, const vo
                                 int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit) {
   if (ksplit < 0 || ksplit > 16 || (ksplit & (ksplit - 1))) return op_fail("vle_op_linear_ws: ksplit must be 0, 1, 2, 4, 8 or 16");
   return op_linear(stream, dtype, a, w, bias, out, resid, M, N, K, epilogue, workspace, ksplit, "vle_op_linear_ws");
-}
-
-extern "C" int vle_op_ln_linear_ws(void* stream, const float* x, const float* gamma, const float* beta, const void* w,
-                                   const float* bias, void* out, int64_t M, int32_t N, int32_t K, int epilogue, void* workspace,
-                                   int32_t ksplit) {
-  if (!x || !gamma || !beta || !w || !out) return op_fail("vle_op_ln_linear_ws: null operand");
-  if (ksplit < 0 || ksplit > 16 || (ksplit & (ksplit - 1))) return op_fail("vle_op_ln_linear_ws: ksplit must be 0, 1, 2, 4, 8 or 16");
-  if (epilogue != EPI_STORE && epilogue != EPI_RELU && epilogue != EPI_F32) return op_fail("vle_op_ln_linear_ws: epilogue must be 0, 1 or 3");
-  if (M < 1 || M > 64 || !gemm_skinny_ln_supports((int)M, N, K, epilogue, 4))
-    return op_fail("vle_op_ln_linear_ws: shape not covered (M <= 64, K in {1024, 1536})");
-  GemmSkinnyArgs g;
-  g.x32 = x; g.gamma = gamma; g.beta = beta; g.w = w; g.bias = bias; g.M = (int)M; g.N = N; g.K = K; g.epi = epilogue; g.out = out;
-  g.workspace = workspace; g.ksplit = ksplit; g.variant = 2; g.wn = g_gs_wn;
-  return op_done(launch_gemm_skinny((hipStream_t)stream, g), "vle_op_ln_linear_ws");
 }
 
 extern "C" int64_t vle_op_linear_workspace_bytes(void) { return (int64_t)gemm_skinny_workspace_bytes(); }

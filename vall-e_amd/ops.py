@@ -84,22 +84,6 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
     return resid if epilogue == EPI_RESID else out
 
 
-def ln_linear(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None,
-              epilogue: int = EPI_STORE, ksplit: int = 0) -> torch.Tensor:
-    """epilogue(LayerNorm(x) @ w.T + bias) in one launch (AR step of 2..64 utterances): x fp32 (M<=64, K), w bf16 (N, K)."""
-    lib = _lib.load()
-    x, w = x.contiguous(), w.contiguous()
-    assert x.dtype == torch.float32 and w.dtype == torch.bfloat16 and x.dim() == 2 and x.shape[1] == w.shape[1]
-    M, K = x.shape
-    N = w.shape[0]
-    out = torch.empty(M, N, dtype=torch.float32 if epilogue == EPI_F32 else torch.bfloat16, device=x.device)
-    b = None if bias is None else bias.contiguous()
-    ws = linear_workspace(x.device)
-    _lib.check(lib.vle_op_ln_linear_ws(_st(x), _p(x), _p(gamma.contiguous()), _p(beta.contiguous()), _p(w), _p(b), _p(out), M, N, K,
-                                       epilogue, _p(ws), int(ksplit)))
-    return out
-
-
 def tune(name: str, value: int) -> None:
     """Process-global kernel-selection knob of the stand-alone operators (vle_op_tune)."""
     _lib.check(_lib.load().vle_op_tune(name.encode(), int(value)))

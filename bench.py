@@ -72,7 +72,7 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=1, help="utterances per GPU (configs[1]: 1; configs[2]: 64)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32"])
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8w"], help="fp8w: bf16 arithmetic on fp8 e4m3 weights (configs[4] weight format)")
     ap.add_argument("--d-model", type=int, default=1024)
     ap.add_argument("--nhead", type=int, default=16)
     ap.add_argument("--layers", type=int, default=12)

@@ -39,6 +39,9 @@ extern "C" {
 /* arithmetic mode of the whole path */
 #define VLE_DTYPE_F32 0  /* fp32 weights / KV / accumulate: token-id-exact vs the reference */
 #define VLE_DTYPE_BF16 1 /* bf16 weights + KV, fp32 residual stream and accumulators       */
+#define VLE_DTYPE_FP8W 2 /* BF16 mode on fp8-representable weights: every Linear weight row is replaced by
+                          * W' = e4m3fn(w / 2^e) * 2^e (one power-of-two scale per row, so W' is exact in bf16); the
+                          * HBM-bound AR step streams the 1-byte codes, prefill / NAR run bf16 MFMA on bf16(W') */
 
 typedef struct vle_engine vle_engine;
 
@@ -145,6 +148,12 @@ int vle_last_timings(vle_engine* e, double* out4);
 /* algorithmic bytes moved per AR step for the current batch at context length ctx */
 int64_t vle_ar_step_bytes(const vle_engine* e, int32_t B, int64_t sum_ctx);
 
+/* The weight format of VLE_DTYPE_FP8W, on HOST buffers (what vle_finalize_weights applies to every Linear weight):
+ * per row n of w[f32, N x K]: scale_out[n] = the smallest power of two with max|w[n]| / scale <= 448,
+ * q_out[n][k] = round-to-nearest-even e4m3fn(w[n][k] / scale) (OCP e4m3fn = torch.float8_e4m3fn),
+ * deq_out[n][k] = q * scale = W'.  q_out / deq_out may be NULL. */
+int vle_quantize_fp8w(const float* w, int64_t N, int64_t K, uint8_t* q_out, float* scale_out, float* deq_out);
+
 /* ---- Transformer-block operator surface (valle/modules/transformer.py, activation.py) -------- */
 /* Stand-alone kernels behind the block API (B3 in SURVEY.md 8b); all pointers DEVICE, row-major.
  * dtype = VLE_DTYPE_*: element type of `x`/`w`/`out` where marked T; fp32 where marked f32. */
@@ -165,6 +174,14 @@ int vle_op_linear(void* stream, int dtype, const void* a, const void* w, const f
 int vle_op_linear_ws(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
                      int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit);
 int64_t vle_op_linear_workspace_bytes(void);
+/* The two weight-streaming kernels of the AR step on FP8W weights (w8 e4m3fn [N x K], wscale f32 [N], DEVICE):
+ * vle_op_linear_skinny_fp8w: one utterance (gemv1.hip), contract of vle_op_linear_skinny with M = 1;
+ * vle_op_linear_fp8w: 1 <= M <= 64 rows of bf16 activations (gemm_skinny.hip), contract of vle_op_linear_ws.
+ * Both equal the bf16 kernels run on W' = w8 * wscale (bit-identical for the GEMV, fp32 accumulation order aside). */
+int vle_op_linear_skinny_fp8w(void* stream, const float* x, const float* gamma, const float* beta, const void* w8,
+                              const float* wscale, const float* bias, float* out, float* resid, int32_t N, int32_t K, int epilogue);
+int vle_op_linear_fp8w(void* stream, const void* a, const void* w8, const float* wscale, const float* bias, void* out, float* resid,
+                       int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit);
 /* Kernel-selection knobs of the stand-alone operators, process-global (tests and microbenchmarks):
  * "glds_big" -1 default | 0 never | n: full-tile count from which the bf16 GEMM uses its 8-wave 256 x 128 tile. */
 int vle_op_tune(const char* name, int64_t value);

@@ -417,3 +417,34 @@ def continual(sd, cfg: OracleConfig, x, x_lens, y, trace=None):
 def expected_gen_len(S: int, prepend_bos: bool = False) -> int:
     """Length cap of the stop rule when EOS never fires (valle.py:1047): G = 16*S + 1 - bos."""
     return 16 * S + 1 - int(prepend_bos)
+
+
+# --------------------------------------------------------------------------------------
+# FP8W weight format (engine mode VLE_DTYPE_FP8W) -- torch restatement used as the checker
+# --------------------------------------------------------------------------------------
+FP8W_MAX = 448.0  # largest finite e4m3fn value
+
+
+def fp8w_quantize(w: torch.Tensor):
+    """Per row of w (N, K) fp32: scale = smallest power of two with max|w_row| / scale <= 448,
+    q = w / scale rounded to torch.float8_e4m3fn (round-to-nearest-even), W' = q * scale.
+    Returns (q as uint8 bit patterns, scale fp32 (N,), W' fp32 (N, K))."""
+    w = w.detach().to(torch.float32)
+    amax = w.abs().amax(dim=1)
+    m, ex = torch.frexp(amax / FP8W_MAX)  # amax / 448 = m * 2^ex, m in [0.5, 1)
+    ex = torch.where(m == 0.5, ex - 1, ex)
+    scale = torch.where(amax > 0, torch.ldexp(torch.ones_like(amax), ex), torch.ones_like(amax))
+    q = (w / scale[:, None]).to(torch.float8_e4m3fn)
+    return q.view(torch.uint8), scale, q.to(torch.float32) * scale[:, None]
+
+
+def fp8w_state_dict(sd):
+    """The state dict the FP8W engine computes with: every nn.Linear weight of the two decoders and of the
+    predict layers replaced by W'; embeddings (also the ones a predict layer is tied to), LayerNorm affines,
+    biases and the AdaLN projections unchanged (the engine folds those in fp32)."""
+    out = {}
+    for k, v in sd.items():
+        lin = (k.endswith("self_attn.in_proj_weight") or k.endswith("self_attn.out_proj.weight") or k.endswith("linear1.weight")
+               or k.endswith("linear2.weight") or k == "ar_predict_layer.weight" or (k.startswith("nar_predict_layers.") and k.endswith(".weight")))
+        out[k] = fp8w_quantize(v)[2] if lin else v.clone()
+    return out

@@ -1,0 +1,58 @@
+"""CPU: the FP8W weight format.  The engine's host quantiser (vle_quantize_fp8w, what vle_finalize_weights
+applies) against the torch restatement in oracle/valle_oracle.py (torch.float8_e4m3fn): codes, scales and
+dequantised values bit-identical, including rows of zeros, exact powers of two, values in the fp8 subnormal
+range and large magnitudes."""
+import pytest
+import torch
+
+from valle_amd import ops
+from oracle import valle_oracle as vo
+
+
+def _cases():
+    g = torch.Generator().manual_seed(3)
+    yield "gauss", torch.randn(64, 256, generator=g) * 0.05
+    yield "wide", torch.randn(32, 128, generator=g) * torch.logspace(-6, 3, 32)[:, None]
+    w = torch.randn(16, 64, generator=g)
+    w[3] = 0.0
+    w[4] = 448.0 * 2.0 ** -3 * torch.sign(w[4])  # amax / 448 an exact power of two
+    w[5, :] = 1e-3 * w[5]
+    w[5, 0] = 7.0  # the rest of the row falls into the fp8 subnormal range
+    w[6, 0] = 3.0e38
+    yield "edges", w
+    yield "ties", (torch.arange(0, 512, dtype=torch.float32).reshape(1, 512) / 8.0).repeat(2, 1) * torch.tensor([[1.0], [-1.0]])
+
+
+@pytest.mark.parametrize("name,w", list(_cases()))
+def test_host_quantiser_equals_torch_float8(name, w):
+    q, s, deq = ops.quantize_fp8w(w)
+    q2, s2, deq2 = vo.fp8w_quantize(w)
+    assert torch.equal(s, s2), name
+    assert torch.all(torch.log2(s) == torch.round(torch.log2(s))), "scales must be powers of two"
+    assert torch.equal(q, q2), (name, (q != q2).sum().item())
+    assert torch.equal(deq, deq2), name
+    assert torch.equal(deq.to(torch.bfloat16).to(torch.float32), deq), "W' must be exact in bf16"
+    amax = w.abs().amax(dim=1)
+    assert torch.all(amax / s <= 448.0) and torch.all((amax / s > 224.0) | (amax == 0)), "scale is the smallest admissible power of two"
+    err = (deq - w).abs()
+    assert torch.all(err <= w.abs() * 2.0 ** -4 + s[:, None] * 2.0 ** -10 + 1e-30), "RNE error bound: half an ulp (3 mantissa bits)"
+
+
+def test_all_256_codes_decode_like_torch():
+    codes = torch.arange(256, dtype=torch.uint8)
+    want = codes.view(torch.float8_e4m3fn).to(torch.float32)
+    finite = ~torch.isnan(want)
+    q, s, deq = ops.quantize_fp8w(torch.where(finite, want, torch.zeros(())).reshape(1, 256))
+    assert s.item() == 1.0  # max 448 -> scale 1
+    assert torch.equal(deq[0][finite], want[finite])
+    assert torch.equal(q[0][finite & (want != 0)], codes[finite & (want != 0)])  # +-0 both quantise to a zero code
+
+
+def test_fp8w_state_dict_touches_only_linear_weights():
+    cfg = vo.OracleConfig(d_model=64, nhead=4, num_layers=2, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 0)
+    sq = vo.fp8w_state_dict(sd)
+    assert list(sq) == list(sd)
+    changed = {k for k in sd if not torch.equal(sd[k], sq[k])}
+    assert changed and all(("proj" in k or "linear" in k or "predict" in k) and k.endswith("weight") and "project_layer" not in k for k in changed)
+    assert "nar_audio_embeddings.2.word_embeddings.weight" not in changed  # tied to nar_predict_layers.0, stays fp32

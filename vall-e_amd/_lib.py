@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvalle_engine.so")
 
 VLE_OK = 0
 VLE_EINVAL, VLE_ESTATE, VLE_EHIP, VLE_EKEY, VLE_ENOTOKEN = -1, -2, -3, -4, -5
-DTYPE_F32, DTYPE_BF16 = 0, 1
+DTYPE_F32, DTYPE_BF16, DTYPE_FP8W = 0, 1, 2
 
 
 class VleConfig(C.Structure):
@@ -49,6 +49,9 @@ SIGNATURES = {
     "vle_op_linear_ws": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int, _P, C.c_int32]),
     "vle_op_linear_workspace_bytes": (C.c_int64, []),
     "vle_op_tune": (C.c_int, [C.c_char_p, C.c_int64]),
+    "vle_quantize_fp8w": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),
+    "vle_op_linear_skinny_fp8w": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int]),
+    "vle_op_linear_fp8w": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int, _P, C.c_int32]),
     "vle_op_linear_skinny": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_decode_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -34,6 +34,52 @@ __host__ __device__ inline uint16_t f32_to_bf16(float f) {
   return (uint16_t)(u >> 16);
 }
 
+// ---- fp8 weights (engine mode FP8W) -------------------------------------------------------------
+// OCP e4m3fn ("fn": finite, no infinities; bias 7, max 448, 0x7f / 0xff = NaN): the format of gfx950's
+// v_cvt_pk_f32_fp8 and of torch.float8_e4m3fn.  A weight row is stored as q[k] (e4m3fn) and ONE power-of-two
+// scale 2^e, so W'[k] = q[k] * 2^e is exactly representable in bf16: the bandwidth-bound AR step streams q,
+// the MFMA-bound passes run on the bf16 copy of the SAME values.
+struct bf16w8_t {  // element type tag of the AR-step kernels in FP8W mode: fp8 weights, bf16 KV cache
+  uint8_t v;
+};
+
+__host__ __device__ inline float e4m3fn_to_f32(uint8_t v) {
+  const int e = (v >> 3) & 15, m = v & 7;
+  float r;
+  if (e == 15 && m == 7) {
+    union { uint32_t u; float f; } c;
+    c.u = 0x7fc00000u;
+    r = c.f;
+  } else if (e == 0) {
+    r = (float)m * 0.001953125f;  // m * 2^-9
+  } else {
+    union { uint32_t u; float f; } c;
+    c.u = ((uint32_t)(e + 120) << 23) | ((uint32_t)m << 20);
+    r = c.f;
+  }
+  return (v & 0x80) ? -r : r;
+}
+// round-to-nearest-even, saturating at +-448 (callers scale rows so that |x| <= 448; NaN -> 0x7f)
+__host__ inline uint8_t f32_to_e4m3fn(float f) {
+  union { uint32_t u; float f; } c;
+  c.f = f;
+  const uint8_t sign = (uint8_t)((c.u >> 24) & 0x80);
+  const uint32_t a = c.u & 0x7fffffffu;
+  if (a > 0x7f800000u) return 0x7f;
+  if (a >= 0x43e80000u) return sign | 0x7e;  // >= 464 would round past the largest finite value: saturate at 448
+  if (a < 0x3c800000u) {                      // < 2^-6: subnormal range, spacing 2^-9
+    c.u = a;
+    const float t = c.f * 512.0f;             // exact
+    const float r = __builtin_rintf(t);       // RNE in the default rounding mode
+    return sign | (uint8_t)r;                 // 0..8 (8 = the smallest normal, encoded 0x08)
+  }
+  uint32_t u = a;
+  const uint32_t odd = (u >> 20) & 1u;
+  u += 0x7ffffu + odd;                        // RNE at bit 20
+  const uint32_t e = (u >> 23) - 120u, m = (u >> 20) & 7u;
+  return sign | (uint8_t)((e << 3) | m);
+}
+
 template <typename T>
 struct Elem;
 template <>
@@ -51,6 +97,11 @@ struct Elem<bf16_t> {
     r.v = f32_to_bf16(v);
     return r;
   }
+};
+
+template <>
+struct Elem<bf16w8_t> {
+  static constexpr int VEC = 8;  // a lane's chunk is 8 elements as in bf16 mode (8 bytes of fp8)
 };
 
 // 16-byte vector load of VEC elements, widened to fp32

@@ -44,6 +44,9 @@ struct LayerW {
   void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;  // T
   float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
   float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;  // AR LayerNorm affine
+  // FP8W (AR decoder only): e4m3fn codes [N][K] + one power-of-two scale per row; wqkv.. then hold bf16(W')
+  void *wqkv8 = nullptr, *wo8 = nullptr, *w18 = nullptr, *w28 = nullptr;
+  float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;
 };
 
 }  // namespace vle
@@ -74,6 +77,9 @@ struct vle_engine {
   std::vector<LayerW> ar, nar;
   float *ar_norm_g = nullptr, *ar_norm_b = nullptr;
   void* ar_predict = nullptr;
+  void* ar_predict8 = nullptr;     // FP8W
+  float* ar_predict_s = nullptr;
+  bool w8 = false;                 // dtype_mode == VLE_DTYPE_FP8W: dtype stays DT_BF16 for activations / KV / MFMA passes
   void* nar_predict[7] = {};
   // folded AdaLN affine, [stage][site] with site = 2*l (norm1), 2*l+1 (norm2), 2*L (final)
   std::vector<std::vector<float*>> nar_gamma, nar_beta;
@@ -168,6 +174,52 @@ int upload_f32(vle_engine* e, float** dst, const float* src, size_t n) {
   return 0;
 }
 
+// FP8W weight format (common.h): per row, scale = the smallest power of two with max|w| / scale <= 448,
+// q = RNE_e4m3fn(w / scale); W' = q * scale is what every kernel of the mode computes with.
+void quantize_rows_fp8w(const float* w, int64_t N, int64_t K, uint8_t* q, float* scale, float* deq) {
+  for (int64_t n = 0; n < N; ++n) {
+    const float* row = w + n * K;
+    float amax = 0.f;
+    for (int64_t k = 0; k < K; ++k) amax = std::max(amax, std::fabs(row[k]));
+    float sc = 1.f;
+    if (amax > 0.f && std::isfinite(amax)) {
+      int ex = 0;
+      const float m = std::frexp(amax / 448.0f, &ex);  // amax / 448 = m * 2^ex, m in [0.5, 1)
+      sc = std::ldexp(1.0f, m == 0.5f ? ex - 1 : ex);
+    }
+    scale[n] = sc;
+    const float inv = 1.0f / sc;  // exact
+    for (int64_t k = 0; k < K; ++k) {
+      const uint8_t c = f32_to_e4m3fn(row[k] * inv);
+      if (q) q[n * K + k] = c;
+      if (deq) deq[n * K + k] = e4m3fn_to_f32(c) * sc;
+    }
+  }
+}
+
+// FP8W upload of one Linear weight [N][K]: bf16(W') -> *dst (prefill / NAR / fallback kernels); when q8 != null also
+// the e4m3fn codes and the row scales for the weight-streaming AR step
+int upload_fp8w(vle_engine* e, void** dst, void** q8, float** sc, const float* src, int64_t N, int64_t K) {
+  std::vector<uint8_t> q((size_t)(N * K));
+  std::vector<float> scale((size_t)N), deq((size_t)(N * K));
+  quantize_rows_fp8w(src, N, K, q.data(), scale.data(), deq.data());
+  std::vector<uint16_t> tmp((size_t)(N * K));
+  for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = f32_to_bf16(deq[i]);  // exact: 4 significant bits * 2^e
+  uint16_t* p = nullptr;
+  int r = dev_alloc(e, &p, tmp.size());
+  if (r) return r;
+  E_HIP(e, hipMemcpy(p, tmp.data(), tmp.size() * 2, hipMemcpyHostToDevice));
+  *dst = p;
+  if (q8) {
+    uint8_t* pq = nullptr;
+    if ((r = dev_alloc(e, &pq, q.size()))) return r;
+    E_HIP(e, hipMemcpy(pq, q.data(), q.size(), hipMemcpyHostToDevice));
+    *q8 = pq;
+    if ((r = upload_f32(e, sc, scale.data(), scale.size()))) return r;
+  }
+  return 0;
+}
+
 // fp32 host tensor -> compute dtype on the device
 int upload_T(vle_engine* e, void** dst, const float* src, size_t n) {
   if (e->dtype == DT_F32) return upload_f32(e, (float**)dst, src, n);
@@ -230,6 +282,12 @@ int launch_ar_linear(vle_engine* e, const SkinnyArgs& a) {
   if (a.B == 1 && !e->opt_no_gemv1) {
     SkinnyArgs t = a;
     t.rpw_override = e->opt_rpw;
+    if (e->w8 && a.w8 != nullptr) {  // FP8W: stream the e4m3fn codes; shapes gemv1 lacks fall through to bf16(W')
+      t.w = a.w8;
+      const int r8 = launch_gemv1(e->st, DT_FP8W, t);
+      if (r8 <= 0) return r8;
+      t.w = a.w;
+    }
     const int r = launch_gemv1(e->st, e->dtype, t);
     if (r <= 0) return r;
   }
@@ -258,13 +316,15 @@ extern "C" int vle_create(const vle_config* c, vle_engine** out) {
   if (c->dtype_mode == VLE_DTYPE_BF16 && c->d_model % 64 != 0) return bad("bf16 mode needs d_model % 64 == 0");
   if (c->num_quantizers < 1 || c->num_quantizers > 8) return bad("num_quantizers must be 1..8");
   if (!(c->prefix_mode == 0 || c->prefix_mode == 1 || c->prefix_mode == 2 || c->prefix_mode == 4)) return bad("bad prefix_mode");
-  if (c->dtype_mode != VLE_DTYPE_F32 && c->dtype_mode != VLE_DTYPE_BF16) return bad("bad dtype_mode");
+  if (c->dtype_mode != VLE_DTYPE_F32 && c->dtype_mode != VLE_DTYPE_BF16 && c->dtype_mode != VLE_DTYPE_FP8W) return bad("bad dtype_mode");
+  if (c->dtype_mode == VLE_DTYPE_FP8W && c->d_model % 64 != 0) return bad("fp8w mode needs d_model % 64 == 0");
   if (c->max_batch < 1 || c->max_text < 1 || c->max_prompt < 0) return bad("bad capacity");
 
   vle_engine* e = new vle_engine();
   e->cfg = *c;
   e->d = c->d_model; e->H = c->nhead; e->dh = dh; e->L = c->num_layers; e->Q = c->num_quantizers;
-  e->bos = c->prepend_bos ? 1 : 0; e->dtype = c->dtype_mode;
+  e->bos = c->prepend_bos ? 1 : 0; e->dtype = c->dtype_mode == VLE_DTYPE_FP8W ? DT_BF16 : c->dtype_mode;
+  e->w8 = c->dtype_mode == VLE_DTYPE_FP8W;
   e->max_B = c->max_batch; e->max_S = c->max_text; e->max_P = c->max_prompt;
   e->max_G = c->max_gen > 0 ? c->max_gen : 16 * c->max_text + 1;
   e->ctx_max = e->max_S + e->max_P + 1 + e->max_G;
@@ -339,20 +399,25 @@ static int load_layer(vle_engine* e, const std::string& p, LayerW& w, bool adapt
   t = find_w(e, p + name, {__VA_ARGS__});       \
   if (!t) return VLE_EKEY
   int r;
+  // one Linear weight: compute dtype, or (FP8W) bf16(W') plus, for the AR decoder, the fp8 codes + row scales
+  auto up = [&](void** dst, void** q8, float** sc, int64_t N, int64_t K) -> int {
+    if (!e->w8) return upload_T(e, dst, t->data(), t->size());
+    return upload_fp8w(e, dst, adaptive ? nullptr : q8, sc, t->data(), N, K);
+  };
   GET(".self_attn.in_proj_weight", 3 * d, d);
-  if ((r = upload_T(e, &w.wqkv, t->data(), t->size()))) return r;
+  if ((r = up(&w.wqkv, &w.wqkv8, &w.sqkv, 3 * d, d))) return r;
   GET(".self_attn.in_proj_bias", 3 * d);
   if ((r = upload_f32(e, &w.bqkv, t->data(), t->size()))) return r;
   GET(".self_attn.out_proj.weight", d, d);
-  if ((r = upload_T(e, &w.wo, t->data(), t->size()))) return r;
+  if ((r = up(&w.wo, &w.wo8, &w.so, d, d))) return r;
   GET(".self_attn.out_proj.bias", d);
   if ((r = upload_f32(e, &w.bo, t->data(), t->size()))) return r;
   GET(".linear1.weight", 4 * d, d);
-  if ((r = upload_T(e, &w.w1, t->data(), t->size()))) return r;
+  if ((r = up(&w.w1, &w.w18, &w.s1, 4 * d, d))) return r;
   GET(".linear1.bias", 4 * d);
   if ((r = upload_f32(e, &w.b1, t->data(), t->size()))) return r;
   GET(".linear2.weight", d, 4 * d);
-  if ((r = upload_T(e, &w.w2, t->data(), t->size()))) return r;
+  if ((r = up(&w.w2, &w.w28, &w.s2, d, 4 * d))) return r;
   GET(".linear2.bias", d);
   if ((r = upload_f32(e, &w.b2, t->data(), t->size()))) return r;
   if (!adaptive) {
@@ -427,7 +492,9 @@ extern "C" int vle_finalize_weights(vle_engine* e) {
   GETK("ar_decoder.norm.bias", d);
   if ((r = upload_f32(e, &e->ar_norm_b, t->data(), t->size()))) return r;
   GETK("ar_predict_layer.weight", V_AR, d);
-  if ((r = upload_T(e, &e->ar_predict, t->data(), t->size()))) return r;
+  if (e->w8) r = upload_fp8w(e, &e->ar_predict, &e->ar_predict8, &e->ar_predict_s, t->data(), V_AR, d);
+  else r = upload_T(e, &e->ar_predict, t->data(), t->size());
+  if (r) return r;
 
   if (e->Q > 1) {
     GETK("nar_text_embedding.word_embeddings.weight", NUM_TEXT_TOKENS, d);
@@ -459,7 +526,9 @@ extern "C" int vle_finalize_weights(vle_engine* e) {
       }
       if ((r = fold_adaln(e, "nar_decoder.norm", stage, &e->nar_gamma[i][2 * e->L], &e->nar_beta[i][2 * e->L]))) return r;
       GETK("nar_predict_layers." + std::to_string(i) + ".weight", NUM_AUDIO_TOKENS, d);
-      if ((r = upload_T(e, &e->nar_predict[i], t->data(), t->size()))) return r;
+      if (e->w8) r = upload_fp8w(e, &e->nar_predict[i], nullptr, nullptr, t->data(), NUM_AUDIO_TOKENS, d);
+      else r = upload_T(e, &e->nar_predict[i], t->data(), t->size());
+      if (r) return r;
     }
   }
 #undef GETK
@@ -637,7 +706,7 @@ int enqueue_ar_logits(vle_engine* e) {
   ProfScope ps(e, 5);
   if (use_skinny(e)) {
     SkinnyArgs a;
-    a.w = e->ar_predict; a.bias = nullptr; a.N = V_AR; a.K = e->d; a.B = e->B;
+    a.w = e->ar_predict; a.w8 = e->ar_predict8; a.wscale = e->ar_predict_s; a.bias = nullptr; a.N = V_AR; a.K = e->d; a.B = e->B;
     a.pro = PRO_LN; a.epi = SEPI_STORE; a.x = e->x_step; a.gamma = e->ar_norm_g; a.beta = e->ar_norm_b; a.out = e->logits;
     E_LAUNCH(e, launch_ar_linear(e, a));
   } else {
@@ -645,7 +714,7 @@ int enqueue_ar_logits(vle_engine* e) {
     if (use_mfma_skinny(e)) {
       GemmSkinnyArgs g;
       g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target;
-      g.x = e->xn_step; g.w = e->ar_predict; g.M = e->B; g.N = V_AR; g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
+      g.x = e->xn_step; g.w = e->w8 ? e->ar_predict8 : e->ar_predict; g.wscale = e->w8 ? e->ar_predict_s : nullptr; g.M = e->B; g.N = V_AR; g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
       E_LAUNCH(e, launch_gemm_skinny(st, g));
     } else {
       E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
@@ -681,7 +750,7 @@ int enqueue_ar_step(vle_engine* e) {
       {
         ProfScope ps(e, 0);
         E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
-        g.x = e->xn_step; g.w = w.wqkv; g.bias = w.bqkv; g.N = 3 * d; g.K = d; g.epi = GS_EPI_QKV;
+        g.x = e->xn_step; g.w = e->w8 ? w.wqkv8 : w.wqkv; g.wscale = e->w8 ? w.sqkv : nullptr; g.bias = w.bqkv; g.N = 3 * d; g.K = d; g.epi = GS_EPI_QKV;
         g.q_out = e->q_step; g.k_cache = kc; g.v_cache = vc; g.kv_len = e->S.kv_len; g.ctx_max = e->ctx_max; g.nhead = e->H; g.dh = e->dh;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
@@ -694,18 +763,18 @@ int enqueue_ar_step(vle_engine* e) {
       {
         ProfScope ps(e, 2);
         if (!direct) E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
-        g.x = e->att_step; g.w = w.wo; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
+        g.x = e->att_step; g.w = e->w8 ? w.wo8 : w.wo; g.wscale = e->w8 ? w.so : nullptr; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       {
         ProfScope ps(e, 3);
         E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
-        g.x = e->xn_step; g.w = w.w1; g.bias = w.b1; g.N = 4 * d; g.K = d; g.epi = GS_EPI_RELU; g.out = e->hT_step;
+        g.x = e->xn_step; g.w = e->w8 ? w.w18 : w.w1; g.wscale = e->w8 ? w.s1 : nullptr; g.bias = w.b1; g.N = 4 * d; g.K = d; g.epi = GS_EPI_RELU; g.out = e->hT_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       {
         ProfScope ps(e, 4);
-        g.x = e->hT_step; g.w = w.w2; g.bias = w.b2; g.N = d; g.K = 4 * d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
+        g.x = e->hT_step; g.w = e->w8 ? w.w28 : w.w2; g.wscale = e->w8 ? w.s2 : nullptr; g.bias = w.b2; g.N = d; g.K = 4 * d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       continue;
@@ -713,7 +782,7 @@ int enqueue_ar_step(vle_engine* e) {
     if (sk) {
       ProfScope ps(e, 0);
       SkinnyArgs a;
-      a.w = w.wqkv; a.bias = w.bqkv; a.N = 3 * d; a.K = d; a.B = e->B; a.pro = PRO_LN; a.epi = SEPI_QKV;
+      a.w = w.wqkv; a.w8 = w.wqkv8; a.wscale = w.sqkv; a.bias = w.bqkv; a.N = 3 * d; a.K = d; a.B = e->B; a.pro = PRO_LN; a.epi = SEPI_QKV;
       a.x = e->x_step; a.gamma = w.g1; a.beta = w.be1; a.q_out = e->q_step; a.k_cache = kc; a.v_cache = vc;
       a.kv_len = e->S.kv_len; a.ctx_max = e->ctx_max; a.nhead = e->H; a.dh = e->dh;
       E_LAUNCH(e, launch_ar_linear(e, a));
@@ -732,21 +801,21 @@ int enqueue_ar_step(vle_engine* e) {
       {
         ProfScope ps(e, 2);
         SkinnyArgs a;
-        a.w = w.wo; a.bias = w.bo; a.N = d; a.K = d; a.B = e->B; a.pro = PRO_ATTN; a.epi = SEPI_RESID;
+        a.w = w.wo; a.w8 = w.wo8; a.wscale = w.so; a.bias = w.bo; a.N = d; a.K = d; a.B = e->B; a.pro = PRO_ATTN; a.epi = SEPI_RESID;
         a.part_o = e->part_o; a.part_ml = e->part_ml; a.nsplit = e->nsplit; a.nhead = e->H; a.dh = e->dh; a.resid = e->x_step;
         E_LAUNCH(e, launch_ar_linear(e, a));
       }
       {
         ProfScope ps(e, 3);
         SkinnyArgs f1;
-        f1.w = w.w1; f1.bias = w.b1; f1.N = 4 * d; f1.K = d; f1.B = e->B; f1.pro = PRO_LN; f1.epi = SEPI_RELU;
+        f1.w = w.w1; f1.w8 = w.w18; f1.wscale = w.s1; f1.bias = w.b1; f1.N = 4 * d; f1.K = d; f1.B = e->B; f1.pro = PRO_LN; f1.epi = SEPI_RELU;
         f1.x = e->x_step; f1.gamma = w.g2; f1.beta = w.be2; f1.out = e->h_step;
         E_LAUNCH(e, launch_ar_linear(e, f1));
       }
       {
         ProfScope ps(e, 4);
         SkinnyArgs f2;
-        f2.w = w.w2; f2.bias = w.b2; f2.N = d; f2.K = 4 * d; f2.B = e->B; f2.pro = PRO_PLAIN; f2.epi = SEPI_RESID;
+        f2.w = w.w2; f2.w8 = w.w28; f2.wscale = w.s2; f2.bias = w.b2; f2.N = d; f2.K = 4 * d; f2.B = e->B; f2.pro = PRO_PLAIN; f2.epi = SEPI_RESID;
         f2.x = e->h_step; f2.resid = e->x_step;
         E_LAUNCH(e, launch_ar_linear(e, f2));
       }
@@ -1249,8 +1318,8 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
-  if (n == "glds_big") {  // process-global tile policy of gemm_glds.hip (same knob as vle_op_tune)
-    g_glds_big = (int)value;
+  if (n == "glds_big" || n == "glds_w8") {  // process-global tile policy of gemm_glds.hip (same knobs as vle_op_tune)
+    (n == "glds_big" ? g_glds_big : g_glds_w8) = (int)value;
     return VLE_OK;
   }
   if (n == "ignore_eos") {
@@ -1315,9 +1384,19 @@ extern "C" int vle_last_timings(vle_engine* e, double* out4) {
 }
 
 // bytes of one AR step = W_AR * w + sum_b (2 L c_b d a  +  2 L d a)
+extern "C" int vle_quantize_fp8w(const float* w, int64_t N, int64_t K, uint8_t* q_out, float* scale_out, float* deq_out) {
+  if (!w || !scale_out || N < 1 || K < 1) return VLE_EINVAL;
+  quantize_rows_fp8w(w, N, K, q_out, scale_out, deq_out);
+  return VLE_OK;
+}
+
 extern "C" int64_t vle_ar_step_bytes(const vle_engine* e, int32_t B, int64_t sum_ctx) {
   if (!e) return VLE_EINVAL;
   const int64_t d = e->d, L = e->L, es = (int64_t)dtype_size(e->dtype);
+  if (e->w8) {  // FP8W: matrices 1 byte / element + one fp32 scale per row; vectors fp32-equivalent counted as in bf16 mode
+    const int64_t mats = L * 12 * d * d + (int64_t)V_AR * d, rows = L * 9 * d + V_AR, vecs = L * 13 * d + 2 * d;
+    return mats + 4 * rows + vecs * es + 2 * L * d * es * (sum_ctx + B);
+  }
   const int64_t w_ar = L * (12 * d * d + 13 * d) + 2 * d + (int64_t)V_AR * d;
   return w_ar * es + 2 * L * d * es * (sum_ctx + B);
 }

@@ -235,6 +235,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
 // tile policy knob (vle_op_tune "glds_big"): 0 = never use the 8-wave 256 x 128 tile, -1 = default threshold
 // (>= 512 full tiles), n > 0 = threshold n
 int g_glds_big = -1;
+int g_glds_w8 = 0;  // "glds_w8": 1 = 8-wave workgroups on the 128-row tiles as well
 
 template <int BM, int BN, int NW = 4>
 static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const float* bias, void* out, float* resid, int64_t M,
@@ -266,6 +267,10 @@ int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* 
   // ds_read -> MFMA latency, and the W panel is re-read half as often
   const int64_t t256 = (M / 256) * ((N + 127) / 128);
   if (g_glds_big != 0 && t256 >= (g_glds_big > 0 ? g_glds_big : 512)) return gg_launch<256, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi);
+  if (g_glds_w8) {  // 8 waves on the one-tile-per-CU shapes too (wave tile 32 x 64 / 32 x 32)
+    if (full128 >= 160) return gg_launch<128, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi);
+    if (t128x64 >= 96) return gg_launch<128, 64, 8>(st, a, w, bias, out, resid, M, N, K, epi);
+  }
   if (full128 >= 160) return gg_launch<128, 128>(st, a, w, bias, out, resid, M, N, K, epi);
   if (t128x64 >= 96) return gg_launch<128, 64>(st, a, w, bias, out, resid, M, N, K, epi);
   return gg_launch<64, 64>(st, a, w, bias, out, resid, M, N, K, epi);

@@ -90,7 +90,22 @@ __device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, i
   }
 }
 
-template <int MF, int EPI>
+// FP8W: 8 e4m3fn weights (two dwords) -> the bf16 MFMA operand; exact (every e4m3fn value is a bf16 value)
+__device__ inline gs_bf16x8 gs_fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
+  typedef float f32x2v_t __attribute__((ext_vector_type(2)));
+  const f32x2v_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)lo, true);
+  const f32x2v_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)hi, true);
+  gs_bf16x8 o;
+  o[0] = (__bf16)a.x; o[1] = (__bf16)a.y; o[2] = (__bf16)b.x; o[3] = (__bf16)b.y;
+  o[4] = (__bf16)c.x; o[5] = (__bf16)c.y; o[6] = (__bf16)d.x; o[7] = (__bf16)d.y;
+  return o;
+}
+
+// W8 (engine mode FP8W): W is e4m3fn [N][K] with one power-of-two scale per row (applied in the epilogue, exact).
+// A lane then takes ONE 16-byte vector per 64-deep chunk = the 16 consecutive k of its quarter of the chunk; the two
+// MFMA k-halves use bytes 0-7 and 8-15, and X is read with the same k assignment (any k permutation is a valid dot
+// product as long as both operands agree), so W is still fetched as full 64-byte sectors per row.
+template <int MF, int EPI, bool W8>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   constexpr int G = 4;  // k-chunks (64 deep) requested per round
   __shared__ __attribute__((aligned(16))) float red[4][MF][64][4];
@@ -104,10 +119,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   const int Kw = K / (4 * KS);  // this wave's share of K (multiple of 64)
   const int kbeg = (ks * 4 + wave) * Kw;
   const int nrow = min(n0 + fr, N - 1);
-  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w) + (int64_t)nrow * K + kbeg + fg * 8;
+  constexpr int KOFS = W8 ? 16 : 8;   // first k of this lane inside a chunk = fg * KOFS
+  constexpr int SSTEP = W8 ? 8 : 32;  // k distance between the lane's two MFMA k-halves
+  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w) + (int64_t)nrow * K + kbeg + fg * 8;            // bf16 W
+  const unsigned char* wp8 = reinterpret_cast<const unsigned char*>(a.w) + (int64_t)nrow * K + kbeg + fg * 16;  // fp8 W
   const bf16_t* xp[MF];
 #pragma unroll
-  for (int i = 0; i < MF; ++i) xp[i] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(i * 16 + fr, M - 1) * K + kbeg + fg * 8;
+  for (int i = 0; i < MF; ++i) xp[i] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(i * 16 + fr, M - 1) * K + kbeg + fg * KOFS;
 
   // epilogue operands requested up front
   const int ncol = n0 + fg * 4;  // first of this lane's 4 output columns
@@ -117,6 +135,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     else {
 #pragma unroll
       for (int r = 0; r < 4; ++r) bias4[r] = ncol + r < N ? a.bias[ncol + r] : 0.f;
+    }
+  }
+  gs_f32x4 scale4 = gs_f32x4{1.f, 1.f, 1.f, 1.f};
+  if constexpr (W8) {
+    if (ncol + 3 < N) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) scale4[r] = ncol + r < N ? a.wscale[ncol + r] : 1.f;
     }
   }
 
@@ -130,12 +156,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int c = min(c0 + g, chunks - 1);  // clamped: a short last round re-reads its final chunk, unused below
-      wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64));
-      wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64 + 32));
+      if constexpr (W8) {
+        wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp8 + c * 64));
+      } else {
+        wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64));
+        wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64 + 32));
+      }
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
         xv[g][i][0] = *reinterpret_cast<const gs_u32x4*>(xp[i] + c * 64);
-        xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xp[i] + c * 64 + 32);
+        xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xp[i] + c * 64 + SSTEP);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -143,11 +173,14 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     for (int g = 0; g < G; ++g) {
       if (c0 + g < chunks) {
 #pragma unroll
-        for (int s = 0; s < 2; ++s)
+        for (int s = 0; s < 2; ++s) {
+          gs_bf16x8 wa;
+          if constexpr (W8) wa = gs_fp8x8_to_bf16(wv[g][0][2 * s], wv[g][0][2 * s + 1]);
+          else wa = __builtin_bit_cast(gs_bf16x8, wv[g][s]);
 #pragma unroll
           for (int i = 0; i < MF; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(gs_bf16x8, wv[g][s]),
-                                                             __builtin_bit_cast(gs_bf16x8, xv[g][i][s]), acc[i], 0, 0, 0);
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(gs_bf16x8, xv[g][i][s]), acc[i], 0, 0, 0);
+        }
       }
     }
   }
@@ -195,7 +228,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     }
   }
   if (wave >= MF) return;
-  v += bias4;
+  if constexpr (W8) v = v * scale4 + bias4;  // * 2^e is exact
+  else v += bias4;
   // lane (fg, fr) holds C[m = 16 i + fr][n = n0 + 4 fg + r]
   gs_epilogue<EPI>(a, v, i * 16 + fr, ncol);
 }
@@ -214,18 +248,23 @@ int gemm_skinny_ksplit(int N, int K, int target_wgs) {
 
 size_t gemm_skinny_workspace_bytes() { return GS_WS_CNT_BYTES + (size_t)GS_WS_MAX_TILES * 64 * 16 * sizeof(float); }
 
-template <int MF>
-static int gs_launch(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
+template <int MF, bool W8>
+static int gs_launch_w(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
   const dim3 grid((a.N + 15) / 16, KS), block(256);
   switch (a.epi) {
-    case GS_EPI_STORE: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_STORE>), grid, block, 0, st, a); break;
-    case GS_EPI_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RELU>), grid, block, 0, st, a); break;
-    case GS_EPI_RESID: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RESID>), grid, block, 0, st, a); break;
-    case GS_EPI_F32: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_F32>), grid, block, 0, st, a); break;
-    case GS_EPI_QKV: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_QKV>), grid, block, 0, st, a); break;
+    case GS_EPI_STORE: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_STORE, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RELU, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_RESID: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RESID, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_F32: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_F32, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_QKV: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_QKV, W8>), grid, block, 0, st, a); break;
     default: return -1;
   }
   return 0;
+}
+
+template <int MF>
+static int gs_launch(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
+  return a.wscale != nullptr ? gs_launch_w<MF, true>(st, a, KS) : gs_launch_w<MF, false>(st, a, KS);
 }
 
 bool gemm_skinny_supports(int M, int N, int K, int epi, int dh) {

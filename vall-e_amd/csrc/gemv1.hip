@@ -45,6 +45,33 @@ __device__ inline void widen16<bf16_t>(const u32x4_t& v, float (&f)[8]) {
   f[6] = __uint_as_float(v.w << 16); f[7] = __uint_as_float(v.w & 0xffff0000u);
 }
 
+// FP8W: the lane's 8 weights of a chunk are 8 bytes of e4m3fn in v.x / v.y (v_cvt_pk_f32_fp8: two values per op)
+template <>
+__device__ inline void widen16<bf16w8_t>(const u32x4_t& v, float (&f)[8]) {
+  typedef float f32x2v_t __attribute__((ext_vector_type(2)));
+  const f32x2v_t a = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, false), b = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.x, true);
+  const f32x2v_t c = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, false), d = __builtin_amdgcn_cvt_pk_f32_fp8((int)v.y, true);
+  f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y; f[6] = d.x; f[7] = d.y;
+}
+
+// weight-stream traits: how a lane fetches its VEC weights of one chunk, and the element type of the KV cache
+template <typename T>
+struct G1W {
+  typedef T cache_t;
+  static constexpr bool kScaled = false;
+  __device__ static inline u32x4_t load(const T* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
+};
+template <>
+struct G1W<bf16w8_t> {
+  typedef bf16_t cache_t;
+  static constexpr bool kScaled = true;
+  __device__ static inline u32x4_t load(const bf16w8_t* p) {
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+    return u32x4_t{t.x, t.y, 0u, 0u};
+  }
+};
+
 // VEC consecutive fp32 values at p (16-byte aligned)
 template <int VEC>
 __device__ inline void load_f32_vec(const float* p, float (&f)[VEC]) {
@@ -108,14 +135,15 @@ __global__ __launch_bounds__(G1_T) void gemv1_kernel(SkinnyArgs a) {
     row = row < N ? row : N - 1;
     const T* wr = W + (int64_t)row * K + lane * VEC;
 #pragma unroll
-    for (int c = 0; c < NCH; ++c) wv[r][c] = __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(wr + c * CH));
+    for (int c = 0; c < NCH; ++c) wv[r][c] = G1W<T>::load(wr + c * CH);
   }
   const int myrow = row0 + lane;
   const bool writer = lane < RPW && myrow < N;
-  float bias_v = 0.f, resid_v = 0.f;
+  float bias_v = 0.f, resid_v = 0.f, scale_v = 1.f;
   int kvl = 0;
   if (writer) {
     if (a.bias) bias_v = a.bias[myrow];
+    if constexpr (G1W<T>::kScaled) scale_v = a.wscale[myrow];  // the row's power-of-two scale (FP8W)
     if constexpr (EPI == SEPI_RESID) resid_v = a.resid[myrow];
     if constexpr (EPI == SEPI_QKV) kvl = a.kv_len[0];
   }
@@ -192,7 +220,7 @@ __global__ __launch_bounds__(G1_T) void gemv1_kernel(SkinnyArgs a) {
 
   // ---- epilogue ----------------------------------------------------------------------------------------
   if (!writer) return;
-  const float v = mine + bias_v;
+  const float v = G1W<T>::kScaled ? fmaf(mine, scale_v, bias_v) : mine + bias_v;  // * 2^e is exact: one rounding, as in bf16 mode
   if constexpr (EPI == SEPI_STORE) {
     a.out[myrow] = v;
   } else if constexpr (EPI == SEPI_RELU) {
@@ -206,7 +234,8 @@ __global__ __launch_bounds__(G1_T) void gemv1_kernel(SkinnyArgs a) {
     } else {
       const int h = j / a.dh, e = j - h * a.dh;
       const int64_t off = ((int64_t)h * a.ctx_max + kvl) * a.dh + e;
-      store_elem<T>(reinterpret_cast<T*>(which == 1 ? a.k_cache : a.v_cache) + off, v);
+      typedef typename G1W<T>::cache_t CT;
+      store_elem<CT>(reinterpret_cast<CT*>(which == 1 ? a.k_cache : a.v_cache) + off, v);
     }
   }
 }
@@ -297,6 +326,7 @@ static int g1_dispatch_nch(hipStream_t st, const SkinnyArgs& a) {
 int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a) {
   if (a.B != 1 || a.N <= 0) return 1;
   if (a.pro == PRO_ATTN && (a.dh % (dtype == DT_F32 ? 4 : 8) != 0)) return 1;
+  if (dtype == DT_FP8W) return a.wscale ? g1_dispatch_nch<bf16w8_t>(st, a) : -1;
   if (dtype == DT_F32) return g1_dispatch_nch<float>(st, a);
   return g1_dispatch_nch<bf16_t>(st, a);
 }

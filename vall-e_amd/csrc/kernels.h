@@ -9,6 +9,7 @@ namespace vle {
 
 constexpr int DT_F32 = 0;
 constexpr int DT_BF16 = 1;
+constexpr int DT_FP8W = 2;  // AR-step linear weights e4m3fn + per-row 2^e scale; everything else as DT_BF16
 inline size_t dtype_size(int dtype) { return dtype == DT_F32 ? 4 : 2; }
 
 // ---- layernorm.hip ---------------------------------------------------------------------------
@@ -33,6 +34,7 @@ int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const f
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
                      int K, int epi);
 
+extern int g_glds_w8;
 extern int g_glds_big;  // gemm_glds.hip tile policy: 0 never the 8-wave 256 x 128 tile, -1 default threshold, n > 0 threshold
 
 // ---- gemm_skinny.hip (AR-step weight-streaming MFMA GEMM, bf16, 2 <= M = batch <= 64) ------------
@@ -41,6 +43,7 @@ struct GemmSkinnyArgs {
   const void* x = nullptr;     // bf16 [M][K]
   const void* w = nullptr;     // bf16 [N][K]
   const float* bias = nullptr; // f32 [N] or null
+  const float* wscale = nullptr;  // FP8W: w is e4m3fn [N][K], row n scaled by wscale[n] (a power of two); null = bf16 w
   int M = 0, N = 0, K = 0, epi = GS_EPI_STORE;
   void* out = nullptr;         // bf16 [M][N] (STORE / RELU) or f32 [M][N] (F32)
   float* resid = nullptr;      // f32 [M][N] += (.)   (RESID)
@@ -70,6 +73,8 @@ enum { SEPI_STORE = 0, SEPI_RELU = 1, SEPI_RESID = 2, SEPI_QKV = 3 };
 struct SkinnyArgs {
   const void* w = nullptr;     // T [N][K]
   const float* bias = nullptr; // f32 [N] or null
+  const float* wscale = nullptr;  // dtype DT_FP8W (gemv1 only): w is e4m3fn [N][K], row n scaled by wscale[n]
+  const void* w8 = nullptr;       // engine: the e4m3fn copy of w (FP8W), tried first by launch_ar_linear
   int N = 0, K = 0, B = 0;
   int pro = PRO_PLAIN, epi = SEPI_STORE;
   const float* x = nullptr;      // f32 [B][K]           (PRO_PLAIN / PRO_LN)

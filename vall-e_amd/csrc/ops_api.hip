@@ -32,6 +32,7 @@ extern "C" int vle_op_tune(const char* name, int64_t value) {
   if (!name) return op_fail("vle_op_tune: null name");
   const std::string n = name;
   if (n == "glds_big" && value >= -1) vle::g_glds_big = (int)value;
+  else if (n == "glds_w8" && value >= 0 && value <= 1) vle::g_glds_w8 = (int)value;
   else return op_fail("vle_op_tune: unknown knob or value out of range");
   return VLE_OK;
 }
@@ -58,6 +59,35 @@ extern "C" int vle_op_linear_ws(void* stream, int dtype, const void* a, const vo
                                 int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit) {
   if (ksplit < 0 || ksplit > 16 || (ksplit & (ksplit - 1))) return op_fail("vle_op_linear_ws: ksplit must be 0, 1, 2, 4, 8 or 16");
   return op_linear(stream, dtype, a, w, bias, out, resid, M, N, K, epilogue, workspace, ksplit, "vle_op_linear_ws");
+}
+
+extern "C" int vle_op_linear_skinny_fp8w(void* stream, const float* x, const float* gamma, const float* beta, const void* w8,
+                                         const float* wscale, const float* bias, float* out, float* resid, int32_t N, int32_t K,
+                                         int epilogue) {
+  if (!x || !w8 || !wscale) return op_fail("vle_op_linear_skinny_fp8w: null operand");
+  SkinnyArgs a;
+  a.w = w8; a.wscale = wscale; a.bias = bias; a.N = N; a.K = K; a.B = 1;
+  a.pro = gamma ? PRO_LN : PRO_PLAIN;
+  a.x = x; a.gamma = gamma; a.beta = beta;
+  a.epi = epilogue == 0 ? SEPI_STORE : epilogue == 1 ? SEPI_RELU : SEPI_RESID;
+  a.out = out; a.resid = resid;
+  if (a.epi == SEPI_RESID ? !resid : !out) return op_fail("vle_op_linear_skinny_fp8w: missing output");
+  if (a.pro == PRO_LN && a.epi == SEPI_RESID) return op_fail("vle_op_linear_skinny_fp8w: LN + residual is not instantiated");
+  const int r = launch_gemv1((hipStream_t)stream, DT_FP8W, a);
+  if (r == 1) return op_fail("vle_op_linear_skinny_fp8w: shape not instantiated (K must be a multiple of 512)");
+  return op_done(r, "vle_op_linear_skinny_fp8w");
+}
+
+extern "C" int vle_op_linear_fp8w(void* stream, const void* a, const void* w8, const float* wscale, const float* bias, void* out,
+                                  float* resid, int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit) {
+  if (!a || !w8 || !wscale) return op_fail("vle_op_linear_fp8w: null operand");
+  if (epilogue == EPI_RESID ? !resid : !out) return op_fail("vle_op_linear_fp8w: missing output");
+  if (ksplit < 0 || ksplit > 16 || (ksplit & (ksplit - 1))) return op_fail("vle_op_linear_fp8w: ksplit must be 0, 1, 2, 4, 8 or 16");
+  if (M < 1 || M > 64 || !gemm_skinny_supports((int)M, N, K, epilogue, 4)) return op_fail("vle_op_linear_fp8w: shape not covered (M <= 64, K % 256 == 0)");
+  GemmSkinnyArgs g;
+  g.x = a; g.w = w8; g.wscale = wscale; g.bias = bias; g.M = (int)M; g.N = N; g.K = K; g.epi = epilogue; g.out = out; g.resid = resid;
+  g.workspace = workspace; g.ksplit = ksplit;
+  return op_done(launch_gemm_skinny((hipStream_t)stream, g), "vle_op_linear_fp8w");
 }
 
 extern "C" int64_t vle_op_linear_workspace_bytes(void) { return (int64_t)gemm_skinny_workspace_bytes(); }

@@ -243,7 +243,7 @@ def add_model_arguments(parser: argparse.ArgumentParser):
     parser.add_argument("--prepend-bos", type=_str2bool, default=False)
     parser.add_argument("--num-quantizers", type=int, default=8)
     parser.add_argument("--scaling-xformers", type=_str2bool, default=False)
-    parser.add_argument("--engine-dtype", type=str, default="fp32", help="HIP engine arithmetic: fp32 (token-exact) or bf16")
+    parser.add_argument("--engine-dtype", type=str, default="fp32", help="HIP engine arithmetic: fp32 (token-exact), bf16, or fp8w (bf16 on fp8 e4m3 weights)")
 
 
 def get_model(params) -> nn.Module:

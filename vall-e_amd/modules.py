@@ -42,30 +42,35 @@ def _need_device(t: Tensor, who: str):
 
 class _HipModule(nn.Module):
     """Parameters stay fp32 (the reference's state dict); ``compute_dtype`` selects the element type the
-    GEMM / attention kernels run in ("fp32": token-exact mode, "bf16": bf16 operands, fp32 accumulate)."""
+    GEMM / attention kernels run in ("fp32": token-exact mode, "bf16": bf16 operands, fp32 accumulate,
+    "fp8w": bf16 kernels on the fp8-representable weights W' of the engine's FP8W mode)."""
 
     compute_dtype: str = "fp32"
 
     def _tdtype(self) -> torch.dtype:
-        return torch.bfloat16 if self.compute_dtype == "bf16" else torch.float32
+        return torch.float32 if self.compute_dtype == "fp32" else torch.bfloat16
 
     def _w(self, p: Tensor) -> Tensor:
-        """The parameter in the compute dtype (bf16 copies are cached until the parameter changes)."""
-        if self.compute_dtype != "bf16":
+        """The parameter in the compute dtype (bf16 copies are cached until the parameter changes); in "fp8w"
+        mode the bf16 copy of W' = e4m3fn(w / 2^e) * 2^e, the values the engine's FP8W mode computes with."""
+        if self.compute_dtype == "fp32":
             return p.detach()
         cache = self.__dict__.setdefault("_wcache", {})
         key = id(p)
         hit = cache.get(key)
         if hit is not None and hit[0] == (p._version, p.data_ptr()):
             return hit[1]
-        w = p.detach().to(torch.bfloat16)
+        if self.compute_dtype == "fp8w" and p.dim() == 2:
+            w = ops.quantize_fp8w(p)[2].to(p.device, torch.bfloat16)  # host quantiser of the engine, once per weight
+        else:
+            w = p.detach().to(torch.bfloat16)
         cache[key] = ((p._version, p.data_ptr()), w)
         return w
 
 
 def set_compute_dtype(module: nn.Module, dtype: str) -> nn.Module:
     """Select "fp32" or "bf16" kernels for every block module under ``module``."""
-    assert dtype in ("fp32", "bf16"), dtype
+    assert dtype in ("fp32", "bf16", "fp8w"), dtype
     for m in module.modules():
         if isinstance(m, _HipModule):
             m.compute_dtype = dtype

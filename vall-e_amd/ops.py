@@ -181,3 +181,55 @@ def adaln_fold(wb: torch.Tensor, g: torch.Tensor, be: torch.Tensor):
     out = torch.empty(2, d, dtype=torch.float32, device=g.device)
     _lib.check(lib.vle_op_adaln_fold(_st(g), _p(wb.contiguous()), _p(g.contiguous()), _p(be.contiguous()), _p(out[0]), _p(out[1]), d))
     return out[0], out[1]
+
+
+# ---- FP8W (VLE_DTYPE_FP8W): fp8 e4m3fn weight rows with one power-of-two scale each ------------------------
+def quantize_fp8w(w: torch.Tensor):
+    """The engine's host-side weight quantiser (vle_quantize_fp8w): w fp32 (N, K) on the CPU ->
+    (q uint8 (N, K) e4m3fn codes, scale fp32 (N,), deq fp32 (N, K) = W').  No GPU involved."""
+    lib = _lib.load()
+    w = w.detach().to("cpu", torch.float32).contiguous()
+    assert w.dim() == 2
+    N, K = w.shape
+    q = torch.empty(N, K, dtype=torch.uint8)
+    scale = torch.empty(N, dtype=torch.float32)
+    deq = torch.empty(N, K, dtype=torch.float32)
+    _lib.check(lib.vle_quantize_fp8w(C.c_void_p(w.data_ptr()), N, K, C.c_void_p(q.data_ptr()), C.c_void_p(scale.data_ptr()),
+                                     C.c_void_p(deq.data_ptr())))
+    return q, scale, deq
+
+
+def linear_skinny_fp8w(x: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = 0,
+                       resid: Optional[torch.Tensor] = None, gamma: Optional[torch.Tensor] = None,
+                       beta: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """linear_skinny for ONE row on FP8W weights (the batch-1 AR step): x fp32 (1, K), w8 uint8 (N, K), wscale fp32 (N,)."""
+    lib = _lib.load()
+    x, w8, wscale = x.contiguous(), w8.contiguous(), wscale.contiguous()
+    assert x.dtype == torch.float32 and w8.dtype == torch.uint8 and wscale.dtype == torch.float32 and x.shape[0] == 1
+    K = x.shape[1]
+    N = w8.shape[0]
+    out = None if epilogue == 2 else torch.empty(1, N, dtype=torch.float32, device=x.device)
+    b = None if bias is None else bias.contiguous()
+    _lib.check(lib.vle_op_linear_skinny_fp8w(_st(x), _p(x), _p(gamma), _p(beta), _p(w8), _p(wscale), _p(b), _p(out), _p(resid), N, K, epilogue))
+    return resid if epilogue == 2 else out
+
+
+def linear_fp8w(a: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: Optional[torch.Tensor] = None, epilogue: int = EPI_STORE,
+                resid: Optional[torch.Tensor] = None, ksplit: int = 0) -> torch.Tensor:
+    """linear for M <= 64 bf16 rows on FP8W weights (the AR step of 2..64 utterances)."""
+    lib = _lib.load()
+    a, w8, wscale = a.contiguous(), w8.contiguous(), wscale.contiguous()
+    assert a.dtype == torch.bfloat16 and w8.dtype == torch.uint8 and wscale.dtype == torch.float32
+    M, K = a.shape
+    N = w8.shape[0]
+    out = None
+    if epilogue == EPI_RESID:
+        assert resid is not None and resid.dtype == torch.float32 and resid.is_contiguous() and resid.shape == (M, N)
+    elif epilogue == EPI_F32:
+        out = torch.empty(M, N, dtype=torch.float32, device=a.device)
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
+    b = None if bias is None else bias.contiguous()
+    ws = linear_workspace(a.device)
+    _lib.check(lib.vle_op_linear_fp8w(_st(a), _p(a), _p(w8), _p(wscale), _p(b), _p(out), _p(resid), M, N, K, epilogue, _p(ws), int(ksplit)))
+    return resid if epilogue == EPI_RESID else out

@@ -12,7 +12,8 @@ utterances per GPU); no collective on the decode path, one all_gather of the res
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (AR step =
 the HBM-bound dominant phase; algorithmic bytes of SURVEY.md 8d / measured hipEvent time) and
 `cpu_baseline` (the CPU oracle -- a restatement of the reference's no-KV-cache algorithm -- timed
-on the host cores on a bounded sample).
+on the host cores on a bounded sample).  The default single-GPU run also carries `c3_batch64`: BASELINE.json
+configs[2] (64 utterances on one GPU) with its own AR (HBM) and NAR (MFMA) roofline fractions.
 """
 from __future__ import annotations
 
@@ -66,6 +67,58 @@ def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
     )
 
 
+MFMA_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
+
+
+def c3_leg(sd, args, dev, B=64, steps=2, warmup=1):
+    """BASELINE.json configs[2] (same architecture, 64 utterances on one GPU) measured beside the headline line:
+    an extra object in the JSON, not `value`.  Same timing rules (inputs resident, whole decode calls)."""
+    import valle_amd
+
+    model = valle_amd.VALLE(args.d_model, args.nhead, args.layers, prefix_mode=1, engine_dtype=args.dtype, max_batch=B)
+    model.load_state_dict(sd)
+    model = model.to(dev).eval()
+    eng = model.engine_for(B, S_TEXT, P_PROMPT)
+    eng.set_option("ignore_eos", 1)  # every utterance runs to the reference's length cap, like the batch-1 line
+    X = torch.stack([synth_inputs(b)[0] for b in range(B)]).to(dev)
+    Y = torch.stack([synth_inputs(b)[1] for b in range(B)]).to(dev)
+    lens = ([S_TEXT] * B, [P_PROMPT] * B)
+
+    def step():
+        eng.prefill(X, lens[0], Y, lens[1])
+        _, gl = eng.generate(top_k=args.top_k, temperature=1.0, seed=0, allow_empty=True)
+        eng.nar(None)
+        return gl
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    tokens, pre, ar, nar, ar_steps, ar_bytes = 0, 0.0, 0.0, 0.0, 0, 0
+    for _ in range(steps):
+        gl = step()
+        tokens += sum(gl) * 8
+        tm = eng.timings()
+        pre += tm["prefill_ms"]; ar += tm["ar_ms"]; nar += tm["nar_ms"]; ar_steps += int(tm["ar_steps"])
+        for t in range(1, max(gl) + 1):
+            ar_bytes += eng.ar_step_bytes(B, B * (S_TEXT + P_PROMPT + t))
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    d, L, N, G = args.d_model, args.layers, S_TEXT + P_PROMPT + gl[0], gl[0]
+    nar_flops = B * (7 * (2 * N * 12 * L * d * d + 4 * L * N * N * d) + 14 * G * d * 1024)  # SURVEY.md 8(d)
+    hbm = (ar_bytes / 1e9) / (ar / 1e3)
+    tfs = nar_flops * steps / 1e12 / (nar / 1e3)
+    model._invalidate()
+    return {
+        "workload": f"dim{d}-L{L}-h{args.nhead} {args.dtype}, batch={B}, S={S_TEXT}, P={P_PROMPT} -> G={G}, greedy, ignore_eos",
+        "value": round(tokens / elapsed, 1), "unit": "audio-tokens/s", "steps": steps, "warmup": warmup,
+        "phase_ms": {"prefill": round(pre / steps, 3), "ar": round(ar / steps, 3), "nar": round(nar / steps, 3)},
+        "roofline_ar": {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
+                        "launch_us": round(ar / ar_steps * 1e3, 2), "bytes_per_launch": int(ar_bytes / ar_steps)},
+        "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_PEAK_TFS, 4)},
+    }
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -79,6 +132,7 @@ def main():
     ap.add_argument("--top-k", type=int, default=1, help="1 = the reference's greedy; -100 = pure multinomial")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-c3", action="store_true", help="skip the extra batch-64 (BASELINE configs[2]) object of the default run")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine tuning option (vle_set_option), repeatable")
     ap.add_argument("--profile-kernels", type=int, default=0, help="extra untimed pass: hipEvent time per AR-step kernel family over n steps")
     args = ap.parse_args()
@@ -215,6 +269,9 @@ def main():
             out["cpu_baseline"] = cpu_baseline(sd_cpu, args.d_model, args.nhead, args.layers, args.cpu_frames)
         else:
             out["cpu_baseline"] = None
+        if args.gpus == 1 and B == 1 and not args.no_c3 and not args.opt and args.profile_kernels == 0:
+            model._invalidate()
+            out["c3_batch64"] = c3_leg(model.state_dict(), args, dev)
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.destroy_process_group()

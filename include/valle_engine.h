@@ -124,6 +124,24 @@ int vle_nar_continual(vle_engine* e, void* stream, const int64_t* text, int64_t 
                       const int64_t* y_codes, int64_t t_stride, const int32_t* y_lens, int32_t B,
                       int64_t* codes, int64_t g_stride, int32_t* gen_lens);
 
+/* ---- slot API: continuous batching (callers either side of inference(): valle/bin/infer.py:223-269 decodes one
+ * utterance at a time) ------------------------------------------------------------------------------------------
+ * The engine's max_batch positions are SLOTS, each free or holding one utterance.  vle_slots_begin frees them all;
+ * vle_slots_prefill admits n new utterances into the listed free slots (prefill of those only + their first sample);
+ * vle_slots_step advances every live slot by nsteps AR steps (finished / free slots cost no KV traffic) and returns the
+ * per-slot done flags and generated lengths (HOST int32 [max_batch]); vle_slots_harvest runs the 7 NAR stages for the
+ * listed FINISHED slots into codes[slot][g][q] (DEVICE int64, row pitch g_stride * num_quantizers) and frees them.
+ * Numerics and stop rule are those of vle_ar_prefill / vle_ar_generate / vle_nar_decode: what an utterance decodes to
+ * does not depend on what shares the batch.  top_k / temperature / seed apply to the samples drawn by that call. */
+int vle_slots_begin(vle_engine* e, void* stream);
+int vle_slots_prefill(vle_engine* e, void* stream, int32_t n, const int32_t* slots, const int64_t* text, int64_t s_stride,
+                      const int32_t* text_lens, const int64_t* prompt_codes, int64_t p_stride, const int32_t* prompt_lens,
+                      int32_t top_k, float temperature, uint64_t seed);
+int vle_slots_step(vle_engine* e, void* stream, int32_t nsteps, int32_t top_k, float temperature, uint64_t seed,
+                   int32_t* done_out, int32_t* gen_lens_out);
+int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slots, const int32_t* enroll_lens, int64_t* codes,
+                      int64_t g_stride);
+
 /* ---- parity / measurement hooks -------------------------------------------------------------- */
 /* options: "trace_ar_logits" (0/1: keep every AR step's fp32 logits), "trace_nar_logits" (0/1),
  *          "nsplit" (0 = auto, else 1|2|4|8|16: KV split of the decode attention),

@@ -1,0 +1,74 @@
+"""GPU: continuous batching (vall-e_amd/serving.py over vle_slots_*): more requests than slots, ragged text / prompt
+lengths, utterances finishing at different steps.  fp32 engine mode => every request's codes must equal the CPU oracle's
+(= the reference's) token for token, whatever shared the batch with it; and the dense batch API must agree."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import valle_amd  # noqa: E402
+from valle_amd import ContinuousBatcher, Request  # noqa: E402
+from oracle import valle_oracle as vo  # noqa: E402
+from tests.test_engine_gpu import build_model  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _requests(n, seed, smin=3, smax=8, pmin=4, pmax=18):
+    g = torch.Generator().manual_seed(seed)
+    S = torch.randint(smin, smax + 1, (n,), generator=g).tolist()
+    P = torch.randint(pmin, pmax + 1, (n,), generator=g).tolist()
+    return [vo.make_inputs(S[i], P[i], seed=500 + i) for i in range(n)]
+
+
+@pytest.mark.parametrize("max_batch,steps_per_round", [(4, 8), (3, 5), (16, 8)])
+def test_continuous_batching_equals_per_utterance_oracle(max_batch, steps_per_round):
+    cfg = vo.OracleConfig(d_model=128, nhead=2, num_layers=2, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 5)
+    ins = _requests(11, 1)
+    want = [vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True)[0] for x, xl, y in ins]
+    assert len({w.shape[0] for w in want}) > 2, "the workload must be ragged in G"
+    m = build_model(cfg, sd, "fp32", max_batch=max_batch)
+    cb = ContinuousBatcher(m, max_batch, max_text=8, max_prompt=18, steps_per_round=steps_per_round)
+    got = cb.decode([Request(x[0], y[0]) for x, _, y in ins], top_k=1)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert g.shape == w.shape, (i, g.shape, w.shape)
+        assert torch.equal(g.cpu(), w), f"request {i} differs"
+    assert cb.stats["admitted"] == len(ins) and cb.stats["harvests"] >= 2
+    # a second workload on the same batcher (slots are reusable), then the dense API on the same engine
+    ins2 = _requests(5, 2)
+    got2 = cb.decode([Request(x[0], y[0]) for x, _, y in ins2], top_k=1)
+    for (x, xl, y), g in zip(ins2, got2):
+        assert torch.equal(g.cpu(), vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True)[0])
+    x, xl, y = ins[0]
+    assert torch.equal(m.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1).cpu()[0], want[0])
+
+
+def test_continuous_batching_prefix_mode_2_and_bos():
+    cfg = vo.OracleConfig(d_model=64, nhead=4, num_layers=2, prefix_mode=2, prepend_bos=True)
+    sd = vo.make_state_dict(cfg, 6)
+    ins = _requests(6, 3, smin=6, smax=9)
+    enroll = [3, 4, 3, 5, 4, 3]
+    want = [vo.inference(sd, cfg, x, xl, y, torch.tensor([en], dtype=torch.int32), top_k=1, kv_cache=True)[0] for (x, xl, y), en in zip(ins, enroll)]
+    m = build_model(cfg, sd, "fp32", max_batch=2)
+    cb = ContinuousBatcher(m, 2, max_text=9, max_prompt=18, steps_per_round=8)
+    got = cb.decode([Request(x[0], y[0], en) for (x, _, y), en in zip(ins, enroll)], top_k=1)
+    for g, w in zip(got, want):
+        assert torch.equal(g.cpu(), w)
+
+
+def test_slot_api_state_errors():
+    cfg = vo.OracleConfig(d_model=64, nhead=4, num_layers=1, prefix_mode=1)
+    m = build_model(cfg, vo.make_state_dict(cfg, 0), "fp32", max_batch=2)
+    eng = m.engine_for(2, 6, 8)
+    x, xl, y = vo.make_inputs(4, 6)
+    with pytest.raises(valle_amd._lib.VleError):
+        eng.slots_step(1)  # before slots_begin
+    eng.slots_begin()
+    eng.slots_prefill([1], x.to(DEV), [4], y.to(DEV), [6])
+    with pytest.raises(valle_amd._lib.VleError):
+        eng.slots_prefill([1], x.to(DEV), [4], y.to(DEV), [6])  # slot busy
+    with pytest.raises(valle_amd._lib.VleError):
+        eng.slots_harvest([1], [1])  # not finished
+    done, gl = eng.slots_step(8)
+    assert done[0] == 1 and gl[0] == 0 and gl[1] == 9  # slot 0 stays free; slot 1: first sample + 8 steps

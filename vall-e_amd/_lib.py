@@ -40,6 +40,10 @@ SIGNATURES = {
     "vle_ar_generate": (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_uint64, C.c_int32, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P]),
     "vle_nar_decode": (C.c_int, [_P, _P, _I32P, _P, C.c_int64]),
     "vle_nar_continual": (C.c_int, [_P, _P, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P, C.c_int32, _P, C.c_int64, _I32P]),
+    "vle_slots_begin": (C.c_int, [_P, _P]),
+    "vle_slots_prefill": (C.c_int, [_P, _P, C.c_int32, _I32P, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P, C.c_int32, C.c_float, C.c_uint64]),
+    "vle_slots_step": (C.c_int, [_P, _P, C.c_int32, C.c_int32, C.c_float, C.c_uint64, _I32P, _I32P]),
+    "vle_slots_harvest": (C.c_int, [_P, _P, C.c_int32, _I32P, _I32P, _P, C.c_int64]),
     "vle_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "vle_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_size_t]),
     "vle_last_timings": (C.c_int, [_P, C.POINTER(C.c_double)]),

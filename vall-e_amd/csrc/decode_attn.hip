@@ -39,7 +39,8 @@ template <typename T, int VEC, int LPK, int NK>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ q, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, const int32_t* __restrict__ kv_len,
                                                           float* __restrict__ part_o, float* __restrict__ part_ml, int nhead,
-                                                          int dh, int ctx_max, int nsplit, T* __restrict__ out_norm) {
+                                                          int dh, int ctx_max, int nsplit, T* __restrict__ out_norm,
+                                                          const int32_t* __restrict__ done) {
   constexpr int KPW = 64 / LPK;         // keys per wave-load
   constexpr int WCH = NK * KPW;         // keys per wave per round
   constexpr int CHUNK = 4 * WCH;        // keys per block per round
@@ -89,6 +90,9 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   int base = s * CHUNK;
   issue(base);
   const int ctx = kv_len[b] + 1;  // the new token's K/V were just written to slot kv_len[b]
+  // finished / free utterance of a batch (slot API, ragged lengths): no KV stream for it; its output row stays stale
+  // and is never read (sampling skips it too).  Requested with the burst above, so a live utterance pays nothing.
+  if (done != nullptr && done[b] != 0) return;
   float qv[VEC];
 #pragma unroll
   for (int j = 0; j < VEC; ++j) qv[j] = active ? q[(int64_t)b * d + h * dh + part * VEC + j] : 0.f;
@@ -189,7 +193,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
 
 template <typename T>
 static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const void* vc, const int32_t* kv_len, float* part_o,
-                           float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit, int nk_override, void* out_norm) {
+                           float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit, int nk_override, void* out_norm,
+                           const int32_t* done) {
   constexpr int VFULL = Elem<T>::VEC;
   if (dh > 254) return -1;
   const dim3 grid(nhead, nsplit, B), block(256);
@@ -204,10 +209,10 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
   do {                                                                                                                      \
     if (nk8)                                                                                                                \
       hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 8>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
-                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm);                                                              \
+                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done);                                                              \
     else                                                                                                                    \
       hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 4>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
-                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm);                                                              \
+                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done);                                                              \
   } while (0)
   if (dh % VFULL == 0) {
     const int nv = dh / VFULL;
@@ -233,12 +238,12 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
 
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
-                            int nsplit, int nk_override, void* out_norm) {
+                            int nsplit, int nk_override, void* out_norm, const int32_t* done) {
   if (B <= 0) return 0;
   if (out_norm != nullptr && nsplit != 1) return -1;
   if (dtype == DT_F32)
-    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm);
-  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm);
+    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done);
+  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done);
 }
 
 }  // namespace vle

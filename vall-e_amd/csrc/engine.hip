@@ -123,6 +123,9 @@ struct vle_engine {
 
   // ---- per-call state -------------------------------------------------------------------------------
   int B = 0;
+  int nseq = 0;            // sequences of the packed pass being enqueued when it differs from B (slot API); 0 = B
+  bool slot_mode = false;  // vle_slots_*: B = max_B slots, each free (done = 1) or holding one utterance
+  std::vector<int32_t> slot_state;  // host copy of the device AR state after the last vle_slots_step
   bool have_prefill = false, have_gen = false;
   std::vector<int32_t> S_len, P_len, G_len;
   int64_t sumG_last = 0;
@@ -662,7 +665,7 @@ int enqueue_layer_rows(vle_engine* e, const LayerW& w, const float* g1, const fl
   E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, nullptr, g1, b1, e->Xn, rows, d));
   E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.wqkv, w.bqkv, e->QKV, nullptr, rows, 3 * d, d, EPI_STORE));
   if (kc) E_LAUNCH(e, launch_kv_scatter(st, e->dtype, e->QKV, kc, vc, row_seq, row_pos, rows, d, e->H, e->ctx_max));
-  E_LAUNCH(e, launch_attention(st, e->dtype, e->QKV, e->ATT, seq_off, text_len, e->B, max_len, d, e->H, causal));
+  E_LAUNCH(e, launch_attention(st, e->dtype, e->QKV, e->ATT, seq_off, text_len, e->nseq > 0 ? e->nseq : e->B, max_len, d, e->H, causal));
   E_LAUNCH(e, launch_gemm(st, e->dtype, e->ATT, w.wo, w.bo, nullptr, e->X, rows, d, d, EPI_RESID));
   E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, nullptr, g2, b2, e->Xn, rows, d));
   E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.w1, w.b1, e->Hb, nullptr, rows, 4 * d, d, EPI_RELU));
@@ -723,10 +726,11 @@ int enqueue_ar_logits(vle_engine* e) {
   return 0;
 }
 
-int enqueue_ar_sample(vle_engine* e, int first) {
+int enqueue_ar_sample(vle_engine* e, int first, const int32_t* slot_map = nullptr, int nslots = 0) {
   ProfScope ps(e, 6);
   ArSampleArgs a{};
-  a.s = e->S; a.dyn = e->dyn_dev; a.logits = e->logits; a.V = V_AR; a.B = e->B; a.d = e->d; a.bos = e->bos; a.first = first;
+  a.s = e->S; a.dyn = e->dyn_dev; a.logits = e->logits; a.V = V_AR; a.B = slot_map ? nslots : e->B; a.d = e->d; a.bos = e->bos; a.first = first;
+  a.slot_map = slot_map;
   a.tokens = e->tokens; a.g_stride = e->max_G; a.sampled = e->sampled;
   a.audio_emb = e->ar_audio_emb; a.pe = e->pe; a.alpha_audio = e->alphas + 1; a.x = e->x_step; a.ctx_max = e->ctx_max;
   E_LAUNCH(e, launch_ar_sample(e->st, a));
@@ -758,7 +762,7 @@ int enqueue_ar_step(vle_engine* e) {
       {
         ProfScope ps(e, 1);
         E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
-                                            e->ctx_max, e->nsplit, e->opt_nk, direct ? e->att_step : nullptr));
+                                            e->ctx_max, e->nsplit, e->opt_nk, direct ? e->att_step : nullptr, e->S.done));
       }
       {
         ProfScope ps(e, 2);
@@ -795,7 +799,7 @@ int enqueue_ar_step(vle_engine* e) {
     {
       ProfScope ps(e, 1);
       E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
-                                          e->ctx_max, e->nsplit, e->opt_nk));
+                                          e->ctx_max, e->nsplit, e->opt_nk, nullptr, e->B > 1 ? e->S.done : nullptr));
     }
     if (sk) {
       {
@@ -875,6 +879,7 @@ extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, 
   if ((r = enter(e, stream))) return r;
   hipStream_t st = e->st;
   e->B = B;
+  e->slot_mode = false;
   e->have_prefill = e->have_gen = false;
   e->nsplit = e->opt_nsplit > 0 ? e->opt_nsplit : choose_nsplit(e, B);
   e->S_len.assign(text_lens, text_lens + B);
@@ -1091,15 +1096,27 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
 
 // The NAR stages on (text, prompt, first codebook).  `mode`: prefix mode to apply (continual() maps
 // 2/4 to 1); drop[b] = enrolled_len - 2 for prefix_mode 2/4 inference, else 0.
-static int run_nar(vle_engine* e, const std::vector<int32_t>& drop, int mode, int64_t* codes, int64_t g_stride) {
+// `slots` (slot API): the utterances to decode, as slot ids; every per-utterance table is then indexed by slot id
+// (sized max_B) except the attention's sequence offsets, which follow the order of the list.  null = utterances 0..B-1.
+static int run_nar(vle_engine* e, const std::vector<int32_t>& drop, int mode, int64_t* codes, int64_t g_stride,
+                   const std::vector<int32_t>* slots = nullptr) {
   hipStream_t st = e->st;
-  const int B = e->B, Q = e->Q, d = e->d;
+  const int Q = e->Q, d = e->d;
+  const int nseq = slots ? (int)slots->size() : e->B;  // sequences in this pass
+  const int B = slots ? e->max_B : e->B;                // extent of the per-utterance tables
+  auto sl = [&](int i) { return slots ? (*slots)[i] : i; };
+  struct NseqScope {  // enqueue_layer_rows launches the attention over e->nseq sequences
+    vle_engine* e;
+    ~NseqScope() { e->nseq = 0; }
+  } nseq_scope{e};
+  e->nseq = nseq;
   int r;
   TableBuilder tb{e};
   std::vector<int> Sn(B), N(B);
   int64_t xrows = 0, arows = 0, grows = 0;
   int max_len = 0;
-  for (int b = 0; b < B; ++b) {
+  for (int i = 0; i < nseq; ++i) {
+    const int b = sl(i);
     Sn[b] = e->S_len[b] - drop[b];
     N[b] = Sn[b] + e->P_len[b] + e->G_len[b];
     xrows += N[b];
@@ -1117,11 +1134,13 @@ static int run_nar(vle_engine* e, const std::vector<int32_t>& drop, int mode, in
       int32_t* d_gp = tb.take(grows, &h_gp);
       if (!d_gs || !d_gp) return e->fail(VLE_EINVAL, "table overflow");
       int64_t o = 0;
-      for (int b = 0; b < B; ++b)
+      for (int i = 0; i < nseq; ++i) {
+        const int b = sl(i);
         for (int g = 0; g < e->G_len[b]; ++g, ++o) {
           h_gs[o] = b;
           h_gp[o] = g;
         }
+      }
       E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
       E_LAUNCH(e, launch_codes_set_first(st, e->tokens, e->max_G, d_gs, d_gp, grows, codes, g_stride, Q));
     }
@@ -1134,7 +1153,7 @@ static int run_nar(vle_engine* e, const std::vector<int32_t>& drop, int mode, in
   int32_t* d_pl = tb.take(B, &h_pl);
   int32_t* d_gl = tb.take(B, &h_gl);
   int32_t* d_aoff = tb.take(B + 1, &h_aoff);
-  int32_t* d_xoff = tb.take(B + 1, &h_xoff);
+  int32_t* d_xoff = tb.take(nseq + 1, &h_xoff);
   int32_t* d_as = tb.take(arows, &h_as);
   int32_t* d_ap = tb.take(arows, &h_ap);
   int32_t* d_xs = tb.take(xrows, &h_xs);
@@ -1142,14 +1161,19 @@ static int run_nar(vle_engine* e, const std::vector<int32_t>& drop, int mode, in
   int32_t* d_gs = tb.take(grows, &h_gs);
   int32_t* d_gp = tb.take(grows, &h_gp);
   int32_t* d_gmap = tb.take(grows, &h_gmap);
-  int32_t* d_tl_zero = tb.take(B, &h_tl_zero);
+  int32_t* d_tl_zero = tb.take(nseq, &h_tl_zero);
   if (!d_tl || !d_td || !d_pl || !d_gl || !d_aoff || !d_xoff || !d_as || !d_ap || !d_xs || !d_xp || !d_gs || !d_gp || !d_gmap ||
       !d_tl_zero)
     return e->fail(VLE_EINVAL, "table overflow");
   int64_t xo = 0, ao = 0, go = 0;
-  for (int b = 0; b < B; ++b) {
-    h_tl[b] = Sn[b]; h_td[b] = drop[b]; h_pl[b] = e->P_len[b]; h_gl[b] = e->G_len[b]; h_tl_zero[b] = 0;
-    h_aoff[b] = (int32_t)ao; h_xoff[b] = (int32_t)xo;
+  if (slots) {
+    memset(h_tl, 0, B * sizeof(int32_t)); memset(h_td, 0, B * sizeof(int32_t)); memset(h_pl, 0, B * sizeof(int32_t));
+    memset(h_gl, 0, B * sizeof(int32_t)); memset(h_aoff, 0, (B + 1) * sizeof(int32_t));
+  }
+  for (int i = 0; i < nseq; ++i) {
+    const int b = sl(i);
+    h_tl[b] = Sn[b]; h_td[b] = drop[b]; h_pl[b] = e->P_len[b]; h_gl[b] = e->G_len[b]; h_tl_zero[i] = 0;
+    h_aoff[b] = (int32_t)ao; h_xoff[i] = (int32_t)xo;
     for (int a = 0; a < e->P_len[b] + e->G_len[b]; ++a) {
       h_as[ao + a] = b;
       h_ap[ao + a] = a;
@@ -1165,7 +1189,7 @@ static int run_nar(vle_engine* e, const std::vector<int32_t>& drop, int mode, in
     }
     ao += e->P_len[b] + e->G_len[b]; xo += N[b]; go += e->G_len[b];
   }
-  h_aoff[B] = (int32_t)ao; h_xoff[B] = (int32_t)xo;
+  h_aoff[B] = (int32_t)ao; h_xoff[nseq] = (int32_t)xo;
   E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
 
   NarEmbedArgs na{};
@@ -1276,6 +1300,222 @@ extern "C" int vle_nar_continual(vle_engine* e, void* stream, const int64_t* tex
 // =================================================================================================
 // hooks
 // =================================================================================================
+// ---- slot API: continuous batching -----------------------------------------------------------
+// The engine's max_batch utterance positions become SLOTS, each free or holding one utterance.  The caller admits new
+// utterances into free slots (prefill of just those), advances every live slot by a few AR steps, and harvests finished
+// slots (their 7 NAR stages), so a finished utterance frees its slot -- and its share of the KV stream, which the decode
+// attention skips for done slots -- while the others keep decoding.  Same kernels, same captured step graph
+// (B = max_batch), same numerics as vle_ar_prefill / vle_ar_generate / vle_nar_decode: an utterance's tokens do not
+// depend on what shares the batch with it.
+
+static int set_dyn(vle_engine* e, int32_t top_k, float temperature, uint64_t seed, int32_t max_new) {
+  ArDyn dyn{};
+  dyn.top_k = top_k; dyn.temperature = temperature; dyn.seed = seed; dyn.max_new = max_new; dyn.ignore_eos = e->opt_ignore_eos ? 1 : 0;
+  dyn.forced_len = e->forced_len_dev;
+  int32_t* hp = e->tables_host + e->tables_cap - (int64_t)(sizeof(ArDyn) / 4 + e->max_B + 4);
+  memcpy(hp, &dyn, sizeof(ArDyn));
+  E_HIP(e, hipMemcpyAsync(e->dyn_dev, hp, sizeof(ArDyn), hipMemcpyHostToDevice, e->st));
+  return 0;
+}
+
+extern "C" int vle_slots_begin(vle_engine* e, void* stream) {
+  if (!e) return VLE_EINVAL;
+  if (!e->finalized) return e->fail(VLE_ESTATE, "weights not finalized");
+  int r;
+  if ((r = enter(e, stream))) return r;
+  e->B = e->max_B;
+  e->nsplit = e->opt_nsplit > 0 ? e->opt_nsplit : choose_nsplit(e, e->B);
+  e->slot_mode = true;
+  e->have_prefill = e->have_gen = false;
+  e->S_len.assign(e->max_B, 0);
+  e->P_len.assign(e->max_B, 0);
+  e->G_len.assign(e->max_B, 0);
+  e->slot_state.assign(6 * e->max_B + 8, 0);
+  for (int b = 0; b < e->max_B; ++b) e->slot_state[3 * e->max_B + b] = 1;  // every slot free = done
+  memcpy(e->tables_host, e->slot_state.data(), e->slot_state.size() * sizeof(int32_t));
+  E_HIP(e, hipMemcpyAsync(e->state_dev, e->tables_host, e->slot_state.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->st));
+  // free slots run through the (row-independent) GEMMs of every step: give them finite inputs
+  E_HIP(e, hipMemsetAsync(e->x_step, 0, (size_t)e->max_B * e->d * sizeof(float), e->st));
+  return leave(e, stream);
+}
+
+extern "C" int vle_slots_prefill(vle_engine* e, void* stream, int32_t n, const int32_t* slots, const int64_t* text, int64_t s_stride,
+                                 const int32_t* text_lens, const int64_t* prompt_codes, int64_t p_stride, const int32_t* prompt_lens,
+                                 int32_t top_k, float temperature, uint64_t seed) {
+  if (!e) return VLE_EINVAL;
+  if (!e->slot_mode) return e->fail(VLE_ESTATE, "vle_slots_prefill needs vle_slots_begin first");
+  if (n < 1 || n > e->max_B || !slots || !text || !text_lens || !prompt_codes || !prompt_lens) return e->fail(VLE_EINVAL, "bad argument");
+  if (!(temperature > 0.f)) return e->fail(VLE_EINVAL, "temperature must be > 0");
+  std::vector<char> seen(e->max_B, 0);
+  for (int i = 0; i < n; ++i) {
+    const int b = slots[i];
+    if (b < 0 || b >= e->max_B || seen[b]) return e->fail(VLE_EINVAL, "slot id out of range or listed twice");
+    seen[b] = 1;
+    if (!e->slot_state[3 * e->max_B + b]) return e->fail(VLE_ESTATE, "slot still holds a live utterance");
+    if (text_lens[i] < 1 || text_lens[i] > e->max_S || text_lens[i] > s_stride) return e->fail(VLE_EINVAL, "text_lens out of range");
+    if (prompt_lens[i] < 0 || prompt_lens[i] > e->max_P || prompt_lens[i] > p_stride) return e->fail(VLE_EINVAL, "prompt_lens out of range");
+    if (prompt_lens[i] + e->bos < 1) return e->fail(VLE_EINVAL, "empty prompt needs prepend_bos");
+  }
+  int r;
+  if ((r = enter(e, stream))) return r;
+  hipStream_t st = e->st;
+  // engine-owned copies of the inputs, at the slot's row (the NAR phase needs them again)
+  const int64_t pp = (int64_t)(e->max_P + e->max_G) * e->Q;
+  for (int i = 0; i < n; ++i) {
+    const int b = slots[i];
+    E_HIP(e, hipMemcpyAsync(e->text_ids + (int64_t)b * e->max_S, text + (int64_t)i * s_stride, text_lens[i] * sizeof(int64_t),
+                            hipMemcpyDeviceToDevice, st));
+    if (prompt_lens[i] > 0)
+      E_HIP(e, hipMemcpyAsync(e->prompt_codes + (int64_t)b * pp, prompt_codes + (int64_t)i * p_stride * e->Q,
+                              (size_t)prompt_lens[i] * e->Q * sizeof(int64_t), hipMemcpyDeviceToDevice, st));
+    e->S_len[b] = text_lens[i];
+    e->P_len[b] = prompt_lens[i];
+    e->G_len[b] = 0;
+  }
+  TableBuilder tb{e};
+  int64_t rows = 0;
+  int max_len = 0;
+  for (int i = 0; i < n; ++i) {
+    const int len = text_lens[i] + e->bos + prompt_lens[i];
+    rows += len;
+    max_len = std::max(max_len, len);
+  }
+  int32_t *h_seq_off, *h_tl_seq, *h_tl_slot, *h_row_seq, *h_row_pos, *h_last, *h_slots, *h_kv, *h_ap, *h_cap;
+  int32_t* d_seq_off = tb.take(n + 1, &h_seq_off);
+  int32_t* d_tl_seq = tb.take(n, &h_tl_seq);            // attention: by sequence order
+  int32_t* d_tl_slot = tb.take(e->max_B, &h_tl_slot);   // embedding: by slot id (row_seq holds slot ids)
+  int32_t* d_row_seq = tb.take(rows, &h_row_seq);
+  int32_t* d_row_pos = tb.take(rows, &h_row_pos);
+  int32_t* d_last = tb.take(n, &h_last);
+  int32_t* d_slots = tb.take(n, &h_slots);
+  int32_t* d_kv = tb.take(n, &h_kv);
+  int32_t* d_ap = tb.take(n, &h_ap);
+  int32_t* d_cap = tb.take(n, &h_cap);
+  if (!d_seq_off || !d_tl_seq || !d_tl_slot || !d_row_seq || !d_row_pos || !d_last || !d_slots || !d_kv || !d_ap || !d_cap)
+    return e->fail(VLE_EINVAL, "table overflow");
+  for (int b = 0; b < e->max_B; ++b) h_tl_slot[b] = e->S_len[b];
+  int64_t off = 0;
+  for (int i = 0; i < n; ++i) {
+    const int b = slots[i], len = text_lens[i] + e->bos + prompt_lens[i];
+    h_seq_off[i] = (int32_t)off;
+    h_tl_seq[i] = text_lens[i];
+    for (int p = 0; p < len; ++p) {
+      h_row_seq[off + p] = b;
+      h_row_pos[off + p] = p;
+    }
+    off += len;
+    h_last[i] = (int32_t)(off - 1);
+    h_slots[i] = b;
+    h_kv[i] = len;                            // kv_len: next free cache position
+    h_ap[i] = e->bos + prompt_lens[i];        // audio_pos of the next token
+    h_cap[i] = 16 * text_lens[i];             // valle.py:1047
+  }
+  h_seq_off[n] = (int32_t)off;
+  E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  E_LAUNCH(e, launch_slot_state_init(st, e->state_dev, e->max_B, d_slots, d_kv, d_ap, d_cap, n));
+
+  PrefillEmbedArgs pa{};
+  pa.text = e->text_ids; pa.s_stride = e->max_S; pa.prompt = e->prompt_codes; pa.p_stride = e->max_P + e->max_G; pa.Q = e->Q;
+  pa.text_len = d_tl_slot; pa.row_seq = d_row_seq; pa.row_pos = d_row_pos;
+  pa.text_emb = e->ar_text_emb; pa.audio_emb = e->ar_audio_emb; pa.pe = e->pe;
+  pa.alpha_text = e->alphas + 0; pa.alpha_audio = e->alphas + 1; pa.bos = e->bos; pa.d = e->d; pa.rows = rows; pa.x = e->X;
+  E_LAUNCH(e, launch_prefill_embed(st, pa));
+  e->nseq = n;
+  for (int l = 0; l < e->L && r == 0; ++l) {
+    const LayerW& w = e->ar[l];
+    r = enqueue_layer_rows(e, w, w.g1, w.be1, w.g2, w.be2, rows, d_seq_off, d_tl_seq, max_len, 1, cache_layer(e, e->kcache, l),
+                           cache_layer(e, e->vcache, l), d_row_seq, d_row_pos);
+  }
+  e->nseq = 0;
+  if (r) return r;
+  // bring the new slots to the state every live slot is in between steps ("x_step = embedding of the next input"):
+  // last prefill row -> x_step[slot]; logits of all rows (the live slots' logits are scratch at this point: a step
+  // rewrites them before sampling); first sample for the new slots only
+  E_LAUNCH(e, launch_scatter_rows(st, e->X, d_last, e->x_step, d_slots, n, e->d));
+  if ((r = enqueue_ar_logits(e))) return r;
+  if ((r = set_dyn(e, top_k, temperature, seed, 0))) return r;
+  if ((r = enqueue_ar_sample(e, 1, d_slots, n))) return r;
+  E_HIP(e, hipStreamSynchronize(st));  // the pinned table mirror is reused by the next call
+  for (int i = 0; i < n; ++i) e->slot_state[3 * e->max_B + slots[i]] = 0;
+  return leave(e, stream);
+}
+
+extern "C" int vle_slots_step(vle_engine* e, void* stream, int32_t nsteps, int32_t top_k, float temperature, uint64_t seed,
+                              int32_t* done_out, int32_t* gen_lens_out) {
+  if (!e) return VLE_EINVAL;
+  if (!e->slot_mode) return e->fail(VLE_ESTATE, "vle_slots_step needs vle_slots_begin first");
+  if (nsteps < 0 || !(temperature > 0.f)) return e->fail(VLE_EINVAL, "bad argument");
+  int r;
+  if ((r = enter(e, stream))) return r;
+  hipStream_t st = e->st;
+  if ((r = set_dyn(e, top_k, temperature, seed, 0))) return r;
+  const int B = e->B;
+  const int spg = e->opt_spg > 0 ? e->opt_spg : (e->cfg.steps_per_graph > 0 ? e->cfg.steps_per_graph : 8);
+  const bool use_graph = e->cfg.use_graph != 0 && !e->opt_profile;
+  int steps_done = 0;
+  hipGraphExec_t g_multi = nullptr, g_single = nullptr;
+  if (use_graph && nsteps > 0) {
+    auto it = e->graphs.find(B * 64 + e->nsplit);
+    if (it == e->graphs.end()) {
+      if ((r = enqueue_ar_step(e))) return r;  // first step eagerly (kernel attributes are set outside capture)
+      steps_done = 1;
+      if ((r = capture_graph(e, spg, &g_multi))) return r;
+      if ((r = capture_graph(e, 1, &g_single))) return r;
+      e->graphs[B * 64 + e->nsplit] = {g_multi, g_single};
+    } else {
+      g_multi = it->second.first;
+      g_single = it->second.second;
+    }
+  }
+  while (steps_done < nsteps) {
+    if (use_graph && nsteps - steps_done >= spg) {
+      E_HIP(e, hipGraphLaunch(g_multi, st));
+      steps_done += spg;
+    } else if (use_graph) {
+      E_HIP(e, hipGraphLaunch(g_single, st));
+      steps_done += 1;
+    } else {
+      if ((r = enqueue_ar_step(e))) return r;
+      steps_done += 1;
+    }
+  }
+  E_HIP(e, hipMemcpyAsync(e->tables_host, e->state_dev, e->slot_state.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  E_HIP(e, hipStreamSynchronize(st));
+  memcpy(e->slot_state.data(), e->tables_host, e->slot_state.size() * sizeof(int32_t));
+  for (int b = 0; b < e->max_B; ++b) {
+    e->G_len[b] = e->slot_state[2 * e->max_B + b];
+    if (done_out) done_out[b] = e->slot_state[3 * e->max_B + b];
+    if (gen_lens_out) gen_lens_out[b] = e->G_len[b];
+  }
+  return leave(e, stream);
+}
+
+extern "C" int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slots, const int32_t* enroll_lens,
+                                 int64_t* codes, int64_t g_stride) {
+  if (!e) return VLE_EINVAL;
+  if (!e->slot_mode) return e->fail(VLE_ESTATE, "vle_slots_harvest needs vle_slots_begin first");
+  if (n < 1 || n > e->max_B || !slots || !codes) return e->fail(VLE_EINVAL, "bad argument");
+  const int mode = e->cfg.prefix_mode;
+  std::vector<int32_t> drop(e->max_B, 0), list(slots, slots + n);
+  for (int i = 0; i < n; ++i) {
+    const int b = slots[i];
+    if (b < 0 || b >= e->max_B) return e->fail(VLE_EINVAL, "slot id out of range");
+    if (e->S_len[b] < 1 || !e->slot_state[3 * e->max_B + b]) return e->fail(VLE_ESTATE, "slot is not a finished utterance");
+    if (e->G_len[b] > g_stride) return e->fail(VLE_EINVAL, "g_stride smaller than generated length");
+    if (mode == 2 || mode == 4) {
+      if (!enroll_lens) return e->fail(VLE_EINVAL, "prefix_mode 2/4 needs enroll_lens (valle.py:1068-1079)");
+      if (enroll_lens[i] < 2 || enroll_lens[i] - 1 > e->S_len[b]) return e->fail(VLE_EINVAL, "enroll_lens out of range");
+      drop[b] = enroll_lens[i] - 2;
+    }
+  }
+  int r;
+  if ((r = enter(e, stream))) return r;
+  if ((r = run_nar(e, drop, mode, codes, g_stride, &list))) return r;
+  if ((r = finish_nar_timing(e))) return r;
+  for (int i = 0; i < n; ++i) e->S_len[slots[i]] = 0;  // the slot is free again
+  return leave(e, stream);
+}
+
 extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
   if (!e || !name) return VLE_EINVAL;
   const std::string n = name;

@@ -108,9 +108,10 @@ int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache,
                       const int32_t* row_pos, int64_t rows, int d, int nhead, int ctx_max);
 // decode_attn.hip: one new query per utterance against the KV cache; writes split partials
 // part_o [B][nsplit][d], part_ml [B][H][nsplit][2]
+// `done` (int32 [B] or null): utterances whose flag is set are skipped (no KV traffic, output row left stale)
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
-                            int nsplit, int nk_override = 0, void* out_norm = nullptr);
+                            int nsplit, int nk_override = 0, void* out_norm = nullptr, const int32_t* done = nullptr);
 // nk_override: keys per lane per round (0 = auto, 4, 8); out_norm (T [B][d], nsplit == 1 only): write the
 // normalised attention output directly instead of partials
 
@@ -180,8 +181,13 @@ struct ArSampleArgs {
   const float* audio_emb; const float* pe; const float* alpha_audio;
   float* x;                                // [B][d] next step's input
   int ctx_max;
+  const int32_t* slot_map = nullptr;       // slot API: block i serves utterance slot_map[i] (B = number of listed slots)
 };
 int launch_ar_sample(hipStream_t st, const ArSampleArgs& a);
+// slot API (continuous batching): per-slot AR state of newly admitted utterances; rows of X scattered to slot rows
+int launch_slot_state_init(hipStream_t st, int32_t* state, int max_B, const int32_t* slots, const int32_t* kv_len,
+                           const int32_t* audio_pos, const int32_t* cap, int n);
+int launch_scatter_rows(hipStream_t st, const float* src, const int32_t* src_rows, float* dst, const int32_t* dst_rows, int rows, int d);
 
 struct NarArgmaxArgs {
   const float* logits; int V;          // [rows][V]

@@ -82,4 +82,40 @@ int launch_codes_set_first(hipStream_t st, const int64_t* first_cb, int64_t fc_s
   return 0;
 }
 
+// ---- slot API (continuous batching) -----------------------------------------------------------------
+// AR state of newly admitted utterances: [kv_len | audio_pos | n_gen | done | cap | iter][max_B]
+__global__ void slot_state_init_kernel(int32_t* state, int max_B, const int32_t* slots, const int32_t* kv_len,
+                                       const int32_t* audio_pos, const int32_t* cap, int n) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int b = slots[i];
+  state[0 * max_B + b] = kv_len[i];
+  state[1 * max_B + b] = audio_pos[i];
+  state[2 * max_B + b] = 0;
+  state[3 * max_B + b] = 0;
+  state[4 * max_B + b] = cap[i];
+  state[5 * max_B + b] = 0;
+}
+
+int launch_slot_state_init(hipStream_t st, int32_t* state, int max_B, const int32_t* slots, const int32_t* kv_len,
+                           const int32_t* audio_pos, const int32_t* cap, int n) {
+  if (n <= 0) return 0;
+  hipLaunchKernelGGL(slot_state_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, state, max_B, slots, kv_len, audio_pos, cap, n);
+  return 0;
+}
+
+__global__ void scatter_rows_kernel(const float* __restrict__ src, const int32_t* __restrict__ src_rows, float* __restrict__ dst,
+                                    const int32_t* __restrict__ dst_rows, int d) {
+  const int r = blockIdx.x;
+  const float4* s = reinterpret_cast<const float4*>(src + (int64_t)src_rows[r] * d);
+  float4* o = reinterpret_cast<float4*>(dst + (int64_t)dst_rows[r] * d);
+  for (int i = threadIdx.x; i < (d >> 2); i += blockDim.x) o[i] = s[i];
+}
+
+int launch_scatter_rows(hipStream_t st, const float* src, const int32_t* src_rows, float* dst, const int32_t* dst_rows, int rows, int d) {
+  if (rows <= 0) return 0;
+  hipLaunchKernelGGL(scatter_rows_kernel, dim3(rows), dim3(256), 0, st, src, src_rows, dst, dst_rows, d);
+  return 0;
+}
+
 }  // namespace vle

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
   __shared__ float wave_tot[SAMP_T / 64];
   __shared__ int sh_next, sh_stop, sh_pos;
 
-  const int b = blockIdx.x, tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int b = a.slot_map ? a.slot_map[blockIdx.x] : (int)blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   if (a.s.done[b]) return;
   const int it = a.s.iter[b];
   const int V = a.V;

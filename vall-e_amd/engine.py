@@ -169,6 +169,40 @@ class Engine:
         self._gen_lens = [int(v) for v in gl]
         return codes, self._gen_lens
 
+    # ---- slot API: continuous batching (vle_slots_*) ---------------------------------------------
+    def slots_begin(self):
+        _lib.check(self.lib.vle_slots_begin(self.h, _stream_ptr(self.device)), self.h)
+        self._B = self.cfg.max_batch
+
+    def slots_prefill(self, slots: Sequence[int], text: torch.Tensor, text_lens: Sequence[int], prompts: torch.Tensor,
+                      prompt_lens: Sequence[int], top_k: int = 1, temperature: float = 1.0, seed: int = 0):
+        """Admit len(slots) utterances into free slots: text int64 (n, S), prompts int64 (n, P, Q) on the engine's device."""
+        assert text.dtype == torch.int64 and prompts.dtype == torch.int64 and text.device == self.device and prompts.device == self.device
+        text, prompts = text.contiguous(), prompts.contiguous()
+        n = len(slots)
+        assert text.shape[0] == n and prompts.shape[0] == n and prompts.shape[2] == self.cfg.num_quantizers
+        _lib.check(self.lib.vle_slots_prefill(self.h, _stream_ptr(self.device), n, _i32(slots), C.c_void_p(text.data_ptr()), text.shape[1],
+                                              _i32(text_lens), C.c_void_p(prompts.data_ptr()), prompts.shape[1], _i32(prompt_lens),
+                                              int(top_k), float(temperature), int(seed) & (2**64 - 1)), self.h)
+
+    def slots_step(self, nsteps: int, top_k: int = 1, temperature: float = 1.0, seed: int = 0):
+        """Advance every live slot by nsteps AR steps; returns (done flags, generated lengths) per slot."""
+        B = self.cfg.max_batch
+        done, gl = (C.c_int32 * B)(), (C.c_int32 * B)()
+        _lib.check(self.lib.vle_slots_step(self.h, _stream_ptr(self.device), int(nsteps), int(top_k), float(temperature),
+                                           int(seed) & (2**64 - 1), done, gl), self.h)
+        return [int(v) for v in done], [int(v) for v in gl]
+
+    def slots_harvest(self, slots: Sequence[int], gen_lens: Sequence[int], enroll_lens: Optional[Sequence[int]] = None):
+        """NAR stages of the listed finished slots; returns one (G, Q) int64 device tensor per listed slot and frees them."""
+        Q = self.cfg.num_quantizers
+        Gmax = max(max(gen_lens), 1)
+        codes = torch.zeros(self.cfg.max_batch, Gmax, Q, dtype=torch.int64, device=self.device)
+        el = _i32(enroll_lens) if enroll_lens is not None else None
+        _lib.check(self.lib.vle_slots_harvest(self.h, _stream_ptr(self.device), len(slots), _i32(slots), el, C.c_void_p(codes.data_ptr()), Gmax),
+                   self.h)
+        return [codes[s, :g] for s, g in zip(slots, gen_lens)]
+
     # ---- hooks --------------------------------------------------------------------------------
     def timings(self) -> Dict[str, float]:
         out = (C.c_double * 4)()

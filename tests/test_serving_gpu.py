@@ -21,20 +21,20 @@ def _requests(n, seed, smin=3, smax=8, pmin=4, pmax=18):
     return [vo.make_inputs(S[i], P[i], seed=500 + i) for i in range(n)]
 
 
-@pytest.mark.parametrize("max_batch,steps_per_round", [(4, 8), (3, 5), (16, 8)])
-def test_continuous_batching_equals_per_utterance_oracle(max_batch, steps_per_round):
+@pytest.mark.parametrize("max_batch,steps_per_round,harvest_min", [(4, 8, None), (3, 5, 1), (16, 8, 2), (4, 8, 3)])
+def test_continuous_batching_equals_per_utterance_oracle(max_batch, steps_per_round, harvest_min):
     cfg = vo.OracleConfig(d_model=128, nhead=2, num_layers=2, prefix_mode=1)
     sd = vo.make_state_dict(cfg, 5)
     ins = _requests(11, 1)
     want = [vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True)[0] for x, xl, y in ins]
     assert len({w.shape[0] for w in want}) > 2, "the workload must be ragged in G"
     m = build_model(cfg, sd, "fp32", max_batch=max_batch)
-    cb = ContinuousBatcher(m, max_batch, max_text=8, max_prompt=18, steps_per_round=steps_per_round)
+    cb = ContinuousBatcher(m, max_batch, max_text=8, max_prompt=18, steps_per_round=steps_per_round, harvest_min=harvest_min)
     got = cb.decode([Request(x[0], y[0]) for x, _, y in ins], top_k=1)
     for i, (g, w) in enumerate(zip(got, want)):
         assert g.shape == w.shape, (i, g.shape, w.shape)
         assert torch.equal(g.cpu(), w), f"request {i} differs"
-    assert cb.stats["admitted"] == len(ins) and cb.stats["harvests"] >= 2
+    assert cb.stats["admitted"] == len(ins) and cb.stats["harvests"] >= 1
     # a second workload on the same batcher (slots are reusable), then the dense API on the same engine
     ins2 = _requests(5, 2)
     got2 = cb.decode([Request(x[0], y[0]) for x, _, y in ins2], top_k=1)

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--max-batch", type=int, default=64)
     ap.add_argument("--smin", type=int, default=8)
     ap.add_argument("--dtype", default="bf16")
+    ap.add_argument("--harvest-min", type=int, nargs="+", default=[1, 8, 16, 32])
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -48,16 +49,20 @@ def main():
             eng.generate(top_k=1, allow_empty=True)
             eng.nar(None)
 
-    cb = ContinuousBatcher(m, B, 47, 225, steps_per_round=8)
-    for name, fn in (("static", static), ("continuous", lambda: cb.decode(reqs, top_k=1))):
+    runs = [("static", static)]
+    cbs = {}
+    for h in args.harvest_min:
+        cbs[h] = ContinuousBatcher(m, B, 47, 225, steps_per_round=8, harvest_min=h)
+        runs.append((f"continuous harvest_min={h}", lambda h=h: cbs[h].decode(reqs, top_k=1)))
+    for name, fn in runs:
         fn()  # warm-up (graph capture)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         fn()
         torch.cuda.synchronize()
         dt = time.perf_counter() - t0
-        print(f"{name:11s}: {tokens / dt:10.0f} tok/s  ({dt * 1e3:.0f} ms for {args.n} requests, {tokens} tokens, max_batch {B})", flush=True)
-    print("scheduler stats", cb.stats)
+        print(f"{name:28s}: {tokens / dt:10.0f} tok/s  ({dt * 1e3:.0f} ms for {args.n} requests, {tokens} tokens, max_batch {B})", flush=True)
+    print("scheduler stats", {h: c.stats for h, c in cbs.items()})
 
 
 if __name__ == "__main__":

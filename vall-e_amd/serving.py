@@ -27,11 +27,17 @@ class Request:
 
 
 class ContinuousBatcher:
-    def __init__(self, model: VALLE, max_batch: int, max_text: int, max_prompt: int, steps_per_round: int = 8):
-        """``steps_per_round``: AR steps between two scheduling points (a finished utterance waits at most that long
-        for its slot to be reused; the engine replays its captured multi-step graph in between)."""
+    def __init__(self, model: VALLE, max_batch: int, max_text: int, max_prompt: int, steps_per_round: int = 8,
+                 harvest_min: Optional[int] = None):
+        """``steps_per_round``: AR steps between two scheduling points (the engine replays its captured multi-step graph
+        in between).  ``harvest_min``: finished utterances are collected until that many wait (default max_batch / 4)
+        before their NAR stages run and their slots are refilled -- the NAR passes and the prefill are MFMA GEMMs whose
+        efficiency grows with the number of packed rows (measured on MI355X, C2: 10 ms for one utterance alone, 3.9 ms
+        per utterance in a batch of 64), while a finished slot that waits costs no KV traffic.  When nothing is waiting
+        for a slot any more, the remaining utterances are harvested together at the end."""
         assert max_batch >= 1 and steps_per_round >= 1
         self.model, self.max_batch, self.steps_per_round = model, max_batch, steps_per_round
+        self.harvest_min = max(1, max_batch // 4) if harvest_min is None else max(1, int(harvest_min))
         self.eng = model.engine_for(max_batch, max_text, max_prompt)
         self.stats = dict(rounds=0, admitted=0, ar_steps=0, harvests=0)
 
@@ -69,7 +75,8 @@ class ContinuousBatcher:
             self.stats["rounds"] += 1
             self.stats["ar_steps"] += self.steps_per_round
             fin = [s for s in live if done[s]]
-            if fin:
+            running = len(live) - len(fin)
+            if fin and (running == 0 or (pending and len(fin) >= self.harvest_min)):
                 enroll = [int(requests[live[s]].enroll_len) for s in fin] if need_enroll else None
                 codes = eng.slots_harvest(fin, [gl[s] for s in fin], enroll)
                 for s, c in zip(fin, codes):

@@ -333,9 +333,10 @@ extern "C" int vle_create(const vle_config* c, vle_engine** out) {
   e->ctx_max = e->max_S + e->max_P + 1 + e->max_G;
   e->max_pos = std::max(e->max_S, e->max_P + 1 + e->max_G) + 1;
   e->max_rows = (int64_t)e->max_B * (e->max_S + e->max_P + 1 + e->max_G);
-  if (hipSetDevice(c->device) != hipSuccess) {
+  if (const hipError_t sr = hipSetDevice(c->device); sr != hipSuccess) {  // no such device / no GPU on this box
     delete e;
-    return bad("hipSetDevice failed");
+    set_global_error((std::string("hipSetDevice failed: ") + hipGetErrorString(sr)).c_str());
+    return VLE_EHIP;
   }
   auto chk = [&](hipError_t r, const char* what) {
     if (r != hipSuccess) {
@@ -1558,8 +1559,8 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
-  if (n == "glds_big" || n == "glds_w8") {  // process-global tile policy of gemm_glds.hip (same knobs as vle_op_tune)
-    (n == "glds_big" ? g_glds_big : g_glds_w8) = (int)value;
+  if (n == "glds_big" || n == "glds_w8" || n == "glds_prio") {  // process-global tile policy of gemm_glds.hip (same knobs as vle_op_tune)
+    (n == "glds_big" ? g_glds_big : n == "glds_w8" ? g_glds_w8 : g_glds_prio) = (int)value;
     return VLE_OK;
   }
   if (n == "ignore_eos") {

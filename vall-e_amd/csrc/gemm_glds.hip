@@ -30,7 +30,7 @@ __device__ inline void gg_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int EPI, int NW>
+template <int BM, int BN, int EPI, int NW, bool PRIO = false>
 __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const float* __restrict__ bias, void* __restrict__ out_,
                                                         float* __restrict__ resid, int64_t M, int N, int K) {
@@ -143,11 +143,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
           const int row = wn0 + j * 16 + fr;
           bfr[j] = *reinterpret_cast<const gg_bf16x8*>(Bs + row * 128 + ((c ^ (row & 7)) << 4));
         }
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);  // MFMA cluster ahead of the other waves' loads (knob "glds_prio")
 #pragma unroll
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j)  // W fragment as the A operand: C^T, see the epilogue
             acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+        if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
       }
     } else if (nlive > 0) {  // tail tile (rows beyond M): only fragment rows that exist
 #pragma unroll
@@ -235,13 +237,20 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
 // tile policy knob (vle_op_tune "glds_big"): 0 = never use the 8-wave 256 x 128 tile, -1 = default threshold
 // (>= 512 full tiles), n > 0 = threshold n
 int g_glds_big = -1;
+int g_glds_prio = 0;  // "glds_prio": s_setprio(1) around the MFMA cluster of the 8-wave tiles (A/B knob)
 int g_glds_w8 = 1;  // "glds_w8": 8-wave workgroups on the 128-row tiles as well (batch-1 NAR 12.0 -> 10.0 ms); 0 = 4 waves
 
 template <int BM, int BN, int NW = 4>
 static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const float* bias, void* out, float* resid, int64_t M,
                      int N, int K, int epi) {
   const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM)), block(NW * 64);
-#define VLE_GG(E) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW>), grid, block, 0, st, A, W, bias, out, resid, M, N, K)
+#define VLE_GG(E)                                                                                                       \
+  do {                                                                                                                  \
+    if (NW == 8 && g_glds_prio)                                                                                         \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, (NW == 8)>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); \
+    else                                                                                                                \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false>), grid, block, 0, st, A, W, bias, out, resid, M, N, K);  \
+  } while (0)
   switch (epi) {
     case EPI_STORE: VLE_GG(EPI_STORE); break;
     case EPI_RELU: VLE_GG(EPI_RELU); break;

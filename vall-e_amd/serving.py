@@ -30,14 +30,16 @@ class ContinuousBatcher:
     def __init__(self, model: VALLE, max_batch: int, max_text: int, max_prompt: int, steps_per_round: int = 8,
                  harvest_min: Optional[int] = None):
         """``steps_per_round``: AR steps between two scheduling points (the engine replays its captured multi-step graph
-        in between).  ``harvest_min``: finished utterances are collected until that many wait (default max_batch / 4)
+        in between).  ``harvest_min``: finished utterances are collected until that many wait (default max_batch / 8)
         before their NAR stages run and their slots are refilled -- the NAR passes and the prefill are MFMA GEMMs whose
         efficiency grows with the number of packed rows (measured on MI355X, C2: 10 ms for one utterance alone, 3.9 ms
         per utterance in a batch of 64), while a finished slot that waits costs no KV traffic.  When nothing is waiting
-        for a slot any more, the remaining utterances are harvested together at the end."""
+        for a slot any more, the remaining utterances are harvested together at the end.  Measured (tools/serve_bench.py,
+        192 requests, G from 129 to 753 frames, 64 slots): harvest_min 1 / 8 / 16 / 32 -> 288 / 331 / 328 / 319 k tok/s,
+        static batches of 64 in arrival order 309 k."""
         assert max_batch >= 1 and steps_per_round >= 1
         self.model, self.max_batch, self.steps_per_round = model, max_batch, steps_per_round
-        self.harvest_min = max(1, max_batch // 4) if harvest_min is None else max(1, int(harvest_min))
+        self.harvest_min = max(1, max_batch // 8) if harvest_min is None else max(1, int(harvest_min))
         self.eng = model.engine_for(max_batch, max_text, max_prompt)
         self.stats = dict(rounds=0, admitted=0, ar_steps=0, harvests=0)
 

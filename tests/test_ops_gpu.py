@@ -231,3 +231,21 @@ def test_linear_split_k_tickets(M, N, K, ksplit, epi):
     if ksplit is not None:
         torch.cuda.synchronize()
         assert int(ops.linear_workspace(a.device)[:4096].view(torch.int32).abs().sum()) == 0, "tickets not reset"
+
+
+@pytest.mark.parametrize("M,N,K", [(17408, 1024, 1024), (1041, 4096, 1024), (300, 1025, 1024), (130, 256, 256)])
+@pytest.mark.parametrize("knob", ["glds_swz", "glds_prio"])
+def test_linear_gemm_tile_policy_knobs(M, N, K, knob):
+    """The A/B variants of the 8-wave GEMM tiles (alternative LDS slot key, s_setprio) compute the same product."""
+    a = _rand(M, K, seed=70).to(torch.bfloat16)
+    w = (_rand(N, K, seed=71) / math.sqrt(K)).to(torch.bfloat16)
+    bias = _rand(N, seed=72) * 0.1
+    ref = a.double() @ w.double().t() + bias.double()
+    base = ops.linear(a, w, bias, ops.EPI_F32, ksplit=None)
+    ops.tune(knob, 1)
+    try:
+        got = ops.linear(a, w, bias, ops.EPI_F32, ksplit=None)
+    finally:
+        ops.tune(knob, 0)
+    assert (got.double() - ref).abs().max().item() < 3e-5 * math.sqrt(K / 64) * max(1.0, ref.abs().max().item())
+    assert torch.equal(got, base)  # same MFMA order, only the LDS placement / issue priority differs

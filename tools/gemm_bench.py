@@ -1,0 +1,48 @@
+#!/usr/bin/env python
+"""TFLOP/s of the prefill / NAR GEMM (gemm_glds.hip) at the row counts of BASELINE configs[1] (1025 rows) and
+configs[2] (65 600 rows), per tile-policy knob.   python tools/gemm_bench.py"""
+import math
+import os
+import sys
+
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from valle_amd import ops  # noqa: E402
+
+DEV = torch.device("cuda", 0)
+
+
+def tflops(M, N, K, epi, reps=20):
+    a = (torch.randn(M, K, device=DEV)).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV)
+    r = torch.zeros(M, N, device=DEV) if epi == ops.EPI_RESID else None
+    for _ in range(3):
+        ops.linear(a, w, bias, epi, resid=r, ksplit=None)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        ops.linear(a, w, bias, epi, resid=r, ksplit=None)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * M * N * K * reps / (e0.elapsed_time(e1) * 1e-3) / 1e12
+
+
+def main():
+    shapes = [("qkv", 3072, 1024, ops.EPI_STORE), ("oproj", 1024, 1024, ops.EPI_RESID), ("ffn1", 4096, 1024, ops.EPI_RELU),
+              ("ffn2", 1024, 4096, ops.EPI_RESID)]
+    for M in (65600, 1025):
+        for knobs in ({}, {"glds_swz": 1}, {"glds_prio": 1}, {"glds_w8": 0}, {"glds_big": 0}):
+            for k, v in knobs.items():
+                ops.tune(k, v)
+            row = [f"{name} {tflops(M, N, K, epi):7.1f}" for name, N, K, epi in shapes]
+            print(f"M={M:6d} {str(knobs):22s} TF/s: " + "  ".join(row), flush=True)
+            for k in knobs:
+                ops.tune(k, {"glds_swz": 0, "glds_prio": 0, "glds_w8": 1, "glds_big": -1}[k])
+
+
+if __name__ == "__main__":
+    main()

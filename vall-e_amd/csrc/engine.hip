@@ -1559,6 +1559,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
+  if (n == "glds_swz") {
+    g_glds_swz = (int)value;
+    return VLE_OK;
+  }
   if (n == "glds_big" || n == "glds_w8" || n == "glds_prio") {  // process-global tile policy of gemm_glds.hip (same knobs as vle_op_tune)
     (n == "glds_big" ? g_glds_big : n == "glds_w8" ? g_glds_w8 : g_glds_prio) = (int)value;
     return VLE_OK;

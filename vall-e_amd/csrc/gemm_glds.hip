@@ -30,7 +30,16 @@ __device__ inline void gg_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int BM, int BN, int EPI, int NW, bool PRIO = false>
+// SWZ selects the XOR key of the 16-byte slot swizzle inside a 128-byte LDS row: 0 = row & 7, 1 = (row >> 1) & 7.
+// A 128-byte row spans half of the 64 banks and consecutive rows alternate halves, so the 16 rows of one ds_read_b128
+// lane group fall 8 + 8 into the two halves: key (row >> 1) & 7 gives the 8 rows of a half 8 distinct slots, key row & 7
+// gives rows r and r + 8 (same half) the same slot.
+template <int SWZ>
+__device__ inline int gg_key(int row) {
+  return SWZ ? ((row >> 1) & 7) : (row & 7);
+}
+
+template <int BM, int BN, int EPI, int NW, bool PRIO = false, int SWZ = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const float* __restrict__ bias, void* __restrict__ out_,
                                                         float* __restrict__ resid, int64_t M, int N, int K) {
@@ -66,20 +75,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   // per-lane source of the DMA pieces: piece p of a wave covers tile rows (p*4 + wave)*8 .. +8;
   // lane -> (row = lane>>3, slot = lane&7), source vector = slot ^ (row & 7)
   const int prow = lane >> 3;
-  const int pvec = (lane & 7) ^ prow;  // (row0 + prow) & 7 == prow because row0 % 8 == 0
   const unsigned char* srcA[NIA];
   const unsigned char* srcB[NIB];
 #pragma unroll
   for (int p = 0; p < NIA; ++p) {
     int64_t gm = m0 + (p * NW + wave) * 8 + prow;
     gm = gm < M ? gm : M - 1;
-    srcA[p] = reinterpret_cast<const unsigned char*>(A + gm * K) + pvec * 16;
+    srcA[p] = reinterpret_cast<const unsigned char*>(A + gm * K) + ((lane & 7) ^ gg_key<SWZ>((p * NW + wave) * 8 + prow)) * 16;
   }
 #pragma unroll
   for (int p = 0; p < NIB; ++p) {
     int gn = n0 + (p * NW + wave) * 8 + prow;
     gn = gn < N ? gn : N - 1;
-    srcB[p] = reinterpret_cast<const unsigned char*>(W + (int64_t)gn * K) + pvec * 16;
+    srcB[p] = reinterpret_cast<const unsigned char*>(W + (int64_t)gn * K) + ((lane & 7) ^ gg_key<SWZ>((p * NW + wave) * 8 + prow)) * 16;
   }
   auto issue = [&](int kt) {
     unsigned char* st = smem + (kt % STAGES) * STAGE_BYTES;
@@ -136,12 +144,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           const int row = wm0 + i * 16 + fr;
-          af[i] = *reinterpret_cast<const gg_bf16x8*>(As + row * 128 + ((c ^ (row & 7)) << 4));
+          af[i] = *reinterpret_cast<const gg_bf16x8*>(As + row * 128 + ((c ^ gg_key<SWZ>(row)) << 4));
         }
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const int row = wn0 + j * 16 + fr;
-          bfr[j] = *reinterpret_cast<const gg_bf16x8*>(Bs + row * 128 + ((c ^ (row & 7)) << 4));
+          bfr[j] = *reinterpret_cast<const gg_bf16x8*>(Bs + row * 128 + ((c ^ gg_key<SWZ>(row)) << 4));
         }
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(1);  // MFMA cluster ahead of the other waves' loads (knob "glds_prio")
 #pragma unroll
@@ -159,13 +167,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
 #pragma unroll
         for (int j = 0; j < FN; ++j) {
           const int row = wn0 + j * 16 + fr;
-          bfr[j] = *reinterpret_cast<const gg_bf16x8*>(Bs + row * 128 + ((c ^ (row & 7)) << 4));
+          bfr[j] = *reinterpret_cast<const gg_bf16x8*>(Bs + row * 128 + ((c ^ gg_key<SWZ>(row)) << 4));
         }
 #pragma unroll
         for (int i = 0; i < FM; ++i) {
           if (i < nlive) {
             const int row = wm0 + i * 16 + fr;
-            const gg_bf16x8 a = *reinterpret_cast<const gg_bf16x8*>(As + row * 128 + ((c ^ (row & 7)) << 4));
+            const gg_bf16x8 a = *reinterpret_cast<const gg_bf16x8*>(As + row * 128 + ((c ^ gg_key<SWZ>(row)) << 4));
 #pragma unroll
             for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], a, acc[i][j], 0, 0, 0);
           }
@@ -237,6 +245,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
 // tile policy knob (vle_op_tune "glds_big"): 0 = never use the 8-wave 256 x 128 tile, -1 = default threshold
 // (>= 512 full tiles), n > 0 = threshold n
 int g_glds_big = -1;
+int g_glds_swz = 0;   // "glds_swz": 1 = slot key (row >> 1) & 7 on the 8-wave tiles (A/B knob)
 int g_glds_prio = 0;  // "glds_prio": s_setprio(1) around the MFMA cluster of the 8-wave tiles (A/B knob)
 int g_glds_w8 = 1;  // "glds_w8": 8-wave workgroups on the 128-row tiles as well (batch-1 NAR 12.0 -> 10.0 ms); 0 = 4 waves
 
@@ -246,10 +255,12 @@ static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const flo
   const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM)), block(NW * 64);
 #define VLE_GG(E)                                                                                                       \
   do {                                                                                                                  \
-    if (NW == 8 && g_glds_prio)                                                                                         \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, (NW == 8)>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); \
+    if (NW == 8 && g_glds_swz)                                                                                          \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, (NW == 8) ? 1 : 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); \
+    else if (NW == 8 && g_glds_prio)                                                                                    \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, (NW == 8), 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); \
     else                                                                                                                \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false>), grid, block, 0, st, A, W, bias, out, resid, M, N, K);  \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K);  \
   } while (0)
   switch (epi) {
     case EPI_STORE: VLE_GG(EPI_STORE); break;

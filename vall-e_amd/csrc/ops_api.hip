@@ -34,6 +34,7 @@ extern "C" int vle_op_tune(const char* name, int64_t value) {
   if (n == "glds_big" && value >= -1) vle::g_glds_big = (int)value;
   else if (n == "glds_w8" && value >= 0 && value <= 1) vle::g_glds_w8 = (int)value;
   else if (n == "glds_prio" && value >= 0 && value <= 1) vle::g_glds_prio = (int)value;
+  else if (n == "glds_swz" && value >= 0 && value <= 1) vle::g_glds_swz = (int)value;
   else return op_fail("vle_op_tune: unknown knob or value out of range");
   return VLE_OK;
 }

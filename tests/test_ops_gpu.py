@@ -233,19 +233,40 @@ def test_linear_split_k_tickets(M, N, K, ksplit, epi):
         assert int(ops.linear_workspace(a.device)[:4096].view(torch.int32).abs().sum()) == 0, "tickets not reset"
 
 
-@pytest.mark.parametrize("M,N,K", [(17408, 1024, 1024), (1041, 4096, 1024), (300, 1025, 1024), (130, 256, 256)])
-@pytest.mark.parametrize("knob", ["glds_swz", "glds_prio"])
+@pytest.mark.parametrize("M,N,K", [(17408, 1024, 1024), (1041, 4096, 1024), (300, 1025, 1024), (130, 256, 256), (4100, 3072, 1536), (2049, 1024, 4096)])
+@pytest.mark.parametrize("knob", ["glds_swz", "glds_prio", "glds_8ph", "glds_8ph+g8_stagger", "glds_8ph+glds_swz", "glds_8ph+g8_stagger+glds_swz"])  # listed = 1, others 0
 def test_linear_gemm_tile_policy_knobs(M, N, K, knob):
     """The A/B variants of the 8-wave GEMM tiles (alternative LDS slot key, s_setprio) compute the same product."""
     a = _rand(M, K, seed=70).to(torch.bfloat16)
     w = (_rand(N, K, seed=71) / math.sqrt(K)).to(torch.bfloat16)
     bias = _rand(N, seed=72) * 0.1
     ref = a.double() @ w.double().t() + bias.double()
-    base = ops.linear(a, w, bias, ops.EPI_F32, ksplit=None)
-    ops.tune(knob, 1)
+    knobs = knob.split("+")
+    defaults = {"glds_swz": 0, "glds_prio": 0, "glds_8ph": -1, "g8_stagger": 1}
+
+    def tune(on):
+        for k, dflt in defaults.items():
+            ops.tune(k, (1 if k in knobs else 0) if on else dflt)
+
+    ops.tune("glds_8ph", 0)
+    base = ops.linear(a, w, bias, ops.EPI_F32, ksplit=None)  # the 8-wave tile kernels of gemm_glds.hip
+
+    tune(1)
     try:
         got = ops.linear(a, w, bias, ops.EPI_F32, ksplit=None)
     finally:
-        ops.tune(knob, 0)
+        tune(0)
     assert (got.double() - ref).abs().max().item() < 3e-5 * math.sqrt(K / 64) * max(1.0, ref.abs().max().item())
-    assert torch.equal(got, base)  # same MFMA order, only the LDS placement / issue priority differs
+    if "glds_8ph" not in knobs:
+        assert torch.equal(got, base)  # same MFMA order, only the LDS placement / issue priority differs
+    else:  # other tile shape: also the store / ReLU / residual epilogues, and repeat runs must agree bit for bit (race screen)
+        r0 = _rand(M, N, seed=73)
+        tune(1)
+        try:
+            outs = [ops.linear(a, w, bias, ops.EPI_RESID, resid=r0.clone(), ksplit=None) for _ in range(4)]
+            relu = ops.linear(a, w, bias, ops.EPI_RELU, ksplit=None)
+        finally:
+            tune(0)
+        assert all(torch.equal(outs[0], o) for o in outs[1:])
+        assert (outs[0].double() - (ref + r0.double())).abs().max().item() < 3e-5 * math.sqrt(K / 64) * max(1.0, ref.abs().max().item())
+        assert (relu.double() - ref.clamp_min(0)).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())

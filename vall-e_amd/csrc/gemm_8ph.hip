@@ -1,0 +1,269 @@
+// bf16 GEMM for the batched prefill / NAR rows (tens of thousands of rows): 256 x 256 tile, 8 waves, LDS-DMA staging
+// in HALF-tiles, the k-loop cut into 4 phases per 64-deep K-tile so that LDS reads, DMA issue and MFMA of different
+// waves overlap ("8-phase" schedule of /opt/skills/guides/cdna_hip_programming.md, 2 K-tiles per trip).
+//   out = epi(A[M x K] @ W[N x K]^T + bias)      same contract and epilogues as gemm_glds.hip
+//   reference ops: in-proj / out-proj `linear` (valle/modules/activation.py:414-421), FFN linear1 / linear2
+//   (valle/modules/transformer.py:332-334) over the packed rows of valle.py:1035-1038, 1125-1127.
+//
+// Why another GEMM: gemm_glds.hip is one barrier per K-tile, every wave in lock step (all read LDS, then all issue
+// MFMAs): measured 750-870 TF/s at 65 600 rows.  Here
+//   * a wave's 128 x 64 outputs are FOUR 64 x 32 quadrants, one from each pair of tile halves:
+//       rows  {wr*64 .. +64} of the tile's top half and of its bottom half,  wr = wave >> 2
+//       cols  {wc*32 .. +32} of the tile's left half and of its right half,  wc = wave & 3
+//     so in a given phase ALL waves read the same half-tiles, and a half-tile is dead for everyone at a known phase;
+//   * per K-tile:  phase 1: read A-top (8 x ds_read_b128) + B-left (4), MFMA quadrant (top, left)     16 MFMAs
+//                  phase 2: read B-right (4),                          MFMA (top, right)
+//                  phase 3: read A-bot (8),                            MFMA (bot, right)
+//                  phase 4: no reads (B-left stayed in registers),     MFMA (bot, left)
+//     = 24 LDS reads per 64 MFMAs (gemm_glds.hip: 32 per 64);
+//   * every phase issues ONE half-tile of LDS-DMA (2 x global_load_lds_dwordx4 per lane): phases 1 / 2 -> A-bot /
+//     B-right of tile t+1 (other buffer), phases 3 / 4 -> B-left / A-top of tile t+2 (this buffer).  Issue order = order
+//     of first use, so ONE counted wait per K-tile (phase 4: vmcnt(4) leaves the two newest half-tiles in flight)
+//     retires exactly tile t+1; it sits before phase 4's first barrier and the data is first read in the next phase
+//     (a DMA is ordered for another wave's ds_read only by the issuer's vmcnt followed by a barrier the reader passed);
+//   * a half is overwritten no earlier than two phases after its last read: those reads were retired by that phase's
+//     lgkmcnt(0) and every wave has passed two more barriers (enough also for the staggered wave groups);
+//   * s_setprio(1) around each MFMA cluster: with the waves spread over different parts of a phase the scheduler can
+//     prefer the ones entering MFMAs;
+//   * LDS image of a half-tile: 128 rows x 128 B, 16-byte slot c of row r holds source vector c ^ (r & 7) (swizzle on
+//     the DMA source address, same XOR on the ds_read side), 2 buffers x 4 halves x 16 KB = 128 KB.
+// Shapes: N % 256 == 0, K % 128 == 0, K >= 256; rows beyond M are clamped on load and masked on store.
+#include "common.h"
+#include "kernels.h"
+
+namespace vle {
+
+typedef __bf16 g8_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 g8_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float g8_f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int G8_HALF = 128 * 128;       // bytes of one half-tile (128 rows x 64 bf16)
+constexpr int G8_BUF = 4 * G8_HALF;      // A-top, A-bot, B-left, B-right
+enum { G8_ATOP = 0, G8_ABOT = 1, G8_BLEFT = 2, G8_BRIGHT = 3 };
+
+template <int N>
+__device__ inline void g8_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// STAGGER: waves 4-7 run one barrier (half a phase) behind waves 0-3, so on every SIMD one wave is in its MFMA cluster
+// while the other issues its LDS reads / DMA.  SWZ: slot key of the swizzle, 0 = row & 7, 1 = (row >> 1) & 7 (a 128-byte
+// row covers half of the 64 banks and consecutive rows alternate halves: key 1 gives the 8 + 8 rows of a 16-lane
+// ds_read_b128 group distinct slots inside each half).
+template <int SWZ>
+__device__ inline int g8_key(int row) {
+  return SWZ ? ((row >> 1) & 7) : (row & 7);
+}
+
+template <int EPI, bool STAGGER, int SWZ>
+__global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                       const float* __restrict__ bias, void* __restrict__ out_,
+                                                       float* __restrict__ resid, int64_t M, int N, int K) {
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G8_BUF];  // the ONLY LDS object (a second one makes
+                                                                           // hipcc drain vmcnt before every ds_read)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+
+  // XCD-aware tile order (block b runs on XCD b % 8: give each XCD a contiguous run of tiles sharing W panels)
+  const int nbx = gridDim.x, nblk = gridDim.x * gridDim.y;
+  int bid = blockIdx.y * nbx + blockIdx.x;
+  {
+    const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+  }
+  const int64_t m0 = (int64_t)(bid / nbx) * 256;
+  const int n0 = (bid % nbx) * 256;
+
+  // ---- DMA sources: half-tile piece j (0, 1) of this lane covers half rows (j*8 + wave)*8 + (lane >> 3) ----
+  const int prow = lane >> 3;
+  const unsigned char* src[4][2];  // [half][piece], advanced by kt * 128 bytes
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int hr = (j * 8 + wave) * 8 + prow;                 // row inside the half (0..127)
+    const int vec = (lane & 7) ^ g8_key<SWZ>(hr);             // swizzled source vector
+    int64_t ga = m0 + hr, gb = m0 + 128 + hr;
+    ga = ga < M ? ga : M - 1;
+    gb = gb < M ? gb : M - 1;
+    src[G8_ATOP][j] = reinterpret_cast<const unsigned char*>(A + ga * K) + vec * 16;
+    src[G8_ABOT][j] = reinterpret_cast<const unsigned char*>(A + gb * K) + vec * 16;
+    src[G8_BLEFT][j] = reinterpret_cast<const unsigned char*>(W + (int64_t)(n0 + hr) * K) + vec * 16;
+    src[G8_BRIGHT][j] = reinterpret_cast<const unsigned char*>(W + (int64_t)(n0 + 128 + hr) * K) + vec * 16;
+  }
+  auto issue = [&](int half, int kt) {  // 2 x 1 KB per wave: one half-tile of K-tile kt into buffer kt & 1
+    unsigned char* dst = smem + (kt & 1) * G8_BUF + half * G8_HALF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[half][j] + (int64_t)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(dst + (j * 8 + wave) * 1024), 16, 0, 0);
+  };
+
+  // bias of this lane's 4 consecutive output columns per n-fragment (requested ahead of the DMA queue)
+  g8_f32x4 bias4[2][2];
+#pragma unroll
+  for (int h = 0; h < 2; ++h)
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int n = n0 + h * 128 + wc * 32 + j * 16 + fg * 4;
+      bias4[h][j] = bias != nullptr ? *reinterpret_cast<const g8_f32x4*>(bias + n) : g8_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+
+  g8_f32x4 acc[2][2][4][2];  // [row half][col half][m-fragment][n-fragment]
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) acc[a][b][i][j] = g8_f32x4{0.f, 0.f, 0.f, 0.f};
+
+  // fragment readers: 64-deep K-tile = 2 MFMA k-steps; slot = (ks*4 + fg) ^ (row & 7)
+  g8_bf16x8 af[4][2], bl[2][2], brt[2][2];
+  auto read_a = [&](const unsigned char* half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wr * 64 + i * 16 + fr;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const g8_bf16x8*>(half + row * 128 + (((ks * 4 + fg) ^ g8_key<SWZ>(row)) << 4));
+    }
+  };
+  auto read_b = [&](const unsigned char* half, g8_bf16x8 (&bf)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wc * 32 + j * 16 + fr;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bf[j][ks] = *reinterpret_cast<const g8_bf16x8*>(half + row * 128 + (((ks * 4 + fg) ^ g8_key<SWZ>(row)) << 4));
+    }
+  };
+  auto mma = [&](g8_f32x4 (&c)[4][2], const g8_bf16x8 (&bf)[2][2]) {  // one 64 x 32 quadrant x K = 64: 16 MFMAs
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j)  // W fragment as the A operand: C^T (a lane owns 4 consecutive output columns)
+          c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][ks], af[i][ks], c[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto phase_sync = [&]() {  // reads of this phase retired for this wave, and every wave is here
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto phase_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  const int KT = K / 64;
+  // Issue schedule (one half-tile per phase, in order of first use, into a half whose last read lies >= 2 phases back,
+  // so it also holds when the two wave groups are half a phase apart):
+  //   phase 1: A-bot of tile t+1      phase 2: B-right of tile t+1     (other buffer)
+  //   phase 3: B-left of tile t+2     phase 4: A-top of tile t+2       (this buffer: both last read in phase 1)
+  // and ONE counted wait per K-tile in phase 4: vmcnt(4) leaves the two halves of tile t+2 in flight and retires all of
+  // tile t+1; it precedes phase 4's first barrier, the data is first read in the next phase.
+  issue(G8_BLEFT, 0); issue(G8_ATOP, 0); issue(G8_BRIGHT, 0); issue(G8_ABOT, 0);
+  issue(G8_BLEFT, 1); issue(G8_ATOP, 1);
+  g8_wait_vm<4>();  // tile 0 landed (this wave's pieces)
+  __builtin_amdgcn_s_barrier();
+  if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();  // pairs with the first in-loop barrier of waves 0-3
+
+  for (int kt = 0; kt < KT; ++kt) {
+    const unsigned char* buf = smem + (kt & 1) * G8_BUF;
+    // ---- phase 1: (top, left) --------------------------------------------------------------------
+    read_b(buf + G8_BLEFT * G8_HALF, bl);
+    __builtin_amdgcn_sched_barrier(0);
+    read_a(buf + G8_ATOP * G8_HALF);
+    if (kt + 1 < KT) issue(G8_ABOT, kt + 1);
+    phase_sync();
+    mma(acc[0][0], bl);
+    phase_end();
+    // ---- phase 2: (top, right) -------------------------------------------------------------------
+    read_b(buf + G8_BRIGHT * G8_HALF, brt);
+    if (kt + 1 < KT) issue(G8_BRIGHT, kt + 1);
+    phase_sync();
+    mma(acc[0][1], brt);
+    phase_end();
+    // ---- phase 3: (bot, right) -------------------------------------------------------------------
+    read_a(buf + G8_ABOT * G8_HALF);
+    if (kt + 2 < KT) issue(G8_BLEFT, kt + 2);
+    phase_sync();
+    mma(acc[1][1], brt);
+    phase_end();
+    // ---- phase 4: (bot, left), and the one counted wait of the K-tile --------------------------------
+    if (kt + 2 < KT) {
+      issue(G8_ATOP, kt + 2);
+      g8_wait_vm<4>();
+    } else {
+      g8_wait_vm<0>();
+    }
+    phase_sync();
+    mma(acc[1][0], bl);
+    phase_end();
+  }
+  if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the last barrier of waves 4-7
+
+  // ---- epilogue: lane (fg, fr) holds C[m = .. + 16 i + fr][n = .. + 16 j + 4 fg + r], r = 0..3 -----------------
+#pragma unroll
+  for (int a = 0; a < 2; ++a)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int64_t m = m0 + a * 128 + wr * 64 + i * 16 + fr;
+      if (m >= M) continue;
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + b * 128 + wc * 32 + j * 16 + fg * 4;
+          g8_f32x4 v = acc[a][b][i][j] + bias4[b][j];
+          if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+            for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+          }
+          if constexpr (EPI == EPI_RESID) {
+            g8_f32x4* o = reinterpret_cast<g8_f32x4*>(resid + m * N + n);
+            *o = *o + v;
+          } else if constexpr (EPI == EPI_F32) {
+            *reinterpret_cast<g8_f32x4*>(reinterpret_cast<float*>(out_) + m * N + n) = v;
+          } else {
+            g8_bf16x4 o4;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) o4[r] = (__bf16)v[r];
+            *reinterpret_cast<g8_bf16x4*>(reinterpret_cast<bf16_t*>(out_) + m * N + n) = o4;
+          }
+        }
+    }
+}
+
+int g_g8_stagger = 1;  // "g8_stagger": waves 4-7 half a phase behind waves 0-3 (measured +7-10 %: 905 -> 970 TF/s); 0 = lock step
+
+// returns 0 = launched, 1 = shape not covered
+int launch_gemm_8ph(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
+                    int K, int epi) {
+  if (N % 256 != 0 || K % 128 != 0 || K < 256 || M < 256) return 1;
+  const dim3 grid(N / 256, (unsigned)((M + 255) / 256)), block(512);
+  const bf16_t* a = (const bf16_t*)A;
+  const bf16_t* w = (const bf16_t*)W;
+#define VLE_G8(E, ST, SW) hipLaunchKernelGGL((gemm_8ph_kernel<E, ST, SW>), grid, block, 0, st, a, w, bias, out, resid, M, N, K)
+#define VLE_G8E(ST, SW)                           \
+  switch (epi) {                                  \
+    case EPI_STORE: VLE_G8(EPI_STORE, ST, SW); break; \
+    case EPI_RELU: VLE_G8(EPI_RELU, ST, SW); break;   \
+    case EPI_RESID: VLE_G8(EPI_RESID, ST, SW); break; \
+    case EPI_F32: VLE_G8(EPI_F32, ST, SW); break;     \
+    default: return -1;                           \
+  }
+  if (g_g8_stagger && g_glds_swz) { VLE_G8E(true, 1) }
+  else if (g_g8_stagger) { VLE_G8E(true, 0) }
+  else if (g_glds_swz) { VLE_G8E(false, 1) }
+  else { VLE_G8E(false, 0) }
+#undef VLE_G8E
+#undef VLE_G8
+  return 0;
+}
+
+}  // namespace vle

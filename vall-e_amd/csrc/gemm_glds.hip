@@ -245,6 +245,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
 // tile policy knob (vle_op_tune "glds_big"): 0 = never use the 8-wave 256 x 128 tile, -1 = default threshold
 // (>= 512 full tiles), n > 0 = threshold n
 int g_glds_big = -1;
+int g_glds_8ph = -1;  // "glds_8ph": 0 = never gemm_8ph.hip, -1 = from 128 full 256 x 256 tiles (measured: ahead of the 256 x 128
+                      // tile from there on, 463 vs 401 TF/s at 128 tiles, 970 vs 740 at 4112), n > 0 = from n tiles
 int g_glds_swz = 0;   // "glds_swz": 1 = slot key (row >> 1) & 7 on the 8-wave tiles (A/B knob)
 int g_glds_prio = 0;  // "glds_prio": s_setprio(1) around the MFMA cluster of the 8-wave tiles (A/B knob)
 int g_glds_w8 = 1;  // "glds_w8": 8-wave workgroups on the 128-row tiles as well (batch-1 NAR 12.0 -> 10.0 ms); 0 = 4 waves
@@ -285,6 +287,9 @@ int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* 
   const bf16_t* w = (const bf16_t*)W;
   // many tiles (batched prefill / NAR rows): 256 x 128 with 8 waves -- two waves per SIMD cover each other's
   // ds_read -> MFMA latency, and the W panel is re-read half as often
+  // enough 256 x 256 tiles: the 4-phase-per-K-tile schedule of gemm_8ph.hip
+  if (g_glds_8ph != 0 && (M / 256) * (N / 256) >= (g_glds_8ph > 0 ? g_glds_8ph : 128) && launch_gemm_8ph(st, A, W, bias, out, resid, M, N, K, epi) == 0)
+    return 0;
   const int64_t t256 = (M / 256) * ((N + 127) / 128);
   if (g_glds_big != 0 && t256 >= (g_glds_big > 0 ? g_glds_big : 512)) return gg_launch<256, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi);
   if (g_glds_w8) {  // 8 waves on the one-tile-per-CU shapes too (wave tile 32 x 64 / 32 x 32)

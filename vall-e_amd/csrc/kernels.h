@@ -34,7 +34,12 @@ int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const f
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
                      int K, int epi);
 
+extern int g_g8_stagger;
+extern int g_glds_8ph;
 extern int g_glds_swz;
+// gemm_8ph.hip: bf16, 256 x 256 tile, phase-split schedule; returns 1 when the shape is not covered
+int launch_gemm_8ph(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
+                    int K, int epi);
 extern int g_glds_prio;
 extern int g_glds_w8;
 extern int g_glds_big;  // gemm_glds.hip tile policy: 0 never the 8-wave 256 x 128 tile, -1 default threshold, n > 0 threshold

@@ -58,7 +58,7 @@ __device__ inline int g8_key(int row) {
 template <int EPI, bool STAGGER, int SWZ>
 __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                        const float* __restrict__ bias, void* __restrict__ out_,
-                                                       float* __restrict__ resid, int64_t M, int N, int K) {
+                                                       float* __restrict__ resid, int64_t M, int N, int K, int GC) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G8_BUF];  // the ONLY LDS object (a second one makes
                                                                            // hipcc drain vmcnt before every ds_read)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -73,8 +73,21 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
     const int q = nblk / 8, r = nblk % 8, xcd = bid % 8, idx = bid / 8;
     bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
   }
-  const int64_t m0 = (int64_t)(bid / nbx) * 256;
-  const int n0 = (bid % nbx) * 256;
+  // Tile order inside that run: column groups of GC tiles swept down the rows.  In plain row-major order the 32 tiles
+  // an XCD runs at a time span all N / 256 column panels, W (8 MB at N = 4096) cycles through the 4 MB L2 once per wave
+  // of tiles and the kernel pulls ~9x its algorithmic bytes from the fabric (PMC: 1.23 GB per FFN1 launch); with GC = 4
+  // an XCD keeps 4 W panels (2 MB) resident and streams the A panels past them.
+  int tr, tc;
+  if (GC > 1 && nbx % GC == 0) {
+    const int per = (int)gridDim.y * GC, cg = bid / per, rem = bid - cg * per;
+    tr = rem / GC;
+    tc = cg * GC + rem % GC;
+  } else {
+    tr = bid / nbx;
+    tc = bid % nbx;
+  }
+  const int64_t m0 = (int64_t)tr * 256;
+  const int n0 = tc * 256;
 
   // ---- DMA sources: half-tile piece j (0, 1) of this lane covers half rows (j*8 + wave)*8 + (lane >> 3) ----
   const int prow = lane >> 3;
@@ -239,6 +252,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
     }
 }
 
+int g_g8_colgroup = 0;  // "g8_colgroup": column tiles per group of the tile order (0 / 1 = row-major)
 int g_g8_stagger = 1;  // "g8_stagger": waves 4-7 half a phase behind waves 0-3 (measured +7-10 %: 905 -> 970 TF/s); 0 = lock step
 
 // returns 0 = launched, 1 = shape not covered
@@ -248,7 +262,7 @@ int launch_gemm_8ph(hipStream_t st, const void* A, const void* W, const float* b
   const dim3 grid(N / 256, (unsigned)((M + 255) / 256)), block(512);
   const bf16_t* a = (const bf16_t*)A;
   const bf16_t* w = (const bf16_t*)W;
-#define VLE_G8(E, ST, SW) hipLaunchKernelGGL((gemm_8ph_kernel<E, ST, SW>), grid, block, 0, st, a, w, bias, out, resid, M, N, K)
+#define VLE_G8(E, ST, SW) hipLaunchKernelGGL((gemm_8ph_kernel<E, ST, SW>), grid, block, 0, st, a, w, bias, out, resid, M, N, K, g_g8_colgroup)
 #define VLE_G8E(ST, SW)                           \
   switch (epi) {                                  \
     case EPI_STORE: VLE_G8(EPI_STORE, ST, SW); break; \

@@ -139,8 +139,18 @@ def test_attention_rows(nhead, dh, causal, dt):
     (2, 96, [1100], [64]),
 ])
 @pytest.mark.parametrize("causal", [True, False])
-def test_attention_mfma_long(nhead, dh, lens, text_lens, causal):
-    """bf16 MFMA flash kernel at NAR / prefill lengths (many key tiles, ragged tails, prefix-LM mask)."""
+@pytest.mark.parametrize("qw", [1, 2])
+def test_attention_mfma_long(nhead, dh, lens, text_lens, causal, qw):
+    """bf16 MFMA flash kernel at NAR / prefill lengths (many key tiles, ragged tails, prefix-LM mask), with 64- and
+    128-query blocks (knob attn_qw)."""
+    ops.tune("attn_qw", qw)
+    try:
+        _attention_mfma_long(nhead, dh, lens, text_lens, causal)
+    finally:
+        ops.tune("attn_qw", 0)
+
+
+def _attention_mfma_long(nhead, dh, lens, text_lens, causal):
     d = nhead * dh
     rows = sum(lens)
     qkv = (_rand(rows, 3 * d, seed=15)).to(torch.bfloat16)

@@ -36,7 +36,9 @@ __device__ inline int am_vpos(int key) {  // slot of key (0..63) inside a V^T ro
   return ((key >> 5) << 5) + (((key & 15) >> 2) << 3) + (((key >> 4) & 1) << 2) + (key & 3);
 }
 
-template <int DH>
+// QW = 16-query fragments per wave: 1 (64 queries per block) or 2 (128: every K / V fragment read from LDS feeds two
+// MFMAs and the K/V tiles are re-read from L2 half as often -- for the batched passes, where there are blocks to spare).
+template <int DH, int QW>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                         const int32_t* __restrict__ seq_off,
                                                         const int32_t* __restrict__ text_len, int d, int nhead, int causal) {
@@ -49,25 +51,31 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
   unsigned char* const Ks = smem;
   unsigned char* const Vt = smem + 64 * KSTR;
 
-  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64;
+  const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * 64 * QW;
   const int off = seq_off[b], len = seq_off[b + 1] - off;
   if (q0 >= len) return;
   const int S = text_len[b];
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int g = lane >> 4, c = lane & 15;
-  const int qrow = q0 + w * 16 + c;
-  const bool qvalid = qrow < len;
-  const int klim = !qvalid ? 0 : (causal ? max(S, qrow + 1) : len);  // keys j < klim are visible
-  const int kmax = causal ? max(S, min(q0 + 64, len)) : len;         // block-wide bound
+  int qrow[QW], klim[QW];
+  bool qvalid[QW];
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    qrow[f] = q0 + (w * QW + f) * 16 + c;
+    qvalid[f] = qrow[f] < len;
+    klim[f] = !qvalid[f] ? 0 : (causal ? max(S, qrow[f] + 1) : len);  // keys j < klim are visible
+  }
+  const int kmax = causal ? max(S, min(q0 + 64 * QW, len)) : len;      // block-wide bound
   const int d3 = 3 * d;
   const bf16_t* base = qkv + (int64_t)off * d3 + h * DH;
 
   // Q rows of this wave as the B operand (kept for the whole kernel)
-  am_bf16x8 qf[KS];
-  {
-    const bf16_t* qp = base + (int64_t)min(qrow, len - 1) * d3 + g * 8;
+  am_bf16x8 qf[QW][KS];
 #pragma unroll
-    for (int ks = 0; ks < KS; ++ks) qf[ks] = *reinterpret_cast<const am_bf16x8*>(qp + ks * 32);
+  for (int f = 0; f < QW; ++f) {
+    const bf16_t* qp = base + (int64_t)min(qrow[f], len - 1) * d3 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[f][ks] = *reinterpret_cast<const am_bf16x8*>(qp + ks * 32);
   }
 
   am_u32x4 kreg[NLD], vreg[NLD];
@@ -96,10 +104,15 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
   }
 
   const float sl2 = 1.4426950408889634f / sqrtf((float)DH);  // log2(e) / sqrt(dh)
-  float m = AM_NEG, l = 0.f;
-  am_f32x4 o[EB];
+  float m[QW], l[QW];
+  am_f32x4 o[QW][EB];
 #pragma unroll
-  for (int eb = 0; eb < EB; ++eb) o[eb] = am_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < QW; ++f) {
+    m[f] = AM_NEG;
+    l[f] = 0.f;
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb) o[f][eb] = am_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   AM_GLOAD(0)
   AM_LSTORE()
@@ -108,58 +121,64 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
     const bool has_next = kt0 + 64 < kmax;
     if (has_next) { AM_GLOAD(kt0 + 64) }
 
-    // ---- S^T = K Q^T ---------------------------------------------------------------------------------
-    am_f32x4 s[4];
+    // ---- S^T = K Q^T: one K fragment read feeds the QW query fragments ---------------------------------
+    am_f32x4 s[QW][4];
 #pragma unroll
     for (int kb = 0; kb < 4; ++kb) {
-      s[kb] = am_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int f = 0; f < QW; ++f) s[f][kb] = am_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const am_bf16x8 a = *reinterpret_cast<const am_bf16x8*>(Ks + (kb * 16 + c) * KSTR + (ks * 4 + g) * 16);
-        s[kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[ks], s[kb], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < QW; ++f) s[f][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[f][ks], s[f][kb], 0, 0, 0);
       }
     }
     // ---- online softmax of query c over this tile's keys (exp2 domain) -----------------------------------
-    float mt = AM_NEG;
+    am_bf16x8 pf[QW][2];
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+    for (int f = 0; f < QW; ++f) {
+      float mt = AM_NEG;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt0 + kb * 16 + g * 4 + r;
-        const float v = key < klim ? s[kb][r] * sl2 : AM_NEG;
-        s[kb][r] = v;
-        mt = fmaxf(mt, v);
-      }
-    mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-    mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-    const float mn = fmaxf(m, mt);
-    const float alpha = __builtin_amdgcn_exp2f(m - mn);
-    m = mn;
-    float rowsum = 0.f;
+      for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-    for (int kb = 0; kb < 4; ++kb)
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt0 + kb * 16 + g * 4 + r;
+          const float v = key < klim[f] ? s[f][kb][r] * sl2 : AM_NEG;
+          s[f][kb][r] = v;
+          mt = fmaxf(mt, v);
+        }
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      const float mn = fmaxf(m[f], mt);
+      const float alpha = __builtin_amdgcn_exp2f(m[f] - mn);
+      m[f] = mn;
+      float rowsum = 0.f;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt0 + kb * 16 + g * 4 + r;
-        const float p = key < klim ? __builtin_amdgcn_exp2f(s[kb][r] - mn) : 0.f;
-        s[kb][r] = p;
-        rowsum += p;
-      }
-    l = fmaf(l, alpha, rowsum);  // per-lane partial of the row sum (the 4 lanes of a query share m)
+      for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
-    for (int eb = 0; eb < EB; ++eb) o[eb] *= alpha;
-    am_bf16x8 pf[2];
+        for (int r = 0; r < 4; ++r) {
+          const int key = kt0 + kb * 16 + g * 4 + r;
+          const float p = key < klim[f] ? __builtin_amdgcn_exp2f(s[f][kb][r] - mn) : 0.f;
+          s[f][kb][r] = p;
+          rowsum += p;
+        }
+      l[f] = fmaf(l[f], alpha, rowsum);  // per-lane partial of the row sum (the 4 lanes of a query share m)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+      for (int eb = 0; eb < EB; ++eb) o[f][eb] *= alpha;
 #pragma unroll
-      for (int t = 0; t < 8; ++t) pf[j][t] = (__bf16)s[2 * j + (t >> 2)][t & 3];
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int t = 0; t < 8; ++t) pf[f][j][t] = (__bf16)s[f][2 * j + (t >> 2)][t & 3];
+    }
     // ---- O^T += V^T P^T -----------------------------------------------------------------------------------
 #pragma unroll
     for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
         const am_bf16x8 a = *reinterpret_cast<const am_bf16x8*>(Vt + (eb * 16 + c) * VSTR + (j * 32 + g * 8) * 2);
-        o[eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[j], o[eb], 0, 0, 0);
+#pragma unroll
+        for (int f = 0; f < QW; ++f) o[f][eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[f][j], o[f][eb], 0, 0, 0);
       }
 
     __syncthreads();  // every wave is done reading this tile
@@ -167,30 +186,44 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
     __syncthreads();
   }
 
-  l += __shfl_xor(l, 16, 64);
-  l += __shfl_xor(l, 32, 64);
-  if (qvalid) {
-    const float inv = 1.0f / l;
-    bf16_t* op = out + (int64_t)(off + qrow) * d + h * DH + g * 4;
 #pragma unroll
-    for (int eb = 0; eb < EB; ++eb) {
-      am_bf16x4 r4;
+  for (int f = 0; f < QW; ++f) {
+    float lf = l[f];
+    lf += __shfl_xor(lf, 16, 64);
+    lf += __shfl_xor(lf, 32, 64);
+    if (qvalid[f]) {
+      const float inv = 1.0f / lf;
+      bf16_t* op = out + (int64_t)(off + qrow[f]) * d + h * DH + g * 4;
 #pragma unroll
-      for (int r = 0; r < 4; ++r) r4[r] = (__bf16)(o[eb][r] * inv);
-      *reinterpret_cast<am_bf16x4*>(op + eb * 16) = r4;
+      for (int eb = 0; eb < EB; ++eb) {
+        am_bf16x4 r4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) r4[r] = (__bf16)(o[f][eb][r] * inv);
+        *reinterpret_cast<am_bf16x4*>(op + eb * 16) = r4;
+      }
     }
   }
 }
+
+int g_attn_qw = 0;  // "attn_qw": 0 / 1 = 64-query blocks, 2 = 128-query blocks (measured neutral at C3: NAR 221.0 vs 222.8 ms --
+                    // the kernel is bound by its softmax VALU work and barriers, not by the K/V re-reads the PMC pass shows)
 
 // returns 0 = launched, 1 = head size not covered (caller uses the generic kernel)
 int launch_attention_mfma(hipStream_t st, const void* qkv, void* out, const int32_t* seq_off, const int32_t* text_len, int B,
                           int max_len, int d, int nhead, int causal) {
   const int dh = d / nhead;
   if (d % 8 != 0) return 1;
-  const dim3 grid((max_len + 63) / 64, nhead, B), block(256);
-#define VLE_AM(DH)                                                                                                      \
-  hipLaunchKernelGGL((attn_mfma_kernel<DH>), grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)out, seq_off, text_len, d, \
-                     nhead, causal)
+  const int qw = g_attn_qw == 2 ? 2 : 1;
+  const dim3 grid((max_len + 64 * qw - 1) / (64 * qw), nhead, B), block(256);
+#define VLE_AM(DH)                                                                                                            \
+  do {                                                                                                                        \
+    if (qw == 2)                                                                                                              \
+      hipLaunchKernelGGL((attn_mfma_kernel<DH, 2>), grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)out, seq_off, text_len, d, \
+                         nhead, causal);                                                                                      \
+    else                                                                                                                      \
+      hipLaunchKernelGGL((attn_mfma_kernel<DH, 1>), grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)out, seq_off, text_len, d, \
+                         nhead, causal);                                                                                      \
+  } while (0)
   switch (dh) {
     case 32: VLE_AM(32); break;
     case 64: VLE_AM(64); break;

@@ -1559,6 +1559,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
+  if (n == "attn_qw") {
+    g_attn_qw = (int)value;
+    return VLE_OK;
+  }
   if (n == "glds_swz" || n == "glds_8ph" || n == "g8_stagger" || n == "g8_colgroup") {
     (n == "glds_swz" ? g_glds_swz : n == "glds_8ph" ? g_glds_8ph : n == "g8_stagger" ? g_g8_stagger : g_g8_colgroup) = (int)value;
     return VLE_OK;

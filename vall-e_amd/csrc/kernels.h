@@ -34,6 +34,7 @@ int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const f
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
                      int K, int epi);
 
+extern int g_attn_qw;
 extern int g_g8_colgroup;
 extern int g_g8_stagger;
 extern int g_glds_8ph;

@@ -292,3 +292,36 @@ def test_reference_assertions_and_unsupported_configs():
         m.inference(x.to(DEV), xl.to(DEV), torch.cat([y, y]).to(DEV), None)  # batch != 1 (valle.py:989)
     with pytest.raises(NotImplementedError):
         valle_amd.VALLE(64, 4, 1, norm_first=False)
+
+
+@pytest.mark.parametrize("top_k,temperature", [(5, 0.8), (40, 1.3), (-100, 1.0)])
+def test_sampling_distribution_matches_reference_definition(top_k, temperature):
+    """the RNG streams differ from torch.multinomial's, the DISTRIBUTION must not.  4096 first-step
+    samples (64 identical utterances x 64 seeds) against softmax(top_k_filter(logits / temperature)) as the reference's
+    topk_sampling defines it (valle.py:1242-1302, restated in the oracle): every token's frequency within 5 sigma of its
+    probability, nothing sampled outside the filter's support."""
+    cfg = vo.OracleConfig(d_model=64, nhead=4, num_layers=1, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 8)
+    x, xl, y = vo.make_inputs(4, 6)
+    B, R = 64, 64
+    m = build_model(cfg, sd, "fp32", max_batch=B)
+    eng = m.engine_for(B, 4, 6)
+    eng.set_option("trace_ar_logits", 1)
+    X, Y = x.repeat(B, 1).to(DEV), y.repeat(B, 1, 1).to(DEV)
+    counts = torch.zeros(1025, dtype=torch.float64)
+    for seed in range(R):
+        eng.prefill(X, [4] * B, Y, [6] * B)
+        eng.generate(top_k=top_k, temperature=temperature, seed=1000 + seed, max_new=1, allow_empty=True)
+        first = eng.fetch_sampled()[:, 0]
+        counts += torch.bincount(first, minlength=1025).double()
+    logits = eng.fetch_ar_logits()[0, 0]  # the first step's logits (identical for every utterance)
+    scaled = logits / temperature if temperature != 1.0 else logits.clone()
+    p = torch.softmax(vo.top_k_filtering(scaled[None].clone(), top_k), dim=-1)[0].double()
+    n = float(B * R)
+    assert counts.sum().item() == n
+    assert counts[p == 0].sum().item() == 0, "sampled a token the top-k filter removed"
+    sigma = torch.sqrt(n * p * (1 - p)).clamp_min(1.0)
+    z = ((counts - n * p).abs() / sigma).max().item()
+    assert z < 5.0, z
+    if top_k > 0:
+        assert int((p > 0).sum()) == top_k

@@ -80,6 +80,22 @@ __host__ inline uint8_t f32_to_e4m3fn(float f) {
   return sign | (uint8_t)((e << 3) | m);
 }
 
+// ---- fragment-major ("XF") layout of the AR-step activations at 2..64 utterances --------------------------------
+// gemm_skinny.hip reads its [M <= 64][K] bf16 X operand one MFMA B-fragment (16 rows x 8 k per lane) at a time; stored
+// row-major, a fragment load touches 16 rows x 64 B (half lines) and the texture path of every CU is the bottleneck
+// (measured: AR step of 64 utterances 675 -> 611 ms with this layout).  XF stores each fragment contiguously in lane
+// order: element (m, k) of an [MF*16][K] matrix sits at
+//     ((c*2 + s)*MF + i)*512 + (fg*16 + fr)*8 + j        c = k / 64, i = m / 16, fr = m % 16, j = k % 8
+// where (s, fg) split k % 64 the way the consumer's lanes do: bf16 weights  s = (k%64)/32, fg = (k%32)/8;
+// fp8 weights (one 16-byte W vector = 16 consecutive k per lane)  fg = (k%64)/16, s = (k%16)/8.
+// Four consecutive k (k % 4 == 0) of one row stay contiguous, so the producers' 8-byte stores survive.
+__host__ __device__ inline int64_t xf_index(int m, int k, int MF, bool w8) {
+  const int c = k >> 6, kk = k & 63, j = kk & 7;
+  const int s = w8 ? ((kk >> 3) & 1) : (kk >> 5);
+  const int fg = w8 ? (kk >> 4) : ((kk >> 3) & 3);
+  return ((int64_t)(c * 2 + s) * MF + (m >> 4)) * 512 + ((fg << 4) + (m & 15)) * 8 + j;
+}
+
 template <typename T>
 struct Elem;
 template <>

@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
                                                           const T* __restrict__ vc, const int32_t* __restrict__ kv_len,
                                                           float* __restrict__ part_o, float* __restrict__ part_ml, int nhead,
                                                           int dh, int ctx_max, int nsplit, T* __restrict__ out_norm,
-                                                          const int32_t* __restrict__ done) {
+                                                          const int32_t* __restrict__ done, int out_xf) {
   constexpr int KPW = 64 / LPK;         // keys per wave-load
   constexpr int WCH = NK * KPW;         // keys per wave per round
   constexpr int CHUNK = 4 * WCH;        // keys per block per round
@@ -176,7 +176,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
         float L = 0.f;
 #pragma unroll
         for (int ww = 0; ww < 4; ++ww) L = fmaf(sm_l[ww], f[ww], L);
-        store_elem<T>(out_norm + (int64_t)b * d + h * dh + tid, o / L);
+        if (out_xf != 0)  // the out-proj GEMM's X, fragment-major (common.h xf_index); rows = gridDim.z utterances
+          store_elem<T>(out_norm + xf_index(b, h * dh + tid, ((int)gridDim.z + 15) >> 4, out_xf == 2), o / L);
+        else
+          store_elem<T>(out_norm + (int64_t)b * d + h * dh + tid, o / L);
       } else {
         part_o[((int64_t)b * nsplit + s) * d + h * dh + tid] = o;
       }
@@ -194,7 +197,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
 template <typename T>
 static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const void* vc, const int32_t* kv_len, float* part_o,
                            float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit, int nk_override, void* out_norm,
-                           const int32_t* done) {
+                           const int32_t* done, int out_xf) {
   constexpr int VFULL = Elem<T>::VEC;
   if (dh > 254) return -1;
   const dim3 grid(nhead, nsplit, B), block(256);
@@ -209,10 +212,10 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
   do {                                                                                                                      \
     if (nk8)                                                                                                                \
       hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 8>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
-                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done);                                                              \
+                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf);                                                              \
     else                                                                                                                    \
       hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 4>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
-                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done);                                                              \
+                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf);                                                              \
   } while (0)
   if (dh % VFULL == 0) {
     const int nv = dh / VFULL;
@@ -238,12 +241,13 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
 
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
-                            int nsplit, int nk_override, void* out_norm, const int32_t* done) {
+                            int nsplit, int nk_override, void* out_norm, const int32_t* done, int out_xf) {
   if (B <= 0) return 0;
+  if (out_xf != 0 && (out_norm == nullptr || dtype != DT_BF16 || B > 64)) return -1;
   if (out_norm != nullptr && nsplit != 1) return -1;
   if (dtype == DT_F32)
-    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done);
-  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done);
+    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf);
+  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf);
 }
 
 }  // namespace vle

@@ -107,6 +107,7 @@ struct vle_engine {
   // forces eager launches; tags: 0 qkv, 1 decode-attention, 2 out-proj, 3 ffn1, 4 ffn2, 5 logits, 6 sample
   bool opt_profile = false;
   bool opt_no_gemm_skinny = false;  // option "no_gemm_skinny": batch 2..64 on the v0 kernels (A/B measurements)
+  bool opt_gs_xf = true;            // option "gs_xf": AR-step activations of the gemm_skinny path in the fragment-major layout
   int opt_gs_target = 0;            // option "gs_target_wgs": workgroups the split-K of gemm_skinny aims for (0 = 256)
   void* gs_ws = nullptr;            // split-K tickets + partial tiles of gemm_skinny (zeroed once)
   bool opt_ignore_eos = false;  // option "ignore_eos": synthetic-weight benchmarks run every utterance to the length cap
@@ -575,13 +576,14 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
   if ((r = dev_alloc(e, &e->logits, B * V_AR))) return r;
   if (B > SKINNY_MAX_B || true) {  // GEMM-path step buffers (also used when the GEMV path cannot hold B rows in LDS)
-    if ((r = dev_alloc(e, &p, (size_t)B * d * es))) return r;
+    const size_t Bp = (size_t)(B + 15) / 16 * 16;  // the fragment-major layout (common.h xf_index) holds whole 16-row fragments
+    if ((r = dev_alloc(e, &p, Bp * d * es))) return r;
     e->xn_step = p;
     if ((r = dev_alloc(e, &p, (size_t)B * 3 * d * es))) return r;
     e->qkv_step = p;
-    if ((r = dev_alloc(e, &p, (size_t)B * d * es))) return r;
+    if ((r = dev_alloc(e, &p, Bp * d * es))) return r;
     e->att_step = p;
-    if ((r = dev_alloc(e, &p, (size_t)B * 4 * d * es))) return r;
+    if ((r = dev_alloc(e, &p, Bp * 4 * d * es))) return r;
     e->hT_step = p;
     if ((r = dev_alloc(e, &p, gemm_skinny_workspace_bytes()))) return r;
     E_HIP(e, hipMemset(p, 0, gemm_skinny_workspace_bytes()));
@@ -699,6 +701,12 @@ bool use_mfma_skinny(const vle_engine* e) {
   return e->dtype == DT_BF16 && e->B >= 2 && e->B <= 64 && !e->opt_no_gemm_skinny && e->d % 256 == 0 && e->dh % 4 == 0;
 }
 
+// step activations of the gemm_skinny path in the fragment-major layout (LayerNorm kernel instantiated for these widths)
+bool use_xf(const vle_engine* e) {
+  const int nv = e->d / 256;
+  return e->opt_gs_xf && use_mfma_skinny(e) && e->d % 256 == 0 && (nv <= 4 || nv == 6 || nv == 8);
+}
+
 bool use_skinny(const vle_engine* e) {
   if (use_mfma_skinny(e)) return false;
   return e->B <= SKINNY_MAX_B && (size_t)(e->B <= 1 ? 1 : e->B <= 2 ? 2 : e->B <= 4 ? 4 : 8) * 4 * e->d * sizeof(float) <= 160 * 1024;
@@ -714,10 +722,12 @@ int enqueue_ar_logits(vle_engine* e) {
     a.pro = PRO_LN; a.epi = SEPI_STORE; a.x = e->x_step; a.gamma = e->ar_norm_g; a.beta = e->ar_norm_b; a.out = e->logits;
     E_LAUNCH(e, launch_ar_linear(e, a));
   } else {
-    E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d));
+    const bool xf = use_xf(e);
+    if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d, e->w8 ? 1 : 0));
+    else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d));
     if (use_mfma_skinny(e)) {
       GemmSkinnyArgs g;
-      g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target;
+      g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target; g.x_xf = xf ? 1 : 0;
       g.x = e->xn_step; g.w = e->w8 ? e->ar_predict8 : e->ar_predict; g.wscale = e->w8 ? e->ar_predict_s : nullptr; g.M = e->B; g.N = V_AR; g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
       E_LAUNCH(e, launch_gemm_skinny(st, g));
     } else {
@@ -752,9 +762,13 @@ int enqueue_ar_step(vle_engine* e) {
       GemmSkinnyArgs g;
       g.M = e->B;
       g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target;
+      const bool xf = use_xf(e);                 // step activations fragment-major (common.h xf_index)
+      const int xfw = xf ? (e->w8 ? 2 : 1) : 0;  // producer-side code: which k split the consuming GEMM uses
       {
         ProfScope ps(e, 0);
-        E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
+        if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, w.g1, w.be1, e->xn_step, e->B, d, e->w8 ? 1 : 0));
+        else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
+        g.x_xf = xf ? 1 : 0;
         g.x = e->xn_step; g.w = e->w8 ? w.wqkv8 : w.wqkv; g.wscale = e->w8 ? w.sqkv : nullptr; g.bias = w.bqkv; g.N = 3 * d; g.K = d; g.epi = GS_EPI_QKV;
         g.q_out = e->q_step; g.k_cache = kc; g.v_cache = vc; g.kv_len = e->S.kv_len; g.ctx_max = e->ctx_max; g.nhead = e->H; g.dh = e->dh;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
@@ -763,22 +777,27 @@ int enqueue_ar_step(vle_engine* e) {
       {
         ProfScope ps(e, 1);
         E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
-                                            e->ctx_max, e->nsplit, e->opt_nk, direct ? e->att_step : nullptr, e->S.done));
+                                            e->ctx_max, e->nsplit, e->opt_nk, direct ? e->att_step : nullptr, e->S.done,
+                                            direct ? xfw : 0));
       }
       {
         ProfScope ps(e, 2);
         if (!direct) E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
+        g.x_xf = (xf && direct) ? 1 : 0;  // the merge kernel of the split path writes row-major
         g.x = e->att_step; g.w = e->w8 ? w.wo8 : w.wo; g.wscale = e->w8 ? w.so : nullptr; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       {
         ProfScope ps(e, 3);
-        E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
+        if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, w.g2, w.be2, e->xn_step, e->B, d, e->w8 ? 1 : 0));
+        else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
+        g.x_xf = xf ? 1 : 0; g.out_xf = xfw;  // FFN1 writes the hidden rows for FFN2 in the same layout
         g.x = e->xn_step; g.w = e->w8 ? w.w18 : w.w1; g.wscale = e->w8 ? w.s1 : nullptr; g.bias = w.b1; g.N = 4 * d; g.K = d; g.epi = GS_EPI_RELU; g.out = e->hT_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       {
         ProfScope ps(e, 4);
+        g.x_xf = xf ? 1 : 0; g.out_xf = 0;
         g.x = e->hT_step; g.w = e->w8 ? w.w28 : w.w2; g.wscale = e->w8 ? w.s2 : nullptr; g.bias = w.b2; g.N = d; g.K = 4 * d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
@@ -1544,8 +1563,9 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
+    else if (n == "gs_xf") e->opt_gs_xf = value != 0;
     else if (n == "gs_target_wgs") e->opt_gs_target = (int)value;  // 1 = no split-K
     else if (n == "no_gemm_skinny") e->opt_no_gemm_skinny = value != 0;
     else if (n == "attn_nk") e->opt_nk = (int)value;

@@ -48,6 +48,13 @@ __device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, i
     for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
   }
   if constexpr (EPI == GS_EPI_STORE || EPI == GS_EPI_RELU) {
+    if (a.out_xf != 0 && vec) {  // [M][N] is the next GEMM's X: fragment-major, 4 consecutive columns stay one 8-byte store
+      gs_bf16x4 o4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o4[r] = (__bf16)v[r];
+      *reinterpret_cast<gs_bf16x4*>(reinterpret_cast<bf16_t*>(a.out) + xf_index(m, ncol, (M + 15) >> 4, a.out_xf == 2)) = o4;
+      return;
+    }
     bf16_t* o = reinterpret_cast<bf16_t*>(a.out) + (int64_t)m * N + ncol;
     if (vec) {
       gs_bf16x4 o4;
@@ -126,6 +133,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   const bf16_t* xp[MF];
 #pragma unroll
   for (int i = 0; i < MF; ++i) xp[i] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(i * 16 + fr, M - 1) * K + kbeg + fg * KOFS;
+  const bool xfrag = a.x_xf != 0;  // X stored fragment-major (common.h xf_index): one contiguous 1 KB per fragment load
+  const bf16_t* xfb = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)(kbeg / 64) * 2 * MF * 512 + lane * 8;
 
   // epilogue operands requested up front
   const int ncol = n0 + fg * 4;  // first of this lane's 4 output columns
@@ -164,8 +173,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
-        xv[g][i][0] = *reinterpret_cast<const gs_u32x4*>(xp[i] + c * 64);
-        xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xp[i] + c * 64 + SSTEP);
+        xv[g][i][0] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 0) * MF + i) * 512 : xp[i] + c * 64);
+        xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 1) * MF + i) * 512 : xp[i] + c * 64 + SSTEP);
       }
     }
     __builtin_amdgcn_sched_barrier(0);

@@ -18,6 +18,8 @@ int launch_layernorm(hipStream_t st, int dtype, const float* x, const int32_t* r
                      const float* beta, void* out, int64_t rows, int d);
 // dst[f32][r] = src[f32][row_map[r]]
 int launch_gather_rows(hipStream_t st, const float* src, const int32_t* row_map, float* dst, int rows, int d);
+// LayerNorm of the AR-step rows (<= 64) written bf16 in the fragment-major layout of common.h (MF = ceil(rows / 16))
+int launch_layernorm_xf(hipStream_t st, const float* x, const float* gamma, const float* beta, void* out, int rows, int d, int w8);
 // block_ops.hip: stand-alone forms of ops the engine runs fused (block API, SURVEY.md 8b seam B3)
 int launch_token_embedding(hipStream_t st, const int64_t* ids, const float* table, float* out, int64_t n, int d);
 int launch_sine_positional(hipStream_t st, const float* x, const float* pe, const float* alpha, float x_scale, float* out,
@@ -66,6 +68,8 @@ struct GemmSkinnyArgs {
   void* workspace = nullptr;
   int ksplit = 0;      // 0 = chosen from N, K and target_wgs
   int target_wgs = 0;  // 0 = 256
+  int x_xf = 0;            // X is stored fragment-major (common.h xf_index) instead of row-major
+  int out_xf = 0;          // STORE / RELU epilogues write `out` fragment-major for the next GEMM: 0 no, 1 bf16-W consumer, 2 fp8-W
   int* ws_cnt = nullptr;   // (filled by the launcher)
   float* ws_part = nullptr;
 };
@@ -120,7 +124,8 @@ int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache,
 // `done` (int32 [B] or null): utterances whose flag is set are skipped (no KV traffic, output row left stale)
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
-                            int nsplit, int nk_override = 0, void* out_norm = nullptr, const int32_t* done = nullptr);
+                            int nsplit, int nk_override = 0, void* out_norm = nullptr, const int32_t* done = nullptr,
+                            int out_xf = 0);  // out_xf: out_norm fragment-major (0 no, 1 bf16-W consumer, 2 fp8-W consumer)
 // nk_override: keys per lane per round (0 = auto, 4, 8); out_norm (T [B][d], nsplit == 1 only): write the
 // normalised attention output directly instead of partials
 

@@ -102,6 +102,66 @@ __global__ __launch_bounds__(256) void layernorm_rows_reg_kernel(const float* __
   }
 }
 
+// The same register-resident LayerNorm for the <= 64 rows of the batched AR step, written bf16 in the fragment-major
+// layout the weight-streaming GEMM reads (common.h xf_index); identical arithmetic and rounding.
+template <int NV>
+__global__ __launch_bounds__(256) void layernorm_rows_xf_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                                const float* __restrict__ beta, bf16_t* __restrict__ out, int rows,
+                                                                int MF, int w8) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+  constexpr int d = NV * 256;
+  const int lane = threadIdx.x & 63;
+  const int r = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const f4* xr = reinterpret_cast<const f4*>(x + (int64_t)r * d) + lane;
+  f4 v[NV], g[NV], bb[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = xr[i * 64];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    g[i] = reinterpret_cast<const f4*>(gamma)[i * 64 + lane];
+    bb[i] = reinterpret_cast<const f4*>(beta)[i * 64 + lane];
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = wave_sum_dpp(s) / (float)d;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const float a = v[i].x - mean, b = v[i].y - mean, c = v[i].z - mean, e = v[i].w - mean;
+    q += (a * a + b * b) + (c * c + e * e);
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum_dpp(q) / (float)d + LN_EPS);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const f4 o = (v[i] - mean) * rstd * g[i] + bb[i];
+    b4 p;
+    p[0] = (__bf16)o.x; p[1] = (__bf16)o.y; p[2] = (__bf16)o.z; p[3] = (__bf16)o.w;
+    *reinterpret_cast<b4*>(out + xf_index(r, (i * 64 + lane) * 4, MF, w8 != 0)) = p;
+  }
+}
+
+int launch_layernorm_xf(hipStream_t st, const float* x, const float* gamma, const float* beta, void* out, int rows, int d, int w8) {
+  if (rows <= 0) return 0;
+  if (rows > 64 || d % 256 != 0) return -1;
+  const int MF = (rows + 15) / 16;
+  const dim3 grid((rows + 3) / 4), block(256);
+#define VLE_LNX(NV) hipLaunchKernelGGL((layernorm_rows_xf_kernel<NV>), grid, block, 0, st, x, gamma, beta, (bf16_t*)out, rows, MF, w8)
+  switch (d / 256) {
+    case 1: VLE_LNX(1); break;
+    case 2: VLE_LNX(2); break;
+    case 3: VLE_LNX(3); break;
+    case 4: VLE_LNX(4); break;
+    case 6: VLE_LNX(6); break;
+    case 8: VLE_LNX(8); break;
+    default: return -1;
+  }
+#undef VLE_LNX
+  return 0;
+}
+
 template <typename T>
 static bool layernorm_reg_dispatch(hipStream_t st, const float* x, const int32_t* row_map, const float* gamma, const float* beta,
                                    T* out, int64_t rows, int d) {

@@ -22,6 +22,10 @@
 //     (4 KB) to a workspace, takes a ticket on the fragment's counter, and the LAST arriver sums the
 //     KS partials in slice order (deterministic, independent of arrival order) and runs the epilogue;
 //     the counter resets itself, so a captured graph replays without a memset.
+// The X operand is read fragment-major when the producer wrote it that way (x_xf, common.h xf_index): stored row-major a
+// fragment load touches 16 rows x 64 B and the launch is bound by the texture path; fragment-major it is one contiguous
+// 1 KB (measured at 64 utterances: AR loop 667 -> 613 ms).  Packing W the same way would add 3 % more (611 -> 592 ms in a
+// timing experiment) at the price of a second 304 MB copy of the AR weights: not done.
 // Measured and rejected (round 1, MI355X, M = 64, per launch in a dependent graph chain): staging the X slice in
 // LDS once per workgroup (full-line loads, waves as 1-2 row fragments x k-ranges) 9.2-9.8 us vs 7.2-7.3 us here --
 // the load -> LDS -> barrier -> ds_read prologue serialises what this kernel requests as one burst; LayerNorm fused

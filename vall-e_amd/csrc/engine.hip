@@ -46,6 +46,9 @@ struct LayerW {
   float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;  // AR LayerNorm affine
   // FP8W (AR decoder only): e4m3fn codes [N][K] + one power-of-two scale per row; wqkv.. then hold bf16(W')
   void *wqkv8 = nullptr, *wo8 = nullptr, *w18 = nullptr, *w28 = nullptr;
+  // fragment-major copies for gemm_skinny.hip (AR decoder of an engine with max_batch >= 2): of the bf16 weights, or of
+  // the fp8 codes in FP8W mode
+  void *wqkv_p = nullptr, *wo_p = nullptr, *w1_p = nullptr, *w2_p = nullptr;
   float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;
 };
 
@@ -78,6 +81,8 @@ struct vle_engine {
   float *ar_norm_g = nullptr, *ar_norm_b = nullptr;
   void* ar_predict = nullptr;
   void* ar_predict8 = nullptr;     // FP8W
+  void* ar_predict_p = nullptr;    // fragment-major copy (see LayerW)
+  bool opt_gs_wpack = true;        // option "gs_wpack": gemm_skinny reads the fragment-major weight copies
   float* ar_predict_s = nullptr;
   bool w8 = false;                 // dtype_mode == VLE_DTYPE_FP8W: dtype stays DT_BF16 for activations / KV / MFMA passes
   void* nar_predict[7] = {};
@@ -552,6 +557,27 @@ extern "C" int vle_finalize_weights(vle_engine* e) {
   e->host_w.clear();
   e->host_shape.clear();
   if ((r = alloc_buffers(e))) return r;
+  if (e->max_B >= 2 && e->dtype == DT_BF16 && e->d % 256 == 0) {  // the batch path of the AR step exists: pack its weights
+    auto pack = [&](const void* src, void** dst, int64_t N, int64_t K) -> int {
+      if (!src) return 0;
+      unsigned char* p = nullptr;
+      const size_t bytes = (size_t)((N + 15) / 16 * 16) * K * (e->w8 ? 1 : 2);
+      int rr = dev_alloc(e, &p, bytes);
+      if (rr) return rr;
+      E_LAUNCH(e, launch_pack_w_frag(e->st, src, p, (int)N, (int)K, e->w8 ? 1 : 0));
+      *dst = p;
+      return 0;
+    };
+    for (int l = 0; l < e->L; ++l) {
+      LayerW& w = e->ar[l];
+      if ((r = pack(e->w8 ? w.wqkv8 : w.wqkv, &w.wqkv_p, 3 * d, d))) return r;
+      if ((r = pack(e->w8 ? w.wo8 : w.wo, &w.wo_p, d, d))) return r;
+      if ((r = pack(e->w8 ? w.w18 : w.w1, &w.w1_p, 4 * d, d))) return r;
+      if ((r = pack(e->w8 ? w.w28 : w.w2, &w.w2_p, d, 4 * d))) return r;
+    }
+    if ((r = pack(e->w8 ? e->ar_predict8 : e->ar_predict, &e->ar_predict_p, V_AR, d))) return r;
+    E_HIP(e, hipStreamSynchronize(e->st));
+  }
   e->finalized = true;
   return VLE_OK;
 }
@@ -728,7 +754,8 @@ int enqueue_ar_logits(vle_engine* e) {
     if (use_mfma_skinny(e)) {
       GemmSkinnyArgs g;
       g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target; g.x_xf = xf ? 1 : 0;
-      g.x = e->xn_step; g.w = e->w8 ? e->ar_predict8 : e->ar_predict; g.wscale = e->w8 ? e->ar_predict_s : nullptr; g.M = e->B; g.N = V_AR; g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
+      g.x = e->xn_step; g.w = e->w8 ? e->ar_predict8 : e->ar_predict; g.wscale = e->w8 ? e->ar_predict_s : nullptr; g.M = e->B; g.N = V_AR;
+      if (e->opt_gs_wpack && e->ar_predict_p) { g.w = e->ar_predict_p; g.w_packed = 1; } g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
       E_LAUNCH(e, launch_gemm_skinny(st, g));
     } else {
       E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
@@ -770,6 +797,9 @@ int enqueue_ar_step(vle_engine* e) {
         else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
         g.x_xf = xf ? 1 : 0;
         g.x = e->xn_step; g.w = e->w8 ? w.wqkv8 : w.wqkv; g.wscale = e->w8 ? w.sqkv : nullptr; g.bias = w.bqkv; g.N = 3 * d; g.K = d; g.epi = GS_EPI_QKV;
+        const bool wpk = e->opt_gs_wpack && w.wqkv_p != nullptr;
+        g.w_packed = wpk ? 1 : 0;
+        if (wpk) g.w = w.wqkv_p;
         g.q_out = e->q_step; g.k_cache = kc; g.v_cache = vc; g.kv_len = e->S.kv_len; g.ctx_max = e->ctx_max; g.nhead = e->H; g.dh = e->dh;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
@@ -784,7 +814,7 @@ int enqueue_ar_step(vle_engine* e) {
         ProfScope ps(e, 2);
         if (!direct) E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
         g.x_xf = (xf && direct) ? 1 : 0;  // the merge kernel of the split path writes row-major
-        g.x = e->att_step; g.w = e->w8 ? w.wo8 : w.wo; g.wscale = e->w8 ? w.so : nullptr; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
+        g.x = e->att_step; g.w = g.w_packed ? w.wo_p : (e->w8 ? w.wo8 : w.wo); g.wscale = e->w8 ? w.so : nullptr; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       {
@@ -792,13 +822,13 @@ int enqueue_ar_step(vle_engine* e) {
         if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, w.g2, w.be2, e->xn_step, e->B, d, e->w8 ? 1 : 0));
         else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
         g.x_xf = xf ? 1 : 0; g.out_xf = xfw;  // FFN1 writes the hidden rows for FFN2 in the same layout
-        g.x = e->xn_step; g.w = e->w8 ? w.w18 : w.w1; g.wscale = e->w8 ? w.s1 : nullptr; g.bias = w.b1; g.N = 4 * d; g.K = d; g.epi = GS_EPI_RELU; g.out = e->hT_step;
+        g.x = e->xn_step; g.w = g.w_packed ? w.w1_p : (e->w8 ? w.w18 : w.w1); g.wscale = e->w8 ? w.s1 : nullptr; g.bias = w.b1; g.N = 4 * d; g.K = d; g.epi = GS_EPI_RELU; g.out = e->hT_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       {
         ProfScope ps(e, 4);
         g.x_xf = xf ? 1 : 0; g.out_xf = 0;
-        g.x = e->hT_step; g.w = e->w8 ? w.w28 : w.w2; g.wscale = e->w8 ? w.s2 : nullptr; g.bias = w.b2; g.N = d; g.K = 4 * d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
+        g.x = e->hT_step; g.w = g.w_packed ? w.w2_p : (e->w8 ? w.w28 : w.w2); g.wscale = e->w8 ? w.s2 : nullptr; g.bias = w.b2; g.N = d; g.K = 4 * d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       continue;
@@ -1563,9 +1593,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
     else if (n == "gs_xf") e->opt_gs_xf = value != 0;
+    else if (n == "gs_wpack") e->opt_gs_wpack = value != 0;
     else if (n == "gs_target_wgs") e->opt_gs_target = (int)value;  // 1 = no split-K
     else if (n == "no_gemm_skinny") e->opt_no_gemm_skinny = value != 0;
     else if (n == "attn_nk") e->opt_nk = (int)value;

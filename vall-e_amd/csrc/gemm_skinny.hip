@@ -24,8 +24,8 @@
 //     the counter resets itself, so a captured graph replays without a memset.
 // The X operand is read fragment-major when the producer wrote it that way (x_xf, common.h xf_index): stored row-major a
 // fragment load touches 16 rows x 64 B and the launch is bound by the texture path; fragment-major it is one contiguous
-// 1 KB (measured at 64 utterances: AR loop 667 -> 613 ms).  Packing W the same way would add 3 % more (611 -> 592 ms in a
-// timing experiment) at the price of a second 304 MB copy of the AR weights: not done.
+// 1 KB (measured at 64 utterances: AR loop 667 -> 613 ms).  W is read the same way from a fragment-major copy the
+// engine makes at vle_finalize_weights for engines with max_batch >= 2 (w_packed; +304 MB at C2, 3 % of the AR loop).
 // Measured and rejected (round 1, MI355X, M = 64, per launch in a dependent graph chain): staging the X slice in
 // LDS once per workgroup (full-line loads, waves as 1-2 row fragments x k-ranges) 9.2-9.8 us vs 7.2-7.3 us here --
 // the load -> LDS -> barrier -> ds_read prologue serialises what this kernel requests as one burst; LayerNorm fused
@@ -169,7 +169,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int c = min(c0 + g, chunks - 1);  // clamped: a short last round re-reads its final chunk, unused below
-      if constexpr (W8) {
+      if (a.w_packed) {  // fragment-major copy (misc.hip pack_w_frag_kernel): one contiguous 1 KB per fragment load
+        const int64_t cc = (int64_t)blockIdx.x * (K >> 6) + (kbeg >> 6) + c;
+        if constexpr (W8) {
+          wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(reinterpret_cast<const unsigned char*>(a.w) + cc * 1024 + lane * 16));
+        } else {
+          const bf16_t* wf = reinterpret_cast<const bf16_t*>(a.w) + cc * 1024 + lane * 8;
+          wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wf));
+          wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wf + 512));
+        }
+      } else if constexpr (W8) {
         wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp8 + c * 64));
       } else {
         wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wp + c * 64));

@@ -68,6 +68,7 @@ struct GemmSkinnyArgs {
   void* workspace = nullptr;
   int ksplit = 0;      // 0 = chosen from N, K and target_wgs
   int target_wgs = 0;  // 0 = 256
+  int w_packed = 0;        // w is the fragment-major copy made by launch_pack_w_frag (engine only)
   int x_xf = 0;            // X is stored fragment-major (common.h xf_index) instead of row-major
   int out_xf = 0;          // STORE / RELU epilogues write `out` fragment-major for the next GEMM: 0 no, 1 bf16-W consumer, 2 fp8-W
   int* ws_cnt = nullptr;   // (filled by the launcher)
@@ -201,6 +202,8 @@ int launch_ar_sample(hipStream_t st, const ArSampleArgs& a);
 // slot API (continuous batching): per-slot AR state of newly admitted utterances; rows of X scattered to slot rows
 int launch_slot_state_init(hipStream_t st, int32_t* state, int max_B, const int32_t* slots, const int32_t* kv_len,
                            const int32_t* audio_pos, const int32_t* cap, int n);
+// fragment-major copy of W[N][K] (bf16 or fp8 codes) for gemm_skinny.hip; dst holds ceil(N/16)*16*K elements
+int launch_pack_w_frag(hipStream_t st, const void* src, void* dst, int N, int K, int fp8);
 int launch_scatter_rows(hipStream_t st, const float* src, const int32_t* src_rows, float* dst, const int32_t* dst_rows, int rows, int d);
 
 struct NarArgmaxArgs {

@@ -118,4 +118,37 @@ int launch_scatter_rows(hipStream_t st, const float* src, const int32_t* src_row
   return 0;
 }
 
+// ---- fragment-major copy of a weight matrix for gemm_skinny.hip -----------------------------------------------
+// W[N][K] (bf16, or e4m3fn codes) -> per 16-row block nb and 64-deep chunk c the bytes of each MFMA A-fragment in lane
+// order, so that a fragment load is one contiguous 1 KB instead of 16 rows x 64 B:
+//   bf16: dst[((nb*(K/64) + c)*2 + s)*512 + lane*8 + j] = W[nb*16 + fr][c*64 + s*32 + fg*8 + j]     lane = fg*16 + fr
+//   fp8 : dst[(nb*(K/64) + c)*1024 + lane*16 + j]       = W[nb*16 + fr][c*64 + fg*16 + j]
+// (rows beyond N repeat row N-1, as the kernel's own clamp does).  One 16-byte vector per thread.
+__global__ void pack_w_frag_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, int N, int K, int fp8) {
+  const int64_t v = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;  // destination vector index
+  const int kc = K >> 6, nblk = (N + 15) / 16;
+  const int64_t total = (int64_t)nblk * kc * (fp8 ? 64 : 128);
+  if (v >= total) return;
+  const int lane = (int)(v & 63), fr = lane & 15, fg = lane >> 4;
+  int64_t t = v >> 6;
+  int s = 0;
+  if (!fp8) {
+    s = (int)(t & 1);
+    t >>= 1;
+  }
+  const int c = (int)(t % kc), nb = (int)(t / kc);
+  const int row = min(nb * 16 + fr, N - 1);
+  const int64_t k = fp8 ? (int64_t)c * 64 + fg * 16 : (int64_t)c * 64 + s * 32 + fg * 8;
+  const int es = fp8 ? 1 : 2;
+  *reinterpret_cast<uint4*>(dst + v * 16) = *reinterpret_cast<const uint4*>(src + ((int64_t)row * K + k) * es);
+}
+
+int launch_pack_w_frag(hipStream_t st, const void* src, void* dst, int N, int K, int fp8) {
+  if (K % 64 != 0 || N < 1) return -1;
+  const int64_t total = (int64_t)((N + 15) / 16) * (K >> 6) * (fp8 ? 64 : 128);
+  hipLaunchKernelGGL(pack_w_frag_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, (const unsigned char*)src,
+                     (unsigned char*)dst, N, K, fp8);
+  return 0;
+}
+
 }  // namespace vle

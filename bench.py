@@ -12,7 +12,8 @@ utterances per GPU); no collective on the decode path, one all_gather of the res
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (AR step =
 the HBM-bound dominant phase; algorithmic bytes of SURVEY.md 8d / measured hipEvent time) and
 `cpu_baseline` (the CPU oracle -- a restatement of the reference's no-KV-cache algorithm -- timed
-on the host cores on a bounded sample).  The default single-GPU run also carries `c3_batch64`: BASELINE.json
+on the host cores on a bounded sample) and `eager_gpu_baseline` (the same restatement as PyTorch-ROCm eager ops on the
+same GPU).  The default single-GPU run also carries `c3_batch64`: BASELINE.json
 configs[2] (64 utterances on one GPU) with its own AR (HBM) and NAR (MFMA) roofline fractions.
 """
 from __future__ import annotations
@@ -65,6 +66,27 @@ def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
         sample=f"first {codes.shape[1]} of 753 frames of utterance 0 (ctx {S_TEXT + P_PROMPT}..{S_TEXT + P_PROMPT + frames}) "
                f"+ 7 NAR stages, fp32, {dt:.1f} s; the full-length run is slower per token (no KV cache: O(G*N))",
     )
+
+
+def eager_gpu_baseline(sd_cpu, d_model, nhead, num_layers, frames, dev):
+    """The same literal (no KV cache) restatement of valle.py:961-1137, fp32, as plain PyTorch-ROCm eager ops on the
+    SAME MI355X -- what running the reference with model.to("cuda") amounts to ("a fairer secondary
+    baseline").  Bounded sample like cpu_baseline; only this leg and cpu_baseline touch oracle/."""
+    from oracle import valle_oracle as vo
+
+    cfg = vo.OracleConfig(d_model=d_model, nhead=nhead, num_layers=num_layers, prefix_mode=1)
+    sd = {k: v.to(dev) for k, v in sd_cpu.items()}
+    x, y = synth_inputs(0)
+    xs, xl, ys = x[None].to(dev), torch.tensor([S_TEXT], dtype=torch.int32), y[None].to(dev)
+    vo.inference(sd, cfg, xs, xl, ys, None, top_k=1, kv_cache=False, max_new=4)  # warm-up (rocBLAS / MIOpen handles)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    codes = vo.inference(sd, cfg, xs, xl, ys, None, top_k=1, kv_cache=False, max_new=frames)
+    torch.cuda.synchronize(dev)
+    dt = time.perf_counter() - t0
+    n_tok = codes.shape[1] * codes.shape[2]
+    return dict(value=round(n_tok / dt, 3), unit="audio-tokens/s", kind="port (PyTorch-ROCm eager ops on the same GPU, fp32, no KV cache)",
+                sample=f"first {codes.shape[1]} of 753 frames of utterance 0 + 7 NAR stages, {dt:.2f} s")
 
 
 MFMA_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
@@ -273,6 +295,12 @@ def main():
                 out["cpu_baseline"] = {"error": repr(err)[:200]}
         else:
             out["cpu_baseline"] = None
+        if sd_cpu is not None:
+            try:
+                model._invalidate()
+                out["eager_gpu_baseline"] = eager_gpu_baseline(sd_cpu, args.d_model, args.nhead, args.layers, args.cpu_frames, dev)
+            except Exception as err:  # noqa: BLE001
+                out["eager_gpu_baseline"] = {"error": repr(err)[:200]}
         if args.gpus == 1 and B == 1 and not args.no_c3 and not args.opt and args.profile_kernels == 0:
             try:
                 model._invalidate()

@@ -180,7 +180,7 @@ def sine_position(x: torch.Tensor, alpha: torch.Tensor, start: int = 0) -> torch
     """SinePositionalEmbedding.forward, embedding.py:93-97 with x_scale = 1 (scale=False at
     valle.py:131,137,221,227) and dropout = identity in eval.  ``start`` only for kv_cache mode."""
     T, d = x.shape[-2], x.shape[-1]
-    pe = sine_pe(start + T, d)[start:]
+    pe = sine_pe(start + T, d)[start:].to(x.device)  # the table is built on the host like the reference's (embedding.py:75-91)
     return x * 1.0 + alpha * pe
 
 
@@ -306,14 +306,14 @@ def ar_decode(
         if not kv_cache:
             y_pos = sine_position(token_embedding(sd, "ar_audio_embedding", y), sd["ar_audio_position.alpha"])  # :1013-1015
             xy_pos = torch.cat([x, y_pos], 0)  # :1016
-            mask = prefix_lm_mask(S, y.shape[0])  # :1018-1033
+            mask = prefix_lm_mask(S, y.shape[0]).to(x.device)  # :1018-1033
             xy_dec = encoder(sd, "ar_decoder", cfg, xy_pos, attn_mask=mask)  # :1035-1038
         else:
             new = y[n_cached_audio:]
             y_pos = sine_position(token_embedding(sd, "ar_audio_embedding", new), sd["ar_audio_position.alpha"], start=n_cached_audio)
             if n_cached_audio == 0:
                 inp = torch.cat([x, y_pos], 0)
-                mask = prefix_lm_mask(S, y.shape[0])
+                mask = prefix_lm_mask(S, y.shape[0]).to(x.device)
             else:
                 inp, mask = y_pos, None  # the new row sees every cached key (causal row = last)
             xy_dec = encoder(sd, "ar_decoder", cfg, inp, attn_mask=mask, kv_states=kv_states)

@@ -119,6 +119,13 @@ template <>
 struct Elem<bf16w8_t> {
   static constexpr int VEC = 8;  // a lane's chunk is 8 elements as in bf16 mode (8 bytes of fp8)
 };
+struct bf16w8t_t {  // bf16w8_t with default-policy (cacheable) weight loads: at one utterance the fp8 AR weights (152 MB at
+  uint8_t v;        // C2) fit the 256 MB memory-side cache, which non-temporal loads would bypass
+};
+template <>
+struct Elem<bf16w8t_t> {
+  static constexpr int VEC = 8;
+};
 
 // 16-byte vector load of VEC elements, widened to fp32
 template <typename T>

@@ -112,6 +112,8 @@ struct vle_engine {
   // forces eager launches; tags: 0 qkv, 1 decode-attention, 2 out-proj, 3 ffn1, 4 ffn2, 5 logits, 6 sample
   bool opt_profile = false;
   bool opt_no_gemm_skinny = false;  // option "no_gemm_skinny": batch 2..64 on the v0 kernels (A/B measurements)
+  int opt_w8_temporal = -1;         // option "w8_temporal": FP8W batch-1 GEMV loads its weights with the default cache policy
+                                    // (-1 = when the fp8 AR weights fit the 256 MB memory-side cache with room for the KV stream)
   bool opt_gs_xf = true;            // option "gs_xf": AR-step activations of the gemm_skinny path in the fragment-major layout
   int opt_gs_target = 0;            // option "gs_target_wgs": workgroups the split-K of gemm_skinny aims for (0 = 256)
   void* gs_ws = nullptr;            // split-K tickets + partial tiles of gemm_skinny (zeroed once)
@@ -293,6 +295,9 @@ int launch_ar_linear(vle_engine* e, const SkinnyArgs& a) {
     t.rpw_override = e->opt_rpw;
     if (e->w8 && a.w8 != nullptr) {  // FP8W: stream the e4m3fn codes; shapes gemv1 lacks fall through to bf16(W')
       t.w = a.w8;
+      // measured at C2 (152 MB of codes): AR loop 173.4 -> 166-171 ms with cacheable loads; non-temporal otherwise
+      const int64_t w8_bytes = (int64_t)e->L * 12 * e->d * e->d + (int64_t)V_AR * e->d;
+      t.temporal = e->opt_w8_temporal >= 0 ? e->opt_w8_temporal : (w8_bytes <= (int64_t)192 << 20 ? 1 : 0);
       const int r8 = launch_gemv1(e->st, DT_FP8W, t);
       if (r8 <= 0) return r8;
       t.w = a.w;
@@ -1593,10 +1598,11 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
     else if (n == "gs_xf") e->opt_gs_xf = value != 0;
     else if (n == "gs_wpack") e->opt_gs_wpack = value != 0;
+    else if (n == "w8_temporal") e->opt_w8_temporal = (int)value;
     else if (n == "gs_target_wgs") e->opt_gs_target = (int)value;  // 1 = no split-K
     else if (n == "no_gemm_skinny") e->opt_no_gemm_skinny = value != 0;
     else if (n == "attn_nk") e->opt_nk = (int)value;

@@ -54,6 +54,11 @@ __device__ inline void widen16<bf16w8_t>(const u32x4_t& v, float (&f)[8]) {
   f[0] = a.x; f[1] = a.y; f[2] = b.x; f[3] = b.y; f[4] = c.x; f[5] = c.y; f[6] = d.x; f[7] = d.y;
 }
 
+template <>
+__device__ inline void widen16<bf16w8t_t>(const u32x4_t& v, float (&f)[8]) {
+  widen16<bf16w8_t>(v, f);
+}
+
 // weight-stream traits: how a lane fetches its VEC weights of one chunk, and the element type of the KV cache
 template <typename T>
 struct G1W {
@@ -68,6 +73,17 @@ struct G1W<bf16w8_t> {
   __device__ static inline u32x4_t load(const bf16w8_t* p) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     const u32x2_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+    return u32x4_t{t.x, t.y, 0u, 0u};
+  }
+};
+
+template <>
+struct G1W<bf16w8t_t> {
+  typedef bf16_t cache_t;
+  static constexpr bool kScaled = true;
+  __device__ static inline u32x4_t load(const bf16w8t_t* p) {
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t t = *reinterpret_cast<const u32x2_t*>(p);  // default cache policy
     return u32x4_t{t.x, t.y, 0u, 0u};
   }
 };
@@ -326,7 +342,7 @@ static int g1_dispatch_nch(hipStream_t st, const SkinnyArgs& a) {
 int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a) {
   if (a.B != 1 || a.N <= 0) return 1;
   if (a.pro == PRO_ATTN && (a.dh % (dtype == DT_F32 ? 4 : 8) != 0)) return 1;
-  if (dtype == DT_FP8W) return a.wscale ? g1_dispatch_nch<bf16w8_t>(st, a) : -1;
+  if (dtype == DT_FP8W) return !a.wscale ? -1 : a.temporal ? g1_dispatch_nch<bf16w8t_t>(st, a) : g1_dispatch_nch<bf16w8_t>(st, a);
   if (dtype == DT_F32) return g1_dispatch_nch<float>(st, a);
   return g1_dispatch_nch<bf16_t>(st, a);
 }

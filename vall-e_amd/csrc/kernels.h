@@ -89,6 +89,7 @@ struct SkinnyArgs {
   const float* bias = nullptr; // f32 [N] or null
   const float* wscale = nullptr;  // dtype DT_FP8W (gemv1 only): w is e4m3fn [N][K], row n scaled by wscale[n]
   const void* w8 = nullptr;       // engine: the e4m3fn copy of w (FP8W), tried first by launch_ar_linear
+  int temporal = 0;               // DT_FP8W gemv1: default-policy weight loads (memory-side cache) instead of non-temporal
   int N = 0, K = 0, B = 0;
   int pro = PRO_PLAIN, epi = SEPI_STORE;
   const float* x = nullptr;      // f32 [B][K]           (PRO_PLAIN / PRO_LN)

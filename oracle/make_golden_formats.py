@@ -1,4 +1,4 @@
-"""TEST INFRASTRUCTURE ONLY -- golden fixtures for vall-e_amd/formats.py, produced by the UNMODIFIED reference
+"""TEST INFRASTRUCTURE ONLY -- golden fixtures for valle_amd/formats.py, produced by the UNMODIFIED reference
 classes under /root/reference (valle/utils/symbol_table.py, valle/data/collation.py, valle/models get_model):
 
     python oracle/make_golden_formats.py      # writes tests/golden/formats/*

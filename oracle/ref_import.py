@@ -2,7 +2,7 @@
 
 Used only by ``oracle/make_golden.py`` (fixture generation, in the build container) and by
 CPU tests that are skipped when ``/root/reference`` is absent (it does not exist on the
-GPU box).  Nothing in the product path (``vall-e_amd/``) may import this module.
+GPU box).  Nothing in the product path (``valle_amd/``) may import this module.
 
 The reference's ``valle`` package imports lhotse / icefall / torchmetrics / encodec /
 phonemizer at import time; none are installed and none are on the decode hot path.  We

@@ -5,7 +5,7 @@ of the algorithm the reference executes in ``VALLE.inference()`` / ``VALLE.conti
 Every function cites the reference file:line it follows (paths relative to
 /root/reference).  It is the *checker* for the HIP engine: only ``tests/``,
 ``__graft_entry__.smoke()`` and ``bench.py``'s ``cpu_baseline`` leg may import it; the
-product path (``vall-e_amd/``) never does.
+product path (``valle_amd/``) never does.
 
 Parity status: PINNED.  ``oracle/make_golden.py`` runs the unmodified reference (imported
 through ``oracle/ref_import.py``) on the weights produced by ``make_state_dict`` here and

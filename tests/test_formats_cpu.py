@@ -1,4 +1,4 @@
-"""CPU: the data formats either side of the decode path (vall-e_amd/formats.py) against fixtures written by the
+"""CPU: the data formats either side of the decode path (valle_amd/formats.py) against fixtures written by the
 reference's own classes (oracle/make_golden_formats.py -> tests/golden/formats): symbol-table file, the phoneme-id
 assignment of TextTokenCollater, and an icefall-layout checkpoint holding a reference VALLE."""
 import json

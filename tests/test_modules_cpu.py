@@ -1,4 +1,4 @@
-"""CPU: host-side contract of the block API (vall-e_amd/modules.py) -- state-dict keys equal the
+"""CPU: host-side contract of the block API (valle_amd/modules.py) -- state-dict keys equal the
 reference modules' (recorded in tests/golden/modules by oracle/make_golden_modules.py), the mask
 classifier, loud failure without a ROCm device and on configurations outside the decode path."""
 import os

@@ -1,4 +1,4 @@
-"""GPU parity of the block API (vall-e_amd/modules.py) against golden vectors produced by the reference's
+"""GPU parity of the block API (valle_amd/modules.py) against golden vectors produced by the reference's
 own modules (oracle/make_golden_modules.py -> tests/golden/modules), plus a cross-check of the two HIP
 paths: the reference's decode loop written against the block modules must give the engine's tokens.
 

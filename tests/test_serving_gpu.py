@@ -1,4 +1,4 @@
-"""GPU: continuous batching (vall-e_amd/serving.py over vle_slots_*): more requests than slots, ragged text / prompt
+"""GPU: continuous batching (valle_amd/serving.py over vle_slots_*): more requests than slots, ragged text / prompt
 lengths, utterances finishing at different steps.  fp32 engine mode => every request's codes must equal the CPU oracle's
 (= the reference's) token for token, whatever shared the batch with it; and the dense batch API must agree."""
 import pytest

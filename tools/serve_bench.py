@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Ragged workload on one GPU: N requests with text lengths S ~ U[smin, 47] (so G = 16 S + 1 frames each, EOS ignored)
 and 3 s prompts, C2 architecture bf16 -- static batches of `max_batch` in arrival order (each runs to its longest
-member) vs continuous batching (vall-e_amd/serving.py).   python tools/serve_bench.py [--n 192] [--max-batch 64]"""
+member) vs continuous batching (valle_amd/serving.py).   python tools/serve_bench.py [--n 192] [--max-batch 64]"""
 import argparse
 import os
 import sys

@@ -46,8 +46,11 @@ def synth_inputs(index: int, S: int = S_TEXT, P: int = P_PROMPT):
 
 def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
     """The CPU oracle (literal no-KV-cache restatement of valle/models/valle.py:961-1137), fp32, on
-    all host cores, on a bounded sample: the first `frames` frames of utterance 0 (+ the 7 NAR
-    stages over them).  Only this leg of bench.py touches oracle/."""
+    the host cores, on a bounded sample: the first `frames` frames of utterance 0 (+ the 7 NAR
+    stages over them).  Only this leg of bench.py touches oracle/.  `full_length_estimate` extrapolates the
+    sample to the whole 753-frame utterance by the literal algorithm's row count (every AR step re-runs all
+    S+P+t rows; the NAR passes run S+P+G rows) -- attention's quadratic term is ignored, so the estimate is an
+    UPPER bound on the full-length rate."""
     from oracle import valle_oracle as vo
 
     # intra-op threads actually used: the reference's per-step ops are small (one utterance), more
@@ -56,15 +59,29 @@ def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
     torch.set_num_threads(cores)
     cfg = vo.OracleConfig(d_model=d_model, nhead=nhead, num_layers=num_layers, prefix_mode=1)
     x, y = synth_inputs(0)
+    xl = torch.tensor([S_TEXT], dtype=torch.int32)
     t0 = time.perf_counter()
-    codes = vo.inference(sd_cpu, cfg, x[None], torch.tensor([S_TEXT], dtype=torch.int32), y[None], None, top_k=1,
-                         kv_cache=False, max_new=frames)
+    yy = vo.ar_decode(sd_cpu, cfg, x[None], xl, y[None], top_k=1, temperature=1.0, kv_cache=False, max_new=frames)
+    t_ar = time.perf_counter() - t0
+    codes = vo.nar_decode(sd_cpu, cfg, x, yy[0], y, P_PROMPT)
     dt = time.perf_counter() - t0
-    n_tok = codes.shape[1] * codes.shape[2]
+    t_nar = dt - t_ar
+    n_frames = codes.shape[1]
+    n_tok = n_frames * codes.shape[2]
+    G_full = 16 * S_TEXT + 1
+    ctx0 = S_TEXT + P_PROMPT
+    rows_sample = sum(ctx0 + t for t in range(n_frames + 1))  # n_frames + 1 loop iterations (the last one stops)
+    rows_full = sum(ctx0 + t for t in range(G_full + 1))
+    est = t_ar * rows_full / rows_sample + t_nar * (ctx0 + G_full) / (ctx0 + n_frames)
     return dict(
         value=round(n_tok / dt, 3), unit="audio-tokens/s", cores=cores, kind="port",
-        sample=f"first {codes.shape[1]} of 753 frames of utterance 0 (ctx {S_TEXT + P_PROMPT}..{S_TEXT + P_PROMPT + frames}) "
-               f"+ 7 NAR stages, fp32, {dt:.1f} s; the full-length run is slower per token (no KV cache: O(G*N))",
+        sample=f"first {n_frames} of {G_full} frames of utterance 0 (ctx {ctx0}..{ctx0 + frames}) "
+               f"+ 7 NAR stages, fp32, {dt:.1f} s (AR {t_ar:.1f} s, NAR {t_nar:.1f} s)",
+        full_length_estimate=dict(
+            value=round(G_full * 8 / est, 3), unit="audio-tokens/s", seconds=round(est, 1),
+            method="row-count extrapolation of the sample (AR: sum over steps of S+P+t rows; NAR: S+P+G rows); "
+                   "ignores attention's quadratic growth => upper bound on the rate; SURVEY.md 6 measured 9.8 tok/s "
+                   "for the unmodified reference at full length on 8 threads"),
     )
 
 
@@ -141,12 +158,85 @@ def c3_leg(sd, args, dev, B=64, steps=2, warmup=1):
     }
 
 
+def decode_step(eng, X, s_lens, Y, p_lens, top_k, world, n_total, dev):
+    """One "step" of the benchmark on this rank: whole decode of its B utterances (prefill + AR loop + 7 NAR stages)
+    and, for N > 1, the all_gather of the result codes (the path's only collective).  Returns (generated lengths of the
+    local utterances, the gathered list of (G, 8) code matrices in global order)."""
+    from valle_amd import dist as vdist
+
+    B = X.shape[0]
+    eng.prefill(X, s_lens, Y, p_lens)
+    _, gl = eng.generate(top_k=top_k, temperature=1.0, seed=0, allow_empty=B > 1)
+    codes = eng.nar(None)
+    out = [codes[b, : gl[b]] for b in range(B)]
+    if world > 1:
+        out = vdist.gather_codes(out, n_total, 8, dev)
+    return gl, out
+
+
+def timed_loop(step_fn, steps, warmup, world, dev, on_step=None):
+    """The timing contract: W untimed warm-up steps, then exactly K steps bracketed by barrier + device sync on both
+    sides; returns the MAX elapsed seconds over ranks."""
+    import torch.distributed as dist
+
+    def fence():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        if world > 1:
+            dist.barrier()
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    for _ in range(warmup):
+        step_fn()
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        r = step_fn()
+        if on_step is not None:
+            on_step(r)
+    fence()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    return elapsed
+
+
+def spawn_ranks(n: int) -> int:
+    """`python bench.py --gpus N` without a launcher: start one process per GPU ourselves (what
+    `python -m torch.distributed.run --nproc-per-node N` does; cf. the reference's per-device mp.spawn,
+    valle/bin/trainer.py:1143-1154).  Rank 0 inherits stdout and prints the JSON line."""
+    import socket
+    import subprocess
+
+    have = torch.cuda.device_count()
+    if have < n:
+        print(f"bench.py: --gpus {n} needs {n} visible GPUs, this box has {have} (torch.cuda.device_count()); "
+              f"no CPU / oversubscribed fallback", file=sys.stderr)
+        return 2
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], env=env))
+    rc = 0
+    for pr in procs:
+        rc = max(rc, abs(pr.wait()))
+    return rc
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=1, help="utterances per GPU (configs[1]: 1; configs[2]: 64)")
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU; default 1 at --gpus 1 (configs[1], the headline) and "
+                                                         "64 at --gpus N > 1 (configs[3]: 512 prompts over 8 GPUs)")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8w"], help="fp8w: bf16 arithmetic on fp8 e4m3 weights (configs[4] weight format)")
     ap.add_argument("--d-model", type=int, default=1024)
     ap.add_argument("--nhead", type=int, default=16)
@@ -159,23 +249,30 @@ def main():
     ap.add_argument("--profile-kernels", type=int, default=0, help="extra untimed pass: hipEvent time per AR-step kernel family over n steps")
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(spawn_ranks(args.gpus))
+
     import valle_amd
     from valle_amd import dist as vdist
 
-    rank, local_rank, world = vdist.init_process_group()
-    if world != args.gpus and world > 1:
-        args.gpus = world
     assert torch.cuda.is_available(), "bench.py needs a GPU (no CPU fallback)"
+    rank, local_rank, world = vdist.env_rank_world()
+    if world != args.gpus:
+        sys.exit(f"bench.py: --gpus {args.gpus} but the launcher started WORLD_SIZE={world} ranks; they must agree")
+    if world > torch.cuda.device_count():
+        sys.exit(f"bench.py: {world} ranks but only {torch.cuda.device_count()} visible GPUs")
+    vdist.init_process_group("nccl")  # RCCL over xGMI; no-op at world size 1
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
+    world_seen = torch.distributed.get_world_size() if world > 1 else 1
+    B = args.batch if args.batch > 0 else (1 if world == 1 else 64)
 
     # random-init weights of the named architecture (no network for checkpoints), reference init distributions
     torch.manual_seed(0)
     model = valle_amd.VALLE(args.d_model, args.nhead, args.layers, prefix_mode=1, engine_dtype=args.dtype,
-                            max_batch=args.batch, use_graph=not args.no_graph)
+                            max_batch=B, use_graph=not args.no_graph)
     sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.gpus == 1 and args.cpu_frames > 0) else None
     model = model.to(dev).eval()
-    B = args.batch
     eng = model.engine_for(B, S_TEXT, P_PROMPT)
     for kv in args.opt:
         name, val = kv.split("=")
@@ -192,46 +289,27 @@ def main():
     X, Y = X.to(dev), Y.to(dev)
     s_lens, p_lens = [S_TEXT] * B, [P_PROMPT] * B
 
+    acc = dict(tokens=0, pre=0.0, ar=0.0, nar=0.0, ar_steps=0, ar_bytes=0, gl=None, n_out=0)
+
     def step():
-        eng.prefill(X, s_lens, Y, p_lens)
-        _, gl = eng.generate(top_k=args.top_k, temperature=1.0, seed=0, allow_empty=B > 1)
-        codes = eng.nar(None)
-        out = [codes[b, : gl[b]] for b in range(B)]
-        if world > 1:
-            vdist.gather_codes(out, world * B, 8, dev)
-        return gl
+        return decode_step(eng, X, s_lens, Y, p_lens, args.top_k, world, world * B, dev)
 
-    def barrier():
-        if world > 1:
-            torch.distributed.barrier()
-
-    for _ in range(args.warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    tokens = 0
-    ar_ms = nar_ms = pre_ms = 0.0
-    ar_steps = 0
-    ar_bytes = 0
-    for _ in range(args.steps):
-        gl = step()
-        tokens += sum(gl) * 8
+    def on_step(r):
+        gl, out = r
+        acc["gl"], acc["n_out"] = gl, len(out)
+        acc["tokens"] += sum(gl) * 8
         tm = eng.timings()
-        pre_ms += tm["prefill_ms"]; ar_ms += tm["ar_ms"]; nar_ms += tm["nar_ms"]; ar_steps += int(tm["ar_steps"])
+        acc["pre"] += tm["prefill_ms"]; acc["ar"] += tm["ar_ms"]; acc["nar"] += tm["nar_ms"]; acc["ar_steps"] += int(tm["ar_steps"])
         # algorithmic bytes of this utterance batch's AR loop: per step W_AR*w + sum_b 2*L*d*a*(c_b + 1)
         for t in range(1, max(gl) + 1):
-            live = [b for b in range(B) if gl[b] >= t]
-            ar_bytes += eng.ar_step_bytes(len(live), sum(S_TEXT + P_PROMPT + t for _ in live))
-    torch.cuda.synchronize(dev)
-    barrier()
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+            live = sum(1 for b in range(B) if gl[b] >= t)
+            acc["ar_bytes"] += eng.ar_step_bytes(live, live * (S_TEXT + P_PROMPT + t))
+
+    elapsed = timed_loop(step, args.steps, args.warmup, world, dev, on_step)
+    tokens, gl = acc["tokens"], acc["gl"]
+    pre_ms, ar_ms, nar_ms, ar_steps, ar_bytes = acc["pre"], acc["ar"], acc["nar"], acc["ar_steps"], acc["ar_bytes"]
+    assert acc["n_out"] == world * B, "the gather did not return every rank's utterances"
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
-        elapsed = float(t.item())
         tk = torch.tensor([tokens], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tk, op=torch.distributed.ReduceOp.SUM)
         tokens = int(tk.item())
@@ -265,6 +343,9 @@ def main():
                             f"P={P_PROMPT} prompt frames (3 s) -> G={gl[0]} frames ({gl[0] / 75:.2f} s), "
                             f"{'greedy (top_k=1)' if args.top_k == 1 else f'top_k={args.top_k}'}, random-init weights",
                 "parallelism": f"batch-sharded x{args.gpus} (independent utterances, gather of codes only)",
+                "batch_per_gpu": B,
+                "world_size": world_seen,
+                "backend": "nccl (RCCL)" if world > 1 else "none (single process)",
                 "hip_graph": not args.no_graph,
             },
             "per_gpu_value": round(tokens / elapsed / args.gpus, 1),
@@ -285,6 +366,9 @@ def main():
                 "launches": ar_steps,
             },
         }
+        if world > 1:
+            out["config"]["scaling_reference"] = ("weak scaling at 64 utterances per GPU: the 1-GPU value of the SAME per-GPU work is the "
+                                                  "`c3_batch64.value` object of the default `--gpus 1` line, not its batch-1 `value`")
         if kernel_prof is not None:
             out["roofline"]["kernel_us"] = kernel_prof
         # the two side legs must never cost the headline line: report their failure instead of raising
@@ -309,6 +393,7 @@ def main():
                 out["c3_batch64"] = {"error": repr(err)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
+        torch.distributed.barrier()
         torch.distributed.destroy_process_group()
 
 

@@ -35,6 +35,9 @@ extern "C" {
 #define VLE_EKEY (-4)     /* unknown / mis-shaped state_dict key                           */
 #define VLE_ENOTOKEN (-5) /* EOS at the very first AR step: the reference raises SyntaxError
                              ("well trained model shouldn't reach here", valle.py:1049-1052) */
+#define VLE_EINDEX (-6)   /* a token id is outside its vocabulary (text >= 512, first codebook > 1024, other codebooks
+                             >= 1024, or negative): the reference's nn.Embedding raises IndexError
+                             (valle/modules/embedding.py:34,44).  The engine replaced the id by 0 before using it. */
 
 /* arithmetic mode of the whole path */
 #define VLE_DTYPE_F32 0  /* fp32 weights / KV / accumulate: token-id-exact vs the reference */
@@ -116,6 +119,13 @@ int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float temperatur
  *   enroll_lens   HOST int32 [B] or NULL (required for prefix_mode 2/4, valle.py:1068-1079)
  *   codes         DEVICE int64 [B, g_stride, Q]: all Q codebooks, frames >= G_b untouched */
 int vle_nar_decode(vle_engine* e, void* stream, const int32_t* enroll_lens, int64_t* codes, int64_t g_stride);
+
+/* Parity hook (the NAR analogue of vle_ar_generate's `forced`): the NEXT vle_nar_decode teacher-forces its stage
+ * history -- after stage i the embedding added to y_emb (valle.py:1133-1134) is the one of forced_codes[b][g][i+1]
+ * instead of the stage's own arg-max; the codes written are still the engine's own arg-max.  This is what makes the
+ * per-stage logits of a reduced-precision mode comparable with the reference's.
+ *   forced_codes  DEVICE int64 [B, f_stride, Q] (must stay valid until that vle_nar_decode returned), or NULL to clear */
+int vle_nar_force(vle_engine* e, const int64_t* forced_codes, int64_t f_stride);
 
 /* ---- VALLE.continual()  (valle/models/valle.py:1139-1238): NAR only ------------------------- */
 /*   y_codes DEVICE int64 [B, t_stride, 8], y_lens HOST int32 [B]; prefix_b = min(T_b/2, 225) (:1173);

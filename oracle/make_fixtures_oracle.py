@@ -1,0 +1,119 @@
+"""TEST INFRASTRUCTURE ONLY -- fixtures produced by the CPU ORACLE (oracle/valle_oracle.py, itself pinned to the
+unmodified reference by tests/golden/*.npz + tests/test_oracle_golden.py) at the shapes BASELINE.json quotes its numbers
+on, where running the reference itself is too slow to be useful (it is batch-1 and has no KV cache):
+
+  c3_b64_d1024   configs[2]/[3] shape: 64 DISTINCT ragged utterances at d1024-L12-h16 -> 64 independent oracle calls
+                 ("B independent reference calls = oracle for a batch"), shortened generation.
+  c5_d1536_L24   configs[4] architecture (d1536-L24-h16, dh 96): 3 utterances, on the fp32 weights AND on the
+                 FP8W-representable weights W' (oracle.fp8w_state_dict) the fp8 engine computes with.
+
+Weights and inputs are regenerated deterministically by the tests (make_state_dict / make_inputs), so a fixture only
+stores the oracle's OUTPUTS (codes, sub-sampled logits in fp16, top1-top2 margins).  Run in the build container:
+
+    python oracle/make_fixtures_oracle.py [--only NAME] [--threads 8]
+"""
+from __future__ import annotations
+
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import valle_oracle as vo  # noqa: E402
+
+OUT_DIR = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "oracle")
+
+SPECS = {
+    "c3_b64_d1024": dict(cfg=dict(d_model=1024, nhead=16, num_layers=12, prefix_mode=1), B=64, wseed=0, s_range=(6, 15), p_range=(16, 61),
+                         iseed0=500, max_new=20, ar_steps=[0, 1, 7, 13, 19], nar_rows=1, variants=["fp32"]),
+    "c5_d1536_L24": dict(cfg=dict(d_model=1536, nhead=16, num_layers=24, prefix_mode=1), B=3, wseed=0, s_range=(6, 10), p_range=(16, 28),
+                         iseed0=700, max_new=12, ar_steps=list(range(13)), nar_rows=4, variants=["fp32", "fp8w"]),
+}
+
+
+def utterance_shapes(spec):
+    """(S_b, P_b, input seed) per utterance -- shared with the tests (tests/test_parity_sizes_gpu.py imports this)."""
+    g = torch.Generator().manual_seed(spec["iseed0"])
+    B = spec["B"]
+    S = torch.randint(spec["s_range"][0], spec["s_range"][1], (B,), generator=g).tolist()
+    P = torch.randint(spec["p_range"][0], spec["p_range"][1], (B,), generator=g).tolist()
+    return [(S[b], P[b], spec["iseed0"] + 1 + b) for b in range(B)]
+
+
+def run_spec(name, spec):
+    cfg = vo.OracleConfig(**spec["cfg"])
+    sd32 = vo.make_state_dict(cfg, spec["wseed"])
+    shapes = utterance_shapes(spec)
+    out = dict(B=np.int32(spec["B"]), wseed=np.int32(spec["wseed"]), max_new=np.int32(spec["max_new"]),
+               ar_steps=np.asarray(spec["ar_steps"], dtype=np.int32), torch_version=np.bytes_(torch.__version__))
+    for k, v in spec["cfg"].items():
+        out[f"cfg_{k}"] = np.asarray(v)
+    for variant in spec["variants"]:
+        sd = sd32 if variant == "fp32" else vo.fp8w_state_dict(sd32)
+        G_max = spec["max_new"]
+        B = spec["B"]
+        codes = np.full((B, G_max, 8), -1, dtype=np.int16)
+        gl = np.zeros(B, dtype=np.int32)
+        ar_lg = np.zeros((B, len(spec["ar_steps"]), 1025), dtype=np.float16)
+        ar_margin = np.zeros((B, G_max + 1), dtype=np.float32)
+        ar_sigma = np.zeros(B, dtype=np.float32)
+        nar_rows = np.zeros((B, spec["nar_rows"]), dtype=np.int32)
+        nar_lg = np.zeros((B, 7, spec["nar_rows"], 1024), dtype=np.float16)
+        nar_margin = np.zeros((B, 7, G_max), dtype=np.float32)
+        nar_sigma = np.zeros((B, 7), dtype=np.float32)
+        t0 = time.time()
+        for b, (S, P, iseed) in enumerate(shapes):
+            x, xl, y = vo.make_inputs(S, P, iseed)
+            tr = {}
+            try:
+                c = vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True, max_new=spec["max_new"], trace=tr)
+            except SyntaxError:  # EOS as the very first arg-max (valle.py:1049-1052): an utterance of 0 frames in a batch
+                print(f"[{name}/{variant}] utterance {b}: EOS at step 0", flush=True)
+                continue
+            G = c.shape[1]
+            gl[b] = G
+            codes[b, :G] = c[0].numpy().astype(np.int16)
+            al = torch.stack(tr["ar_logits"])  # (G + 1, 1025)
+            top2 = torch.topk(al, 2, dim=-1)[0]
+            ar_margin[b, : G + 1] = (top2[:, 0] - top2[:, 1]).numpy()
+            ar_sigma[b] = al.std().item()
+            for j, stp in enumerate(spec["ar_steps"]):
+                if stp <= G:
+                    ar_lg[b, j] = al[stp].numpy().astype(np.float16)
+            rows = np.linspace(0, G - 1, spec["nar_rows"]).astype(np.int32)
+            nar_rows[b] = rows
+            for i in range(7):
+                nl = tr["nar_logits"][i]  # (G, 1024)
+                nar_lg[b, i] = nl[rows].numpy().astype(np.float16)
+                t2 = torch.topk(nl, 2, dim=-1)[0]
+                nar_margin[b, i, :G] = (t2[:, 0] - t2[:, 1]).numpy()
+                nar_sigma[b, i] = nl.std().item()
+            print(f"[{name}/{variant}] utterance {b}: S={S} P={P} G={G}  ({time.time() - t0:.0f} s)", flush=True)
+        pre = "" if variant == "fp32" else "w8_"
+        out.update({pre + "codes": codes, pre + "gen_lens": gl, pre + "ar_logits_f16": ar_lg, pre + "ar_margin": ar_margin,
+                    pre + "ar_sigma": ar_sigma, pre + "nar_rows": nar_rows, pre + "nar_logits_f16": nar_lg,
+                    pre + "nar_margin": nar_margin, pre + "nar_sigma": nar_sigma})
+    os.makedirs(OUT_DIR, exist_ok=True)
+    path = os.path.join(OUT_DIR, f"{name}.npz")
+    np.savez_compressed(path, **out)
+    print(f"[fixture] {name} -> {path} ({os.path.getsize(path) / 1024:.0f} KiB)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default=None)
+    ap.add_argument("--threads", type=int, default=8)
+    args = ap.parse_args()
+    torch.set_num_threads(args.threads)
+    for name, spec in SPECS.items():
+        if args.only and name != args.only:
+            continue
+        run_spec(name, spec)
+
+
+if __name__ == "__main__":
+    main()

@@ -63,6 +63,22 @@ def main():
         assert k not in ckpt
         ckpt[k] = v
     torch.save(ckpt, os.path.join(OUT, "ckpt_tiny.pt"))
+
+    # the same layout at a shape the HIP engine runs (d_model % 32 == 0): the GPU test goes file -> engine -> codes
+    torch.manual_seed(1)
+    hp2 = dict(hp, decoder_dim=32, nhead=2, num_decoder_layers=2)
+    model2 = vm.get_model(AttributeDict(hp2)).eval()
+    ckpt2 = {"model": model2.state_dict(), "model_avg": None, "optimizer": None, "scheduler": None, "grad_scaler": None, "sampler": None}
+    for k, v in dict(params, **hp2).items():
+        ckpt2[k] = v
+    torch.save(ckpt2, os.path.join(OUT, "ckpt_d32.pt"))
+    # and the reference's own decode of a seeded input with that model, so the test needs no reference at run time
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import valle_oracle as vo
+    x, xl, y = vo.make_inputs(7, 11, seed=42)
+    with torch.no_grad():
+        codes = model2.inference(x, xl, y, enroll_x_lens=None, top_k=1, temperature=1.0)
+    torch.save({"x": x, "x_lens": xl, "y": y, "codes": codes}, os.path.join(OUT, "ckpt_d32_decode.pt"))
     print("wrote", OUT, sorted(os.listdir(OUT)))
 
 

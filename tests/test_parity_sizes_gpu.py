@@ -1,0 +1,309 @@
+"""GPU parity AT THE SIZES THE NUMBERS ARE QUOTED ON (BASELINE.json configs[1], [2]/[3], [4]):
+
+  C2  d1024-L12-h16, one utterance, S=47 / P=225 -> G=753 -- against a golden produced by the UNMODIFIED reference at that
+      exact size (tests/golden/c2_d1024_L12_full.npz, oracle/make_golden.py): fp32 engine token-exact over 753 x 8 ids;
+      bf16 engine teacher-forced on the reference's history over ALL 753 AR steps and the 7 NAR stages.
+  C3  64 DISTINCT ragged utterances at d1024-L12 in one batch -- against 64 independent oracle calls
+      (tests/golden/oracle/c3_b64_d1024.npz, oracle/make_fixtures_oracle.py): fp32 token-exact; bf16 batch path
+      (LayerNorm-fused gemm_skinny.hip + decode attention) teacher-forced.
+  C5  the d1536-L24-h16 (dh 96) architecture as a whole model, bf16 on the fp32 weights and FP8W on W'.
+
+Bars (stated in BASELINE.json north_star / SURVEY.md 8c): fp32 mode token ids bit-identical; bf16 / fp8w teacher-forced
+max|dlogit| <= 5 % of sigma_logit, mean <= 1 %, and token equality wherever the reference's top1-top2 margin > 2 tau.
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import valle_amd  # noqa: E402
+from oracle import valle_oracle as vo  # noqa: E402
+from oracle.make_fixtures_oracle import SPECS, utterance_shapes  # noqa: E402
+from tests.golden_util import GOLDEN_DIR, load_case  # noqa: E402
+
+DEV = "cuda:0"
+TAU = 0.05  # fraction of sigma_logit (max); mean bar 0.01
+
+
+def build_model(cfg, sd, dtype, **kw):
+    m = valle_amd.VALLE(cfg.d_model, cfg.nhead, cfg.num_layers, prefix_mode=cfg.prefix_mode, engine_dtype=dtype, **kw)
+    m.load_state_dict(sd, strict=True)
+    return m.to(DEV).eval()
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# C2 at full size, against the reference itself
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c2_full():
+    return load_case("c2_d1024_L12_full")
+
+
+def test_c2_full_size_fp32_token_exact_vs_reference(c2_full):
+    """BASELINE.json configs[1] shape, fp32 engine: 753 x 8 ids bit-identical to the reference's run of the same size."""
+    case = c2_full
+    z = case["z"]
+    m = build_model(case["cfg"], case["sd"], "fp32")
+    eng = m.engine_for(1, 47, 225)
+    eng.set_option("trace_ar_logits", 1)
+    codes = m.inference(case["x"].to(DEV), case["x_lens"].to(DEV), case["y"].to(DEV), None, top_k=1).cpu()
+    assert codes.shape == (1, 753, 8)
+    nd = int((codes != case["codes"]).sum())
+    assert nd == 0, f"{nd} of {codes.numel()} token ids differ from the reference"
+    mine = eng.fetch_ar_logits()[:, 0]
+    ref = torch.from_numpy(z["ar_logits_all_f16"].astype(np.float32))
+    assert mine.shape == ref.shape == (754, 1025)
+    sigma = float(z["ar_logit_std"])
+    # fp16 storage of the golden: |err| <= 2^-11 |logit| (~2e-3 at |logit| 4)
+    assert (mine - ref).abs().max().item() <= 2e-3 * max(1.0, sigma) + 2.5e-3
+    strided = torch.from_numpy(z["ar_logits"])
+    assert (mine[:: int(z["ar_stride"])] - strided).abs().max().item() <= 2e-3 * max(1.0, sigma)
+
+
+def test_c2_full_size_bf16_teacher_forced_all_steps(c2_full):
+    """bf16 engine (the benchmark's mode) forced on the reference's 753-token history: every step's logits within
+    5 % sigma (mean 1 %), tokens equal wherever the reference's margin allows, and the same for the 7 NAR stages
+    (teacher-forced through vle_nar_force)."""
+    case = c2_full
+    z = case["z"]
+    m = build_model(case["cfg"], case["sd"], "bf16")
+    eng = m.engine_for(1, 47, 225)
+    eng.set_option("trace_ar_logits", 1)
+    eng.set_option("trace_nar_logits", 1)
+    ref_codes = case["codes"][0]           # (753, 8)
+    ref_tokens = ref_codes[:, 0]
+    eng.prefill(case["x"].to(DEV), [47], case["y"].to(DEV), [225])
+    _, gl = eng.generate(top_k=1, forced=ref_tokens[None].to(DEV), forced_lens=[753])
+    assert gl == [753]
+    mine = eng.fetch_ar_logits()[:, 0]
+    ref = torch.from_numpy(z["ar_logits_all_f16"].astype(np.float32))
+    sigma = float(z["ar_logit_std"])
+    diff = (mine - ref).abs()
+    assert diff.max().item() <= TAU * sigma, (diff.max().item(), sigma)
+    assert diff.mean().item() <= 0.01 * sigma
+    sampled = eng.fetch_sampled()[0, :753]
+    margin = torch.from_numpy(z["ar_margin"][:753])
+    safe = margin > 2 * TAU * sigma
+    assert torch.equal(sampled[safe], ref_tokens[safe])
+    agree = (sampled == ref_tokens).float().mean().item()
+    print(f"C2 full bf16: AR max|dlogit| {diff.max().item():.4f} mean {diff.mean().item():.5f} (sigma {sigma:.3f}); argmax agreement {agree:.4f}")
+    assert agree > 0.95
+    # NAR stages, teacher-forced on the reference's codes
+    codes = eng.nar(None, forced=ref_codes[None]).cpu()[0]
+    assert torch.equal(codes[:, 0], ref_tokens)
+    rows = z["nar_rows"]
+    for i in range(7):
+        lg = eng.fetch_nar_logits(i)
+        s_i = float(z["nar_logit_std"][i])
+        d_i = (lg[rows] - torch.from_numpy(z["nar_logits"][i])).abs()
+        assert d_i.max().item() <= TAU * s_i, (i, d_i.max().item(), s_i)
+        safe_i = torch.from_numpy(z["nar_margin"][i]) > 2 * TAU * s_i
+        assert torch.equal(codes[safe_i, i + 1], ref_codes[safe_i, i + 1]), f"NAR stage {i}: a safe-margin code differs"
+    nar_agree = (codes[:, 1:] == ref_codes[:, 1:]).float().mean().item()
+    print(f"C2 full bf16: NAR code agreement {nar_agree:.4f}")
+    assert nar_agree > 0.9
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# C3 shape: 64 distinct ragged utterances at d1024-L12 against 64 oracle calls
+# ------------------------------------------------------------------------------------------------------------------------
+def _load_fixture(name):
+    path = os.path.join(GOLDEN_DIR, "oracle", f"{name}.npz")
+    z = np.load(path)
+    spec = SPECS[name]
+    cfg = vo.OracleConfig(**{k[4:]: z[k].item() for k in z.files if k.startswith("cfg_")})
+    shapes = utterance_shapes(spec)
+    B = len(shapes)
+    Smax, Pmax = max(s for s, _, _ in shapes), max(p for _, p, _ in shapes)
+    X = torch.zeros(B, Smax, dtype=torch.int64)
+    Y = torch.zeros(B, Pmax, 8, dtype=torch.int64)
+    for b, (S, P, seed) in enumerate(shapes):
+        x, _, y = vo.make_inputs(S, P, seed)
+        X[b, :S], Y[b, :P] = x[0], y[0]
+    return z, spec, cfg, shapes, X, Y
+
+
+def _check_forced_batch(eng, z, spec, shapes, X, Y, pre=""):
+    """Teacher-force the batch on the oracle's per-utterance histories; compare AR logits at the stored steps, the
+    sampled tokens at safe margins, and the NAR stages (forced) at the stored rows."""
+    B = len(shapes)
+    S = [s for s, _, _ in shapes]
+    P = [p for _, p, _ in shapes]
+    gl_ref = [int(v) for v in z[pre + "gen_lens"]]
+    codes_ref = torch.from_numpy(z[pre + "codes"].astype(np.int64))  # (B, Gmax, 8), -1 beyond G_b
+    forced = codes_ref[..., 0].clamp_min(0)
+    eng.set_option("trace_ar_logits", 1)
+    eng.set_option("trace_nar_logits", 1)
+    eng.prefill(X.to(DEV), S, Y.to(DEV), P)
+    _, gl = eng.generate(top_k=1, forced=forced.to(DEV), forced_lens=gl_ref, allow_empty=True)
+    assert gl == gl_ref
+    lg = eng.fetch_ar_logits()  # (steps + 1, B, 1025)
+    sampled = eng.fetch_sampled()
+    steps = [int(v) for v in z["ar_steps"]]
+    worst, n_tok, n_agree = 0.0, 0, 0
+    for b in range(B):
+        G = gl_ref[b]
+        if G == 0:
+            continue
+        sigma = float(z[pre + "ar_sigma"][b])
+        for j, stp in enumerate(steps):
+            if stp > G:
+                continue
+            d = (lg[stp, b] - torch.from_numpy(z[pre + "ar_logits_f16"][b, j].astype(np.float32))).abs().max().item()
+            worst = max(worst, d / sigma)
+            assert d <= TAU * sigma + 2.5e-3, (b, stp, d, sigma)
+        margin = torch.from_numpy(z[pre + "ar_margin"][b, :G])
+        safe = margin > 2 * TAU * sigma
+        assert torch.equal(sampled[b, :G][safe], codes_ref[b, :G, 0][safe]), f"utterance {b}: a safe-margin AR token differs"
+        n_tok += G
+        n_agree += int((sampled[b, :G] == codes_ref[b, :G, 0]).sum())
+    codes = eng.nar(None, forced=codes_ref.clamp_min(0)).cpu()
+    off, nar_tok, nar_agree = 0, 0, 0
+    for b in range(B):
+        G = gl_ref[b]
+        if G == 0:
+            continue
+        assert torch.equal(codes[b, :G, 0], codes_ref[b, :G, 0])
+        rows = z[pre + "nar_rows"][b]
+        for i in range(7):
+            s_i = float(z[pre + "nar_sigma"][b, i])
+            mine = eng.fetch_nar_logits(i)[off: off + G]
+            d = (mine[rows] - torch.from_numpy(z[pre + "nar_logits_f16"][b, i].astype(np.float32))).abs().max().item()
+            assert d <= TAU * s_i + 0.02, (b, i, d, s_i)  # fp16 storage of logits of magnitude ~50: +-0.02
+            safe = torch.from_numpy(z[pre + "nar_margin"][b, i, :G]) > 2 * TAU * s_i + 0.04
+            assert torch.equal(codes[b, :G, i + 1][safe], codes_ref[b, :G, i + 1][safe]), f"utterance {b} NAR stage {i}"
+        nar_tok += 7 * G
+        nar_agree += int((codes[b, :G, 1:] == codes_ref[b, :G, 1:]).sum())
+        off += G
+    print(f"forced batch ({pre or 'fp32-weights'}): worst AR |dlogit|/sigma {worst:.4f}; AR argmax agreement {n_agree / max(n_tok, 1):.4f}; "
+          f"NAR agreement {nar_agree / max(nar_tok, 1):.4f}")
+    assert n_agree / max(n_tok, 1) > 0.95 and nar_agree / max(nar_tok, 1) > 0.9
+
+
+@pytest.fixture(scope="module")
+def c3_fixture():
+    z, spec, cfg, shapes, X, Y = _load_fixture("c3_b64_d1024")
+    sd = vo.make_state_dict(cfg, int(z["wseed"]))
+    return z, spec, cfg, shapes, X, Y, sd
+
+
+def test_c3_batch64_distinct_fp32_token_exact_vs_64_oracle_calls(c3_fixture):
+    z, spec, cfg, shapes, X, Y, sd = c3_fixture
+    B = len(shapes)
+    m = build_model(cfg, sd, "fp32", max_batch=B)
+    S = [s for s, _, _ in shapes]
+    P = [p for _, p, _ in shapes]
+    out = m.inference_batch(X.to(DEV), torch.tensor(S, dtype=torch.int32), Y.to(DEV), P, None, top_k=1, max_new=int(z["max_new"]))
+    codes_ref = torch.from_numpy(z["codes"].astype(np.int64))
+    for b in range(B):
+        G = int(z["gen_lens"][b])
+        assert out[b].shape == (G, 8), (b, out[b].shape, G)
+        assert torch.equal(out[b].cpu(), codes_ref[b, :G]), f"utterance {b}: {(out[b].cpu() != codes_ref[b, :G]).sum().item()} ids differ"
+
+
+def test_c3_batch64_distinct_bf16_batch_path_teacher_forced(c3_fixture):
+    """The bf16 AR batch path (gemm_skinny.hip with the fused LayerNorm, fragment-major layouts, decode attention) and the
+    packed NAR passes at d1024-L12, 64 distinct ragged utterances, each against ITS OWN oracle call."""
+    z, spec, cfg, shapes, X, Y, sd = c3_fixture
+    B = len(shapes)
+    m = build_model(cfg, sd, "bf16", max_batch=B)
+    eng = m.engine_for(B, X.shape[1], Y.shape[1])
+    _check_forced_batch(eng, z, spec, shapes, X, Y)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# C5 architecture (d1536-L24-h16, dh 96): bf16 and FP8W whole-model parity
+# ------------------------------------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def c5_fixture():
+    z, spec, cfg, shapes, X, Y = _load_fixture("c5_d1536_L24")
+    sd = vo.make_state_dict(cfg, int(z["wseed"]))
+    return z, spec, cfg, shapes, X, Y, sd
+
+
+@pytest.mark.parametrize("dtype,pre", [("bf16", ""), ("fp8w", "w8_")])
+def test_c5_architecture_whole_model_teacher_forced(c5_fixture, dtype, pre):
+    """BASELINE.json configs[4] architecture: the bf16 engine against the oracle on the fp32 weights, the FP8W engine
+    against the oracle on W' = e4m3fn-representable weights (oracle.fp8w_state_dict); batch of 3 (batch path) and
+    utterance 0 alone (batch-1 GEMV path)."""
+    z, spec, cfg, shapes, X, Y, sd = c5_fixture
+    B = len(shapes)
+    m = build_model(cfg, sd, dtype, max_batch=B)
+    eng = m.engine_for(B, X.shape[1], Y.shape[1])
+    _check_forced_batch(eng, z, spec, shapes, X, Y, pre)
+    # utterance 0 alone: the batch-1 kernels (gemv1.hip; fp8 GEMV in FP8W mode)
+    S0, P0, _ = shapes[0]
+    G0 = int(z[pre + "gen_lens"][0])
+    ref0 = torch.from_numpy(z[pre + "codes"][0, :G0].astype(np.int64))
+    eng.set_option("trace_ar_logits", 1)
+    eng.prefill(X[:1, :S0].contiguous().to(DEV), [S0], Y[:1, :P0].contiguous().to(DEV), [P0])
+    _, gl = eng.generate(top_k=1, forced=ref0[None, :, 0].contiguous().to(DEV), forced_lens=[G0])
+    assert gl == [G0]
+    lg = eng.fetch_ar_logits()[:, 0]
+    sigma = float(z[pre + "ar_sigma"][0])
+    for j, stp in enumerate(int(v) for v in z["ar_steps"]):
+        if stp <= G0:
+            d = (lg[stp] - torch.from_numpy(z[pre + "ar_logits_f16"][0, j].astype(np.float32))).abs().max().item()
+            assert d <= TAU * sigma + 2.5e-3, (stp, d, sigma)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# formats -> engine: a reference-written checkpoint file decodes like the oracle
+# ------------------------------------------------------------------------------------------------------------------------
+def test_reference_checkpoint_file_to_engine_equals_reference_decode():
+    """valle_amd.load_checkpoint(tests/golden/formats/ckpt_d32.pt) -- a file in the trainer's icefall layout holding a
+    REFERENCE VALLE's state dict (oracle/make_golden_formats.py) -> HIP-backed model on the GPU -> inference() ==
+    the reference's own decode of the same seeded input (stored beside it), and == the oracle on that state dict."""
+    path = os.path.join(GOLDEN_DIR, "formats", "ckpt_d32.pt")
+    model, text_tokens = valle_amd.load_checkpoint(path, device=DEV, engine_dtype="fp32")
+    assert text_tokens == "data/tokenized/unique_text_tokens.k2symbols"
+    ref = torch.load(os.path.join(GOLDEN_DIR, "formats", "ckpt_d32_decode.pt"), map_location="cpu", weights_only=False)
+    got = model.inference(ref["x"].to(DEV), ref["x_lens"].to(DEV), ref["y"].to(DEV), None, top_k=1).cpu()
+    assert got.shape == ref["codes"].shape and torch.equal(got, ref["codes"])
+    sd = torch.load(path, map_location="cpu", weights_only=False)["model"]
+    cfg = vo.OracleConfig(d_model=32, nhead=2, num_layers=2, prefix_mode=1)
+    want = vo.inference(sd, cfg, ref["x"], ref["x_lens"], ref["y"], None, top_k=1, kv_cache=True)
+    assert torch.equal(got, want)
+
+
+# ------------------------------------------------------------------------------------------------------------------------
+# token-id range: IndexError like the reference's nn.Embedding, never an out-of-bounds gather
+# ------------------------------------------------------------------------------------------------------------------------
+def test_out_of_range_token_ids_raise_index_error():
+    cfg = vo.OracleConfig(d_model=64, nhead=4, num_layers=1, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 0)
+    m = build_model(cfg, sd, "fp32", max_batch=2)
+    x, xl, y = vo.make_inputs(5, 7)
+    good = m.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1).cpu()
+    for bad_x, bad_y in [(512, None), (-1, None), (None, (0, 1025)), (None, (3, 1024)), (None, (0, -5))]:
+        xx, yy = x.clone(), y.clone()
+        if bad_x is not None:
+            xx[0, 2] = bad_x
+        if bad_y is not None:
+            yy[0, 4, bad_y[0]] = bad_y[1]
+        with pytest.raises(IndexError):
+            m.inference(xx.to(DEV), xl.to(DEV), yy.to(DEV), None, top_k=1)
+    # ids beyond the stated lengths are padding and must NOT raise; the engine still works afterwards
+    xp = torch.cat([x, torch.full((1, 3), 9999)], dim=1)
+    again = m.inference_batch(xp.to(DEV), xl, y.to(DEV), [7], None, top_k=1)[0].cpu()
+    assert torch.equal(again, good[0])
+    # EOS (1024) is a valid first-codebook id
+    yy = y.clone()
+    yy[0, 2, 0] = 1024
+    m.inference(x.to(DEV), xl.to(DEV), yy.to(DEV), None, top_k=1)
+    # continual(): same rule
+    y2 = vo.make_inputs(5, 20)[2]
+    y2[0, 3, 5] = 1024
+    with pytest.raises(IndexError):
+        m.continual(x.to(DEV), xl.to(DEV), y2.to(DEV))
+    # forced history outside the vocabulary
+    eng = m.engine_for(1, 5, 7)
+    eng.prefill(x.to(DEV), [5], y.to(DEV), [7])
+    with pytest.raises(IndexError):
+        eng.generate(top_k=1, forced=torch.tensor([[5, 2000, 7]]), forced_lens=[3])
+    # block API
+    with pytest.raises(IndexError):
+        valle_amd.ops.token_embedding(torch.tensor([[1, 600]], device=DEV), m.ar_text_embedding.word_embeddings.weight)

@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvalle_engine.so")
 
 VLE_OK = 0
-VLE_EINVAL, VLE_ESTATE, VLE_EHIP, VLE_EKEY, VLE_ENOTOKEN = -1, -2, -3, -4, -5
+VLE_EINVAL, VLE_ESTATE, VLE_EHIP, VLE_EKEY, VLE_ENOTOKEN, VLE_EINDEX = -1, -2, -3, -4, -5, -6
 DTYPE_F32, DTYPE_BF16, DTYPE_FP8W = 0, 1, 2
 
 
@@ -39,6 +39,7 @@ SIGNATURES = {
     "vle_ar_prefill": (C.c_int, [_P, _P, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P, C.c_int32]),
     "vle_ar_generate": (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_uint64, C.c_int32, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P]),
     "vle_nar_decode": (C.c_int, [_P, _P, _I32P, _P, C.c_int64]),
+    "vle_nar_force": (C.c_int, [_P, _P, C.c_int64]),
     "vle_nar_continual": (C.c_int, [_P, _P, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P, C.c_int32, _P, C.c_int64, _I32P]),
     "vle_slots_begin": (C.c_int, [_P, _P]),
     "vle_slots_prefill": (C.c_int, [_P, _P, C.c_int32, _I32P, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P, C.c_int32, C.c_float, C.c_uint64]),
@@ -102,4 +103,6 @@ def check(code: int, handle=None):
     if code == VLE_OK:
         return
     msg = load().vle_last_error(handle)
+    if code == VLE_EINDEX:  # what nn.Embedding raises in the reference (valle/modules/embedding.py:34,44)
+        raise IndexError(msg.decode() if msg else "token id out of range")
     raise VleError(code, msg.decode() if msg else "?")

@@ -99,6 +99,9 @@ struct vle_engine {
   int64_t *tokens = nullptr, *sampled = nullptr;  // [max_B][max_G]
   int64_t *text_ids = nullptr, *prompt_codes = nullptr;  // [max_B][max_S], [max_B][max_P + max_G][Q]
   int32_t* forced_len_dev = nullptr;
+  const int64_t* nar_forced = nullptr; int64_t nar_forced_stride = 0;  // vle_nar_force: consumed by the next NAR call
+  int32_t* id_err_dev = nullptr;  // token-id range flag (1 text, 2 prompt / continuation codes, 4 forced tokens): VLE_EINDEX
+  hipEvent_t ev_chk = nullptr;
   float *X = nullptr, *yemb = nullptr, *nar_logits = nullptr;
   void *Xn = nullptr, *QKV = nullptr, *ATT = nullptr, *Hb = nullptr;
   int32_t* tables_dev = nullptr;  // row tables
@@ -360,6 +363,7 @@ extern "C" int vle_create(const vle_config* c, vle_engine** out) {
   bool ok = chk(hipStreamCreateWithFlags(&e->st, hipStreamNonBlocking), "hipStreamCreate");
   ok = ok && chk(hipEventCreateWithFlags(&e->ev_in, hipEventDisableTiming), "hipEventCreate");
   ok = ok && chk(hipEventCreateWithFlags(&e->ev_out, hipEventDisableTiming), "hipEventCreate");
+  ok = ok && chk(hipEventCreateWithFlags(&e->ev_chk, hipEventDisableTiming), "hipEventCreate");
   for (int i = 0; i < 6 && ok; ++i) ok = chk(hipEventCreate(&e->ev_t[i]), "hipEventCreate");
   if (!ok) {
     vle_destroy(e);
@@ -385,6 +389,7 @@ extern "C" void vle_destroy(vle_engine* e) {
     if (e->ev_t[i]) (void)hipEventDestroy(e->ev_t[i]);
   if (e->ev_in) (void)hipEventDestroy(e->ev_in);
   if (e->ev_out) (void)hipEventDestroy(e->ev_out);
+  if (e->ev_chk) (void)hipEventDestroy(e->ev_chk);
   if (e->st) (void)hipStreamDestroy(e->st);
   delete e;
 }
@@ -634,6 +639,8 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->text_ids, (size_t)B * e->max_S))) return r;
   if ((r = dev_alloc(e, &e->prompt_codes, (size_t)B * (e->max_P + e->max_G) * 8))) return r;
   if ((r = dev_alloc(e, &e->forced_len_dev, B))) return r;
+  if ((r = dev_alloc(e, &e->id_err_dev, 4))) return r;
+  E_HIP(e, hipMemset(e->id_err_dev, 0, 4 * sizeof(int32_t)));
   const int64_t R = e->max_rows;
   if ((r = dev_alloc(e, &e->X, (size_t)R * d))) return r;
   if ((r = dev_alloc(e, &p, (size_t)R * d * es))) return r;
@@ -689,6 +696,10 @@ int leave(vle_engine* e, void* caller_stream) {
 inline void* cache_layer(vle_engine* e, void* base, int l) {
   return (char*)base + (size_t)l * e->B * e->H * e->ctx_max * e->dh * dtype_size(e->dtype);
 }
+
+const char* kIdErrMsg = "token id out of range: text ids must be in [0, 512), first-codebook ids in [0, 1024], the other "
+                        "codebooks in [0, 1024) (the reference's nn.Embedding raises IndexError)";
+constexpr int POLL_IDERR = 40;  // poll_host slot of the id-range flag
 
 // one transformer layer over packed rows (prefill: AR weights + prefix-LM mask; NAR: no mask, folded AdaLN)
 int enqueue_layer_rows(vle_engine* e, const LayerW& w, const float* g1, const float* b1, const float* g2, const float* b2,
@@ -773,7 +784,7 @@ int enqueue_ar_sample(vle_engine* e, int first, const int32_t* slot_map = nullpt
   ProfScope ps(e, 6);
   ArSampleArgs a{};
   a.s = e->S; a.dyn = e->dyn_dev; a.logits = e->logits; a.V = V_AR; a.B = slot_map ? nslots : e->B; a.d = e->d; a.bos = e->bos; a.first = first;
-  a.slot_map = slot_map;
+  a.slot_map = slot_map; a.id_err = e->id_err_dev;
   a.tokens = e->tokens; a.g_stride = e->max_G; a.sampled = e->sampled;
   a.audio_emb = e->ar_audio_emb; a.pe = e->pe; a.alpha_audio = e->alphas + 1; a.x = e->x_step; a.ctx_max = e->ctx_max;
   E_LAUNCH(e, launch_ar_sample(e->st, a));
@@ -958,20 +969,22 @@ extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, 
     rows += n;
     max_len = std::max(max_len, n);
   }
-  int32_t *h_seq_off, *h_text_len, *h_row_seq, *h_row_pos, *h_last, *h_state;
+  int32_t *h_seq_off, *h_text_len, *h_row_seq, *h_row_pos, *h_last, *h_state, *h_prompt_len;
   int32_t* d_seq_off = tb.take(B + 1, &h_seq_off);
   int32_t* d_text_len = tb.take(B, &h_text_len);
+  int32_t* d_prompt_len = tb.take(B, &h_prompt_len);
   int32_t* d_row_seq = tb.take(rows, &h_row_seq);
   int32_t* d_row_pos = tb.take(rows, &h_row_pos);
   int32_t* d_last = tb.take(B, &h_last);
   int32_t* d_state = tb.take(6 * e->max_B + 8, &h_state);
-  if (!d_seq_off || !d_text_len || !d_row_seq || !d_row_pos || !d_last || !d_state) return e->fail(VLE_EINVAL, "table overflow");
+  if (!d_seq_off || !d_text_len || !d_prompt_len || !d_row_seq || !d_row_pos || !d_last || !d_state) return e->fail(VLE_EINVAL, "table overflow");
   int64_t off = 0;
   memset(h_state, 0, (6 * e->max_B + 8) * sizeof(int32_t));
   for (int b = 0; b < B; ++b) {
     const int n = text_lens[b] + e->bos + prompt_lens[b];
     h_seq_off[b] = (int32_t)off;
     h_text_len[b] = text_lens[b];
+    h_prompt_len[b] = prompt_lens[b];
     for (int p = 0; p < n; ++p) {
       h_row_seq[off + p] = b;
       h_row_pos[off + p] = p;
@@ -985,6 +998,13 @@ extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, 
   h_seq_off[B] = (int32_t)off;
   E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
   E_HIP(e, hipMemcpyAsync(e->state_dev, d_state, (6 * e->max_B + 8) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  // id range check on the engine-owned copies (sanitises them); the flag is read at the end of this call, by which
+  // time these three tiny operations have long completed -- no stall of the stream
+  E_HIP(e, hipMemsetAsync(e->id_err_dev, 0, sizeof(int32_t), st));
+  E_LAUNCH(e, launch_check_ids(st, e->text_ids, e->max_S, 1, 1, d_text_len, nullptr, B, e->max_S, NUM_TEXT_TOKENS, 0, e->id_err_dev, 1));
+  E_LAUNCH(e, launch_check_ids(st, e->prompt_codes, pp, e->Q, e->Q, d_prompt_len, nullptr, B, e->max_P, V_AR, NUM_AUDIO_TOKENS, e->id_err_dev, 2));
+  E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_IDERR, e->id_err_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  E_HIP(e, hipEventRecord(e->ev_chk, st));
 
   PrefillEmbedArgs pa{};
   pa.text = e->text_ids; pa.s_stride = e->max_S; pa.prompt = e->prompt_codes; pa.p_stride = e->max_P + e->max_G; pa.Q = e->Q;
@@ -1001,6 +1021,11 @@ extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, 
   E_LAUNCH(e, launch_gather_rows(st, e->X, d_last, e->x_step, B, e->d));
   if ((r = enqueue_ar_logits(e))) return r;
   E_HIP(e, hipEventRecord(e->ev_t[1], st));
+  E_HIP(e, hipEventSynchronize(e->ev_chk));
+  if (e->poll_host[POLL_IDERR] != 0) {
+    (void)leave(e, stream);
+    return e->fail(VLE_EINDEX, kIdErrMsg);
+  }
   e->have_prefill = true;
   return leave(e, stream);
 }
@@ -1055,6 +1080,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
     memcpy(hf, forced_lens, B * sizeof(int32_t));
     E_HIP(e, hipMemcpyAsync(e->forced_len_dev, hf, B * sizeof(int32_t), hipMemcpyHostToDevice, st));
   }
+  E_HIP(e, hipMemsetAsync(e->id_err_dev, 0, sizeof(int32_t), st));
   E_HIP(e, hipEventRecord(e->ev_t[2], st));
 
   // iteration 0: sample from the prefill's logits
@@ -1115,6 +1141,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   // results
   std::vector<int32_t> st_host(6 * e->max_B + 8);
   E_HIP(e, hipMemcpyAsync(e->tables_host, e->state_dev, st_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_IDERR, e->id_err_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   if (codes0)
     E_HIP(e, hipMemcpy2DAsync(codes0, g_stride * sizeof(int64_t), e->tokens, e->max_G * sizeof(int64_t),
                               std::min<int64_t>(g_stride, e->max_G) * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
@@ -1144,6 +1171,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   if (hipEventElapsedTime(&ms, e->ev_t[0], e->ev_t[1]) == hipSuccess) e->t_prefill = ms;
   e->have_gen = true;
   if ((r = leave(e, stream))) return r;
+  if (e->poll_host[POLL_IDERR] != 0) return e->fail(VLE_EINDEX, "forced token id outside the audio vocabulary (the reference's nn.Embedding raises IndexError)");
   if (not_done) return e->fail(VLE_ESTATE, "AR loop ended with unfinished utterances (capacity too small?)");
   if (no_token) return e->fail(VLE_ENOTOKEN, "well trained model shouldn't reach here.");
   return VLE_OK;
@@ -1275,6 +1303,7 @@ static int run_nar(vle_engine* e, const std::vector<int32_t>& drop, int mode, in
     aa.prompt_len = d_pl; aa.codes = codes; aa.g_stride = g_stride; aa.Q = Q; aa.col = i + 1;
     aa.next_emb = i < Q - 2 ? e->nar_audio_emb[i + 1] : nullptr;  // valle.py:1133-1134
     aa.y_emb = e->yemb; aa.d = d;
+    aa.forced = e->nar_forced; aa.f_stride = e->nar_forced_stride;
     E_LAUNCH(e, launch_nar_argmax(st, aa));
     if (mode == 0 && i < Q - 2) E_LAUNCH(e, launch_nar_yemb_add_prompt(st, na, i + 1));  // valle.py:1104-1107
   }
@@ -1307,9 +1336,19 @@ extern "C" int vle_nar_decode(vle_engine* e, void* stream, const int32_t* enroll
     if (e->G_len[b] > g_stride) return e->fail(VLE_EINVAL, "g_stride smaller than generated length");
   int r;
   if ((r = enter(e, stream))) return r;
-  if ((r = run_nar(e, drop, mode, codes, g_stride))) return r;
+  r = run_nar(e, drop, mode, codes, g_stride);
+  e->nar_forced = nullptr;  // one-shot
+  if (r) return r;
   if ((r = finish_nar_timing(e))) return r;
   return leave(e, stream);
+}
+
+extern "C" int vle_nar_force(vle_engine* e, const int64_t* forced_codes, int64_t f_stride) {
+  if (!e) return VLE_EINVAL;
+  if (forced_codes && f_stride < 1) return e->fail(VLE_EINVAL, "f_stride must be >= 1");
+  e->nar_forced = forced_codes;
+  e->nar_forced_stride = f_stride;
+  return VLE_OK;
 }
 
 extern "C" int vle_nar_continual(vle_engine* e, void* stream, const int64_t* text, int64_t s_stride, const int32_t* text_lens,
@@ -1320,30 +1359,56 @@ extern "C" int vle_nar_continual(vle_engine* e, void* stream, const int64_t* tex
   if (e->Q != 8) return e->fail(VLE_EINVAL, "continual() asserts num_quantizers == 8 (valle.py:1160)");
   if (!text || !text_lens || !y_codes || !y_lens || !codes || !gen_lens) return e->fail(VLE_EINVAL, "null argument");
   if (B < 1 || B > e->max_B) return e->fail(VLE_EINVAL, "batch exceeds max_batch");
-  e->S_len.assign(B, 0); e->P_len.assign(B, 0); e->G_len.assign(B, 0);
+  // validate into locals; the engine's per-call state is committed only after every check passed
+  std::vector<int32_t> S_new(B, 0), P_new(B, 0), G_new(B, 0);
   for (int b = 0; b < B; ++b) {
     if (text_lens[b] < 1 || text_lens[b] > e->max_S || text_lens[b] > s_stride) return e->fail(VLE_EINVAL, "text_lens out of range");
     if (y_lens[b] < 1 || y_lens[b] > t_stride || y_lens[b] > e->max_P + e->max_G) return e->fail(VLE_EINVAL, "y_lens out of range");
     const int prefix = std::min((int)(y_lens[b] * 0.5), 3 * 75);  // valle.py:1173
-    e->S_len[b] = text_lens[b]; e->P_len[b] = prefix; e->G_len[b] = y_lens[b] - prefix;
-    if (e->P_len[b] > e->max_P + e->max_G || e->G_len[b] > e->max_G || e->G_len[b] > g_stride) return e->fail(VLE_EINVAL, "capacity exceeded");
-    gen_lens[b] = e->G_len[b];
+    S_new[b] = text_lens[b]; P_new[b] = prefix; G_new[b] = y_lens[b] - prefix;
+    if (P_new[b] > e->max_P + e->max_G || G_new[b] > e->max_G || G_new[b] > g_stride) return e->fail(VLE_EINVAL, "capacity exceeded");
   }
   int r;
   if ((r = enter(e, stream))) return r;
   hipStream_t st = e->st;
+  // commit point: this call replaces whatever prefill / generate / slot state the engine held
   e->B = B;
+  e->slot_mode = false;
   e->have_prefill = e->have_gen = false;
+  e->S_len = S_new; e->P_len = P_new; e->G_len = G_new;
+  for (int b = 0; b < B; ++b) gen_lens[b] = G_new[b];
   E_HIP(e, hipMemcpy2DAsync(e->text_ids, e->max_S * sizeof(int64_t), text, s_stride * sizeof(int64_t),
                             std::min<int64_t>(s_stride, e->max_S) * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
   const int64_t pp = (int64_t)(e->max_P + e->max_G) * 8;
   E_HIP(e, hipMemcpy2DAsync(e->prompt_codes, pp * sizeof(int64_t), y_codes, t_stride * 8 * sizeof(int64_t),
                             std::min<int64_t>(t_stride, e->max_P + e->max_G) * 8 * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
-  // first codebook of the continuation: codes = [y[:, prefix_len:, 0]] (valle.py:1178)
+  {  // id range check on the engine-owned copies: all 8 codebooks of the prefix rows, the first codebook of every row
+    TableBuilder tb0{e};
+    int32_t *h_s, *h_p, *h_t;
+    int32_t* d_s = tb0.take(B, &h_s);
+    int32_t* d_p = tb0.take(B, &h_p);
+    int32_t* d_t = tb0.take(B, &h_t);
+    if (!d_s || !d_p || !d_t) return e->fail(VLE_EINVAL, "table overflow");
+    for (int b = 0; b < B; ++b) {
+      h_s[b] = S_new[b]; h_p[b] = P_new[b]; h_t[b] = y_lens[b];
+    }
+    E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb0.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
+    E_HIP(e, hipMemsetAsync(e->id_err_dev, 0, sizeof(int32_t), st));
+    E_LAUNCH(e, launch_check_ids(st, e->text_ids, e->max_S, 1, 1, d_s, nullptr, B, e->max_S, NUM_TEXT_TOKENS, 0, e->id_err_dev, 1));
+    E_LAUNCH(e, launch_check_ids(st, e->prompt_codes, pp, 8, 8, d_p, nullptr, B, e->max_P + e->max_G, V_AR, NUM_AUDIO_TOKENS, e->id_err_dev, 2));
+    E_LAUNCH(e, launch_check_ids(st, e->prompt_codes, pp, 8, 1, d_t, nullptr, B, e->max_P + e->max_G, V_AR, 0, e->id_err_dev, 2));
+    E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_IDERR, e->id_err_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+    E_HIP(e, hipStreamSynchronize(st));  // run_nar below rebuilds the pinned table mirror
+    if (e->poll_host[POLL_IDERR] != 0) {
+      (void)leave(e, stream);
+      return e->fail(VLE_EINDEX, kIdErrMsg);
+    }
+  }
+  // first codebook of the continuation: codes = [y[:, prefix_len:, 0]] (valle.py:1178), from the checked copy
   for (int b = 0; b < B; ++b)
     if (e->G_len[b] > 0)
       E_HIP(e, hipMemcpy2DAsync(e->tokens + (size_t)b * e->max_G, sizeof(int64_t),
-                                y_codes + ((size_t)b * t_stride + e->P_len[b]) * 8, 8 * sizeof(int64_t), sizeof(int64_t),
+                                e->prompt_codes + ((size_t)b * pp + (size_t)e->P_len[b] * 8), 8 * sizeof(int64_t), sizeof(int64_t),
                                 e->G_len[b], hipMemcpyDeviceToDevice, st));
   std::vector<int32_t> drop(B, 0);
   const int mode = e->cfg.prefix_mode == 0 ? 0 : 1;
@@ -1435,9 +1500,10 @@ extern "C" int vle_slots_prefill(vle_engine* e, void* stream, int32_t n, const i
     rows += len;
     max_len = std::max(max_len, len);
   }
-  int32_t *h_seq_off, *h_tl_seq, *h_tl_slot, *h_row_seq, *h_row_pos, *h_last, *h_slots, *h_kv, *h_ap, *h_cap;
+  int32_t *h_seq_off, *h_tl_seq, *h_tl_slot, *h_row_seq, *h_row_pos, *h_last, *h_slots, *h_kv, *h_ap, *h_cap, *h_pl_seq;
   int32_t* d_seq_off = tb.take(n + 1, &h_seq_off);
   int32_t* d_tl_seq = tb.take(n, &h_tl_seq);            // attention: by sequence order
+  int32_t* d_pl_seq = tb.take(n, &h_pl_seq);
   int32_t* d_tl_slot = tb.take(e->max_B, &h_tl_slot);   // embedding: by slot id (row_seq holds slot ids)
   int32_t* d_row_seq = tb.take(rows, &h_row_seq);
   int32_t* d_row_pos = tb.take(rows, &h_row_pos);
@@ -1446,7 +1512,7 @@ extern "C" int vle_slots_prefill(vle_engine* e, void* stream, int32_t n, const i
   int32_t* d_kv = tb.take(n, &h_kv);
   int32_t* d_ap = tb.take(n, &h_ap);
   int32_t* d_cap = tb.take(n, &h_cap);
-  if (!d_seq_off || !d_tl_seq || !d_tl_slot || !d_row_seq || !d_row_pos || !d_last || !d_slots || !d_kv || !d_ap || !d_cap)
+  if (!d_seq_off || !d_tl_seq || !d_pl_seq || !d_tl_slot || !d_row_seq || !d_row_pos || !d_last || !d_slots || !d_kv || !d_ap || !d_cap)
     return e->fail(VLE_EINVAL, "table overflow");
   for (int b = 0; b < e->max_B; ++b) h_tl_slot[b] = e->S_len[b];
   int64_t off = 0;
@@ -1454,6 +1520,7 @@ extern "C" int vle_slots_prefill(vle_engine* e, void* stream, int32_t n, const i
     const int b = slots[i], len = text_lens[i] + e->bos + prompt_lens[i];
     h_seq_off[i] = (int32_t)off;
     h_tl_seq[i] = text_lens[i];
+    h_pl_seq[i] = prompt_lens[i];
     for (int p = 0; p < len; ++p) {
       h_row_seq[off + p] = b;
       h_row_pos[off + p] = p;
@@ -1467,6 +1534,17 @@ extern "C" int vle_slots_prefill(vle_engine* e, void* stream, int32_t n, const i
   }
   h_seq_off[n] = (int32_t)off;
   E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
+  // id range check on the slots' copies BEFORE any slot state changes on the device
+  E_HIP(e, hipMemsetAsync(e->id_err_dev, 0, sizeof(int32_t), st));
+  E_LAUNCH(e, launch_check_ids(st, e->text_ids, e->max_S, 1, 1, d_tl_seq, d_slots, n, e->max_S, NUM_TEXT_TOKENS, 0, e->id_err_dev, 1));
+  E_LAUNCH(e, launch_check_ids(st, e->prompt_codes, pp, e->Q, e->Q, d_pl_seq, d_slots, n, e->max_P, V_AR, NUM_AUDIO_TOKENS, e->id_err_dev, 2));
+  E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_IDERR, e->id_err_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  E_HIP(e, hipStreamSynchronize(st));
+  if (e->poll_host[POLL_IDERR] != 0) {
+    for (int i = 0; i < n; ++i) e->S_len[slots[i]] = 0;  // the slots stay free
+    (void)leave(e, stream);
+    return e->fail(VLE_EINDEX, kIdErrMsg);
+  }
   E_LAUNCH(e, launch_slot_state_init(st, e->state_dev, e->max_B, d_slots, d_kv, d_ap, d_cap, n));
 
   PrefillEmbedArgs pa{};

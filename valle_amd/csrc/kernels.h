@@ -198,6 +198,7 @@ struct ArSampleArgs {
   float* x;                                // [B][d] next step's input
   int ctx_max;
   const int32_t* slot_map = nullptr;       // slot API: block i serves utterance slot_map[i] (B = number of listed slots)
+  int32_t* id_err = nullptr;               // |= 4 when a forced token is outside the audio vocabulary (it is replaced by 0)
 };
 int launch_ar_sample(hipStream_t st, const ArSampleArgs& a);
 // slot API (continuous batching): per-slot AR state of newly admitted utterances; rows of X scattered to slot rows
@@ -215,6 +216,7 @@ struct NarArgmaxArgs {
   int64_t* codes; int64_t g_stride; int Q; int col;  // codes[b][g][col] = argmax
   const float* next_emb;  // table added to y_emb rows (null at the last stage)
   float* y_emb; int d;
+  const int64_t* forced = nullptr; int64_t f_stride = 0;  // parity hook: y_emb += next_emb[forced[b][g][col]] instead of the own arg-max
 };
 int launch_nar_argmax(hipStream_t st, const NarArgmaxArgs& a);
 
@@ -225,6 +227,9 @@ int launch_qkv_split(hipStream_t st, int dtype, const void* qkv, float* q, void*
 // merge decode-attention partials -> out[T][B][d]
 int launch_attn_combine(hipStream_t st, int dtype, const float* part_o, const float* part_ml, void* out, int B, int nhead,
                         int dh, int nsplit);
+// token-id range check + sanitise on the engine-owned input copies (flag |= code when an id is out of range; see misc.hip)
+int launch_check_ids(hipStream_t st, int64_t* ids, int64_t stride0, int row_stride, int inner, const int32_t* lens, const int32_t* slot_map,
+                     int n, int max_rows, int limit0, int limit_rest, int32_t* flag, int code);
 // codes[b][g][0] = first_cb[b][g] for the generated rows
 int launch_codes_set_first(hipStream_t st, const int64_t* first_cb, int64_t fc_stride, const int32_t* grow_seq,
                            const int32_t* grow_pos, int64_t rows, int64_t* codes, int64_t g_stride, int Q);

@@ -151,4 +151,36 @@ int launch_pack_w_frag(hipStream_t st, const void* src, void* dst, int N, int K,
   return 0;
 }
 
+// Range check of token ids on the engine-owned copies of the inputs (the reference's nn.Embedding raises IndexError,
+// valle/modules/embedding.py:34,44): utterance i's rows live at ids + (slot_map ? slot_map[i] : i) * stride0, rows are
+// row_stride ids apart and their first `inner` ids are checked; the first id of a row must be < limit0, the others < limit_rest.  An offending id is REPLACED by 0 (the
+// gathers downstream stay in bounds) and the flag is raised; the host turns the flag into VLE_EINDEX.
+__global__ __launch_bounds__(256) void check_ids_kernel(int64_t* __restrict__ ids, int64_t stride0, int row_stride, int inner,
+                                                        const int32_t* __restrict__ lens, const int32_t* __restrict__ slot_map, int n,
+                                                        int max_rows, int limit0, int limit_rest, int32_t* __restrict__ flag, int code) {
+  const int64_t t = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  if (t >= (int64_t)n * max_rows) return;
+  const int i = (int)(t / max_rows), r = (int)(t % max_rows);
+  if (r >= lens[i]) return;
+  int64_t* row = ids + (int64_t)(slot_map ? slot_map[i] : i) * stride0 + (int64_t)r * row_stride;
+  bool bad = false;
+  for (int j = 0; j < inner; ++j) {
+    const int64_t v = row[j];
+    if (v < 0 || v >= (j == 0 ? limit0 : limit_rest)) {
+      row[j] = 0;
+      bad = true;
+    }
+  }
+  if (bad) atomicOr(flag, code);
+}
+
+int launch_check_ids(hipStream_t st, int64_t* ids, int64_t stride0, int row_stride, int inner, const int32_t* lens, const int32_t* slot_map,
+                     int n, int max_rows, int limit0, int limit_rest, int32_t* flag, int code) {
+  if (n <= 0 || max_rows <= 0) return 0;
+  const int64_t total = (int64_t)n * max_rows;
+  hipLaunchKernelGGL(check_ids_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, ids, stride0, row_stride, inner, lens, slot_map,
+                     n, max_rows, limit0, limit_rest, flag, code);
+  return 0;
+}
+
 }  // namespace vle

@@ -179,7 +179,14 @@ __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
     if (n >= (int)a.g_stride || kvl >= a.ctx_max) stop = 1;  // capacity guard
     int next = sample;
     if (!stop) {
-      if (dyn.has_forced) next = (int)dyn.forced[(int64_t)b * dyn.forced_stride + n];
+      if (dyn.has_forced) {
+        const int64_t f = dyn.forced[(int64_t)b * dyn.forced_stride + n];
+        next = (int)f;
+        if (f < 0 || f >= (int64_t)a.V + a.bos) {  // outside ar_audio_embedding: the reference's nn.Embedding raises IndexError
+          next = 0;
+          if (a.id_err) atomicOr(a.id_err, 4);
+        }
+      }
       a.tokens[(int64_t)b * a.g_stride + n] = next;
       a.sampled[(int64_t)b * a.g_stride + n] = sample;
       a.s.n_gen[b] = n + 1;
@@ -236,7 +243,12 @@ __global__ __launch_bounds__(NARG_NW * 64) void nar_argmax_kernel(NarArgmaxArgs 
   const int b = a.grow_seq[r], g = a.grow_pos[r];
   if (lane == 0) a.codes[((int64_t)b * a.g_stride + g) * a.Q + a.col] = code;
   if (a.next_emb != nullptr) {
-    const float4* e = reinterpret_cast<const float4*>(a.next_emb + (int64_t)code * a.d);
+    int ecode = code;
+    if (a.forced != nullptr) {  // teacher-forced NAR (parity hook): the next stage sees the given history
+      const int64_t f = a.forced[((int64_t)b * a.f_stride + g) * a.Q + a.col];
+      ecode = f < 0 ? 0 : (f >= a.V ? a.V - 1 : (int)f);
+    }
+    const float4* e = reinterpret_cast<const float4*>(a.next_emb + (int64_t)ecode * a.d);
     float4* y = reinterpret_cast<float4*>(a.y_emb + ((int64_t)a.aoff[b] + a.prompt_len[b] + g) * a.d);
     for (int i = lane; i < (a.d >> 2); i += 64) {
       const float4 yv = y[i], ev = e[i];

@@ -41,28 +41,34 @@ def shard_range(n_items: int, rank: int, world: int) -> Tuple[int, int]:
 
 def gather_codes(local: Sequence[torch.Tensor], n_total: int, Q: int = 8, device=None) -> List[torch.Tensor] | None:
     """All ranks contribute their utterances' (G_b, Q) code matrices; every rank gets the full list in
-    global order.  Codes travel as int16 (< 1025), padded to the longest utterance."""
+    global order.  Codes travel as int16 (ids < 1025), padded to the longest utterance; the lengths travel
+    separately as int32 (an utterance may be longer than an int16 can count: cap 16 * S + 1)."""
     rank, _, world = env_rank_world()
     if world == 1 or not dist.is_initialized():
         return list(local)
     device = device if device is not None else (local[0].device if len(local) else torch.device("cpu"))
-    per_rank = max(shard_range(n_total, r, world)[1] - shard_range(n_total, r, world)[0] for r in range(world))
-    gmax_local = torch.tensor([max([int(t.shape[0]) for t in local] + [0])], dtype=torch.int64, device=device)
-    dist.all_reduce(gmax_local, op=dist.ReduceOp.MAX)
-    gmax = int(gmax_local.item())
-    buf = torch.full((per_rank, gmax + 1, Q), -1, dtype=torch.int16, device=device)
+    spans = [shard_range(n_total, r, world) for r in range(world)]
+    per_rank = max(hi - lo for lo, hi in spans)
+    assert len(local) == spans[rank][1] - spans[rank][0], "rank decoded a different number of utterances than its shard"
+    lens = torch.zeros(per_rank, dtype=torch.int32, device=device)
     for i, t in enumerate(local):
-        buf[i, 0, 0] = t.shape[0]  # header row: length
-        buf[i, 1 : 1 + t.shape[0]] = t.to(device=device, dtype=torch.int16)
-    out = torch.empty((world,) + tuple(buf.shape), dtype=torch.int16, device=device)
+        assert t.dim() == 2 and t.shape[1] == Q, "each utterance is a (G, Q) code matrix"
+        lens[i] = t.shape[0]
+    all_lens = torch.empty(world * per_rank, dtype=torch.int32, device=device)
+    dist.all_gather_into_tensor(all_lens, lens)
+    all_lens = all_lens.view(world, per_rank).cpu()
+    gmax = max(int(all_lens.max().item()), 1)
+    buf = torch.zeros((per_rank, gmax, Q), dtype=torch.int16, device=device)
+    for i, t in enumerate(local):
+        buf[i, : t.shape[0]] = t.to(device=device, dtype=torch.int16)
+    out = torch.empty((world * per_rank, gmax, Q), dtype=torch.int16, device=device)
     # neither NCCL/RCCL nor gloo has an int16 collective type: ship the same bytes as uint8
-    dist.all_gather_into_tensor(out.view(world * per_rank, gmax + 1, Q).view(torch.uint8), buf.view(torch.uint8))
+    dist.all_gather_into_tensor(out.view(torch.uint8), buf.view(torch.uint8))
+    out = out.view(world, per_rank, gmax, Q)
     res: List[torch.Tensor] = []
-    for r in range(world):
-        lo, hi = shard_range(n_total, r, world)
+    for r, (lo, hi) in enumerate(spans):
         for i in range(hi - lo):
-            n = int(out[r, i, 0, 0].item())
-            res.append(out[r, i, 1 : 1 + n].to(torch.int64))
+            res.append(out[r, i, : int(all_lens[r, i])].to(torch.int64))
     return res
 
 

@@ -143,11 +143,16 @@ class Engine:
             _lib.check(rc, self.h)
         return codes0, self._gen_lens
 
-    def nar(self, enroll_lens: Optional[Sequence[int]] = None) -> torch.Tensor:
+    def nar(self, enroll_lens: Optional[Sequence[int]] = None, forced: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """The 7 NAR stages; ``forced`` int64 (B, >=G, Q) teacher-forces the stage history (parity hook, vle_nar_force)."""
         B, Q = self._B, self.cfg.num_quantizers
         Gmax = max(max(self._gen_lens), 1)
         codes = torch.zeros(B, Gmax, Q, dtype=torch.int64, device=self.device)
         el = _i32(enroll_lens) if enroll_lens is not None else None
+        if forced is not None:
+            forced = forced.to(self.device, torch.int64).contiguous()
+            assert forced.dim() == 3 and forced.shape[0] == B and forced.shape[2] == Q and forced.shape[1] >= max(self._gen_lens)
+            _lib.check(self.lib.vle_nar_force(self.h, C.c_void_p(forced.data_ptr()), forced.shape[1]), self.h)
         _lib.check(self.lib.vle_nar_decode(self.h, _stream_ptr(self.device), el, C.c_void_p(codes.data_ptr()), Gmax), self.h)
         return codes
 

@@ -155,6 +155,10 @@ def token_embedding(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     assert ids.dtype == torch.int64 and table.dtype == torch.float32 and table.dim() == 2
     ids, table = ids.contiguous(), table.contiguous()
     d = table.shape[1]
+    if ids.numel():  # nn.Embedding raises IndexError (valle/modules/embedding.py:34,44); the kernel gathers table + id * d unchecked
+        lo, hi = torch.aminmax(ids)
+        if int(lo) < 0 or int(hi) >= table.shape[0]:
+            raise IndexError(f"token id out of range for an embedding table of {table.shape[0]} rows: min {int(lo)}, max {int(hi)}")
     out = torch.empty(*ids.shape, d, dtype=torch.float32, device=table.device)
     _lib.check(lib.vle_op_token_embedding(_st(table), _p(ids), _p(table), _p(out), ids.numel(), d))
     return out

@@ -251,6 +251,12 @@ int vle_op_token_embedding(void* stream, const int64_t* ids, const float* table,
  * x/out f32 [B x T x d], pe f32 [>= T x d] (built as embedding.py:75-91), alpha f32 DEVICE scalar. */
 int vle_op_sine_positional(void* stream, const float* x, const float* pe, const float* alpha_dev, float x_scale, float* out,
                            int64_t B, int32_t T, int32_t d);
+/* Rows of the teacher-forced forward's losses and metrics (VALLE.forward, valle/models/valle.py:875, 877-879, 936-956):
+ * loss[r] = logsumexp(logits[r]) - logits[r][targets[r]] (0 when targets[r] == ignore_index or is outside [0, V)),
+ * hit[r] = 1 / 0 whether the target is among the topk largest logits (ties towards the lower index), -1 for an ignored
+ * row.  logits f32 [rows x V], targets i64 [rows], loss f32 [rows], hit i32 [rows], all DEVICE. */
+int vle_op_cross_entropy(void* stream, const float* logits, const int64_t* targets, float* loss, int32_t* hit, int64_t rows, int32_t V,
+                         int32_t ignore_index, int32_t topk);
 /* AdaptiveLayerNorm.forward (transformer.py:93-108) as an affine fold: with wb = project_layer(stage_emb)
  * [f32, 2d] = [w ; b] and the inner norm's (g, be): gamma_out = w * g, beta_out = w * be + b, so that
  * vle_op_layernorm(x, gamma_out, beta_out) == w * LayerNorm(x) + b (the fold vle_finalize_weights applies). */

@@ -1,0 +1,76 @@
+"""TEST INFRASTRUCTURE ONLY -- golden fixtures for the teacher-forced forward, produced by the
+UNMODIFIED reference's ``VALLE.forward`` (valle/models/valle.py:762-959) in eval mode on CPU fp32:
+
+    python oracle/make_golden_forward.py      # writes tests/golden/forward/*.npz
+
+The reference draws ``nar_stage`` from ``self.rng`` (:891-895) and, for prefix_mode 1, ``prefix_len`` from
+``torch.randint`` (:348-350): both draws are captured (wrapping ``_prepare_prompts`` from outside) and stored, so the
+oracle / engine are called with the same values.  The Top10Accuracy metrics come from the stand-in of
+oracle/ref_import.py (torchmetrics is not installed): the LOSS is pinned by the reference, the metrics are not."""
+import os
+import random
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+from oracle import valle_oracle as vo  # noqa: E402
+from oracle.make_golden import build_reference  # noqa: E402
+from oracle.ref_import import import_reference  # noqa: E402
+
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "forward")
+
+CASES = {
+    "fwd_pm1_n1": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=1), N=1, S=7, T=24, train_stage=0, seed=3),
+    "fwd_pm0_n2": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=0), N=2, S=6, T=17, train_stage=0, seed=5),
+    "fwd_pm1_ar_only": dict(cfg=dict(d_model=128, nhead=2, num_layers=2, prefix_mode=1), N=2, S=9, T=30, train_stage=1, seed=7),
+    "fwd_pm1_nar_only": dict(cfg=dict(d_model=128, nhead=2, num_layers=2, prefix_mode=1), N=3, S=5, T=40, train_stage=2, seed=11),
+    "fwd_pm0_bos": dict(cfg=dict(d_model=64, nhead=4, num_layers=1, prefix_mode=0, prepend_bos=True), N=1, S=5, T=13, train_stage=0, seed=13),
+}
+
+
+def make_batch(N, S, T, seed):
+    xs, ys = [], []
+    for b in range(N):
+        x, _, y = vo.make_inputs(S, T, seed * 100 + b)
+        xs.append(x[0])
+        ys.append(y[0])
+    return torch.stack(xs), torch.full((N,), S, dtype=torch.int32), torch.stack(ys), torch.full((N,), T, dtype=torch.int32)
+
+
+def main():
+    vm = import_reference()
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(4)
+    for name, spec in CASES.items():
+        cfg = vo.OracleConfig(**spec["cfg"])
+        sd = vo.make_state_dict(cfg, 0)
+        model = build_reference(vm, cfg, sd)
+        x, xl, y, yl = make_batch(spec["N"], spec["S"], spec["T"], spec["seed"])
+        model.rng = random.Random(spec["seed"])
+        torch.manual_seed(spec["seed"])
+        drawn = {}
+        orig = model._prepare_prompts
+
+        def spy(y_, y_lens_, codes_, nar_stage, y_prompts_codes):
+            emb, plen = orig(y_, y_lens_, codes_, nar_stage, y_prompts_codes)
+            drawn.update(nar_stage=int(nar_stage), prefix_len=int(plen))
+            return emb, plen
+
+        model._prepare_prompts = spy
+        with torch.no_grad():
+            _, loss, metrics = model(x, xl, y, yl, reduction="sum", train_stage=spec["train_stage"])
+        out = dict(loss=np.float64(float(loss)), N=np.int32(spec["N"]), S=np.int32(spec["S"]), T=np.int32(spec["T"]),
+                   seed=np.int32(spec["seed"]), train_stage=np.int32(spec["train_stage"]),
+                   nar_stage=np.int32(drawn.get("nar_stage", -1)), prefix_len=np.int32(drawn.get("prefix_len", -1)),
+                   ar_top10=np.float64(metrics.get("ArTop10Accuracy", -1.0)), nar_top10=np.float64(metrics.get("NarTop10Accuracy", -1.0)),
+                   torch_version=np.bytes_(torch.__version__))
+        for k, v in spec["cfg"].items():
+            out[f"cfg_{k}"] = np.asarray(v)
+        np.savez_compressed(os.path.join(OUT, f"{name}.npz"), **out)
+        print(name, float(loss), drawn, metrics)
+
+
+if __name__ == "__main__":
+    main()

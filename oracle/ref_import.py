@@ -45,11 +45,23 @@ def _make_pad_mask(lengths, max_len=0):
 
 
 class _NoMetric(torch.nn.Module):
-    def __init__(self, *a, **k):
-        super().__init__()
+    """Stand-in for torchmetrics.classification.MulticlassAccuracy / BinaryAccuracy (torchmetrics is not installed).
+    For the configuration VALLE constructs (valle.py:157-163: top_k=10, average="micro", multidim_average="global",
+    ignore_index=1024) it restates the published definition: the fraction of non-ignored targets that are among the
+    top_k classes of the prediction along dim 1.  Any other configuration returns 0 (never called on the decode path)."""
 
-    def forward(self, *a, **k):
-        return torch.tensor(0.0)
+    def __init__(self, num_classes=None, top_k=1, average="micro", multidim_average="global", ignore_index=None, **k):
+        super().__init__()
+        self.top_k, self.ignore_index = top_k, ignore_index
+        self.supported = num_classes is not None and average == "micro" and multidim_average == "global"
+
+    def forward(self, preds=None, target=None, *a, **k):
+        if not self.supported or preds is None or target is None or preds.dim() != target.dim() + 1:
+            return torch.tensor(0.0)
+        top = preds.topk(min(self.top_k, preds.shape[1]), dim=1).indices  # (N, k, ...)
+        hit = (top == target.unsqueeze(1)).any(dim=1)
+        keep = target != self.ignore_index if self.ignore_index is not None else torch.ones_like(hit)
+        return (hit & keep).sum().float() / keep.sum().clamp_min(1).float()
 
 
 class PromptedFeatures:

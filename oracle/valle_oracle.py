@@ -448,3 +448,98 @@ def fp8w_state_dict(sd):
                or k.endswith("linear2.weight") or k == "ar_predict_layer.weight" or (k.startswith("nar_predict_layers.") and k.endswith(".weight")))
         out[k] = fp8w_quantize(v)[2] if lin else v.clone()
     return out
+
+
+# --------------------------------------------------------------------------------------
+# teacher-forced forward: VALLE.forward, valle/models/valle.py:762-959, in eval mode
+# --------------------------------------------------------------------------------------
+def _topk_accuracy(logits: torch.Tensor, targets: torch.Tensor, k: int = 10, ignore_index: int = NUM_AUDIO_TOKENS) -> torch.Tensor:
+    """torchmetrics MulticlassAccuracy(top_k=10, average="micro", ignore_index=1024) as constructed at valle.py:157-163,
+    273-279 (third-party, not installed: restated from its published definition -- this metric is parity-UNPINNED).
+    logits (rows, C), targets (rows,)."""
+    hits, keep = _topk_counts(logits, targets, k, ignore_index)
+    return hits / keep.clamp_min(1)
+
+
+def _topk_counts(logits: torch.Tensor, targets: torch.Tensor, k: int = 10, ignore_index: int = NUM_AUDIO_TOKENS):
+    top = logits.topk(min(k, logits.shape[1]), dim=1).indices
+    hit = (top == targets[:, None]).any(dim=1)
+    keep = targets != ignore_index
+    return (hit & keep).sum().float(), keep.sum().float()
+
+
+@torch.no_grad()
+def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum", train_stage: int = 0,
+            nar_stage: Optional[int] = None, prefix_len: Optional[int] = None, trace=None):
+    """VALLE.forward (valle.py:762-959) for UNPADDED batches (every x_lens == x.shape[1], every y_lens == y.shape[1]) and
+    prefix_mode 0 / 1, dropout off (eval).  The two random draws of the reference -- ``nar_stage`` (self.rng.choices,
+    :891-895) and, for prefix_mode 1, ``prefix_len`` (torch.randint, :348-350) -- are explicit arguments.
+    Returns (total_loss, metrics) like the last two elements of the reference's tuple."""
+    cfg.check_supported()
+    assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3 and y_lens.ndim == 1  # :789-790, 801-802
+    assert reduction == "sum"
+    assert cfg.prefix_mode in (0, 1)
+    N, S = x.shape
+    T = y.shape[1]
+    assert all(int(v) == S for v in x_lens) and all(int(v) == T for v in y_lens), "unpadded batches only"
+    codes = y.to(torch.int64)
+    bos = int(cfg.prepend_bos)
+    total = torch.zeros(())
+    metrics = {}
+    if train_stage in (0, 1):
+        ar_loss = torch.zeros(())
+        hits, kept = torch.zeros(()), torch.zeros(())
+        for b in range(N):
+            yb = codes[b, :, 0]
+            targets = torch.cat([yb[1:], torch.tensor([NUM_AUDIO_TOKENS])]) if not bos else torch.cat([yb, torch.tensor([NUM_AUDIO_TOKENS])])  # pad_y_eos :322-333
+            inputs = yb if not bos else F.pad(yb, (1, 0), value=NUM_AUDIO_TOKENS + 1)
+            xe = sine_position(token_embedding(sd, "ar_text_embedding", x[b]), sd["ar_text_position.alpha"])  # :827-829
+            ye = sine_position(token_embedding(sd, "ar_audio_embedding", inputs), sd["ar_audio_position.alpha"])  # :861-863
+            mask = prefix_lm_mask(S, inputs.shape[0])  # :833-859 without padding
+            dec = encoder(sd, "ar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=mask)  # :867-872
+            logits = F.linear(dec[S:], sd["ar_predict_layer.weight"])  # :873
+            if trace is not None:
+                trace.setdefault("ar_logits", []).append(logits.clone())
+            ar_loss = ar_loss + F.cross_entropy(logits, targets, reduction="sum")  # :875
+            h, kp = _topk_counts(logits, targets)
+            hits, kept = hits + h, kept + kp
+        total = total + ar_loss
+        metrics["ArTop10Accuracy"] = float(hits / kept.clamp_min(1)) * float(N * T)  # :877-879 (micro accuracy x y_lens.sum())
+    if cfg.num_quantizers == 1:
+        return total, metrics
+    if train_stage in (0, 2):
+        assert nar_stage is not None and 1 <= nar_stage < cfg.num_quantizers
+        P = 0
+        if cfg.prefix_mode == 1:
+            assert prefix_len is not None
+            P = int(prefix_len)
+        nar_loss = torch.zeros(())
+        hits, kept = torch.zeros(()), torch.zeros(())
+        for b in range(N):
+            y0 = codes[b, :, 0]
+            xe = sine_position(token_embedding(sd, "nar_text_embedding", x[b]), sd["nar_text_position.alpha"])  # :897-899
+            y_emb = token_embedding(sd, "nar_audio_embeddings.0", y0).clone()  # _prepare_prompts :335-393
+            if cfg.prefix_mode == 0:
+                for j in range(1, nar_stage):
+                    y_emb += token_embedding(sd, f"nar_audio_embeddings.{j}", codes[b, :, j])
+            else:
+                for j in range(1, cfg.num_quantizers):
+                    y_emb[:P] += token_embedding(sd, f"nar_audio_embeddings.{j}", codes[b, :P, j])
+                    if j < nar_stage:
+                        y_emb[P:] += token_embedding(sd, f"nar_audio_embeddings.{j}", codes[b, P:, j])
+            targets = codes[b, P:, nar_stage]  # :906, :916-917
+            ye = sine_position(y_emb, sd["nar_audio_position.alpha"])  # :919-920
+            stage = sd[f"nar_stage_embeddings.{nar_stage - 1}.word_embeddings.weight"]
+            dec = encoder(sd, "nar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=None, stage_emb=stage)  # :922-926
+            logits = F.linear(dec[S + P:], sd[f"nar_predict_layers.{nar_stage - 1}.weight"])  # :927-932
+            if trace is not None:
+                trace.setdefault("nar_logits", []).append(logits.clone())
+            nar_loss = nar_loss + F.cross_entropy(logits, targets, reduction="sum")  # :936-942 (no padded targets here)
+            h, kp = _topk_counts(logits, targets)  # the reference pads a 1025th class with the global minimum: never in the top 10
+            hits, kept = hits + h, kept + kp
+        total_length = float(N * T)
+        total = total + nar_loss * (total_length / (total_length - P * N))  # :943
+        metrics["NarTop10Accuracy"] = float(hits / kept.clamp_min(1)) * total_length  # :945-956
+    if train_stage == 0:
+        total = total / 2.0  # :958-959
+    return total, metrics

@@ -72,4 +72,46 @@ int launch_adaln_fold(hipStream_t st, const float* wb, const float* g, const flo
   return 0;
 }
 
+// Cross-entropy rows of the teacher-forced forward: F.cross_entropy(logits, targets, reduction=
+// "sum", ignore_index) of valle/models/valle.py:875, 936-942 and the top-k hit of its Top10Accuracy metrics (:877-879,
+// 945-956).  One wave per row: max, log-sum-exp, the target's logit, and the target's rank (number of strictly larger
+// logits; ties resolved towards the lower index like torch.topk).  loss[r] = lse - logit[target] (0 for an ignored or
+// out-of-range target), hit[r] = 1 if the target is among the top k, -1 if the row is ignored.
+__global__ __launch_bounds__(BO_NW * 64) void cross_entropy_kernel(const float* __restrict__ logits, const int64_t* __restrict__ targets,
+                                                                    float* __restrict__ loss, int32_t* __restrict__ hit, int64_t rows,
+                                                                    int V, int ignore_index, int topk) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * BO_NW + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const float* lg = logits + r * V;
+  const int64_t t = targets[r];
+  const bool ignored = t == ignore_index || t < 0 || t >= V;
+  float m = -INFINITY;
+  for (int i = lane; i < V; i += 64) m = fmaxf(m, lg[i]);
+  m = wave_max(m);
+  const float tl = ignored ? 0.f : lg[t];
+  float s = 0.f;
+  int above = 0;
+  for (int i = lane; i < V; i += 64) {
+    const float v = lg[i];
+    s += expf(v - m);
+    above += (v > tl) || (v == tl && i < (int)t);
+  }
+  s = wave_sum(s);
+  above = wave_sum_i(above);
+  if (lane == 0) {
+    loss[r] = ignored ? 0.f : (m + logf(s)) - tl;
+    hit[r] = ignored ? -1 : (above < topk ? 1 : 0);
+  }
+}
+
+int launch_cross_entropy(hipStream_t st, const float* logits, const int64_t* targets, float* loss, int32_t* hit, int64_t rows, int V,
+                         int ignore_index, int topk) {
+  if (rows <= 0) return 0;
+  if (V < 1) return -1;
+  hipLaunchKernelGGL(cross_entropy_kernel, dim3((unsigned)((rows + BO_NW - 1) / BO_NW)), dim3(BO_NW * 64), 0, st, logits, targets, loss,
+                     hit, rows, V, ignore_index, topk);
+  return 0;
+}
+
 }  // namespace vle

@@ -227,6 +227,28 @@ __device__ inline float block_sum(float v, float* red) {
   return t;
 }
 
+// ---- in-kernel timeline of the AR step (option "ktrace"; SURVEY.md 8d "kernel-gap timeline") ---------------------------------
+// rocprofv3's kernel trace serialises the dispatches of a graph replay (every kernel reads ~4.7 us, gaps 0), so the
+// un-perturbed timeline is taken by the kernels themselves: every wave stamps the constant-rate wall clock (100 MHz) at
+// entry and before its epilogue store into ITS OWN 16-byte slot [step & 31][kernel index][wave id] (plain stores, nothing
+// waits for them; atomics on shared min/max words cost ~70 us per kernel).  buf == null (always, outside the
+// diagnostic) costs one uniform branch.
+constexpr int KT_STEPS = 32, KT_KERNELS = 64, KT_WAVES = 2048;
+struct KTrace {
+  unsigned long long* buf = nullptr;  // [KT_STEPS][KT_KERNELS][KT_WAVES][2]
+  const int32_t* step = nullptr;      // device word that counts AR iterations
+  int idx = 0;                        // kernel index within the step
+};
+__device__ inline unsigned long long ktrace_begin(const KTrace& t) { return t.buf ? wall_clock64() : 0ull; }
+__device__ inline void ktrace_end(const KTrace& t, unsigned long long t0, int wave_id) {  // call from ONE lane per wave
+  if (!t.buf || wave_id >= KT_WAVES || t.idx >= KT_KERNELS) return;
+  typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+  ull2 v;
+  v.x = t0;
+  v.y = wall_clock64();
+  *reinterpret_cast<ull2*>(t.buf + (((size_t)((*t.step) & (KT_STEPS - 1)) * KT_KERNELS + t.idx) * KT_WAVES + wave_id) * 2) = v;
+}
+
 // order-preserving float <-> uint key (for arg-max with lowest-index tie-break and k-th largest)
 __device__ inline uint32_t float_key(float f) {
   uint32_t u = __float_as_uint(f);

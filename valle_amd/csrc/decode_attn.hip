@@ -40,7 +40,8 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
                                                           const T* __restrict__ vc, const int32_t* __restrict__ kv_len,
                                                           float* __restrict__ part_o, float* __restrict__ part_ml, int nhead,
                                                           int dh, int ctx_max, int nsplit, T* __restrict__ out_norm,
-                                                          const int32_t* __restrict__ done, int out_xf) {
+                                                          const int32_t* __restrict__ done, int out_xf, KTrace kt) {
+  const unsigned long long kt0 = ktrace_begin(kt);
   constexpr int KPW = 64 / LPK;         // keys per wave-load
   constexpr int WCH = NK * KPW;         // keys per wave per round
   constexpr int CHUNK = 4 * WCH;        // keys per block per round
@@ -162,6 +163,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
     for (int j = 0; j < VEC; ++j) sm_o[w][part * VEC + j] = acc[j];
   }
   __syncthreads();
+  if (lane == 0) ktrace_end(kt, kt0, (((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x) * 4 + w);
   // ---- merge the 4 waves, write the partial -------------------------------------------------------------
   if (tid < dh || tid == 255) {
     const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
@@ -197,7 +199,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
 template <typename T>
 static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const void* vc, const int32_t* kv_len, float* part_o,
                            float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit, int nk_override, void* out_norm,
-                           const int32_t* done, int out_xf) {
+                           const int32_t* done, int out_xf, KTrace kt) {
   constexpr int VFULL = Elem<T>::VEC;
   if (dh > 254) return -1;
   const dim3 grid(nhead, nsplit, B), block(256);
@@ -212,10 +214,10 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
   do {                                                                                                                      \
     if (nk8)                                                                                                                \
       hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 8>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
-                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf);                                                              \
+                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf, kt);                                                              \
     else                                                                                                                    \
       hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 4>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
-                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf);                                                              \
+                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf, kt);                                                              \
   } while (0)
   if (dh % VFULL == 0) {
     const int nv = dh / VFULL;
@@ -241,13 +243,13 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
 
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
-                            int nsplit, int nk_override, void* out_norm, const int32_t* done, int out_xf) {
+                            int nsplit, int nk_override, void* out_norm, const int32_t* done, int out_xf, KTrace kt) {
   if (B <= 0) return 0;
   if (out_xf != 0 && (out_norm == nullptr || dtype != DT_BF16 || B > 64)) return -1;
   if (out_norm != nullptr && nsplit != 1) return -1;
   if (dtype == DT_F32)
-    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf);
-  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf);
+    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf, kt);
+  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf, kt);
 }
 
 }  // namespace vle

@@ -7,6 +7,7 @@
 // here is exact because of the prefix-LM mask (valle.py:1019-1033): text rows never see audio
 // columns and audio rows are causal, so the hidden state of a position never changes once computed.
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstring>
@@ -108,12 +109,26 @@ struct vle_engine {
   int32_t* tables_host = nullptr; // pinned mirror
   int64_t tables_cap = 0;
   int32_t* poll_host = nullptr;   // pinned [64]
+  int32_t* prog_host = nullptr;   // pinned + mapped [16]: progress words the sample kernel writes (ArSampleArgs::host_prog)
+  int32_t* prog_dev = nullptr;    // device address of prog_host
+  bool opt_host_prog = true;      // option "host_prog": 0 = poll through a D2H copy + event per graph replay (round-1 behaviour)
   float* trace_ar = nullptr; int64_t trace_ar_cap = 0;
   float* trace_nar = nullptr;     // [Q-1][sumG_max][1024]
   bool opt_trace_ar = false, opt_trace_nar = false;
   // per-kernel timing of the AR step with hipEvents on the engine stream (option "profile_kernels"):
   // forces eager launches; tags: 0 qkv, 1 decode-attention, 2 out-proj, 3 ffn1, 4 ffn2, 5 logits, 6 sample
   bool opt_profile = false;
+  // option "ktrace": the batch-1 step kernels stamp the wall clock into ktrace_buf (common.h KTrace); kt_idx counts launches of a step
+  unsigned long long* ktrace_buf = nullptr;
+  bool opt_ktrace = false;
+  int kt_idx = 0;
+  KTrace next_kt() {
+    KTrace k;
+    if (opt_ktrace && ktrace_buf) {
+      k.buf = ktrace_buf; k.step = S.iter; k.idx = kt_idx++;
+    }
+    return k;
+  }
   bool opt_no_gemm_skinny = false;  // option "no_gemm_skinny": batch 2..64 on the v0 kernels (A/B measurements)
   int opt_w8_temporal = -1;         // option "w8_temporal": FP8W batch-1 GEMV loads its weights with the default cache policy
                                     // (-1 = when the fp8 AR weights fit the 256 MB memory-side cache with room for the KV stream)
@@ -296,6 +311,7 @@ int launch_ar_linear(vle_engine* e, const SkinnyArgs& a) {
   if (a.B == 1 && !e->opt_no_gemv1) {
     SkinnyArgs t = a;
     t.rpw_override = e->opt_rpw;
+    t.kt = e->next_kt();
     if (e->w8 && a.w8 != nullptr) {  // FP8W: stream the e4m3fn codes; shapes gemv1 lacks fall through to bf16(W')
       t.w = a.w8;
       // measured at C2 (152 MB of codes): AR loop 173.4 -> 166-171 ms with cacheable loads; non-temporal otherwise
@@ -385,6 +401,7 @@ extern "C" void vle_destroy(vle_engine* e) {
   for (void* p : e->allocs) (void)hipFree(p);
   if (e->tables_host) (void)hipHostFree(e->tables_host);
   if (e->poll_host) (void)hipHostFree(e->poll_host);
+  if (e->prog_host) (void)hipHostFree(e->prog_host);
   for (int i = 0; i < 6; ++i)
     if (e->ev_t[i]) (void)hipEventDestroy(e->ev_t[i]);
   if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -660,6 +677,9 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->tables_dev, e->tables_cap))) return r;
   E_HIP(e, hipHostMalloc((void**)&e->tables_host, e->tables_cap * sizeof(int32_t), hipHostMallocDefault));
   E_HIP(e, hipHostMalloc((void**)&e->poll_host, 64 * sizeof(int32_t), hipHostMallocDefault));
+  E_HIP(e, hipHostMalloc((void**)&e->prog_host, 16 * sizeof(int32_t), hipHostMallocMapped));
+  memset(e->prog_host, 0, 16 * sizeof(int32_t));
+  E_HIP(e, hipHostGetDevicePointer((void**)&e->prog_dev, e->prog_host, 0));
   return 0;
 }
 
@@ -785,6 +805,8 @@ int enqueue_ar_sample(vle_engine* e, int first, const int32_t* slot_map = nullpt
   ArSampleArgs a{};
   a.s = e->S; a.dyn = e->dyn_dev; a.logits = e->logits; a.V = V_AR; a.B = slot_map ? nslots : e->B; a.d = e->d; a.bos = e->bos; a.first = first;
   a.slot_map = slot_map; a.id_err = e->id_err_dev;
+  if (!first) a.kt = e->next_kt();
+  if (e->opt_host_prog && !slot_map) a.host_prog = e->prog_dev;
   a.tokens = e->tokens; a.g_stride = e->max_G; a.sampled = e->sampled;
   a.audio_emb = e->ar_audio_emb; a.pe = e->pe; a.alpha_audio = e->alphas + 1; a.x = e->x_step; a.ctx_max = e->ctx_max;
   E_LAUNCH(e, launch_ar_sample(e->st, a));
@@ -795,6 +817,7 @@ int enqueue_ar_sample(vle_engine* e, int first, const int32_t* slot_map = nullpt
 int enqueue_ar_step(vle_engine* e) {
   hipStream_t st = e->st;
   const int d = e->d;
+  e->kt_idx = 0;
   const bool sk = use_skinny(e);
   const bool gs = use_mfma_skinny(e);
   for (int l = 0; l < e->L; ++l) {
@@ -865,7 +888,7 @@ int enqueue_ar_step(vle_engine* e) {
     {
       ProfScope ps(e, 1);
       E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
-                                          e->ctx_max, e->nsplit, e->opt_nk, nullptr, e->B > 1 ? e->S.done : nullptr));
+                                          e->ctx_max, e->nsplit, e->opt_nk, nullptr, e->B > 1 ? e->S.done : nullptr, 0, e->next_kt()));
     }
     if (sk) {
       {
@@ -1042,6 +1065,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   if ((r = enter(e, stream))) return r;
   hipStream_t st = e->st;
   const int B = e->B;
+  e->prog_host[0] = e->prog_host[1] = 0;  // enter() synchronised the stream: no kernel is writing them
 
   // upper bound on loop iterations (stop rule valle.py:1047): n + bos > 16 S  first holds at n = 16 S + 1 - bos
   int bound = 0;
@@ -1108,12 +1132,16 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
       g_single = it->second.second;
     }
   }
-  // run; poll the device-side done counter with a lag so the host never stalls the stream
+  // run; the host must not stall the stream, and must not run unboundedly ahead of it either (utterances stop early)
   constexpr int RING = 8, LAG = 3;
   hipEvent_t evs[RING];
-  for (int i = 0; i < RING; ++i) E_HIP(e, hipEventCreateWithFlags(&evs[i], hipEventDisableTiming));
+  for (int i = 0; i < RING; ++i) evs[i] = nullptr;
+  const bool hostprog = e->opt_host_prog;
+  if (!hostprog)
+    for (int i = 0; i < RING; ++i) E_HIP(e, hipEventCreateWithFlags(&evs[i], hipEventDisableTiming));
+  volatile int32_t* hprog = e->prog_host;
   int launches = 0;
-  bool all_done = false;
+  bool all_done = false, stalled = false;
   while (steps_done < bound && !all_done) {
     if (use_graph) {
       if (bound - steps_done >= spg) {
@@ -1127,16 +1155,37 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
       if ((r = enqueue_ar_step(e))) return r;
       steps_done += 1;
     }
-    const int slot = launches % RING;
-    E_HIP(e, hipMemcpyAsync(e->poll_host + slot, e->S.done_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
-    E_HIP(e, hipEventRecord(evs[slot], st));
     ++launches;
-    if (launches > LAG) {
-      const int old = (launches - 1 - LAG) % RING;
-      E_HIP(e, hipEventSynchronize(evs[old]));
-      if (e->poll_host[old] >= B) all_done = true;
+    if (hostprog) {
+      // progress words written by the sample kernel into pinned host memory: nothing goes on the stream between two
+      // replays.  hp[1] counts sample launches (iteration 0 included), hp[0] the utterances done one launch earlier.
+      const int ahead = LAG * (use_graph ? spg : 8);
+      const auto t_start = std::chrono::steady_clock::now();
+      unsigned spins = 0;
+      while (steps_done + 1 - hprog[1] > ahead && hprog[0] < B) {
+        if ((++spins & 0xfff) == 0) {
+          if (hipStreamQuery(st) == hipSuccess) break;  // everything enqueued has run (also: the kernels were not built to report)
+          if (std::chrono::steady_clock::now() - t_start > std::chrono::seconds(30)) {
+            stalled = true;
+            break;
+          }
+        }
+        __builtin_ia32_pause();
+      }
+      if (stalled) break;
+      if (hprog[0] >= B) all_done = true;
+    } else {
+      const int slot = (launches - 1) % RING;
+      E_HIP(e, hipMemcpyAsync(e->poll_host + slot, e->S.done_count, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+      E_HIP(e, hipEventRecord(evs[slot], st));
+      if (launches > LAG) {
+        const int old = (launches - 1 - LAG) % RING;
+        E_HIP(e, hipEventSynchronize(evs[old]));
+        if (e->poll_host[old] >= B) all_done = true;
+      }
     }
   }
+  if (stalled) return e->fail(VLE_EHIP, "AR loop made no progress for 30 s");
   E_HIP(e, hipEventRecord(e->ev_t[3], st));
   // results
   std::vector<int32_t> st_host(6 * e->max_B + 8);
@@ -1146,7 +1195,8 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
     E_HIP(e, hipMemcpy2DAsync(codes0, g_stride * sizeof(int64_t), e->tokens, e->max_G * sizeof(int64_t),
                               std::min<int64_t>(g_stride, e->max_G) * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
   E_HIP(e, hipStreamSynchronize(st));
-  for (int i = 0; i < RING; ++i) (void)hipEventDestroy(evs[i]);
+  for (int i = 0; i < RING; ++i)
+    if (evs[i]) (void)hipEventDestroy(evs[i]);
   if (e->opt_profile) {
     for (size_t i = 0; i < e->prof_tags.size(); ++i) {
       float pm = 0.f;
@@ -1676,6 +1726,16 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     return VLE_OK;
   }
+  if (n == "host_prog") {
+    e->opt_host_prog = value != 0;
+    (void)hipStreamSynchronize(e->st);
+    for (auto& kv : e->graphs) {
+      if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
+      if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+    }
+    e->graphs.clear();
+    return VLE_OK;
+  }
   if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
     else if (n == "gs_xf") e->opt_gs_xf = value != 0;
@@ -1704,6 +1764,23 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
   }
   if (n == "glds_big" || n == "glds_w8" || n == "glds_prio") {  // process-global tile policy of gemm_glds.hip (same knobs as vle_op_tune)
     (n == "glds_big" ? g_glds_big : n == "glds_w8" ? g_glds_w8 : g_glds_prio) = (int)value;
+    return VLE_OK;
+  }
+  if (n == "ktrace") {  // changes the kernels' arguments: drop the captured graphs
+    e->opt_ktrace = value != 0;
+    if (e->opt_ktrace && !e->ktrace_buf && e->finalized) {
+      unsigned long long* p = nullptr;
+      int r = dev_alloc(e, &p, (size_t)KT_STEPS * KT_KERNELS * KT_WAVES * 2);
+      if (r) return r;
+      e->ktrace_buf = p;
+    }
+    if (e->ktrace_buf) (void)hipMemset(e->ktrace_buf, 0xFF, (size_t)KT_STEPS * KT_KERNELS * KT_WAVES * 2 * sizeof(unsigned long long));
+    (void)hipStreamSynchronize(e->st);
+    for (auto& kv : e->graphs) {
+      if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
+      if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+    }
+    e->graphs.clear();
     return VLE_OK;
   }
   if (n == "ignore_eos") {
@@ -1750,6 +1827,10 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
     const size_t nb = std::min(bytes, sizeof(buf));
     memcpy(host_dst, buf, nb);
     return (int64_t)nb;
+  } else if (w == "ktrace") {
+    if (!e->ktrace_buf) return e->fail(VLE_ESTATE, "ktrace was not enabled");
+    src = e->ktrace_buf;
+    n = (size_t)KT_STEPS * KT_KERNELS * KT_WAVES * 2 * sizeof(unsigned long long);
   } else if (w == "last_logits") {
     src = e->logits;
     n = (size_t)e->B * V_AR * sizeof(float);

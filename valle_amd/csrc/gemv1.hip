@@ -108,6 +108,7 @@ __global__ __launch_bounds__(G1_T) void gemv1_kernel(SkinnyArgs a) {
   const int row0 = wave * RPW;
   const int N = a.N;
   if (row0 >= N) return;  // wave-uniform
+  const unsigned long long kt0 = ktrace_begin(a.kt);
   const T* W = reinterpret_cast<const T*>(a.w);
 
   // ---- the burst, in the order the data is needed (vmcnt retires loads in issue order): activations
@@ -235,6 +236,7 @@ __global__ __launch_bounds__(G1_T) void gemv1_kernel(SkinnyArgs a) {
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------------
+  if (lane == 0) ktrace_end(a.kt, kt0, wave);
   if (!writer) return;
   const float v = G1W<T>::kScaled ? fmaf(mine, scale_v, bias_v) : mine + bias_v;  // * 2^e is exact: one rounding, as in bf16 mode
   if constexpr (EPI == SEPI_STORE) {

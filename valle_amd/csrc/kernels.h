@@ -5,6 +5,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "common.h"
+
 namespace vle {
 
 constexpr int DT_F32 = 0;
@@ -25,6 +27,8 @@ int launch_token_embedding(hipStream_t st, const int64_t* ids, const float* tabl
 int launch_sine_positional(hipStream_t st, const float* x, const float* pe, const float* alpha, float x_scale, float* out,
                            int64_t B, int T, int d);
 int launch_adaln_fold(hipStream_t st, const float* wb, const float* g, const float* be, float* gamma_out, float* beta_out, int d);
+int launch_cross_entropy(hipStream_t st, const float* logits, const int64_t* targets, float* loss, int32_t* hit, int64_t rows, int V,
+                         int ignore_index, int topk);
 
 // ---- gemm.hip -------------------------------------------------------------------------------
 enum { EPI_STORE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_F32 = 3 };
@@ -106,6 +110,7 @@ struct SkinnyArgs {
   const int32_t* kv_len = nullptr; // [B] slot the new token's K/V go to
   int ctx_max = 0;
   int rpw_override = 0;          // tuning hook of the batch-1 path (rows per wave), 0 = heuristic
+  KTrace kt;                     // diagnostic timeline (gemv1 only)
 };
 int launch_skinny(hipStream_t st, int dtype, const SkinnyArgs& a);
 // gemv1.hip: batch-1 wave-autonomous variant; returns 1 when the shape is not instantiated (use launch_skinny)
@@ -127,7 +132,7 @@ int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache,
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
                             int nsplit, int nk_override = 0, void* out_norm = nullptr, const int32_t* done = nullptr,
-                            int out_xf = 0);  // out_xf: out_norm fragment-major (0 no, 1 bf16-W consumer, 2 fp8-W consumer)
+                            int out_xf = 0, KTrace kt = KTrace());  // out_xf: out_norm fragment-major (0 no, 1 bf16-W consumer, 2 fp8-W consumer)
 // nk_override: keys per lane per round (0 = auto, 4, 8); out_norm (T [B][d], nsplit == 1 only): write the
 // normalised attention output directly instead of partials
 
@@ -199,6 +204,10 @@ struct ArSampleArgs {
   int ctx_max;
   const int32_t* slot_map = nullptr;       // slot API: block i serves utterance slot_map[i] (B = number of listed slots)
   int32_t* id_err = nullptr;               // |= 4 when a forced token is outside the audio vocabulary (it is replaced by 0)
+  KTrace kt;
+  // host-visible progress (pinned, mapped): [0] = utterances done before this launch, [1] = sample launches so far.  The host
+  // polls these words instead of putting a D2H copy + event on the stream after every graph replay.
+  int32_t* host_prog = nullptr;
 };
 int launch_ar_sample(hipStream_t st, const ArSampleArgs& a);
 // slot API (continuous batching): per-slot AR state of newly admitted utterances; rows of X scattered to slot rows

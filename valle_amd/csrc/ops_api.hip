@@ -170,3 +170,9 @@ extern "C" int vle_op_adaln_fold(void* stream, const float* wb, const float* g, 
   if (!wb || !g || !be || !gamma_out || !beta_out || d < 1) return op_fail("vle_op_adaln_fold: bad argument");
   return op_done(launch_adaln_fold((hipStream_t)stream, wb, g, be, gamma_out, beta_out, d), "vle_op_adaln_fold");
 }
+
+extern "C" int vle_op_cross_entropy(void* stream, const float* logits, const int64_t* targets, float* loss, int32_t* hit, int64_t rows,
+                                    int32_t V, int32_t ignore_index, int32_t topk) {
+  if (!logits || !targets || !loss || !hit || rows < 0 || V < 1 || topk < 1) return op_fail("vle_op_cross_entropy: bad argument");
+  return op_done(launch_cross_entropy((hipStream_t)stream, logits, targets, loss, hit, rows, V, ignore_index, topk), "vle_op_cross_entropy");
+}

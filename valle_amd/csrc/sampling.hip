@@ -67,7 +67,15 @@ __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
 
   const int b = a.slot_map ? a.slot_map[blockIdx.x] : (int)blockIdx.x;
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  if (a.host_prog != nullptr && blockIdx.x == 0 && tid == 0) {
+    // done_count is complete as of the previous launch (kernel boundary); [1] is a launch counter only this thread writes
+    const int dc = a.s.done_count[0], sc = a.s.done_count[1] + 1;
+    a.s.done_count[1] = sc;
+    __hip_atomic_store(a.host_prog + 0, dc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(a.host_prog + 1, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
   if (a.s.done[b]) return;
+  const unsigned long long kt0 = ktrace_begin(a.kt);
   const int it = a.s.iter[b];
   const int V = a.V;
   const ArDyn dyn = *a.dyn;
@@ -169,6 +177,7 @@ __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
   }
 
   if (tid == 0) {
+    ktrace_end(a.kt, kt0, (int)blockIdx.x);  // before a.s.iter moves on: the stamp lands in this step's slot
     const int n = a.s.n_gen[b];
     const int kvl = a.s.kv_len[b] + (a.first ? 0 : 1);
     const int ap = a.s.audio_pos[b] + (a.first ? 0 : 1);

@@ -13,6 +13,7 @@ nar_scale_factor = 1); other combinations raise -- there is no PyTorch fallback.
 from __future__ import annotations
 
 import argparse
+import random
 from typing import List, Optional, Sequence
 
 import torch
@@ -96,6 +97,7 @@ class VALLE(nn.Module):
             if share_embedding:
                 for j in range(0, num_quantizers - 2):  # valle.py:268-271
                     self.nar_predict_layers[j].weight = self.nar_audio_embeddings[j + 2].weight
+        self.rng = random.Random(0)  # valle.py:165 (forward() draws nar_stage from it)
         self.requires_grad_(False)
         set_compute_dtype(self, engine_dtype)  # the block modules run the same element type as the engine
         self._engine: Optional[Engine] = None
@@ -222,6 +224,107 @@ class VALLE(nn.Module):
         dev = eng.device
         codes, gl = eng.continual(x.to(dev, torch.int64), [int(x_lens.max())], y.to(dev, torch.int64), [T])
         return codes[:, : gl[0]]
+
+
+    # ---- VALLE.forward (valle/models/valle.py:762-959), teacher-forced, eval mode ----------------------------
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, x_lens: torch.Tensor, y: torch.Tensor, y_lens: torch.Tensor, reduction: str = "sum",
+                train_stage: int = 0, *, nar_stage: Optional[int] = None, prefix_len: Optional[int] = None, **kwargs):
+        """The reference's teacher-forced pass as a SCORING function (validation loss / Top10Accuracy of given codes):
+        returns ``((x_emb, codes), total_loss, metrics)`` like valle.py:959, computed by the HIP block modules (AR: one
+        prefix-LM pass over [text; y]; NAR: one unmasked pass at stage ``nar_stage``) and ``vle_op_cross_entropy``.
+
+        Scope: eval mode (no dropout, no gradients), prefix_mode 0 / 1, ``reduction="sum"``, unpadded batches (every
+        ``x_lens == x.shape[1]`` and ``y_lens == y.shape[1]``; the reference's AR loss also sums over PADDED positions
+        (:875 has no ignore_index), which only a padded evaluation reproduces).  The reference's two random draws are
+        keyword arguments; left None they are drawn the way the reference draws them: ``nar_stage`` from ``self.rng``
+        (random.Random(0) at construction, :165, :891-895), prefix_mode 1's ``prefix_len`` from torch's global generator
+        (:348-350)."""
+        from . import ops
+
+        assert x.ndim == 2, x.shape
+        assert x_lens.ndim == 1, x_lens.shape
+        assert y.ndim == 3, y.shape
+        assert y_lens.ndim == 1, y_lens.shape
+        if self.training:
+            raise NotImplementedError("forward() is a scoring pass: call .eval() first (training is outside the decode path)")
+        if reduction != "sum":
+            raise NotImplementedError("only reduction='sum' (the trainer's, valle/bin/trainer.py) is implemented")
+        if self.prefix_mode not in (0, 1):
+            raise NotImplementedError("forward(): prefix_mode 2 / 4 (random prompt segments, PromptedFeatures) is not implemented")
+        N, S = x.shape
+        T = y.shape[1]
+        if any(int(v) != S for v in x_lens) or any(int(v) != T for v in y_lens):
+            raise NotImplementedError("forward(): unpadded batches only (the reference's AR loss sums padded positions too)")
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("the HIP operators need the model on a ROCm device: call .to('cuda') first (no CPU path)")
+        x, codes = x.to(dev, torch.int64), y.to(dev, torch.int64)
+        bos = int(self.ar_audio_prepend_bos)
+        tdt = self.ar_decoder._tdtype()
+
+        def predict(h2d, weight):  # nn.Linear(d, V, bias=False) on the MFMA GEMM path
+            return ops.linear(h2d.to(tdt).contiguous(), self.ar_decoder._w(weight), None, epilogue=ops.EPI_F32)
+
+        total_loss = torch.zeros((), device=dev)
+        metrics = {}
+        total_length = float(N * T)
+        if train_stage in (0, 1):
+            y0 = codes[..., 0]
+            eos = torch.full((N, 1), NUM_AUDIO_TOKENS, dtype=torch.int64, device=dev)
+            if bos:  # pad_y_eos, valle.py:322-333
+                inputs = torch.cat([torch.full((N, 1), NUM_AUDIO_TOKENS + 1, dtype=torch.int64, device=dev), y0], dim=1)
+                targets = torch.cat([y0, eos], dim=1)
+            else:
+                inputs, targets = y0, torch.cat([y0[:, 1:], eos], dim=1)
+            Ta = inputs.shape[1]
+            xe = self.ar_text_position(self.ar_text_embedding(x))                    # :827-829
+            ye = self.ar_audio_position(self.ar_audio_embedding(inputs))             # :861-863
+            i = torch.arange(S + Ta, device=dev)
+            allowed = i[None, :] < torch.maximum(i[:, None] + 1, torch.tensor(S, device=dev))  # prefix-LM mask, :833-859
+            h, _ = self.ar_decoder((torch.cat([xe, ye], dim=1), None), mask=~allowed)  # :867-872
+            logits = predict(h[:, S:].reshape(N * Ta, -1), self.ar_predict_layer.weight)  # :873
+            loss_rows, hit = ops.cross_entropy_rows(logits, targets.reshape(-1), ignore_index=-100, topk=10)
+            total_loss = total_loss + loss_rows.sum()                                 # :875 (no ignore_index)
+            kept = targets.reshape(-1) != NUM_AUDIO_TOKENS                           # the metric ignores EOS targets (:157-163)
+            acc = (hit[kept] == 1).sum().float() / kept.sum().clamp_min(1).float()
+            metrics["ArTop10Accuracy"] = acc * total_length                           # :877-879
+        if self.num_quantizers == 1:
+            return ((x, codes), total_loss, metrics)
+        x_emb = x
+        if train_stage in (0, 2):
+            if nar_stage is None:
+                nq = self.num_quantizers - 1
+                nar_stage = self.rng.choices(list(range(1, self.num_quantizers)), weights=[1.0 / nq] * nq, k=1)[0]  # :891-895
+            assert 1 <= nar_stage < self.num_quantizers
+            P = 0
+            if self.prefix_mode == 1:
+                if prefix_len is None:
+                    int_low = int(0.25 * T)
+                    prefix_len = min(int(torch.randint(int_low, int_low * 2, size=()).item()), 225)  # :348-350
+                P = int(prefix_len)
+            xe = self.nar_text_position(self.nar_text_embedding(x))                  # :897-899
+            x_emb = xe
+            y_emb = self.nar_audio_embeddings[0](codes[..., 0])                      # _prepare_prompts :335-393
+            if self.prefix_mode == 0:
+                for j in range(1, nar_stage):
+                    y_emb = y_emb + self.nar_audio_embeddings[j](codes[..., j])
+            else:
+                for j in range(1, self.num_quantizers):
+                    y_emb[:, :P] += self.nar_audio_embeddings[j](codes[:, :P, j])
+                    if j < nar_stage:
+                        y_emb[:, P:] += self.nar_audio_embeddings[j](codes[:, P:, j])
+            targets = codes[:, P:, nar_stage].reshape(-1)                            # :906, :916-917
+            ye = self.nar_audio_position(y_emb)                                      # :919-920
+            h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), self.nar_stage_embeddings[nar_stage - 1].weight))  # :922-926
+            logits = predict(h[:, S + P:].reshape(N * (T - P), -1), self.nar_predict_layers[nar_stage - 1].weight)  # :927-932
+            loss_rows, hit = ops.cross_entropy_rows(logits, targets, ignore_index=NUM_AUDIO_TOKENS, topk=10)
+            total_loss = total_loss + loss_rows.sum() * (total_length / (total_length - P * N))  # :936-943
+            kept = hit >= 0
+            metrics["NarTop10Accuracy"] = (hit == 1).sum().float() / kept.sum().clamp_min(1).float() * total_length  # :945-956
+        if train_stage == 0:
+            total_loss = total_loss / 2.0                                             # :958
+        return ((x_emb, codes), total_loss, metrics)
 
 
 # ---- valle/models/__init__.py surface ---------------------------------------------------------------

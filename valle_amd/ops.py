@@ -237,3 +237,16 @@ def linear_fp8w(a: torch.Tensor, w8: torch.Tensor, wscale: torch.Tensor, bias: O
     ws = linear_workspace(a.device)
     _lib.check(lib.vle_op_linear_fp8w(_st(a), _p(a), _p(w8), _p(wscale), _p(b), _p(out), _p(resid), M, N, K, epilogue, _p(ws), int(ksplit)))
     return resid if epilogue == EPI_RESID else out
+
+
+def cross_entropy_rows(logits: torch.Tensor, targets: torch.Tensor, ignore_index: int = -100, topk: int = 10):
+    """Per-row cross-entropy and top-k hit flags of the teacher-forced forward (valle.py:875, 877-879, 936-956).
+    logits fp32 (rows, V), targets int64 (rows,) -> (loss fp32 (rows,), hit int32 (rows,): 1 / 0, -1 = ignored)."""
+    lib = _lib.load()
+    assert logits.dtype == torch.float32 and logits.dim() == 2 and targets.dtype == torch.int64 and targets.shape == (logits.shape[0],)
+    logits, targets = logits.contiguous(), targets.contiguous()
+    loss = torch.empty(logits.shape[0], dtype=torch.float32, device=logits.device)
+    hit = torch.empty(logits.shape[0], dtype=torch.int32, device=logits.device)
+    _lib.check(lib.vle_op_cross_entropy(_st(logits), _p(logits), _p(targets), _p(loss), _p(hit), logits.shape[0], logits.shape[1],
+                                        int(ignore_index), int(topk)))
+    return loss, hit

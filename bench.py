@@ -237,7 +237,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--batch", type=int, default=0, help="utterances per GPU; default 1 at --gpus 1 (configs[1], the headline) and "
                                                          "64 at --gpus N > 1 (configs[3]: 512 prompts over 8 GPUs)")
-    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8w"], help="fp8w: bf16 arithmetic on fp8 e4m3 weights (configs[4] weight format)")
+    ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8w", "fp8"],
+                    help="fp8w: bf16 arithmetic on fp8 e4m3 weights; fp8: fp8w + fp8 activations on the CDNA4 fp8 MFMA (configs[4])")
     ap.add_argument("--d-model", type=int, default=1024)
     ap.add_argument("--nhead", type=int, default=16)
     ap.add_argument("--layers", type=int, default=12)

@@ -42,6 +42,9 @@ extern "C" {
 /* arithmetic mode of the whole path */
 #define VLE_DTYPE_F32 0  /* fp32 weights / KV / accumulate: token-id-exact vs the reference */
 #define VLE_DTYPE_BF16 1 /* bf16 weights + KV, fp32 residual stream and accumulators       */
+#define VLE_DTYPE_FP8 3  /* FP8W plus fp8 ACTIVATIONS on the MFMA-bound passes (prefill, NAR): every Linear there runs
+                            e4m3fn x e4m3fn on CDNA4's block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) with the
+                            activations quantised per row (power-of-two scale); the AR step is FP8W's (BASELINE configs[4]) */
 #define VLE_DTYPE_FP8W 2 /* BF16 mode on fp8-representable weights: every Linear weight row is replaced by
                           * W' = e4m3fn(w / 2^e) * 2^e (one power-of-two scale per row, so W' is exact in bf16); the
                           * HBM-bound AR step streams the 1-byte codes, prefill / NAR run bf16 MFMA on bf16(W') */
@@ -255,6 +258,15 @@ int vle_op_sine_positional(void* stream, const float* x, const float* pe, const 
  * loss[r] = logsumexp(logits[r]) - logits[r][targets[r]] (0 when targets[r] == ignore_index or is outside [0, V)),
  * hit[r] = 1 / 0 whether the target is among the topk largest logits (ties towards the lower index), -1 for an ignored
  * row.  logits f32 [rows x V], targets i64 [rows], loss f32 [rows], hit i32 [rows], all DEVICE. */
+/* Engine mode FP8 (BASELINE configs[4], "CDNA4 fp8 MFMA"), stand-alone:
+ * vle_op_quantize_rows_fp8: x[bf16, rows x K] -> q[e4m3fn, rows x K] + scale[f32, rows] (the smallest power of two with
+ *   max|x_row| / scale <= 448; round-to-nearest-even);  K = 512 * {1,2,3,4,6,8,12,16}.
+ * vle_op_linear_fp8: epilogue((a8 @ w8^T) * a_scale[m] * w_scale[n] + bias) on v_mfma_scale_f32_16x16x128_f8f6f4 (unit
+ *   block scales); a8 [M x K], w8 [N x K] e4m3fn codes; out bf16 (STORE / RELU) or f32 (F32), resid f32 += (RESID);
+ *   K % 128 == 0, N % 4 == 0.  Replaces the same `linear` calls as vle_op_linear. */
+int vle_op_quantize_rows_fp8(void* stream, const void* x_bf16, void* q_out, float* scale_out, int64_t rows, int32_t K);
+int vle_op_linear_fp8(void* stream, const void* a8, const float* a_scale, const void* w8, const float* w_scale, const float* bias,
+                      void* out, float* resid, int64_t M, int32_t N, int32_t K, int epilogue);
 int vle_op_cross_entropy(void* stream, const float* logits, const int64_t* targets, float* loss, int32_t* hit, int64_t rows, int32_t V,
                          int32_t ignore_index, int32_t topk);
 /* AdaptiveLayerNorm.forward (transformer.py:93-108) as an affine fold: with wb = project_layer(stage_emb)

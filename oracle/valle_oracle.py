@@ -205,14 +205,26 @@ def norm_site(sd, prefix: str, x, stage_emb):
     return w * layer_norm(x, sd[f"{prefix}.norm.weight"], sd[f"{prefix}.norm.bias"]) + b
 
 
-def mha(sd, prefix: str, x, nhead: int, attn_mask: Optional[torch.Tensor], kv_state=None):
+def fp8a_rows(x: torch.Tensor) -> torch.Tensor:
+    """Engine mode FP8 (valle_amd/csrc/misc.hip quantize_rows_fp8_kernel): the activations of a Linear in the packed passes are
+    rounded to bf16, then per row to e4m3fn with one power-of-two scale (the rule of fp8w_quantize); returns the dequantised
+    values the fp8 MFMA effectively multiplies."""
+    xb = x.to(torch.bfloat16).to(torch.float32)
+    return fp8w_quantize(xb)[2]
+
+
+def _lin(x, w, b, act_fp8: bool):
+    return F.linear(fp8a_rows(x) if act_fp8 else x, w, b)
+
+
+def mha(sd, prefix: str, x, nhead: int, attn_mask: Optional[torch.Tensor], kv_state=None, act_fp8: bool = False):
     """MultiheadAttention.forward (valle/modules/activation.py:199-431) ->
     F.multi_head_attention_forward: packed in-proj rows [Q;K;V], heads = contiguous dh slices,
     softmax(Q K^T / sqrt(dh) + mask) V, out_proj.  ``attn_mask``: bool (T,T), True = blocked
     (valle.py:1019-1033).  x: (T, d)."""
     T, d = x.shape
     dh = d // nhead
-    qkv = F.linear(x, sd[f"{prefix}.in_proj_weight"], sd[f"{prefix}.in_proj_bias"])
+    qkv = _lin(x, sd[f"{prefix}.in_proj_weight"], sd[f"{prefix}.in_proj_bias"], act_fp8)
     q, k, v = qkv[:, :d], qkv[:, d : 2 * d], qkv[:, 2 * d :]
     if kv_state is not None:  # incremental mode: append to cached keys/values
         if kv_state.get("k") is not None:
@@ -228,25 +240,26 @@ def mha(sd, prefix: str, x, nhead: int, attn_mask: Optional[torch.Tensor], kv_st
         scores = scores.masked_fill(attn_mask[None], float("-inf"))
     p = torch.softmax(scores, dim=-1)
     o = torch.matmul(p, vh).transpose(0, 1).reshape(T, d)
-    return F.linear(o, sd[f"{prefix}.out_proj.weight"], sd[f"{prefix}.out_proj.bias"])
+    return _lin(o, sd[f"{prefix}.out_proj.weight"], sd[f"{prefix}.out_proj.bias"], act_fp8)
 
 
-def encoder_layer(sd, prefix: str, x, nhead: int, attn_mask, stage_emb, kv_state=None):
+def encoder_layer(sd, prefix: str, x, nhead: int, attn_mask, stage_emb, kv_state=None, act_fp8: bool = False):
     """TransformerEncoderLayer.forward, pre-norm branch (transformer.py:296-302):
     x += SA(norm1(x)); x += W2 relu(W1 norm2(x) + b1) + b2 (ReLU: transformer.py:187, :333)."""
-    x = x + mha(sd, f"{prefix}.self_attn", norm_site(sd, f"{prefix}.norm1", x, stage_emb), nhead, attn_mask, kv_state)
-    h = F.relu(F.linear(norm_site(sd, f"{prefix}.norm2", x, stage_emb), sd[f"{prefix}.linear1.weight"], sd[f"{prefix}.linear1.bias"]))
-    x = x + F.linear(h, sd[f"{prefix}.linear2.weight"], sd[f"{prefix}.linear2.bias"])
+    x = x + mha(sd, f"{prefix}.self_attn", norm_site(sd, f"{prefix}.norm1", x, stage_emb), nhead, attn_mask, kv_state, act_fp8)
+    h = F.relu(_lin(norm_site(sd, f"{prefix}.norm2", x, stage_emb), sd[f"{prefix}.linear1.weight"], sd[f"{prefix}.linear1.bias"], act_fp8))
+    x = x + _lin(h, sd[f"{prefix}.linear2.weight"], sd[f"{prefix}.linear2.bias"], act_fp8)
     return x
 
 
-def encoder(sd, prefix: str, cfg: OracleConfig, x, attn_mask=None, stage_emb=None, kv_states=None, layer_states=None):
+def encoder(sd, prefix: str, cfg: OracleConfig, x, attn_mask=None, stage_emb=None, kv_states=None, layer_states=None,
+            act_fp8: bool = False):
     """TransformerEncoder.forward (transformer.py:363-406): L layers, then the final norm
     (LayerNorm for AR, valle.py:151; AdaptiveLayerNorm(nn.LayerNorm) for NAR, valle.py:242-244)."""
     for l in range(cfg.num_layers):
         x = encoder_layer(
             sd, f"{prefix}.layers.{l}", x, cfg.nhead, attn_mask, stage_emb,
-            None if kv_states is None else kv_states[l],
+            None if kv_states is None else kv_states[l], act_fp8,
         )
         if layer_states is not None:
             layer_states.append(x.clone())
@@ -283,7 +296,7 @@ def topk_sampling(logits: torch.Tensor, top_k: int, temperature: float, generato
 def ar_decode(
     sd, cfg: OracleConfig, x_ids, x_lens, prompts, top_k=-100, temperature=1.0,
     kv_cache=False, force_tokens: Optional[torch.Tensor] = None, max_new: Optional[int] = None,
-    trace: Optional[Dict[str, List]] = None, generator=None,
+    trace: Optional[Dict[str, List]] = None, generator=None, act_fp8: bool = False,
 ):
     """The AR ``while True`` loop, valle.py:993-1059.  Returns y (1, [bos+]P+G) int64.
 
@@ -316,7 +329,8 @@ def ar_decode(
                 mask = prefix_lm_mask(S, y.shape[0]).to(x.device)
             else:
                 inp, mask = y_pos, None  # the new row sees every cached key (causal row = last)
-            xy_dec = encoder(sd, "ar_decoder", cfg, inp, attn_mask=mask, kv_states=kv_states)
+            # engine mode FP8: only the packed prefill pass quantises its activations; the single-row steps do not
+            xy_dec = encoder(sd, "ar_decoder", cfg, inp, attn_mask=mask, kv_states=kv_states, act_fp8=act_fp8 and mask is not None)
             n_cached_audio = y.shape[0]
         logits = F.linear(xy_dec[-1:], sd["ar_predict_layer.weight"])  # :1039  (1, 1025)
         if trace is not None:
@@ -343,7 +357,7 @@ def ar_decode(
     return y[None]
 
 
-def nar_decode(sd, cfg: OracleConfig, text_ids, y0, prompts, prefix_len, enroll_x_lens=None, trace=None):
+def nar_decode(sd, cfg: OracleConfig, text_ids, y0, prompts, prefix_len, enroll_x_lens=None, trace=None, act_fp8: bool = False):
     """The seven NAR stages, valle.py:1062-1137 (also the body of continual(), :1176-1238).
 
     text_ids (S,) ; y0 (P+G,) first-codebook stream without BOS ; prompts (P,Q)."""
@@ -365,7 +379,7 @@ def nar_decode(sd, cfg: OracleConfig, text_ids, y0, prompts, prefix_len, enroll_
         y_pos = sine_position(y_emb, sd["nar_audio_position.alpha"])  # :1121-1122
         xy_pos = torch.cat([x, y_pos], 0)  # :1123
         stage = sd[f"nar_stage_embeddings.{i}.word_embeddings.weight"]  # (1, d)  :1126
-        xy_dec = encoder(sd, "nar_decoder", cfg, xy_pos, attn_mask=None, stage_emb=stage)  # :1125-1127
+        xy_dec = encoder(sd, "nar_decoder", cfg, xy_pos, attn_mask=None, stage_emb=stage, act_fp8=act_fp8)  # :1125-1127
         logits = F.linear(xy_dec[S + prefix_len :], sd[f"nar_predict_layers.{i}.weight"])  # :1128
         if trace is not None:
             trace.setdefault("nar_logits", []).append(logits.clone())
@@ -382,17 +396,18 @@ def nar_decode(sd, cfg: OracleConfig, text_ids, y0, prompts, prefix_len, enroll_
 @torch.no_grad()
 def inference(
     sd, cfg: OracleConfig, x, x_lens, y, enroll_x_lens=None, top_k=-100, temperature=1.0,
-    kv_cache=False, force_tokens=None, max_new=None, trace=None, generator=None, quiet=True,
+    kv_cache=False, force_tokens=None, max_new=None, trace=None, generator=None, quiet=True, act_fp8=False,
 ):
     """VALLE.inference, valle/models/valle.py:961-1137.  x (1,S) int64, x_lens (1,) int32,
     y (1,P,Q) int64 -> (1,G,Q) int64."""
     cfg.check_supported()
-    yy = ar_decode(sd, cfg, x, x_lens, y, top_k, temperature, kv_cache, force_tokens, max_new, trace, generator)
+    assert not act_fp8 or kv_cache, "act_fp8 models the engine's packed prefill + single-row steps: needs kv_cache=True"
+    yy = ar_decode(sd, cfg, x, x_lens, y, top_k, temperature, kv_cache, force_tokens, max_new, trace, generator, act_fp8)
     P = y.shape[1]
     if not quiet:
         print(f"VALL-E EOS [{P} -> {yy.shape[1]}]")  # :1054
     y0 = yy[0, int(cfg.prepend_bos) :]
-    return nar_decode(sd, cfg, x[0], y0, y[0], P, enroll_x_lens, trace)
+    return nar_decode(sd, cfg, x[0], y0, y[0], P, enroll_x_lens, trace, act_fp8)
 
 
 @torch.no_grad()

@@ -1,0 +1,121 @@
+"""GPU: engine mode FP8 -- BASELINE.json configs[4] "fp8 weights (CDNA4 fp8 MFMA)": the prefill / NAR Linears run
+e4m3fn x e4m3fn on v_mfma_scale_f32_16x16x128_f8f6f4 (gemm_fp8.hip) with per-row power-of-two scales on both operands.
+
+* the activation quantiser is bit-identical to torch.float8_e4m3fn under the FP8W scale rule;
+* the fp8 GEMM equals the fp32 product of the DEQUANTISED operands up to fp32 summation order (the quantisation is
+  exact by construction: codes * power-of-two scales), every epilogue, full and ragged tiles;
+* the FP8 engine against the oracle that applies the same quantisation (oracle act_fp8=True on W'), teacher-forced:
+  logits within 5 % of sigma; and against the plain fp32 oracle at the stated fp8-activation tolerance (15 % max, 3 % mean).
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import valle_amd  # noqa: E402
+from oracle import valle_oracle as vo  # noqa: E402
+from valle_amd import ops  # noqa: E402
+
+DEV = "cuda:0"
+
+
+@pytest.mark.parametrize("rows,K", [(5, 512), (130, 1024), (257, 1536), (64, 6144)])
+def test_activation_quantiser_bit_identical_to_torch_float8(rows, K):
+    g = torch.Generator().manual_seed(rows + K)
+    x = (torch.randn(rows, K, generator=g) * torch.logspace(-3, 2, rows)[:, None]).to(torch.bfloat16)
+    x[0, :] = 0  # an all-zero row: scale 1, codes 0
+    q, sc = ops.quantize_rows_fp8(x.to(DEV))
+    qr, scr, _ = vo.fp8w_quantize(x.float())
+    assert torch.equal(sc.cpu(), scr)
+    assert torch.equal(q.cpu(), qr), f"{(q.cpu() != qr).sum().item()} codes differ"
+
+
+@pytest.mark.parametrize("M,N,K", [(1025, 3072, 1024), (300, 1024, 4096), (16, 1536, 1536), (4100, 4096, 1024), (129, 1028, 512)])
+@pytest.mark.parametrize("epi", [ops.EPI_STORE, ops.EPI_RELU, ops.EPI_RESID, ops.EPI_F32])
+def test_fp8_gemm_equals_product_of_dequantised_operands(M, N, K, epi):
+    g = torch.Generator().manual_seed(M * 7 + N)
+    a = (torch.randn(M, K, generator=g) * 1.7).to(torch.bfloat16)
+    w = torch.randn(N, K, generator=g) * 0.05
+    bias = torch.randn(N, generator=g)
+    qa, sa, da = vo.fp8w_quantize(a.float())
+    qw, sw, dw = vo.fp8w_quantize(w)
+    ref = da.double() @ dw.double().T + bias.double()
+    resid0 = torch.randn(M, N, generator=g)
+    got = ops.linear_fp8(qa.to(DEV), sa.to(DEV), qw.to(DEV), sw.to(DEV), bias.to(DEV), epilogue=epi,
+                         resid=resid0.clone().to(DEV) if epi == ops.EPI_RESID else None).float().cpu()
+    if epi == ops.EPI_RELU:
+        ref = ref.clamp_min(0)
+    if epi == ops.EPI_RESID:
+        ref = ref + resid0.double()
+    scale = ref.abs().max().item()
+    tol = 5e-5 * scale if epi in (ops.EPI_RESID, ops.EPI_F32) else 5e-3 * scale  # fp32 summation order; bf16 outputs: one rounding at 2^-9
+    assert (got.double() - ref).abs().max().item() <= tol, ((got.double() - ref).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize("d,h,L,B", [(512, 8, 2, 3), (1024, 16, 2, 5)])
+def test_fp8_engine_teacher_forced_vs_quantising_oracle(d, h, L, B):
+    cfg = vo.OracleConfig(d_model=d, nhead=h, num_layers=L, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 31)
+    sd8 = vo.fp8w_state_dict(sd)
+    g = torch.Generator().manual_seed(4)
+    S = torch.randint(4, 9, (B,), generator=g).tolist()
+    P = torch.randint(40, 70, (B,), generator=g).tolist()   # > 128 packed rows: full and tail tiles of the fp8 GEMM
+    n = 10
+    X = torch.zeros(B, max(S), dtype=torch.int64)
+    Y = torch.zeros(B, max(P), 8, dtype=torch.int64)
+    refs, refs32 = [], []
+    for b in range(B):
+        x, xl, y = vo.make_inputs(S[b], P[b], seed=40 + b)
+        X[b, : S[b]] = x[0]; Y[b, : P[b]] = y[0]
+        tr = {}
+        c = vo.inference(sd8, cfg, x, xl, y, None, top_k=1, kv_cache=True, max_new=n, trace=tr, act_fp8=True)
+        refs.append((c[0], torch.stack(tr["ar_logits"]), tr["nar_logits"]))
+        tr32 = {}
+        vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True, force_tokens=c[0, :, 0], trace=tr32)
+        refs32.append(torch.stack(tr32["ar_logits"]))
+    m = valle_amd.VALLE(d, h, L, prefix_mode=1, engine_dtype="fp8", max_batch=B)
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    eng = m.engine_for(B, max(S), max(P))
+    eng.set_option("trace_ar_logits", 1)
+    eng.set_option("trace_nar_logits", 1)
+    G = [int(r[0].shape[0]) for r in refs]  # an utterance may reach EOS before max_new
+    forced = torch.zeros(B, n, dtype=torch.int64)
+    fcodes = torch.zeros(B, n, 8, dtype=torch.int64)
+    for b in range(B):
+        forced[b, : G[b]] = refs[b][0][:, 0]
+        fcodes[b, : G[b]] = refs[b][0]
+    eng.prefill(X.to(DEV), S, Y.to(DEV), P)
+    _, gl = eng.generate(top_k=1, forced=forced.to(DEV), forced_lens=G)
+    assert gl == G
+    lg = eng.fetch_ar_logits()
+    worst = worst32 = 0.0
+    for b in range(B):
+        sigma = refs[b][1].std().item()
+        d8 = (lg[: G[b] + 1, b] - refs[b][1]).abs()
+        assert d8.max().item() <= 0.05 * sigma, (b, d8.max().item(), sigma)
+        assert d8.mean().item() <= 0.01 * sigma
+        d32 = (lg[: G[b] + 1, b] - refs32[b]).abs()
+        assert d32.max().item() <= 0.15 * sigma and d32.mean().item() <= 0.03 * sigma, (b, d32.max().item(), d32.mean().item(), sigma)
+        worst, worst32 = max(worst, d8.max().item() / sigma), max(worst32, d32.max().item() / sigma)
+    codes = eng.nar(None, forced=fcodes).cpu()
+    off = 0
+    agree = 0
+    for b in range(B):
+        for i in range(7):
+            mine = eng.fetch_nar_logits(i)[off: off + G[b]]
+            ref = refs[b][2][i]
+            s_i = ref.std().item()
+            assert (mine - ref).abs().max().item() <= 0.05 * s_i, (b, i, (mine - ref).abs().max().item(), s_i)
+        agree += int((codes[b, : G[b]] == refs[b][0]).sum())
+        off += G[b]
+    tot = sum(G) * 8
+    print(f"FP8 engine vs quantising oracle: worst AR |dlogit|/sigma {worst:.4f} (vs fp32 oracle on the original weights {worst32:.4f}); "
+          f"code agreement {agree / tot:.4f}")
+    assert agree / tot > 0.9
+    # A/B hook: the same engine on the bf16 kernels (fp8_gemm = 0) is the FP8W engine
+    eng.set_option("fp8_gemm", 0)
+    eng.prefill(X.to(DEV), S, Y.to(DEV), P)
+    eng.generate(top_k=1, forced=forced.to(DEV), forced_lens=G)
+    lgw = eng.fetch_ar_logits()
+    assert (lgw[:2] - lg[:2]).abs().max().item() > 0  # the two paths really differ (fp8 activations)

@@ -13,7 +13,7 @@ LIB_PATH = os.path.join(_HERE, "libvalle_engine.so")
 
 VLE_OK = 0
 VLE_EINVAL, VLE_ESTATE, VLE_EHIP, VLE_EKEY, VLE_ENOTOKEN, VLE_EINDEX = -1, -2, -3, -4, -5, -6
-DTYPE_F32, DTYPE_BF16, DTYPE_FP8W = 0, 1, 2
+DTYPE_F32, DTYPE_BF16, DTYPE_FP8W, DTYPE_FP8 = 0, 1, 2, 3
 
 
 class VleConfig(C.Structure):
@@ -63,6 +63,8 @@ SIGNATURES = {
     "vle_op_attn_out_proj": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vle_op_token_embedding": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32]),
     "vle_op_sine_positional": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int32, C.c_int32]),
+    "vle_op_quantize_rows_fp8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32]),
+    "vle_op_linear_fp8": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_cross_entropy": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "vle_op_adaln_fold": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32]),
 }

@@ -51,6 +51,8 @@ struct LayerW {
   // the fp8 codes in FP8W mode
   void *wqkv_p = nullptr, *wo_p = nullptr, *w1_p = nullptr, *w2_p = nullptr;
   float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;
+  // fused LayerNorm of the batched step (kernels.h LnConsumer): wg = W gamma, wb = W beta + bias, fp32, of the effective weights
+  float *wg_qkv = nullptr, *wb_qkv = nullptr, *wg_1 = nullptr, *wb_1 = nullptr;
 };
 
 }  // namespace vle
@@ -85,7 +87,11 @@ struct vle_engine {
   void* ar_predict_p = nullptr;    // fragment-major copy (see LayerW)
   bool opt_gs_wpack = true;        // option "gs_wpack": gemm_skinny reads the fragment-major weight copies
   float* ar_predict_s = nullptr;
-  bool w8 = false;                 // dtype_mode == VLE_DTYPE_FP8W: dtype stays DT_BF16 for activations / KV / MFMA passes
+  bool w8 = false;                 // dtype_mode == VLE_DTYPE_FP8W / FP8: dtype stays DT_BF16 for activations / KV / MFMA passes
+  bool a8 = false;                 // dtype_mode == VLE_DTYPE_FP8: the packed passes run gemm_fp8.hip on per-row-quantised activations
+  unsigned char* A8 = nullptr;     // [max_rows][4 d] e4m3fn codes of the current GEMM's activations
+  float* a8_scale = nullptr;       // [max_rows]
+  bool opt_fp8_gemm = true;        // option "fp8_gemm": 0 = FP8 mode runs the bf16 kernels on bf16(W') like FP8W (A/B)
   void* nar_predict[7] = {};
   // folded AdaLN affine, [stage][site] with site = 2*l (norm1), 2*l+1 (norm2), 2*L (final)
   std::vector<std::vector<float*>> nar_gamma, nar_beta;
@@ -135,6 +141,9 @@ struct vle_engine {
   bool opt_gs_xf = true;            // option "gs_xf": AR-step activations of the gemm_skinny path in the fragment-major layout
   int opt_gs_target = 0;            // option "gs_target_wgs": workgroups the split-K of gemm_skinny aims for (0 = 256)
   void* gs_ws = nullptr;            // split-K tickets + partial tiles of gemm_skinny (zeroed once)
+  bool opt_gs_fuse_ln = true;       // option "gs_fuse_ln": LayerNorm folded into the gemm_skinny launches (no LayerNorm kernels in the step)
+  float* ln_stats = nullptr;        // [64][d / 16][2] group statistics of the residual rows (kernels.h LnProducer)
+  float *wg_pred = nullptr, *wb_pred = nullptr;  // final LayerNorm + ar_predict_layer
   bool opt_ignore_eos = false;  // option "ignore_eos": synthetic-weight benchmarks run every utterance to the length cap
   bool opt_no_gemv1 = false;  // option "no_gemv1": force the generic skinny kernel at batch 1 (A/B measurements)
   int opt_nsplit = 0;         // option "nsplit": 0 = chosen per batch
@@ -249,6 +258,34 @@ int upload_fp8w(vle_engine* e, void** dst, void** q8, float** sc, const float* s
   return 0;
 }
 
+// wg[n] = sum_k Weff[n][k] * gamma[k], wb[n] = sum_k Weff[n][k] * beta[k] + bias[n] for the fused LayerNorm of the batched
+// step; Weff = the values the GEMM multiplies with (bf16-rounded weights, or W' in FP8W mode)
+int upload_wg_wb(vle_engine* e, const float* w, int64_t N, int64_t K, const float* gamma, const float* beta, const float* bias,
+                 float** wg_dev, float** wb_dev) {
+  std::vector<float> deq;
+  if (e->w8) {
+    deq.resize((size_t)(N * K));
+    std::vector<float> sc((size_t)N);
+    quantize_rows_fp8w(w, N, K, nullptr, sc.data(), deq.data());
+    w = deq.data();
+  }
+  std::vector<float> wg((size_t)N), wb((size_t)N);
+  for (int64_t n = 0; n < N; ++n) {
+    const float* row = w + n * K;
+    double ag = 0.0, ab = 0.0;
+    for (int64_t k = 0; k < K; ++k) {
+      const double wv = e->w8 ? (double)row[k] : (double)bf16_to_f32(f32_to_bf16(row[k]));
+      ag += wv * (double)gamma[k];
+      ab += wv * (double)beta[k];
+    }
+    wg[n] = (float)ag;
+    wb[n] = (float)(ab + (bias ? (double)bias[n] : 0.0));
+  }
+  int r = upload_f32(e, wg_dev, wg.data(), wg.size());
+  if (r) return r;
+  return upload_f32(e, wb_dev, wb.data(), wb.size());
+}
+
 // fp32 host tensor -> compute dtype on the device
 int upload_T(vle_engine* e, void** dst, const float* src, size_t n) {
   if (e->dtype == DT_F32) return upload_f32(e, (float**)dst, src, n);
@@ -349,15 +386,19 @@ extern "C" int vle_create(const vle_config* c, vle_engine** out) {
   if (c->dtype_mode == VLE_DTYPE_BF16 && c->d_model % 64 != 0) return bad("bf16 mode needs d_model % 64 == 0");
   if (c->num_quantizers < 1 || c->num_quantizers > 8) return bad("num_quantizers must be 1..8");
   if (!(c->prefix_mode == 0 || c->prefix_mode == 1 || c->prefix_mode == 2 || c->prefix_mode == 4)) return bad("bad prefix_mode");
-  if (c->dtype_mode != VLE_DTYPE_F32 && c->dtype_mode != VLE_DTYPE_BF16 && c->dtype_mode != VLE_DTYPE_FP8W) return bad("bad dtype_mode");
+  if (c->dtype_mode != VLE_DTYPE_F32 && c->dtype_mode != VLE_DTYPE_BF16 && c->dtype_mode != VLE_DTYPE_FP8W && c->dtype_mode != VLE_DTYPE_FP8)
+    return bad("bad dtype_mode");
   if (c->dtype_mode == VLE_DTYPE_FP8W && c->d_model % 64 != 0) return bad("fp8w mode needs d_model % 64 == 0");
+  if (c->dtype_mode == VLE_DTYPE_FP8 && c->d_model % 512 != 0) return bad("fp8 mode needs d_model % 512 == 0");
   if (c->max_batch < 1 || c->max_text < 1 || c->max_prompt < 0) return bad("bad capacity");
 
   vle_engine* e = new vle_engine();
   e->cfg = *c;
   e->d = c->d_model; e->H = c->nhead; e->dh = dh; e->L = c->num_layers; e->Q = c->num_quantizers;
-  e->bos = c->prepend_bos ? 1 : 0; e->dtype = c->dtype_mode == VLE_DTYPE_FP8W ? DT_BF16 : c->dtype_mode;
-  e->w8 = c->dtype_mode == VLE_DTYPE_FP8W;
+  e->bos = c->prepend_bos ? 1 : 0;
+  e->dtype = (c->dtype_mode == VLE_DTYPE_FP8W || c->dtype_mode == VLE_DTYPE_FP8) ? DT_BF16 : c->dtype_mode;
+  e->w8 = c->dtype_mode == VLE_DTYPE_FP8W || c->dtype_mode == VLE_DTYPE_FP8;
+  e->a8 = c->dtype_mode == VLE_DTYPE_FP8;
   e->max_B = c->max_batch; e->max_S = c->max_text; e->max_P = c->max_prompt;
   e->max_G = c->max_gen > 0 ? c->max_gen : 16 * c->max_text + 1;
   e->ctx_max = e->max_S + e->max_P + 1 + e->max_G;
@@ -439,7 +480,7 @@ static int load_layer(vle_engine* e, const std::string& p, LayerW& w, bool adapt
   // one Linear weight: compute dtype, or (FP8W) bf16(W') plus, for the AR decoder, the fp8 codes + row scales
   auto up = [&](void** dst, void** q8, float** sc, int64_t N, int64_t K) -> int {
     if (!e->w8) return upload_T(e, dst, t->data(), t->size());
-    return upload_fp8w(e, dst, adaptive ? nullptr : q8, sc, t->data(), N, K);
+    return upload_fp8w(e, dst, (adaptive && !e->a8) ? nullptr : q8, sc, t->data(), N, K);  // FP8 mode: the NAR decoder's codes too
   };
   GET(".self_attn.in_proj_weight", 3 * d, d);
   if ((r = up(&w.wqkv, &w.wqkv8, &w.sqkv, 3 * d, d))) return r;
@@ -466,6 +507,19 @@ static int load_layer(vle_engine* e, const std::string& p, LayerW& w, bool adapt
     if ((r = upload_f32(e, &w.g2, t->data(), t->size()))) return r;
     GET(".norm2.bias", d);
     if ((r = upload_f32(e, &w.be2, t->data(), t->size()))) return r;
+    if (e->max_B >= 2 && e->dtype == DT_BF16 && e->d % 256 == 0) {  // the batched step exists: fused-LayerNorm vectors
+      const auto* wq = find_w(e, p + ".self_attn.in_proj_weight", {3 * d, d});
+      const auto* bq = find_w(e, p + ".self_attn.in_proj_bias", {3 * d});
+      const auto* w1 = find_w(e, p + ".linear1.weight", {4 * d, d});
+      const auto* b1 = find_w(e, p + ".linear1.bias", {4 * d});
+      const auto* g1 = find_w(e, p + ".norm1.weight", {d});
+      const auto* be1 = find_w(e, p + ".norm1.bias", {d});
+      const auto* g2 = find_w(e, p + ".norm2.weight", {d});
+      const auto* be2 = find_w(e, p + ".norm2.bias", {d});
+      if (!wq || !bq || !w1 || !b1 || !g1 || !be1 || !g2 || !be2) return VLE_EKEY;
+      if ((r = upload_wg_wb(e, wq->data(), 3 * d, d, g1->data(), be1->data(), bq->data(), &w.wg_qkv, &w.wb_qkv))) return r;
+      if ((r = upload_wg_wb(e, w1->data(), 4 * d, d, g2->data(), be2->data(), b1->data(), &w.wg_1, &w.wb_1))) return r;
+    }
   }
 #undef GET
   return 0;
@@ -532,6 +586,12 @@ extern "C" int vle_finalize_weights(vle_engine* e) {
   if (e->w8) r = upload_fp8w(e, &e->ar_predict, &e->ar_predict8, &e->ar_predict_s, t->data(), V_AR, d);
   else r = upload_T(e, &e->ar_predict, t->data(), t->size());
   if (r) return r;
+  if (e->max_B >= 2 && e->dtype == DT_BF16 && e->d % 256 == 0) {
+    const auto* ng = find_w(e, "ar_decoder.norm.weight", {d});
+    const auto* nb = find_w(e, "ar_decoder.norm.bias", {d});
+    if (!ng || !nb) return VLE_EKEY;
+    if ((r = upload_wg_wb(e, t->data(), V_AR, d, ng->data(), nb->data(), nullptr, &e->wg_pred, &e->wb_pred))) return r;
+  }
 
   if (e->Q > 1) {
     GETK("nar_text_embedding.word_embeddings.weight", NUM_TEXT_TOKENS, d);
@@ -641,6 +701,10 @@ static int alloc_buffers(vle_engine* e) {
     if ((r = dev_alloc(e, &p, gemm_skinny_workspace_bytes()))) return r;
     E_HIP(e, hipMemset(p, 0, gemm_skinny_workspace_bytes()));
     e->gs_ws = p;
+    // free / finished slots keep whatever they held: start from finite values
+    E_HIP(e, hipMemset(e->xn_step, 0, Bp * d * es));
+    if ((r = dev_alloc(e, &e->ln_stats, (size_t)64 * (d / 16 + 1) * 2))) return r;
+    E_HIP(e, hipMemset(e->ln_stats, 0, (size_t)64 * (d / 16 + 1) * 2 * sizeof(float)));
   }
   if ((r = dev_alloc(e, &e->state_dev, 6 * B + 8))) return r;
   e->S.kv_len = e->state_dev;
@@ -668,6 +732,10 @@ static int alloc_buffers(vle_engine* e) {
   e->ATT = p;
   if ((r = dev_alloc(e, &p, (size_t)R * 4 * d * es))) return r;
   e->Hb = p;
+  if (e->a8) {
+    if ((r = dev_alloc(e, &e->A8, (size_t)R * 4 * d))) return r;
+    if ((r = dev_alloc(e, &e->a8_scale, (size_t)R))) return r;
+  }
   if (e->Q > 1) {
     if ((r = dev_alloc(e, &e->yemb, (size_t)B * (e->max_P + e->max_G) * d))) return r;
     if ((r = dev_alloc(e, &e->nar_logits, (size_t)B * e->max_G * NUM_AUDIO_TOKENS))) return r;
@@ -722,19 +790,34 @@ const char* kIdErrMsg = "token id out of range: text ids must be in [0, 512), fi
 constexpr int POLL_IDERR = 40;  // poll_host slot of the id-range flag
 
 // one transformer layer over packed rows (prefill: AR weights + prefix-LM mask; NAR: no mask, folded AdaLN)
+// one Linear over packed rows: engine mode FP8 quantises the bf16 activations per row and runs the fp8 MFMA GEMM on the
+// layer's e4m3fn codes (gemm_fp8.hip); every other mode (and shapes that kernel does not cover) the bf16 / fp32 GEMM
+int gemm_rows(vle_engine* e, const void* A, const void* w, const void* w8, const float* wscale, const float* bias, void* out,
+              float* resid, int64_t rows, int N, int K, int epi) {
+  if (e->a8 && e->opt_fp8_gemm && w8 != nullptr && wscale != nullptr) {
+    const int q = launch_quantize_rows_fp8(e->st, A, e->A8, e->a8_scale, rows, K);
+    if (q < 0) return q;
+    if (q == 0) {
+      const int g = launch_gemm_fp8(e->st, e->A8, e->a8_scale, w8, wscale, bias, out, resid, rows, N, K, epi);
+      if (g <= 0) return g;
+    }
+  }
+  return launch_gemm(e->st, e->dtype, A, w, bias, out, resid, rows, N, K, epi);
+}
+
 int enqueue_layer_rows(vle_engine* e, const LayerW& w, const float* g1, const float* b1, const float* g2, const float* b2,
                        int64_t rows, const int32_t* seq_off, const int32_t* text_len, int max_len, int causal,
                        void* kc, void* vc, const int32_t* row_seq, const int32_t* row_pos) {
   const int d = e->d;
   hipStream_t st = e->st;
   E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, nullptr, g1, b1, e->Xn, rows, d));
-  E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.wqkv, w.bqkv, e->QKV, nullptr, rows, 3 * d, d, EPI_STORE));
+  E_LAUNCH(e, gemm_rows(e, e->Xn, w.wqkv, w.wqkv8, w.sqkv, w.bqkv, e->QKV, nullptr, rows, 3 * d, d, EPI_STORE));
   if (kc) E_LAUNCH(e, launch_kv_scatter(st, e->dtype, e->QKV, kc, vc, row_seq, row_pos, rows, d, e->H, e->ctx_max));
   E_LAUNCH(e, launch_attention(st, e->dtype, e->QKV, e->ATT, seq_off, text_len, e->nseq > 0 ? e->nseq : e->B, max_len, d, e->H, causal));
-  E_LAUNCH(e, launch_gemm(st, e->dtype, e->ATT, w.wo, w.bo, nullptr, e->X, rows, d, d, EPI_RESID));
+  E_LAUNCH(e, gemm_rows(e, e->ATT, w.wo, w.wo8, w.so, w.bo, nullptr, e->X, rows, d, d, EPI_RESID));
   E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, nullptr, g2, b2, e->Xn, rows, d));
-  E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.w1, w.b1, e->Hb, nullptr, rows, 4 * d, d, EPI_RELU));
-  E_LAUNCH(e, launch_gemm(st, e->dtype, e->Hb, w.w2, w.b2, nullptr, e->X, rows, d, 4 * d, EPI_RESID));
+  E_LAUNCH(e, gemm_rows(e, e->Xn, w.w1, w.w18, w.s1, w.b1, e->Hb, nullptr, rows, 4 * d, d, EPI_RELU));
+  E_LAUNCH(e, gemm_rows(e, e->Hb, w.w2, w.w28, w.s2, w.b2, nullptr, e->X, rows, d, 4 * d, EPI_RESID));
   return 0;
 }
 
@@ -769,13 +852,25 @@ bool use_xf(const vle_engine* e) {
   return e->opt_gs_xf && use_mfma_skinny(e) && e->d % 256 == 0 && (nv <= 4 || nv == 6 || nv == 8);
 }
 
+// LayerNorm folded into the gemm_skinny launches of the batched step (kernels.h LnProducer / LnConsumer)
+bool use_fuse_ln(const vle_engine* e) {
+  return e->opt_gs_fuse_ln && use_xf(e) && !e->ar.empty() && e->ar[0].wg_qkv != nullptr && e->wg_pred != nullptr && e->ln_stats != nullptr &&
+         e->d <= 2048;
+}
+LnProducer ln_producer(const vle_engine* e, const float* gamma) {
+  LnProducer p;
+  p.gamma = gamma; p.xg_out = e->xn_step; p.stats_out = e->ln_stats; p.w8 = e->w8 ? 1 : 0; p.MF = (e->B + 15) / 16;
+  return p;
+}
+
 bool use_skinny(const vle_engine* e) {
   if (use_mfma_skinny(e)) return false;
   return e->B <= SKINNY_MAX_B && (size_t)(e->B <= 1 ? 1 : e->B <= 2 ? 2 : e->B <= 4 ? 4 : 8) * 4 * e->d * sizeof(float) <= 160 * 1024;
 }
 
 // logits of the current x_step rows: final LayerNorm (valle.py:151) + ar_predict_layer (valle.py:1039)
-int enqueue_ar_logits(vle_engine* e) {
+// `fused`: x_step's producer (the last layer's FFN2 epilogue) already left bf16(x * gamma_final) + group statistics
+int enqueue_ar_logits(vle_engine* e, bool fused = false) {
   hipStream_t st = e->st;
   ProfScope ps(e, 5);
   if (use_skinny(e)) {
@@ -785,16 +880,25 @@ int enqueue_ar_logits(vle_engine* e) {
     E_LAUNCH(e, launch_ar_linear(e, a));
   } else {
     const bool xf = use_xf(e);
-    if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d, e->w8 ? 1 : 0));
-    else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, e->xn_step, e->B, e->d));
+    fused = fused && use_fuse_ln(e);
+    // un-fused calls (prefill, slot admission) normalise into a scratch buffer: with the fused step xn_step holds the live
+    // utterances' bf16(x * gamma) for their NEXT step and must survive
+    void* xn = fused ? e->xn_step : e->att_step;
+    if (!fused) {
+      if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, e->ar_norm_g, e->ar_norm_b, xn, e->B, e->d, e->w8 ? 1 : 0));
+      else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, e->ar_norm_g, e->ar_norm_b, xn, e->B, e->d));
+    }
     if (use_mfma_skinny(e)) {
       GemmSkinnyArgs g;
       g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target; g.x_xf = xf ? 1 : 0;
-      g.x = e->xn_step; g.w = e->w8 ? e->ar_predict8 : e->ar_predict; g.wscale = e->w8 ? e->ar_predict_s : nullptr; g.M = e->B; g.N = V_AR;
+      if (fused) {
+        g.lnc.stats = e->ln_stats; g.lnc.wg = e->wg_pred; g.lnc.nslots = e->d / 16; g.bias = e->wb_pred;
+      }
+      g.x = xn; g.w = e->w8 ? e->ar_predict8 : e->ar_predict; g.wscale = e->w8 ? e->ar_predict_s : nullptr; g.M = e->B; g.N = V_AR;
       if (e->opt_gs_wpack && e->ar_predict_p) { g.w = e->ar_predict_p; g.w_packed = 1; } g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
       E_LAUNCH(e, launch_gemm_skinny(st, g));
     } else {
-      E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
+      E_LAUNCH(e, launch_gemm(st, e->dtype, xn, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
     }
   }
   return 0;
@@ -807,6 +911,7 @@ int enqueue_ar_sample(vle_engine* e, int first, const int32_t* slot_map = nullpt
   a.slot_map = slot_map; a.id_err = e->id_err_dev;
   if (!first) a.kt = e->next_kt();
   if (e->opt_host_prog && !slot_map) a.host_prog = e->prog_dev;
+  if (use_mfma_skinny(e) && use_fuse_ln(e)) a.lnp = ln_producer(e, e->ar[0].g1);
   a.tokens = e->tokens; a.g_stride = e->max_G; a.sampled = e->sampled;
   a.audio_emb = e->ar_audio_emb; a.pe = e->pe; a.alpha_audio = e->alphas + 1; a.x = e->x_step; a.ctx_max = e->ctx_max;
   E_LAUNCH(e, launch_ar_sample(e->st, a));
@@ -830,12 +935,20 @@ int enqueue_ar_step(vle_engine* e) {
       g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target;
       const bool xf = use_xf(e);                 // step activations fragment-major (common.h xf_index)
       const int xfw = xf ? (e->w8 ? 2 : 1) : 0;  // producer-side code: which k split the consuming GEMM uses
+      const bool fuse = use_fuse_ln(e);          // no LayerNorm launches: producers emit x * gamma + statistics (kernels.h)
+      LnConsumer lnc;
+      lnc.stats = e->ln_stats; lnc.nslots = d / 16;
       {
         ProfScope ps(e, 0);
-        if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, w.g1, w.be1, e->xn_step, e->B, d, e->w8 ? 1 : 0));
-        else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
+        if (!fuse) {
+          if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, w.g1, w.be1, e->xn_step, e->B, d, e->w8 ? 1 : 0));
+          else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g1, w.be1, e->xn_step, e->B, d));
+        }
         g.x_xf = xf ? 1 : 0;
         g.x = e->xn_step; g.w = e->w8 ? w.wqkv8 : w.wqkv; g.wscale = e->w8 ? w.sqkv : nullptr; g.bias = w.bqkv; g.N = 3 * d; g.K = d; g.epi = GS_EPI_QKV;
+        if (fuse) {
+          g.lnc = lnc; g.lnc.wg = w.wg_qkv; g.bias = w.wb_qkv;
+        }
         const bool wpk = e->opt_gs_wpack && w.wqkv_p != nullptr;
         g.w_packed = wpk ? 1 : 0;
         if (wpk) g.w = w.wqkv_p;
@@ -853,22 +966,33 @@ int enqueue_ar_step(vle_engine* e) {
         ProfScope ps(e, 2);
         if (!direct) E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
         g.x_xf = (xf && direct) ? 1 : 0;  // the merge kernel of the split path writes row-major
+        g.lnc = LnConsumer();
         g.x = e->att_step; g.w = g.w_packed ? w.wo_p : (e->w8 ? w.wo8 : w.wo); g.wscale = e->w8 ? w.so : nullptr; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
+        if (fuse) g.lnp = ln_producer(e, w.g2);  // the residual it completes is read by this layer's norm2 next
         E_LAUNCH(e, launch_gemm_skinny(st, g));
+        g.lnp = LnProducer();
       }
       {
         ProfScope ps(e, 3);
-        if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, w.g2, w.be2, e->xn_step, e->B, d, e->w8 ? 1 : 0));
-        else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
+        if (!fuse) {
+          if (xf) E_LAUNCH(e, launch_layernorm_xf(st, e->x_step, w.g2, w.be2, e->xn_step, e->B, d, e->w8 ? 1 : 0));
+          else E_LAUNCH(e, launch_layernorm(st, e->dtype, e->x_step, nullptr, w.g2, w.be2, e->xn_step, e->B, d));
+        }
         g.x_xf = xf ? 1 : 0; g.out_xf = xfw;  // FFN1 writes the hidden rows for FFN2 in the same layout
         g.x = e->xn_step; g.w = g.w_packed ? w.w1_p : (e->w8 ? w.w18 : w.w1); g.wscale = e->w8 ? w.s1 : nullptr; g.bias = w.b1; g.N = 4 * d; g.K = d; g.epi = GS_EPI_RELU; g.out = e->hT_step;
+        if (fuse) {
+          g.lnc = lnc; g.lnc.wg = w.wg_1; g.bias = w.wb_1;
+        }
         E_LAUNCH(e, launch_gemm_skinny(st, g));
+        g.lnc = LnConsumer();
       }
       {
         ProfScope ps(e, 4);
         g.x_xf = xf ? 1 : 0; g.out_xf = 0;
         g.x = e->hT_step; g.w = g.w_packed ? w.w2_p : (e->w8 ? w.w28 : w.w2); g.wscale = e->w8 ? w.s2 : nullptr; g.bias = w.b2; g.N = d; g.K = 4 * d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
+        if (fuse) g.lnp = ln_producer(e, l + 1 < e->L ? e->ar[l + 1].g1 : e->ar_norm_g);  // next layer's norm1, or the final norm
         E_LAUNCH(e, launch_gemm_skinny(st, g));
+        g.lnp = LnProducer();
       }
       continue;
     }
@@ -930,7 +1054,7 @@ int enqueue_ar_step(vle_engine* e) {
     }
   }
   int r;
-  if ((r = enqueue_ar_logits(e))) return r;
+  if ((r = enqueue_ar_logits(e, gs))) return r;
   return enqueue_ar_sample(e, 0);
 }
 
@@ -1736,8 +1860,9 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal" || n == "gs_fuse_ln") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
+    else if (n == "gs_fuse_ln") e->opt_gs_fuse_ln = value != 0;
     else if (n == "gs_xf") e->opt_gs_xf = value != 0;
     else if (n == "gs_wpack") e->opt_gs_wpack = value != 0;
     else if (n == "w8_temporal") e->opt_w8_temporal = (int)value;
@@ -1781,6 +1906,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
       if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
     }
     e->graphs.clear();
+    return VLE_OK;
+  }
+  if (n == "fp8_gemm") {
+    e->opt_fp8_gemm = value != 0;
     return VLE_OK;
   }
   if (n == "ignore_eos") {

@@ -43,7 +43,7 @@ typedef unsigned int gs_u32x4 __attribute__((ext_vector_type(4)));
 
 // epilogue of one lane: v = 4 consecutive output columns ncol..ncol+3 of row m (bias already added)
 template <int EPI>
-__device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, int ncol) {
+__device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, int ncol, gs_f32x4 gamma4) {
   const int M = a.M, N = a.N;
   if (m >= M || ncol >= N) return;
   const bool vec = ncol + 3 < N && (N & 3) == 0;
@@ -80,8 +80,35 @@ __device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, i
     }
   } else if constexpr (EPI == GS_EPI_RESID) {
     float* o = a.resid + (int64_t)m * N + ncol;
-    if (vec) *reinterpret_cast<gs_f32x4*>(o) = *reinterpret_cast<const gs_f32x4*>(o) + v;
-    else {
+    if (vec) {
+      const gs_f32x4 x4 = *reinterpret_cast<const gs_f32x4*>(o) + v;
+      *reinterpret_cast<gs_f32x4*>(o) = x4;
+      if (a.lnp.gamma != nullptr) {
+        // producer side of the fused LayerNorm (kernels.h LnProducer): the 4 lanes fg = 0..3 of a row hold this workgroup's 16
+        // columns of it (N % 16 == 0, so the four lanes are active together): bf16(x * gamma_next) into the next GEMM's X,
+        // and the group's (mean, M2) into slot blockIdx.x of the row
+        gs_bf16x4 o4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) o4[r] = (__bf16)(x4[r] * gamma4[r]);
+        *reinterpret_cast<gs_bf16x4*>(reinterpret_cast<bf16_t*>(a.lnp.xg_out) + xf_index(m, ncol, a.lnp.MF, a.lnp.w8 != 0)) = o4;
+        float s = (x4[0] + x4[1]) + (x4[2] + x4[3]);
+        s += __shfl_xor(s, 16, 64);
+        s += __shfl_xor(s, 32, 64);
+        const float mean = s * (1.0f / 16.0f);
+        float q = 0.f;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float t = x4[r] - mean;
+          q = fmaf(t, t, q);
+        }
+        q += __shfl_xor(q, 16, 64);
+        q += __shfl_xor(q, 32, 64);
+        if ((threadIdx.x & 63) < 16) {
+          typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
+          *reinterpret_cast<gs_f32x2*>(a.lnp.stats_out + ((int64_t)m * (N >> 4) + (ncol >> 4)) * 2) = gs_f32x2{mean, q};
+        }
+      }
+    } else {
 #pragma unroll
       for (int r = 0; r < 4; ++r)
         if (ncol + r < N) o[r] += v[r];
@@ -157,6 +184,30 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
 #pragma unroll
       for (int r = 0; r < 4; ++r) scale4[r] = ncol + r < N ? a.wscale[ncol + r] : 1.f;
     }
+  }
+
+  // fused LayerNorm (kernels.h): consumer operands (wg of this lane's 4 columns; the group statistics of the row this lane
+  // finishes, 16 rows per wave, the lane's quarter of the row's slots) and the producer's gamma, all requested up front
+  gs_f32x4 wg4 = gs_f32x4{0.f, 0.f, 0.f, 0.f}, gamma4 = gs_f32x4{1.f, 1.f, 1.f, 1.f};
+  constexpr int LN_MAXQ = 16;  // float4 (= 2 slots) per lane: rows up to 4 * 32 * 16 = 2048 wide
+  gs_f32x4 lst[LN_MAXQ];
+  const bool ln_in = a.lnc.stats != nullptr;
+  const int ln_nq = ln_in ? a.lnc.nslots >> 3 : 0;  // float4 per lane = (nslots / 4 lanes) / 2
+  if (ln_in) {
+    if (ncol + 3 < N) wg4 = *reinterpret_cast<const gs_f32x4*>(a.lnc.wg + ncol);
+    else {
+#pragma unroll
+      for (int r = 0; r < 4; ++r) wg4[r] = ncol + r < N ? a.lnc.wg[ncol + r] : 0.f;
+    }
+    if (wave < MF) {
+      const float* sp = a.lnc.stats + ((int64_t)min(wave * 16 + fr, M - 1) * a.lnc.nslots + fg * (a.lnc.nslots >> 2)) * 2;
+#pragma unroll
+      for (int j = 0; j < LN_MAXQ; ++j)
+        if (j < ln_nq) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 4);
+    }
+  }
+  if constexpr (EPI == GS_EPI_RESID) {
+    if (a.lnp.gamma != nullptr && ncol + 3 < N) gamma4 = *reinterpret_cast<const gs_f32x4*>(a.lnp.gamma + ncol);
   }
 
   gs_f32x4 acc[MF];
@@ -250,10 +301,41 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     }
   }
   if (wave >= MF) return;
-  if constexpr (W8) v = v * scale4 + bias4;  // * 2^e is exact
-  else v += bias4;
+  if (ln_in) {
+    // merge the row's 16-column groups in slot order (Chan et al.: mean / M2 of a union; every group has 16 elements), then
+    // the four quarters held by lanes fg = 0..3 with formulas symmetric in the two halves, so all four lanes agree bitwise
+    float mean = lst[0][0], m2 = lst[0][1], cnt = 16.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j) {
+      if (j < ln_nq) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          if (j == 0 && h == 0) continue;
+          const float mb = lst[j][2 * h], qb = lst[j][2 * h + 1];
+          const float delta = mb - mean, tot = cnt + 16.f;
+          mean = fmaf(delta, 16.f / tot, mean);
+          m2 += qb + delta * delta * (cnt * 16.f / tot);
+          cnt = tot;
+        }
+      }
+    }
+#pragma unroll
+    for (int o = 16; o <= 32; o <<= 1) {
+      const float mo = __shfl_xor(mean, o, 64), qo = __shfl_xor(m2, o, 64);
+      const float delta = mo - mean;
+      mean = 0.5f * (mean + mo);
+      m2 = (m2 + qo) + delta * delta * (cnt * 0.5f);
+      cnt *= 2.f;
+    }
+    const float rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
+    if constexpr (W8) v = v * scale4;
+    v = (v - mean * wg4) * rstd + bias4;  // bias4 = wb = W beta + bias
+  } else {
+    if constexpr (W8) v = v * scale4 + bias4;  // * 2^e is exact
+    else v += bias4;
+  }
   // lane (fg, fr) holds C[m = 16 i + fr][n = n0 + 4 fg + r]
-  gs_epilogue<EPI>(a, v, i * 16 + fr, ncol);
+  gs_epilogue<EPI>(a, v, i * 16 + fr, ncol, gamma4);
 }
 
 // K slices across workgroups: enough to give every CU a workgroup (target), each wave keeping >= 64 of K
@@ -298,6 +380,8 @@ bool gemm_skinny_supports(int M, int N, int K, int epi, int dh) {
 // returns 0 = launched, 1 = shape not covered
 int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a) {
   if (!gemm_skinny_supports(a.M, a.N, a.K, a.epi, a.dh)) return 1;
+  if (a.lnc.stats != nullptr && (a.lnc.wg == nullptr || a.bias == nullptr || a.lnc.nslots * 16 != a.K || a.lnc.nslots % 8 != 0 || a.lnc.nslots > 128)) return -1;
+  if (a.lnp.gamma != nullptr && (a.epi != GS_EPI_RESID || a.N % 16 != 0 || !a.lnp.xg_out || !a.lnp.stats_out || a.lnp.MF < 1)) return -1;
   int KS = 1;
   if (a.workspace != nullptr) {  // [GS_WS_CNT_BYTES of zeroed tickets][partial tiles]
     KS = a.ksplit > 0 ? a.ksplit : gemm_skinny_ksplit(a.N, a.K, a.target_wgs > 0 ? a.target_wgs : 256);

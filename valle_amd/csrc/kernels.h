@@ -48,13 +48,38 @@ extern int g_glds_swz;
 // gemm_8ph.hip: bf16, 256 x 256 tile, phase-split schedule; returns 1 when the shape is not covered
 int launch_gemm_8ph(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
                     int K, int epi);
+// gemm_fp8.hip: e4m3fn x e4m3fn on v_mfma_scale_f32_16x16x128_f8f6f4, per-row power-of-two scales on both operands
+// (engine mode FP8); returns 1 when the shape is not covered
+int launch_gemm_fp8(hipStream_t st, const void* A8, const float* a_scale, const void* W8, const float* w_scale, const float* bias,
+                    void* out, float* resid, int64_t M, int N, int K, int epi);
+// misc.hip: bf16 rows -> e4m3fn codes + one power-of-two scale per row; returns 1 when K is not instantiated
+int launch_quantize_rows_fp8(hipStream_t st, const void* x_bf16, void* q, float* scale, int64_t rows, int K);
 extern int g_glds_prio;
 extern int g_glds_w8;
 extern int g_glds_big;  // gemm_glds.hip tile policy: 0 never the 8-wave 256 x 128 tile, -1 default threshold, n > 0 threshold
 
 // ---- gemm_skinny.hip (AR-step weight-streaming MFMA GEMM, bf16, 2 <= M = batch <= 64) ------------
 enum { GS_EPI_STORE = 0, GS_EPI_RELU = 1, GS_EPI_RESID = 2, GS_EPI_F32 = 3, GS_EPI_QKV = 4 };
+// LayerNorm fused across the GEMMs of the batched AR step (no LayerNorm launch):
+//   y[n] = rstd * (sum_k W[n][k] * (gamma[k] x[k]) - mean * wg[n]) + wb[n],   wg = W gamma,  wb = W beta + bias
+// The PRODUCER of a residual row (RESID epilogue, sampling kernel) also writes bf16(x * gamma_next) in the fragment-major X
+// layout and, per 16-column group, the group's (mean, M2 = sum (x - mean)^2); the CONSUMER merges the d/16 groups of a row in a
+// fixed order (Chan's parallel-variance update: exact two-pass quality, deterministic) and applies the algebra in its epilogue.
+struct LnProducer {
+  const float* gamma = nullptr;  // [d] of the LayerNorm that reads this residual next; null = plain epilogue
+  void* xg_out = nullptr;        // bf16, fragment-major [MF * 16][d]
+  float* stats_out = nullptr;    // [rows][d / 16][2]
+  int w8 = 0;                    // xf_index variant the consuming GEMM uses (FP8W weights)
+  int MF = 0;                    // row fragments of the step's batch
+};
+struct LnConsumer {
+  const float* stats = nullptr;  // [rows][nslots][2]; null = X already normalised
+  const float* wg = nullptr;     // [N]; `bias` then holds wb
+  int nslots = 0;                // K / 16
+};
 struct GemmSkinnyArgs {
+  LnProducer lnp;
+  LnConsumer lnc;
   const void* x = nullptr;     // bf16 [M][K]
   const void* w = nullptr;     // bf16 [N][K]
   const float* bias = nullptr; // f32 [N] or null
@@ -205,6 +230,7 @@ struct ArSampleArgs {
   const int32_t* slot_map = nullptr;       // slot API: block i serves utterance slot_map[i] (B = number of listed slots)
   int32_t* id_err = nullptr;               // |= 4 when a forced token is outside the audio vocabulary (it is replaced by 0)
   KTrace kt;
+  LnProducer lnp;                          // batched step with fused LayerNorm: also emit bf16(x * gamma) + group statistics
   // host-visible progress (pinned, mapped): [0] = utterances done before this launch, [1] = sample launches so far.  The host
   // polls these words instead of putting a D2H copy + event on the stream after every graph replay.
   int32_t* host_prog = nullptr;

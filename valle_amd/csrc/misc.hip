@@ -183,4 +183,72 @@ int launch_check_ids(hipStream_t st, int64_t* ids, int64_t stride0, int row_stri
   return 0;
 }
 
+// Per-row fp8 quantisation of the activations that feed gemm_fp8.hip (engine mode FP8): row r of x[bf16, rows x K] ->
+// e4m3fn codes + ONE power-of-two scale (the smallest 2^e with max|x_row| / 2^e <= 448, the rule of the FP8W weights,
+// common.h), so code * scale is exact and the GEMM epilogue's rescaling is exact.  One wave per row, the row in registers
+// (NV 16-byte vectors per lane), v_cvt_pk_fp8_f32 (round-to-nearest-even, OCP e4m3fn on gfx950).
+template <int NV>
+__global__ __launch_bounds__(256) void quantize_rows_fp8_kernel(const bf16_t* __restrict__ x, unsigned char* __restrict__ q,
+                                                                float* __restrict__ scale, int64_t rows) {
+  constexpr int K = NV * 512;
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (r >= rows) return;
+  const uint4* xr = reinterpret_cast<const uint4*>(x + r * K) + lane;
+  uint4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) v[i] = xr[i * 64];
+  float f[NV][8];
+  float amax = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    f[i][0] = __uint_as_float(v[i].x << 16); f[i][1] = __uint_as_float(v[i].x & 0xffff0000u);
+    f[i][2] = __uint_as_float(v[i].y << 16); f[i][3] = __uint_as_float(v[i].y & 0xffff0000u);
+    f[i][4] = __uint_as_float(v[i].z << 16); f[i][5] = __uint_as_float(v[i].z & 0xffff0000u);
+    f[i][6] = __uint_as_float(v[i].w << 16); f[i][7] = __uint_as_float(v[i].w & 0xffff0000u);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) amax = fmaxf(amax, fabsf(f[i][j]));
+  }
+  amax = wave_max_dpp(amax);
+  float sc = 1.f;
+  if (amax > 0.f && amax < INFINITY) {
+    int ex = 0;
+    const float m = frexpf(amax / 448.0f, &ex);
+    sc = ldexpf(1.0f, m == 0.5f ? ex - 1 : ex);
+  }
+  const float inv = 1.0f / sc;  // exact
+  uint2* qr = reinterpret_cast<uint2*>(q + r * K) + lane;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int lo = 0, hi = 0;
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[i][0] * inv, f[i][1] * inv, lo, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[i][2] * inv, f[i][3] * inv, lo, true);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[i][4] * inv, f[i][5] * inv, hi, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[i][6] * inv, f[i][7] * inv, hi, true);
+    qr[i * 64] = uint2{(unsigned)lo, (unsigned)hi};
+  }
+  if (lane == 0) scale[r] = sc;
+}
+
+// returns 0 = launched, 1 = width not instantiated
+int launch_quantize_rows_fp8(hipStream_t st, const void* x_bf16, void* q, float* scale, int64_t rows, int K) {
+  if (rows <= 0) return 0;
+  if (K % 512 != 0) return 1;
+  const dim3 grid((unsigned)((rows + 3) / 4)), block(256);
+#define VLE_Q8(NV) hipLaunchKernelGGL((quantize_rows_fp8_kernel<NV>), grid, block, 0, st, (const bf16_t*)x_bf16, (unsigned char*)q, scale, rows)
+  switch (K / 512) {
+    case 1: VLE_Q8(1); break;
+    case 2: VLE_Q8(2); break;
+    case 3: VLE_Q8(3); break;
+    case 4: VLE_Q8(4); break;
+    case 6: VLE_Q8(6); break;
+    case 8: VLE_Q8(8); break;
+    case 12: VLE_Q8(12); break;
+    case 16: VLE_Q8(16); break;
+    default: return 1;
+  }
+#undef VLE_Q8
+  return 0;
+}
+
 }  // namespace vle

@@ -176,3 +176,19 @@ extern "C" int vle_op_cross_entropy(void* stream, const float* logits, const int
   if (!logits || !targets || !loss || !hit || rows < 0 || V < 1 || topk < 1) return op_fail("vle_op_cross_entropy: bad argument");
   return op_done(launch_cross_entropy((hipStream_t)stream, logits, targets, loss, hit, rows, V, ignore_index, topk), "vle_op_cross_entropy");
 }
+
+extern "C" int vle_op_quantize_rows_fp8(void* stream, const void* x_bf16, void* q_out, float* scale_out, int64_t rows, int32_t K) {
+  if (!x_bf16 || !q_out || !scale_out || rows < 0 || K < 512) return op_fail("vle_op_quantize_rows_fp8: bad argument");
+  const int r = launch_quantize_rows_fp8((hipStream_t)stream, x_bf16, q_out, scale_out, rows, K);
+  if (r == 1) return op_fail("vle_op_quantize_rows_fp8: K must be 512 * {1,2,3,4,6,8,12,16}");
+  return op_done(r, "vle_op_quantize_rows_fp8");
+}
+
+extern "C" int vle_op_linear_fp8(void* stream, const void* a8, const float* a_scale, const void* w8, const float* w_scale, const float* bias,
+                                 void* out, float* resid, int64_t M, int32_t N, int32_t K, int epilogue) {
+  if (!a8 || !a_scale || !w8 || !w_scale || M < 1 || N < 4 || K < 128) return op_fail("vle_op_linear_fp8: bad argument");
+  if (epilogue == EPI_RESID ? resid == nullptr : out == nullptr) return op_fail("vle_op_linear_fp8: output missing");
+  const int r = launch_gemm_fp8((hipStream_t)stream, a8, a_scale, w8, w_scale, bias, out, resid, M, N, K, epilogue);
+  if (r == 1) return op_fail("vle_op_linear_fp8: shape not covered (K % 128, N % 4)");
+  return op_done(r, "vle_op_linear_fp8");
+}

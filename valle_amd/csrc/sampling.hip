@@ -219,8 +219,30 @@ __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
   float4* xo = reinterpret_cast<float4*>(a.x + (int64_t)b * a.d);
   for (int i = tid; i < (a.d >> 2); i += SAMP_T) {
     const float4 ev = e[i], pv = pe[i];
-    xo[i] = make_float4(__fadd_rn(ev.x, __fmul_rn(alpha, pv.x)), __fadd_rn(ev.y, __fmul_rn(alpha, pv.y)),
-                        __fadd_rn(ev.z, __fmul_rn(alpha, pv.z)), __fadd_rn(ev.w, __fmul_rn(alpha, pv.w)));
+    const float4 xv = make_float4(__fadd_rn(ev.x, __fmul_rn(alpha, pv.x)), __fadd_rn(ev.y, __fmul_rn(alpha, pv.y)),
+                                  __fadd_rn(ev.z, __fmul_rn(alpha, pv.z)), __fadd_rn(ev.w, __fmul_rn(alpha, pv.w)));
+    xo[i] = xv;
+    if (a.lnp.gamma != nullptr) {
+      // producer side of the fused LayerNorm of the batched step (kernels.h LnProducer): bf16(x * gamma) of the first layer's
+      // LayerNorm in the fragment-major X layout + (mean, M2) of every 16-column group (4 consecutive threads; d % 16 == 0)
+      typedef __bf16 b4 __attribute__((ext_vector_type(4)));
+      const float4 g = reinterpret_cast<const float4*>(a.lnp.gamma)[i];
+      b4 o4;
+      o4[0] = (__bf16)(xv.x * g.x); o4[1] = (__bf16)(xv.y * g.y); o4[2] = (__bf16)(xv.z * g.z); o4[3] = (__bf16)(xv.w * g.w);
+      *reinterpret_cast<b4*>(reinterpret_cast<bf16_t*>(a.lnp.xg_out) + xf_index(b, i * 4, a.lnp.MF, a.lnp.w8 != 0)) = o4;
+      float s = (xv.x + xv.y) + (xv.z + xv.w);
+      s += __shfl_xor(s, 1, 64);
+      s += __shfl_xor(s, 2, 64);
+      const float mean = s * (1.0f / 16.0f);
+      const float t0 = xv.x - mean, t1 = xv.y - mean, t2 = xv.z - mean, t3 = xv.w - mean;
+      float q = fmaf(t3, t3, fmaf(t2, t2, fmaf(t1, t1, t0 * t0)));
+      q += __shfl_xor(q, 1, 64);
+      q += __shfl_xor(q, 2, 64);
+      if ((i & 3) == 0) {
+        typedef float f2 __attribute__((ext_vector_type(2)));
+        *reinterpret_cast<f2*>(a.lnp.stats_out + ((int64_t)b * (a.d >> 4) + (i >> 2)) * 2) = f2{mean, q};
+      }
+    }
   }
 }
 

@@ -26,6 +26,7 @@ class EngineConfig:
     prefix_mode: int = 0
     prepend_bos: bool = False
     dtype: str = "bf16"  # "fp32" (token-exact) | "bf16" | "fp8w" (bf16 arithmetic on fp8-representable weights)
+    #                      | "fp8" (fp8w + fp8 activations on CDNA4's block-scaled fp8 MFMA in the prefill / NAR passes)
     max_batch: int = 1
     max_text: int = 64
     max_prompt: int = 225
@@ -67,7 +68,7 @@ class Engine:
         c = _lib.VleConfig()
         c.d_model, c.nhead, c.num_layers, c.num_quantizers = cfg.d_model, cfg.nhead, cfg.num_layers, cfg.num_quantizers
         c.prefix_mode, c.prepend_bos, c.norm_first, c.add_prenet = cfg.prefix_mode, int(cfg.prepend_bos), 1, 0
-        c.dtype_mode = {"fp32": _lib.DTYPE_F32, "f32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "fp8w": _lib.DTYPE_FP8W}[cfg.dtype]
+        c.dtype_mode = {"fp32": _lib.DTYPE_F32, "f32": _lib.DTYPE_F32, "bf16": _lib.DTYPE_BF16, "fp8w": _lib.DTYPE_FP8W, "fp8": _lib.DTYPE_FP8}[cfg.dtype]
         c.max_batch, c.max_text, c.max_prompt, c.max_gen = cfg.max_batch, cfg.max_text, cfg.max_prompt, cfg.max_gen
         c.device, c.use_graph, c.steps_per_graph = cfg.device, int(cfg.use_graph), cfg.steps_per_graph
         h = C.c_void_p()

@@ -99,7 +99,9 @@ class VALLE(nn.Module):
                     self.nar_predict_layers[j].weight = self.nar_audio_embeddings[j + 2].weight
         self.rng = random.Random(0)  # valle.py:165 (forward() draws nar_stage from it)
         self.requires_grad_(False)
-        set_compute_dtype(self, engine_dtype)  # the block modules run the same element type as the engine
+        # the block modules run the same element type as the engine ("fp8": the engine's fp8 activations exist only in
+        # its packed passes; the block API then computes like "fp8w": bf16 kernels on W')
+        set_compute_dtype(self, "fp8w" if engine_dtype == "fp8" else engine_dtype)
         self._engine: Optional[Engine] = None
         self._engine_key = None
 
@@ -346,7 +348,7 @@ def add_model_arguments(parser: argparse.ArgumentParser):
     parser.add_argument("--prepend-bos", type=_str2bool, default=False)
     parser.add_argument("--num-quantizers", type=int, default=8)
     parser.add_argument("--scaling-xformers", type=_str2bool, default=False)
-    parser.add_argument("--engine-dtype", type=str, default="fp32", help="HIP engine arithmetic: fp32 (token-exact), bf16, or fp8w (bf16 on fp8 e4m3 weights)")
+    parser.add_argument("--engine-dtype", type=str, default="fp32", help="HIP engine arithmetic: fp32 (token-exact), bf16, fp8w (bf16 on fp8 e4m3 weights), or fp8 (fp8w + fp8 activations on the fp8 MFMA)")
 
 
 def get_model(params) -> nn.Module:

@@ -250,3 +250,35 @@ def cross_entropy_rows(logits: torch.Tensor, targets: torch.Tensor, ignore_index
     _lib.check(lib.vle_op_cross_entropy(_st(logits), _p(logits), _p(targets), _p(loss), _p(hit), logits.shape[0], logits.shape[1],
                                         int(ignore_index), int(topk)))
     return loss, hit
+
+
+def quantize_rows_fp8(x: torch.Tensor):
+    """Per-row activation quantiser of engine mode FP8: x bf16 (rows, K) -> (codes uint8 (rows, K) e4m3fn, scale fp32 (rows,))."""
+    lib = _lib.load()
+    assert x.dtype == torch.bfloat16 and x.dim() == 2
+    x = x.contiguous()
+    q = torch.empty(x.shape, dtype=torch.uint8, device=x.device)
+    sc = torch.empty(x.shape[0], dtype=torch.float32, device=x.device)
+    _lib.check(lib.vle_op_quantize_rows_fp8(_st(x), _p(x), _p(q), _p(sc), x.shape[0], x.shape[1]))
+    return q, sc
+
+
+def linear_fp8(a8: torch.Tensor, a_scale: torch.Tensor, w8: torch.Tensor, w_scale: torch.Tensor, bias: Optional[torch.Tensor] = None,
+               epilogue: int = EPI_STORE, resid: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """epilogue((a8 @ w8.T) * a_scale[:, None] * w_scale[None, :] + bias) on the block-scaled fp8 MFMA; codes uint8 e4m3fn."""
+    lib = _lib.load()
+    assert a8.dtype == torch.uint8 and w8.dtype == torch.uint8 and a8.shape[1] == w8.shape[1]
+    a8, w8 = a8.contiguous(), w8.contiguous()
+    M, K = a8.shape
+    N = w8.shape[0]
+    out = None
+    if epilogue == EPI_RESID:
+        assert resid is not None and resid.dtype == torch.float32 and resid.is_contiguous() and resid.shape == (M, N)
+    elif epilogue == EPI_F32:
+        out = torch.empty(M, N, dtype=torch.float32, device=a8.device)
+    else:
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=a8.device)
+    b = None if bias is None else bias.contiguous()
+    _lib.check(lib.vle_op_linear_fp8(_st(a8), _p(a8), _p(a_scale.contiguous()), _p(w8), _p(w_scale.contiguous()), _p(b), _p(out), _p(resid),
+                                     M, N, K, epilogue))
+    return resid if epilogue == EPI_RESID else out

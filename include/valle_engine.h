@@ -275,6 +275,26 @@ int vle_op_cross_entropy(void* stream, const float* logits, const int64_t* targe
 int vle_op_adaln_fold(void* stream, const float* wb, const float* g, const float* be, float* gamma_out, float* beta_out,
                       int32_t d);
 
+/* ---- EnCodec 24 kHz decoder: codes -> waveform --------------------------------------------------
+ * Replaces audio_tokenizer.decode([(codes.transpose(2, 1), None)]) (valle/bin/infer.py:261-263; AudioTokenizer.decode ->
+ * EncodecModel.decode, valle/data/tokenizer.py:241-242; third-party `encodec`, encodec_model_24khz at 6 kbps = 8 codebooks).
+ * Parity is UNPINNED (no weights / package offline): the implementation follows the published architecture and is checked
+ * against oracle/encodec_oracle.py.
+ *   vle_codec_load_tensor: HOST fp32 tensors under the encodec state-dict names -- quantizer.vq.layers.{q}._codebook.embed
+ *     (1024, 128); decoder.model.{0,15}.conv.conv.{weight_g, weight_v, bias}; decoder.model.1.lstm.{weight,bias}_{ih,hh}_l{0,1};
+ *     decoder.model.{3,6,9,12}.convtr.convtr.{weight_g, weight_v, bias}; decoder.model.{4,7,10,13}.{block.1, block.3,
+ *     shortcut}.conv.conv.* (a plain `weight`, or torch's parametrizations.weight.original{0,1}, is accepted for weight_g/v)
+ *   vle_codec_finalize: folds weight_norm, re-lays every convolution out as a GEMM operand, uploads
+ *   vle_codec_decode: codes DEVICE int64 [T, n_q] (one utterance, the layout VALLE.inference returns) -> wav DEVICE f32 [320 T],
+ *     24 kHz mono; asynchronous w.r.t. the host like the engine's calls. */
+typedef struct vle_codec vle_codec;
+int vle_codec_create(int32_t device, int32_t n_q, vle_codec** out);
+int vle_codec_load_tensor(vle_codec* c, const char* key, const float* host_data, const int64_t* shape, int ndim);
+int vle_codec_finalize(vle_codec* c);
+int vle_codec_decode(vle_codec* c, void* stream, const int64_t* codes, int64_t T, float* wav);
+const char* vle_codec_last_error(const vle_codec* c);
+void vle_codec_destroy(vle_codec* c);
+
 #ifdef __cplusplus
 }
 #endif

@@ -25,18 +25,25 @@ def main():
     ap.add_argument("--out", default="gpurun_out/ktrace")
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--spg", default="1,2,4,8,16,32,64")
+    ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--d-model", type=int, default=1024)
+    ap.add_argument("--layers", type=int, default=12)
+    ap.add_argument("--opt", action="append", default=[])
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    L = 12
-    model = valle_amd.VALLE(1024, 16, L, prefix_mode=1, engine_dtype=args.dtype).to(dev).eval()
-    eng = model.engine_for(1, bench.S_TEXT, bench.P_PROMPT)
-    x, y = bench.synth_inputs(0)
-    X, Y = x[None].to(dev), y[None].to(dev)
+    L, B = args.layers, args.batch
+    model = valle_amd.VALLE(args.d_model, 16, L, prefix_mode=1, engine_dtype=args.dtype, max_batch=B).to(dev).eval()
+    eng = model.engine_for(B, bench.S_TEXT, bench.P_PROMPT)
+    eng.set_option("ignore_eos", 1)
+    for kv in args.opt:
+        eng.set_option(kv.split("=")[0], int(kv.split("=")[1]))
+    X = torch.stack([bench.synth_inputs(b)[0] for b in range(B)]).to(dev)
+    Y = torch.stack([bench.synth_inputs(b)[1] for b in range(B)]).to(dev)
 
     def run(max_new=0):
-        eng.prefill(X, [bench.S_TEXT], Y, [bench.P_PROMPT])
-        eng.generate(top_k=1, max_new=max_new)
+        eng.prefill(X, [bench.S_TEXT] * B, Y, [bench.P_PROMPT] * B)
+        eng.generate(top_k=1, max_new=max_new, allow_empty=True)
         return eng.timings()
 
     run(); run()
@@ -58,26 +65,30 @@ def main():
     tm = run(28)
     kt = eng.fetch_ktrace().double() * 0.01  # us
     nk = 5 * L + 2
+    assert nk <= 64 or B == 1, 'the trace holds 64 kernels per step'
+    nk = min(nk, 64)
     steps = list(range(9, 25))  # two whole 8-step graph replays, away from both ends
     rows = []
     fam = {}
     for k in range(nk):
-        gap = ramp = body = spread = 0.0
+        gap = ramp = body = spread = ph1 = ph2 = 0.0
         for s in steps:
             cur = kt[s, k]
-            prev_end = kt[s, k - 1, 3] if k > 0 else kt[s - 1, nk - 1, 3]
+            prev_end = kt[s, k - 1, 7] if k > 0 else kt[s - 1, nk - 1, 7]
             gap += float(cur[0] - prev_end)
             ramp += float(cur[1] - cur[0])
-            body += float(cur[3] - cur[0])
-            spread += float(cur[3] - cur[2])
+            body += float(cur[7] - cur[0])
+            spread += float(cur[7] - cur[6])
+            ph1 += float(cur[3] - cur[0])
+            ph2 += float(cur[5] - cur[3])
         n = len(steps)
         name = NAMES[k % 5] if k < 5 * L else ("final_LN+predict" if k == 5 * L else "sample+stop+embed")
-        rows.append((k, name, gap / n, ramp / n, body / n, spread / n))
+        rows.append((k, name, gap / n, ramp / n, body / n, spread / n, ph1 / n, ph2 / n))
         f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
         f[0] += 1; f[1] += gap / n; f[2] += body / n; f[3] += ramp / n
     wall = sum(float(kt[s + 1, 0, 0] - kt[s, 0, 0]) for s in steps) / len(steps)
     # graph boundary: gap before kernel 0 of the first step of each replay vs inside a replay
-    g0 = [float(kt[s, 0, 0] - kt[s - 1, nk - 1, 3]) for s in range(3, 28)]
+    g0 = [float(kt[s, 0, 0] - kt[s - 1, nk - 1, 7]) for s in range(3, 28)]
     out.update(
         ktrace_note="stamps: first/last wave entry, first/last wave before its epilogue store; 100 MHz clock (10 ns); "
                     "body = last end - first start, gap = first start - previous kernel's last end (store drain + boundary + dispatch)",
@@ -90,9 +101,9 @@ def main():
     )
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     with open(args.out + "_timeline.csv", "w") as f:
-        f.write("idx,kernel,gap_before_us,start_ramp_us,body_us,end_spread_us\n")
+        f.write("idx,kernel,gap_before_us,start_ramp_us,body_us,end_spread_us,start_to_last_mark1_us,mark1_to_last_mark2_us\n")
         for r in rows:
-            f.write(f"{r[0]},{r[1]},{r[2]:.3f},{r[3]:.3f},{r[4]:.3f},{r[5]:.3f}\n")
+            f.write(f"{r[0]},{r[1]},{r[2]:.3f},{r[3]:.3f},{r[4]:.3f},{r[5]:.3f},{r[6]:.3f},{r[7]:.3f}\n")
     json.dump(out, open(args.out + "_summary.json", "w"), indent=1)
     print(json.dumps(out)[:3000])
 

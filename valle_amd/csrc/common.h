@@ -235,18 +235,23 @@ __device__ inline float block_sum(float v, float* red) {
 // diagnostic) costs one uniform branch.
 constexpr int KT_STEPS = 32, KT_KERNELS = 64, KT_WAVES = 2048;
 struct KTrace {
-  unsigned long long* buf = nullptr;  // [KT_STEPS][KT_KERNELS][KT_WAVES][2]
+  unsigned long long* buf = nullptr;  // [KT_STEPS][KT_KERNELS][KT_WAVES][4]: entry, two optional phase marks, end
   const int32_t* step = nullptr;      // device word that counts AR iterations
   int idx = 0;                        // kernel index within the step
 };
 __device__ inline unsigned long long ktrace_begin(const KTrace& t) { return t.buf ? wall_clock64() : 0ull; }
-__device__ inline void ktrace_end(const KTrace& t, unsigned long long t0, int wave_id) {  // call from ONE lane per wave
+__device__ inline unsigned long long ktrace_mark(const KTrace& t) { return t.buf ? wall_clock64() : 0ull; }
+__device__ inline void ktrace_end(const KTrace& t, unsigned long long t0, int wave_id, unsigned long long m1 = 0ull,
+                                  unsigned long long m2 = 0ull) {  // call from ONE lane per wave
   if (!t.buf || wave_id >= KT_WAVES || t.idx >= KT_KERNELS) return;
   typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-  ull2 v;
-  v.x = t0;
-  v.y = wall_clock64();
-  *reinterpret_cast<ull2*>(t.buf + (((size_t)((*t.step) & (KT_STEPS - 1)) * KT_KERNELS + t.idx) * KT_WAVES + wave_id) * 2) = v;
+  const unsigned long long t1 = wall_clock64();
+  ull2* p = reinterpret_cast<ull2*>(t.buf + (((size_t)((*t.step) & (KT_STEPS - 1)) * KT_KERNELS + t.idx) * KT_WAVES + wave_id) * 4);
+  ull2 a, b;
+  a.x = t0; a.y = m1 ? m1 : t1;
+  b.x = m2 ? m2 : t1; b.y = t1;
+  p[0] = a;
+  p[1] = b;
 }
 
 // order-preserving float <-> uint key (for arg-max with lowest-index tie-break and k-th largest)

@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
     for (int j = 0; j < VEC; ++j) sm_o[w][part * VEC + j] = acc[j];
   }
   __syncthreads();
-  if (lane == 0) ktrace_end(kt, kt0, (((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x) * 4 + w);
+  if (tid == 0) ktrace_end(kt, kt0, ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x);  // one stamp per block (past the barrier)
   // ---- merge the 4 waves, write the partial -------------------------------------------------------------
   if (tid < dh || tid == 255) {
     const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));

@@ -40,7 +40,7 @@ __device__ inline void mma_step<float>(const uint4& a, const uint4& b, f32x4_t& 
 template <typename T, int BM, int BN, int EPI>
 __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                    const float* __restrict__ bias, void* __restrict__ out_,
-                                                   float* __restrict__ resid, int64_t M, int N, int K) {
+                                                   float* __restrict__ resid, int64_t M, int N, int K, int64_t lda) {
   constexpr int KE = 128 / sizeof(T);  // K elements per stage
   constexpr int WM = BM / 2, WN = BN / 2, FM = WM / 16, FN = WN / 16;
   constexpr int AV = BM * 8 / 256, BV = BN * 8 / 256;  // staged vectors per thread
@@ -75,7 +75,7 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, cons
       const int vi = tid + v * 256, row = vi >> 3, c = vi & 7;
       int64_t gm = m0 + row;
       gm = gm < M ? gm : M - 1;
-      ra[v] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(A + gm * K) + (int64_t)kt * 128 + c * 16);
+      ra[v] = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(A + gm * lda) + (int64_t)kt * 128 + c * 16);
     }
 #pragma unroll
     for (int v = 0; v < BV; ++v) {
@@ -156,13 +156,13 @@ __global__ __launch_bounds__(256) void gemm_kernel(const T* __restrict__ A, cons
 
 template <typename T, int BM, int BN>
 static int gemm_dispatch_epi(hipStream_t st, const T* A, const T* W, const float* bias, void* out, float* resid, int64_t M,
-                             int N, int K, int epi) {
+                             int N, int K, int epi, int64_t lda) {
   const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM)), block(256);
   switch (epi) {
-    case EPI_STORE: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI_STORE>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); break;
-    case EPI_RELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI_RELU>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); break;
-    case EPI_RESID: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI_RESID>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); break;
-    case EPI_F32: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI_F32>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); break;
+    case EPI_STORE: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI_STORE>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, lda); break;
+    case EPI_RELU: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI_RELU>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, lda); break;
+    case EPI_RESID: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI_RESID>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, lda); break;
+    case EPI_F32: hipLaunchKernelGGL((gemm_kernel<T, BM, BN, EPI_F32>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, lda); break;
     default: return -1;
   }
   return 0;
@@ -170,13 +170,14 @@ static int gemm_dispatch_epi(hipStream_t st, const T* A, const T* W, const float
 
 template <typename T>
 static int gemm_dispatch(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M,
-                         int N, int K, int epi) {
+                         int N, int K, int epi, int64_t lda = 0) {
   if (K % (int)(128 / sizeof(T)) != 0) return -1;
+  if (lda == 0) lda = K;
   // 128x128 tiles only when they alone fill the chip; otherwise 64x64 (4x the blocks)
   const int64_t big_blocks = ((M + 127) / 128) * ((N + 127) / 128);
   if (big_blocks >= 256)
-    return gemm_dispatch_epi<T, 128, 128>(st, (const T*)A, (const T*)W, bias, out, resid, M, N, K, epi);
-  return gemm_dispatch_epi<T, 64, 64>(st, (const T*)A, (const T*)W, bias, out, resid, M, N, K, epi);
+    return gemm_dispatch_epi<T, 128, 128>(st, (const T*)A, (const T*)W, bias, out, resid, M, N, K, epi, lda);
+  return gemm_dispatch_epi<T, 64, 64>(st, (const T*)A, (const T*)W, bias, out, resid, M, N, K, epi, lda);
 }
 
 int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const float* bias, void* out, float* resid,
@@ -186,6 +187,16 @@ int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const f
   // bf16: the LDS-DMA pipelined kernel (gemm_glds.hip) when it has the shape
   if (launch_gemm_glds(st, A, W, bias, out, resid, M, N, K, epi) == 0) return 0;
   return gemm_dispatch<bf16_t>(st, A, W, bias, out, resid, M, N, K, epi);
+}
+
+// fp32 GEMM whose A rows start `lda` elements apart (lda * 4 bytes a multiple of 16, lda < K allowed: overlapping rows).  With a
+// time-major [T][C] signal, row t of "A with lda = C, K = k * C" is the k consecutive frames t .. t+k-1 -- the im2col matrix of
+// a 1-D convolution without materialising it (codec.hip).
+int launch_gemm_f32_strided(hipStream_t st, const float* A, int64_t lda, const float* W, const float* bias, float* out, float* resid,
+                            int64_t M, int N, int K, int epi) {
+  if (M <= 0 || N <= 0) return 0;
+  if (lda < 4 || lda % 4 != 0) return -1;
+  return gemm_dispatch<float>(st, A, W, bias, out, resid, M, N, K, epi, lda);
 }
 
 }  // namespace vle

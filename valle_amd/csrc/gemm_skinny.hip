@@ -43,7 +43,7 @@ typedef unsigned int gs_u32x4 __attribute__((ext_vector_type(4)));
 
 // epilogue of one lane: v = 4 consecutive output columns ncol..ncol+3 of row m (bias already added)
 template <int EPI>
-__device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, int ncol, gs_f32x4 gamma4) {
+__device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, int ncol, gs_f32x4 gamma4, gs_f32x4 old4, int kvl) {
   const int M = a.M, N = a.N;
   if (m >= M || ncol >= N) return;
   const bool vec = ncol + 3 < N && (N & 3) == 0;
@@ -81,7 +81,7 @@ __device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, i
   } else if constexpr (EPI == GS_EPI_RESID) {
     float* o = a.resid + (int64_t)m * N + ncol;
     if (vec) {
-      const gs_f32x4 x4 = *reinterpret_cast<const gs_f32x4*>(o) + v;
+      const gs_f32x4 x4 = old4 + v;  // the residual's old value was requested with the kernel's first burst
       *reinterpret_cast<gs_f32x4*>(o) = x4;
       if (a.lnp.gamma != nullptr) {
         // producer side of the fused LayerNorm (kernels.h LnProducer): the 4 lanes fg = 0..3 of a row hold this workgroup's 16
@@ -119,7 +119,7 @@ __device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, i
       *reinterpret_cast<gs_f32x4*>(a.q_out + (int64_t)m * d + j) = v;
     } else {
       const int h = j / a.dh, e = j - h * a.dh;  // dh % 4 == 0: the 4 columns stay inside one head
-      const int64_t off = (((int64_t)m * a.nhead + h) * a.ctx_max + a.kv_len[m]) * a.dh + e;
+      const int64_t off = (((int64_t)m * a.nhead + h) * a.ctx_max + kvl) * a.dh + e;  // kv_len[m], requested up front
       gs_bf16x4 o4;
 #pragma unroll
       for (int r = 0; r < 4; ++r) o4[r] = (__bf16)v[r];
@@ -145,17 +145,25 @@ __device__ inline gs_bf16x8 gs_fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
 // product as long as both operands agree), so W is still fetched as full 64-byte sectors per row.
 template <int MF, int EPI, bool W8>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
-  constexpr int G = 4;  // k-chunks (64 deep) requested per round
+  // k-chunks (64 deep) requested per round
+  constexpr int G = 4;  // (8 / 16 at M <= 32 / 16 measured slower: 256 VGPRs + AGPR spills leave one workgroup per CU)
   __shared__ __attribute__((aligned(16))) float red[4][MF][64][4];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned long long kt0 = ktrace_begin(a.kt);
   const int fr = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.x * 16;
   const int K = a.K, N = a.N, M = a.M;
   const int KS = gridDim.y, ks = blockIdx.y;
   const int Kw = K / (4 * KS);  // this wave's share of K (multiple of 64)
-  const int kbeg = (ks * 4 + wave) * Kw;
+  // Every workgroup reads ALL of X (<= 128 KB, L2-resident) while streaming its own 16 rows of W.  If all workgroups walked X
+  // in the same order they would hit the same L2 channels at the same moment; so the K quarter a wave takes and the order of
+  // the row fragments inside a chunk are rotated by the workgroup index (sums stay in K order: the combine indexes by quarter).
+  const int wq = a.rot ? (wave + (int)blockIdx.x) & 3 : wave;
+  const int frot = a.rot ? ((int)blockIdx.x >> 2) & 3 : 0;
+  auto fi = [&](int i) -> int { return MF == 4 ? (i ^ frot) : MF == 2 ? (i ^ (frot & 1)) : MF == 3 ? (i + frot) % 3 : 0; };
+  const int kbeg = (ks * 4 + wq) * Kw;
   const int nrow = min(n0 + fr, N - 1);
   constexpr int KOFS = W8 ? 16 : 8;   // first k of this lane inside a chunk = fg * KOFS
   constexpr int SSTEP = W8 ? 8 : 32;  // k distance between the lane's two MFMA k-halves
@@ -163,7 +171,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   const unsigned char* wp8 = reinterpret_cast<const unsigned char*>(a.w) + (int64_t)nrow * K + kbeg + fg * 16;  // fp8 W
   const bf16_t* xp[MF];
 #pragma unroll
-  for (int i = 0; i < MF; ++i) xp[i] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(i * 16 + fr, M - 1) * K + kbeg + fg * KOFS;
+  for (int i = 0; i < MF; ++i) xp[i] = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(fi(i) * 16 + fr, M - 1) * K + kbeg + fg * KOFS;
   const bool xfrag = a.x_xf != 0;  // X stored fragment-major (common.h xf_index): one contiguous 1 KB per fragment load
   const bf16_t* xfb = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)(kbeg / 64) * 2 * MF * 512 + lane * 8;
 
@@ -206,8 +214,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
         if (j < ln_nq) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 4);
     }
   }
+  gs_f32x4 old4 = gs_f32x4{0.f, 0.f, 0.f, 0.f};
+  int kvl = 0;
   if constexpr (EPI == GS_EPI_RESID) {
     if (a.lnp.gamma != nullptr && ncol + 3 < N) gamma4 = *reinterpret_cast<const gs_f32x4*>(a.lnp.gamma + ncol);
+    // the residual row this lane finishes (wave i: fragment i): nobody else writes it during this launch
+    if (wave < MF && wave * 16 + fr < M && ncol + 3 < N && (N & 3) == 0)
+      old4 = *reinterpret_cast<const gs_f32x4*>(a.resid + (int64_t)(wave * 16 + fr) * N + ncol);
+  }
+  if constexpr (EPI == GS_EPI_QKV) {
+    if (wave < MF) kvl = a.kv_len[min(wave * 16 + fr, M - 1)];
   }
 
   gs_f32x4 acc[MF];
@@ -237,8 +253,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
-        xv[g][i][0] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 0) * MF + i) * 512 : xp[i] + c * 64);
-        xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 1) * MF + i) * 512 : xp[i] + c * 64 + SSTEP);
+        xv[g][i][0] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 0) * MF + fi(i)) * 512 : xp[i] + c * 64);
+        xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 1) * MF + fi(i)) * 512 : xp[i] + c * 64 + SSTEP);
       }
     }
     __builtin_amdgcn_sched_barrier(0);
@@ -259,9 +275,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   }
 
   // ---- combine the four K quarters through LDS; wave i finishes m-fragment i ------------------------
+  const unsigned long long ktm1 = ktrace_mark(a.kt);  // MFMAs issued (the loads they wait for have landed)
 #pragma unroll
-  for (int i = 0; i < MF; ++i) *reinterpret_cast<gs_f32x4*>(&red[wave][i][lane][0]) = acc[i];
+  for (int i = 0; i < MF; ++i) *reinterpret_cast<gs_f32x4*>(&red[wq][fi(i)][lane][0]) = acc[i];  // [K quarter][row fragment]
   __syncthreads();
+  const unsigned long long ktm2 = ktrace_mark(a.kt);  // past the block barrier
   const int i = wave;  // waves >= MF only take part in the barriers below
   gs_f32x4 v = gs_f32x4{0.f, 0.f, 0.f, 0.f};
   if (wave < MF) {
@@ -335,7 +353,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     else v += bias4;
   }
   // lane (fg, fr) holds C[m = 16 i + fr][n = n0 + 4 fg + r]
-  gs_epilogue<EPI>(a, v, i * 16 + fr, ncol, gamma4);
+  gs_epilogue<EPI>(a, v, i * 16 + fr, ncol, gamma4, old4, kvl);
+  if (lane == 0) ktrace_end(a.kt, kt0, ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave, ktm1, ktm2);
 }
 
 // K slices across workgroups: enough to give every CU a workgroup (target), each wave keeping >= 64 of K

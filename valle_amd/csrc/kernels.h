@@ -36,6 +36,9 @@ enum { EPI_STORE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_F32 = 3 };
 int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const float* bias, void* out, float* resid,
                 int64_t M, int N, int K, int epi);
 
+int launch_gemm_f32_strided(hipStream_t st, const float* A, int64_t lda, const float* W, const float* bias, float* out, float* resid,
+                            int64_t M, int N, int K, int epi);
+
 // gemm_glds.hip: bf16, M >= 128, K % 64 == 0: LDS-DMA multi-stage pipeline; returns 1 when the shape is not covered
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
                      int K, int epi);
@@ -80,6 +83,8 @@ struct LnConsumer {
 struct GemmSkinnyArgs {
   LnProducer lnp;
   LnConsumer lnc;
+  KTrace kt;  // diagnostic timeline (option "ktrace")
+  int rot = 0;  // rotate the order in which a workgroup walks X by its index (option "gs_rot")
   const void* x = nullptr;     // bf16 [M][K]
   const void* w = nullptr;     // bf16 [N][K]
   const float* bias = nullptr; // f32 [N] or null

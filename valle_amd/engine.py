@@ -244,17 +244,20 @@ class Engine:
         return {nm: round(buf[i] * 1e3 / buf[8 + i], 3) for i, nm in enumerate(names) if buf[8 + i] > 0}
 
     def fetch_ktrace(self) -> torch.Tensor:
-        """(32 step slots, 64 kernel slots, 4) int64 wall-clock stamps in 10 ns ticks (option "ktrace"), reduced over the
-        waves of each kernel: [first wave start, last wave start, first wave end, last wave end]; -1 where nothing stamped."""
-        raw = torch.empty(32, 64, 2048, 2, dtype=torch.int64)
+        """(32 step slots, 64 kernel slots, 8) int64 wall-clock stamps in 10 ns ticks (option "ktrace"), reduced over the
+        waves of each kernel: [first start, last start, first mark1, last mark1, first mark2, last mark2, first end, last end]
+        (kernels without phase marks repeat the end stamp there); -1 where nothing was stamped."""
+        raw = torch.empty(32, 64, 2048, 4, dtype=torch.int64)
         n = self.lib.vle_debug_fetch(self.h, b"ktrace", C.c_void_p(raw.data_ptr()), raw.numel() * 8)
         if n < 0:
             _lib.check(int(n), self.h)
         valid = raw[..., 0] != -1
         big = torch.iinfo(torch.int64).max
-        s, e = raw[..., 0], raw[..., 1]
-        out = torch.stack([torch.where(valid, s, big).amin(-1), torch.where(valid, s, -1).amax(-1),
-                           torch.where(valid, e, big).amin(-1), torch.where(valid, e, -1).amax(-1)], dim=-1)
+        cols = []
+        for k in range(4):
+            v = raw[..., k]
+            cols += [torch.where(valid, v, big).amin(-1), torch.where(valid, v, -1).amax(-1)]
+        out = torch.stack(cols, dim=-1)
         out[~valid.any(-1)] = -1
         self.ktrace_waves = valid.sum(-1)
         return out

@@ -139,15 +139,18 @@ def test_attention_rows(nhead, dh, causal, dt):
     (2, 96, [1100], [64]),
 ])
 @pytest.mark.parametrize("causal", [True, False])
-@pytest.mark.parametrize("qw", [1, 2])
-def test_attention_mfma_long(nhead, dh, lens, text_lens, causal, qw):
-    """bf16 MFMA flash kernel at NAR / prefill lengths (many key tiles, ragged tails, prefix-LM mask), with 64- and
-    128-query blocks (knob attn_qw)."""
+@pytest.mark.parametrize("v2,qw", [(2, 0), (0, 1), (0, 2)])
+def test_attention_mfma_long(nhead, dh, lens, text_lens, causal, v2, qw):
+    """bf16 MFMA flash kernels at NAR / prefill lengths (many key tiles, ragged tails, prefix-LM mask): the second-generation
+    kernel (attn_mfma2.hip: V^T pre-pass, double-buffered tiles, 128-query blocks) and round 1's (attn_mfma.hip) with 64- and
+    128-query blocks (knobs attn_v2 / attn_qw)."""
+    ops.tune("attn_v2", v2)
     ops.tune("attn_qw", qw)
     try:
         _attention_mfma_long(nhead, dh, lens, text_lens, causal)
     finally:
         ops.tune("attn_qw", 0)
+        ops.tune("attn_v2", 1)
 
 
 def _attention_mfma_long(nhead, dh, lens, text_lens, causal):

@@ -125,7 +125,11 @@ int launch_attention(hipStream_t st, int dtype, const void* qkv, void* out, cons
                      int B, int max_len, int d, int nhead, int causal) {
   if (B <= 0 || max_len <= 0) return 0;
   if (dtype == DT_F32) return attention_dispatch<float>(st, qkv, out, seq_off, text_len, B, max_len, d, nhead, causal);
-  // bf16: the MFMA flash kernel (attn_mfma.hip) when it has the head size
+  // bf16: the MFMA flash kernels when they have the head size (attn_mfma2.hip, else round 1's attn_mfma.hip)
+  {
+    const int r2 = launch_attention_mfma2(st, qkv, out, seq_off, text_len, B, max_len, (int64_t)B * max_len, d, nhead, causal);
+    if (r2 <= 0) return r2;
+  }
   if (launch_attention_mfma(st, qkv, out, seq_off, text_len, B, max_len, d, nhead, causal) == 0) return 0;
   return attention_dispatch<bf16_t>(st, qkv, out, seq_off, text_len, B, max_len, d, nhead, causal);
 }

@@ -1,0 +1,345 @@
+// Flash-style MFMA attention for the prefill and the 7 NAR passes, second generation (bf16, head size 32 / 64 / 96 / 128).
+//   reference: F.multi_head_attention_forward as called from MultiheadAttention.forward
+//   (valle/modules/activation.py:408-427): softmax(Q K^T / sqrt(dh) + mask) V per head; AR mask = prefix-LM
+//   (valle/models/valle.py:1019-1033), NAR: none.  Same contract as attn_mfma.hip, which it replaces where it applies.
+//
+// What round 1's kernel spent its time on (profiles/README.md: 18.6 % MFMA utilisation, K/V tiles re-read 5x from the
+// fabric): sixteen 2-byte LDS stores per thread per tile to build V^T, two block barriers per 64-key tile around a single
+// LDS buffer, and ~9 VALU instructions per score.  Here:
+//   * V^T is built ONCE per (sequence, head) by a pre-pass (vt_pack_kernel) into a global scratch, key-permuted the way the
+//     second MFMA wants it, instead of once per (query block, tile): the main kernel stages K rows and V^T rows with plain
+//     16-byte loads / stores;
+//   * two LDS buffers, ONE barrier per tile: tile t+1 is written while tile t is being multiplied, the global loads of
+//     tile t+2 are issued a whole tile ahead of the store that needs them;
+//   * 128 queries per block (each K / V^T fragment read from LDS feeds two MFMAs, the tiles are re-read from L2 half as often);
+//   * softmax in ~5 VALU per score: the 1/sqrt(dh) log2 e factor rides on the exp2 argument's FMA (max is taken on raw scores),
+//     the causal / length mask is evaluated only on tiles that cross a boundary (wave-uniform test), and the accumulator is
+//     rescaled only when some row's maximum actually grew (wave-uniform test; exact: alpha = 1 otherwise).
+// Both products are still computed transposed (S^T = K Q^T, O^T = V^T P^T) so that P leaves the first MFMA in the operand
+// layout of the second (see attn_mfma.hip for the lane maps; am_vpos below is the key permutation of a V^T row).
+#include <mutex>
+
+#include "common.h"
+#include "kernels.h"
+
+namespace vle {
+
+typedef __bf16 a2_bf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 a2_bf16x4 __attribute__((ext_vector_type(4)));
+typedef float a2_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int a2_u32x4 __attribute__((ext_vector_type(4)));
+
+constexpr float A2_NEG = -1e30f;
+
+__device__ __host__ inline int a2_vpos(int key) {  // slot of key (0..63) inside a 64-key V^T tile row
+  return ((key >> 5) << 5) + (((key & 15) >> 2) << 3) + (((key >> 4) & 1) << 2) + (key & 3);
+}
+// first V^T column of sequence b: 64-aligned, and far enough from the previous sequence's last (padded) tile
+__device__ __host__ inline int64_t a2_vt_start(int off, int b) { return (int64_t)(off & ~63) + 128 * (int64_t)b; }
+
+// ---- pre-pass: VT[h * DH + e][a2_vt_start(b) + tile * 64 + a2_vpos(key)] = V[b][tile * 64 + key][h][e] (0 beyond the sequence) ----
+template <int DH>
+__global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ vt,
+                                                      const int32_t* __restrict__ seq_off, int d, int64_t rp) {
+  constexpr int STR = 64 + 8;  // elements per LDS row (padding: the 2-byte scatter spreads over the banks)
+  __shared__ uint16_t tile[DH * STR];
+  const int b = blockIdx.z, h = blockIdx.y, kt0 = blockIdx.x * 64;
+  const int off = seq_off[b], len = seq_off[b + 1] - off;
+  if (kt0 >= len) return;
+  const int tid = threadIdx.x;
+  const int key = tid & 63;
+  const bool live = kt0 + key < len;
+  const bf16_t* src = qkv + (int64_t)(off + min(kt0 + key, len - 1)) * 3 * d + 2 * d + h * DH;
+  for (int vv = tid >> 6; vv < DH / 8; vv += 4) {
+    a2_u32x4 v = *reinterpret_cast<const a2_u32x4*>(src + vv * 8);
+    if (!live) v = a2_u32x4{0u, 0u, 0u, 0u};
+    uint16_t* dst = tile + (vv * 8) * STR + a2_vpos(key);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      dst[(2 * t) * STR] = (uint16_t)(v[t] & 0xffffu);
+      dst[(2 * t + 1) * STR] = (uint16_t)(v[t] >> 16);
+    }
+  }
+  __syncthreads();
+  const int64_t col0 = a2_vt_start(off, b) + kt0;
+  for (int idx = tid; idx < DH * 8; idx += 256) {
+    const int e = idx >> 3, vec = idx & 7;
+    *reinterpret_cast<a2_u32x4*>(vt + ((int64_t)h * DH + e) * rp + col0 + vec * 8) = *reinterpret_cast<const a2_u32x4*>(tile + e * STR + vec * 8);
+  }
+}
+
+template <int DH, int QW, bool XCD_REMAP>
+__global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
+                                                    const int32_t* __restrict__ seq_off, const int32_t* __restrict__ text_len, int d,
+                                                    int nhead, int causal, int64_t rp) {
+  constexpr int NV = DH / 8;           // 16-byte vectors per K row
+  constexpr int KSTR = DH * 2 + 16;    // bytes per K row in LDS (one vector of padding: bank spread)
+  constexpr int VSTR = 64 * 2 + 16;    // bytes per V^T row
+  constexpr int NLD = 64 * NV / 256;   // staged vectors per thread per tile (K and V^T each): DH / 32
+  constexpr int KS = DH / 32, EB = DH / 16;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (64 * KSTR + DH * VSTR)];
+
+  // XCD-aware block order (block L runs on XCD L % 8, each with its own 4 MB L2): the query blocks of one (sequence, head) read
+  // the same K / V -- give every XCD a CONTIGUOUS run of the (b, h, query-block) order so that they meet in one L2 instead of
+  // pulling the tiles over the fabric 8 times (PMC, round 1: 5x the algorithmic bytes fetched)
+  int qblk, h, b;
+  {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int nb = gx * gy * (int)gridDim.z;
+    int L = ((int)blockIdx.z * gy + (int)blockIdx.y) * gx + (int)blockIdx.x;
+    if (XCD_REMAP) {
+      const int q = nb / 8, r = nb % 8, xcd = L % 8, idx = L / 8;
+      L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    qblk = L % gx;
+    h = (L / gx) % gy;
+    b = L / (gx * gy);
+  }
+  const int q0 = qblk * 64 * QW;
+  const int off = seq_off[b], len = seq_off[b + 1] - off;
+  if (q0 >= len) return;
+  const int S = text_len[b];
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int g = lane >> 4, c = lane & 15;
+  int qrow[QW], klim[QW];
+  bool qvalid[QW];
+  int kfull = 0x7fffffff;  // keys below kfull are visible to every query of this lane (invalid rows do not constrain)
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    qrow[f] = q0 + (w * QW + f) * 16 + c;
+    qvalid[f] = qrow[f] < len;
+    klim[f] = !qvalid[f] ? 0 : (causal ? max(S, qrow[f] + 1) : len);  // keys j < klim are visible
+    if (qvalid[f]) kfull = min(kfull, klim[f]);
+  }
+  const int kmax = causal ? max(S, min(q0 + 64 * QW, len)) : len;      // block-wide bound
+  const int d3 = 3 * d;
+  const bf16_t* base = qkv + (int64_t)off * d3 + h * DH;
+  const bf16_t* vbase = vt + (int64_t)h * DH * rp + a2_vt_start(off, b);
+
+  a2_bf16x8 qf[QW][KS];
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    const bf16_t* qp = base + (int64_t)min(qrow[f], len - 1) * d3 + g * 8;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) qf[f][ks] = *reinterpret_cast<const a2_bf16x8*>(qp + ks * 32);
+  }
+
+  constexpr int BUF = 64 * KSTR + DH * VSTR;
+  a2_u32x4 kreg[NLD], vreg[NLD];
+  auto gload = [&](int kt0) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 256;
+      const int kkey = idx / NV, kv = idx - kkey * NV;
+      kreg[i] = *reinterpret_cast<const a2_u32x4*>(base + (int64_t)min(kt0 + kkey, len - 1) * d3 + d + kv * 8);
+      const int e = idx >> 3, vec = idx & 7;  // V^T: DH rows x 8 vectors of 8 (permuted) keys
+      vreg[i] = *reinterpret_cast<const a2_u32x4*>(vbase + (int64_t)e * rp + kt0 + vec * 8);
+    }
+  };
+  auto lstore = [&](unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NLD; ++i) {
+      const int idx = tid + i * 256;
+      const int kkey = idx / NV, kv = idx - kkey * NV;
+      *reinterpret_cast<a2_u32x4*>(buf + kkey * KSTR + kv * 16) = kreg[i];
+      const int e = idx >> 3, vec = idx & 7;
+      *reinterpret_cast<a2_u32x4*>(buf + 64 * KSTR + e * VSTR + vec * 16) = vreg[i];
+    }
+  };
+
+  const float sl2 = 1.4426950408889634f / sqrtf((float)DH);  // log2(e) / sqrt(dh)
+  float m[QW], l[QW];  // m: running max of the RAW scores of the row (shared by its 4 lanes); l: this lane's part of the row sum
+  a2_f32x4 o[QW][EB];
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    m[f] = A2_NEG;
+    l[f] = 0.f;
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb) o[f][eb] = a2_f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  // (Measured and rejected: issuing the scores of tile t+1 ahead of the softmax of tile t -- K ring one tile ahead of the V^T
+  //  ring -- 365 -> 328 TF/s at the C3 NAR shape: the extra score registers cost more occupancy than the overlap returns.)
+  const int ntile = (kmax + 63) >> 6;
+  gload(0);
+  lstore(smem);
+  __syncthreads();
+  if (ntile > 1) gload(64);
+  for (int t = 0; t < ntile; ++t) {
+    const int kt0 = t * 64;
+    const unsigned char* Ks = smem + (t & 1) * BUF;
+    const unsigned char* Vt = Ks + 64 * KSTR;
+
+    // ---- S^T = K Q^T: one K fragment read feeds the QW query fragments ---------------------------------
+    a2_f32x4 s[QW][4];
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int f = 0; f < QW; ++f) s[f][kb] = a2_f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const a2_bf16x8 a = *reinterpret_cast<const a2_bf16x8*>(Ks + (kb * 16 + c) * KSTR + (ks * 4 + g) * 16);
+#pragma unroll
+        for (int f = 0; f < QW; ++f) s[f][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[f][ks], s[f][kb], 0, 0, 0);
+      }
+    }
+    // ---- online softmax (exp2 domain; lane (g, c) holds keys 16 kb + 4 g + r of query c) ------------------
+    const bool all_visible = __all(kt0 + 64 <= kfull);  // wave-uniform: no key of this tile is masked for any query of the wave
+    a2_bf16x8 pf[QW][2];
+#pragma unroll
+    for (int f = 0; f < QW; ++f) {
+      if (!all_visible) {
+#pragma unroll
+        for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+          for (int r = 0; r < 4; ++r)
+            if (kt0 + kb * 16 + g * 4 + r >= klim[f]) s[f][kb][r] = A2_NEG;
+      }
+      float mt = fmaxf(fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3])),
+                       fmaxf(fmaxf(s[f][1][0], s[f][1][1]), fmaxf(s[f][1][2], s[f][1][3])));
+      mt = fmaxf(mt, fmaxf(fmaxf(fmaxf(s[f][2][0], s[f][2][1]), fmaxf(s[f][2][2], s[f][2][3])),
+                           fmaxf(fmaxf(s[f][3][0], s[f][3][1]), fmaxf(s[f][3][2], s[f][3][3]))));
+      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      if (!__all(mt <= m[f])) {  // some row's maximum grew: rescale (alpha = 1 exactly for the rows whose maximum did not)
+        const float mn = fmaxf(m[f], mt);
+        const float alpha = __builtin_amdgcn_exp2f((m[f] - mn) * sl2);
+        m[f] = mn;
+        l[f] *= alpha;
+#pragma unroll
+        for (int eb = 0; eb < EB; ++eb) o[f][eb] *= alpha;
+      }
+      const float nm = -m[f] * sl2;
+      float rowsum = 0.f;
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = __builtin_amdgcn_exp2f(fmaf(s[f][kb][r], sl2, nm));  // masked scores: exp2(-1e30 * sl2 + ...) = 0
+          s[f][kb][r] = p;
+          rowsum += p;
+        }
+      l[f] += rowsum;
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int tt = 0; tt < 8; ++tt) pf[f][j][tt] = (__bf16)s[f][2 * j + (tt >> 2)][tt & 3];
+    }
+    // ---- O^T += V^T P^T -----------------------------------------------------------------------------------
+#pragma unroll
+    for (int eb = 0; eb < EB; ++eb)
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const a2_bf16x8 a = *reinterpret_cast<const a2_bf16x8*>(Vt + (eb * 16 + c) * VSTR + (j * 32 + g * 8) * 2);
+#pragma unroll
+        for (int f = 0; f < QW; ++f) o[f][eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[f][j], o[f][eb], 0, 0, 0);
+      }
+
+    // ---- tile t+1 (in registers since the previous iteration) -> the other buffer; tile t+2 -> registers -------
+    if (t + 1 < ntile) {
+      lstore(smem + ((t + 1) & 1) * BUF);  // last read during iteration t-1, i.e. before the barrier that ended it
+      if (t + 2 < ntile) gload(kt0 + 128);
+    }
+    __syncthreads();  // tile t+1 visible; everyone is done reading tile t
+  }
+
+#pragma unroll
+  for (int f = 0; f < QW; ++f) {
+    float lf = l[f];
+    lf += __shfl_xor(lf, 16, 64);
+    lf += __shfl_xor(lf, 32, 64);
+    if (qvalid[f]) {
+      const float inv = 1.0f / lf;
+      bf16_t* op = out + (int64_t)(off + qrow[f]) * d + h * DH + g * 4;
+#pragma unroll
+      for (int eb = 0; eb < EB; ++eb) {
+        a2_bf16x4 r4;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) r4[r] = (__bf16)(o[f][eb][r] * inv);
+        *reinterpret_cast<a2_bf16x4*>(op + eb * 16) = r4;
+      }
+    }
+  }
+}
+
+// ---- V^T scratch: one per device, grown on demand (never during stream capture: attention is not part of the captured AR step)
+namespace {
+struct VtScratch {
+  void* p = nullptr;
+  size_t bytes = 0;
+};
+std::mutex g_vt_mu;
+VtScratch g_vt[16];
+}  // namespace
+
+int attn2_reserve(int64_t rows, int B, int d) {
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
+  const size_t need = (size_t)d * (size_t)(rows + 128 * (int64_t)(B + 1) + 64) * 2;
+  std::lock_guard<std::mutex> lk(g_vt_mu);
+  if (g_vt[dev].bytes >= need) return 0;
+  if (g_vt[dev].p) {
+    if (hipDeviceSynchronize() != hipSuccess) return -3;
+    (void)hipFree(g_vt[dev].p);
+    g_vt[dev] = VtScratch();
+  }
+  void* p = nullptr;
+  if (hipMalloc(&p, need) != hipSuccess) return -3;
+  if (hipMemset(p, 0, need) != hipSuccess) return -3;  // columns between sequences are read (and multiplied by P = 0): keep them finite
+  g_vt[dev].p = p;
+  g_vt[dev].bytes = need;
+  return 0;
+}
+
+int g_attn_v2 = 1;    // "attn_v2": 0 = round 1's kernel (attn_mfma.hip) for A/B
+int g_attn_xcd = 1;   // "attn_xcd": XCD-aware block order (A/B)
+int g_attn_q128 = 0;  // "attn_q128": 128-query blocks: 0 never (measured: 64-query blocks win at every shape of the engine), 1 always,
+                      // -1 = for sequences longer than 384
+
+// returns 0 = launched, 1 = not covered (caller uses attn_mfma.hip / the generic kernel), < 0 error.  `rows` = packed rows of qkv.
+int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int32_t* seq_off, const int32_t* text_len, int B,
+                           int max_len, int64_t rows, int d, int nhead, int causal) {
+  const int dh = d / nhead;
+  if (!g_attn_v2 || d % 8 != 0 || !(dh == 32 || dh == 64 || dh == 96 || dh == 128)) return 1;
+  if (rows <= 0) return 1;
+  // measured (tools/attn_bench.py, MI355X): ahead of round 1's kernel on the un-masked NAR passes (C3 shape 305 -> 365 TF/s, C5's
+  // dh 96 308 -> 319), behind it on the short causal prefill (120 vs 114) -- g_attn_v2 = 2 forces this kernel for every shape
+  if (g_attn_v2 == 1 && (causal || max_len < 512)) return 1;
+  int r = attn2_reserve(rows, B, d);
+  if (r) return r;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  bf16_t* vt = (bf16_t*)g_vt[dev].p;
+  const int64_t rp = rows + 128 * (int64_t)(B + 1) + 64;  // >= every sequence's last padded column
+  const int64_t rp8 = rp & ~(int64_t)7;                    // row pitch: a multiple of 8 elements (16-byte vectors)
+  const dim3 pgrid((max_len + 63) / 64, nhead, B), block(256);
+  const bool q128 = g_attn_q128 < 0 ? max_len > 384 : g_attn_q128 != 0;  // short sequences: 64-query blocks (less masked work, more blocks)
+  const dim3 grid(q128 ? (max_len + 127) / 128 : (max_len + 63) / 64, nhead, B);
+#define VLE_A2K(DH, QW)                                                                                                              \
+  do {                                                                                                                               \
+    if (g_attn_xcd)                                                                                                                  \
+      hipLaunchKernelGGL((attn2_kernel<DH, QW, true>), grid, block, 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, seq_off, \
+                         text_len, d, nhead, causal, rp8);                                                                           \
+    else                                                                                                                             \
+      hipLaunchKernelGGL((attn2_kernel<DH, QW, false>), grid, block, 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, seq_off, \
+                         text_len, d, nhead, causal, rp8);                                                                           \
+  } while (0)
+#define VLE_A2(DH)                                                                                                              \
+  do {                                                                                                                          \
+    hipLaunchKernelGGL((vt_pack_kernel<DH>), pgrid, block, 0, st, (const bf16_t*)qkv, vt, seq_off, d, rp8);                     \
+    if (q128) VLE_A2K(DH, 2);                                                                                                   \
+    else VLE_A2K(DH, 1);                                                                                                        \
+  } while (0)
+  switch (dh) {
+    case 32: VLE_A2(32); break;
+    case 64: VLE_A2(64); break;
+    case 96: VLE_A2(96); break;
+    case 128: VLE_A2(128); break;
+    default: return 1;
+  }
+#undef VLE_A2
+#undef VLE_A2K
+  return 0;
+}
+
+}  // namespace vle

@@ -733,6 +733,7 @@ static int alloc_buffers(vle_engine* e) {
   e->ATT = p;
   if ((r = dev_alloc(e, &p, (size_t)R * 4 * d * es))) return r;
   e->Hb = p;
+  if (e->dtype == DT_BF16 && attn2_reserve(R, (int)B, (int)d) != 0) return e->fail(VLE_EHIP, "V^T scratch of the attention kernel: allocation failed");
   if (e->a8) {
     if ((r = dev_alloc(e, &e->A8, (size_t)R * 4 * d))) return r;
     if ((r = dev_alloc(e, &e->a8_scale, (size_t)R))) return r;
@@ -1888,6 +1889,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
   }
   if (n == "attn_qw") {
     g_attn_qw = (int)value;
+    return VLE_OK;
+  }
+  if (n == "attn_v2" || n == "attn_xcd" || n == "attn_q128") {
+    (n == "attn_v2" ? g_attn_v2 : n == "attn_xcd" ? g_attn_xcd : g_attn_q128) = (int)value;
     return VLE_OK;
   }
   if (n == "glds_swz" || n == "glds_8ph" || n == "g8_stagger" || n == "g8_colgroup") {

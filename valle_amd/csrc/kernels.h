@@ -153,6 +153,12 @@ int launch_attention(hipStream_t st, int dtype, const void* qkv, void* out, cons
 // attn_mfma.hip: bf16 MFMA flash kernel, dh in {32,64,96,128}; returns 1 when the head size is not covered
 int launch_attention_mfma(hipStream_t st, const void* qkv, void* out, const int32_t* seq_off, const int32_t* text_len, int B,
                           int max_len, int d, int nhead, int causal);
+// attn_mfma2.hip: second-generation flash kernel (V^T pre-pass, double-buffered LDS, 128-query blocks); `rows` = an upper bound on
+// the packed rows of qkv (sizes the V^T scratch); returns 1 when not covered, < 0 on error
+int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int32_t* seq_off, const int32_t* text_len, int B,
+                           int max_len, int64_t rows, int d, int nhead, int causal);
+int attn2_reserve(int64_t rows, int B, int d);
+extern int g_attn_v2, g_attn_xcd, g_attn_q128;
 // copy K,V of packed prefill rows into the cache: cache[b][h][pos][e]
 int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache, void* v_cache, const int32_t* row_seq,
                       const int32_t* row_pos, int64_t rows, int d, int nhead, int ctx_max);

@@ -39,6 +39,9 @@ extern "C" int vle_op_tune(const char* name, int64_t value) {
   else if (n == "g8_stagger" && value >= 0 && value <= 1) vle::g_g8_stagger = (int)value;
   else if (n == "g8_colgroup" && value >= 0 && value <= 16) vle::g_g8_colgroup = (int)value;
   else if (n == "attn_qw" && value >= 0 && value <= 2) vle::g_attn_qw = (int)value;
+  else if (n == "attn_v2" && value >= 0 && value <= 2) vle::g_attn_v2 = (int)value;
+  else if (n == "attn_xcd" && value >= 0 && value <= 1) vle::g_attn_xcd = (int)value;
+  else if (n == "attn_q128" && value >= -1 && value <= 1) vle::g_attn_q128 = (int)value;
   else return op_fail("vle_op_tune: unknown knob or value out of range");
   return VLE_OK;
 }

@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 S_TEXT, P_PROMPT = 47, 225  # 47 phonemes, 3 s x 75 Hz prompt
-PMC_STEP_BYTES = 351_600_000  # (2 x FETCH_SIZE + WRITE_SIZE) KB summed over the 62 kernels of one AR step, mean context
+PMC_STEP_BYTES = 352_700_000  # (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the 62 kernels of one AR step, mean context (round 2 PMC pass)
 
 
 def synth_inputs(index: int, S: int = S_TEXT, P: int = P_PROMPT):
@@ -158,6 +158,54 @@ def c3_leg(sd, args, dev, B=64, steps=2, warmup=1):
     }
 
 
+def c5_leg(args, dev, B=32, steps=2, warmup=1):
+    """BASELINE.json configs[4]'s per-GPU share on one GPU: d1536-L24-h16 (dh 96), fp8 weights, fp8 activations on the
+    block-scaled fp8 MFMA in the prefill / NAR passes (engine mode "fp8"), 32 utterances.  Extra object, not `value`."""
+    import valle_amd
+
+    torch.manual_seed(0)
+    d, L, H = 1536, 24, 16
+    model = valle_amd.VALLE(d, H, L, prefix_mode=1, engine_dtype="fp8", max_batch=B).to(dev).eval()
+    eng = model.engine_for(B, S_TEXT, P_PROMPT)
+    eng.set_option("ignore_eos", 1)
+    X = torch.stack([synth_inputs(b)[0] for b in range(B)]).to(dev)
+    Y = torch.stack([synth_inputs(b)[1] for b in range(B)]).to(dev)
+
+    def step():
+        eng.prefill(X, [S_TEXT] * B, Y, [P_PROMPT] * B)
+        _, gl = eng.generate(top_k=1, temperature=1.0, seed=0, allow_empty=True)
+        eng.nar(None)
+        return gl
+
+    for _ in range(warmup):
+        step()
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    tokens, pre, ar, nar, ar_steps, ar_bytes = 0, 0.0, 0.0, 0.0, 0, 0
+    for _ in range(steps):
+        gl = step()
+        tokens += sum(gl) * 8
+        tm = eng.timings()
+        pre += tm["prefill_ms"]; ar += tm["ar_ms"]; nar += tm["nar_ms"]; ar_steps += int(tm["ar_steps"])
+        for t in range(1, max(gl) + 1):
+            ar_bytes += eng.ar_step_bytes(B, B * (S_TEXT + P_PROMPT + t))
+    torch.cuda.synchronize(dev)
+    elapsed = time.perf_counter() - t0
+    N, G = S_TEXT + P_PROMPT + gl[0], gl[0]
+    nar_flops = B * (7 * (2 * N * 12 * L * d * d + 4 * L * N * N * d) + 14 * G * d * 1024)
+    hbm = (ar_bytes / 1e9) / (ar / 1e3)
+    tfs = nar_flops * steps / 1e12 / (nar / 1e3)
+    model._invalidate()
+    return {
+        "workload": f"dim{d}-L{L}-h{H} fp8 weights + fp8-MFMA prefill/NAR, batch={B}, S={S_TEXT}, P={P_PROMPT} -> G={G}, greedy, ignore_eos",
+        "value": round(tokens / elapsed, 1), "unit": "audio-tokens/s", "steps": steps, "warmup": warmup,
+        "phase_ms": {"prefill": round(pre / steps, 3), "ar": round(ar / steps, 3), "nar": round(nar / steps, 3)},
+        "roofline_ar": {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
+                        "launch_us": round(ar / ar_steps * 1e3, 2), "bytes_per_launch": int(ar_bytes / ar_steps)},
+        "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": 5000.0, "unit": "TFLOP/s (vs the dense fp8 MX peak)", "frac": round(tfs / 5000.0, 4)},
+    }
+
+
 def decode_step(eng, X, s_lens, Y, p_lens, top_k, world, n_total, dev):
     """One "step" of the benchmark on this rank: whole decode of its B utterances (prefill + AR loop + 7 NAR stages)
     and, for N > 1, the all_gather of the result codes (the path's only collective).  Returns (generated lengths of the
@@ -246,6 +294,8 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the extra batch-64 (BASELINE configs[2]) object of the default run")
+    ap.add_argument("--c5", action="store_true", help="add the per-GPU share of BASELINE configs[4] (d1536-L24-h16, fp8 weights + fp8 MFMA, "
+                                                      "32 utterances) as an extra object (~2 min: 1.6 B parameters are initialised and quantised)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine tuning option (vle_set_option), repeatable")
     ap.add_argument("--profile-kernels", type=int, default=0, help="extra untimed pass: hipEvent time per AR-step kernel family over n steps")
     args = ap.parse_args()
@@ -359,7 +409,7 @@ def main():
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
                 # HBM bytes per AR step from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-                # FETCH_SIZE doubled per the gfx950 correction): profiles/r01_s2_pmc_*_by_kernel.csv, profiles/README.md.
+                # FETCH_SIZE doubled per the gfx950 correction): profiles/r02_pmc_*_by_kernel.csv, profiles/README.md.
                 # Measured for the default workload only (C2, batch 1, bf16).
                 "traffic": PMC_STEP_BYTES if (B == 1 and args.dtype == "bf16" and args.d_model == 1024 and args.layers == 12) else None,
                 "launch_us": round(step_ms * 1e3, 2),
@@ -392,6 +442,13 @@ def main():
                 out["c3_batch64"] = c3_leg(model.state_dict(), args, dev)
             except Exception as err:  # noqa: BLE001
                 out["c3_batch64"] = {"error": repr(err)[:200]}
+        if args.c5 and args.gpus == 1:
+            try:
+                model._invalidate()
+                del model
+                out["c5_share_fp8"] = c5_leg(args, dev)
+            except Exception as err:  # noqa: BLE001
+                out["c5_share_fp8"] = {"error": repr(err)[:200]}
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -123,6 +123,15 @@ int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float temperatur
  *   codes         DEVICE int64 [B, g_stride, Q]: all Q codebooks, frames >= G_b untouched */
 int vle_nar_decode(vle_engine* e, void* stream, const int32_t* enroll_lens, int64_t* codes, int64_t g_stride);
 
+/* Grow the capacities chosen at vle_create IN PLACE (each becomes max(old, requested); max_gen 0 = 16 * max_text + 1): the
+ * weights, their packed / quantised copies and the tuned options stay; only the capacity-dependent buffers (KV cache,
+ * activations, tables, traces) are re-created and the captured graphs dropped.  Call between decodes (any prefill / slot state
+ * is lost).  pe: HOST fp32 [pe_rows, d] sinusoid table built like SinePositionalEmbedding.extend_pe
+ * (valle/modules/embedding.py:75-91), needed when the position range grows (NULL = the engine's own restatement of it).
+ * Before vle_finalize_weights it only records the new sizes. */
+int vle_reserve(vle_engine* e, int32_t max_batch, int32_t max_text, int32_t max_prompt, int32_t max_gen, const float* pe,
+                int64_t pe_rows);
+
 /* Parity hook (the NAR analogue of vle_ar_generate's `forced`): the NEXT vle_nar_decode teacher-forces its stage
  * history -- after stage i the embedding added to y_emb (valle.py:1133-1134) is the one of forced_codes[b][g][i+1]
  * instead of the stage's own arg-max; the codes written are still the engine's own arg-max.  This is what makes the

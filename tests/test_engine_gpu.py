@@ -365,3 +365,40 @@ def test_fused_layernorm_batch_step_matches_layernorm_kernels(B, d, h, L, dtype)
     err = (runs[0] - ref_lg).abs().max().item()
     assert err <= 0.02 * sigma, (err, sigma)  # two bf16 roundings of different quantities: each within ~1 % of exact
     assert (runs[0][0] - ref_lg[0]).abs().max().item() == 0.0  # step 0 = the prefill's logits: same kernels in both modes
+
+
+def test_engine_grows_capacities_without_reloading_weights():
+    """engine_for() on a bigger request re-creates the buffers in place (vle_reserve) -- same engine object, same weights on the
+    device -- and the decodes before / after equal the oracle; a batch-1 engine grows into the batched (fused-LayerNorm) path."""
+    cfg = vo.OracleConfig(d_model=256, nhead=4, num_layers=2, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 6)
+    m = build_model(cfg, sd, "fp32")
+    x, xl, y = vo.make_inputs(4, 6)
+    a = m.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1).cpu()
+    eng0 = m._engine
+    assert torch.equal(a, vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True))
+    x2, xl2, y2 = vo.make_inputs(9, 30, seed=77)   # longer text (position table grows), longer prompt
+    b = m.inference(x2.to(DEV), xl2.to(DEV), y2.to(DEV), None, top_k=1).cpu()
+    assert m._engine is eng0 and eng0.cfg.max_text >= 9 and eng0.cfg.max_prompt >= 30
+    assert torch.equal(b, vo.inference(sd, cfg, x2, xl2, y2, None, top_k=1, kv_cache=True))
+    X = torch.zeros(3, 9, dtype=torch.int64); Y = torch.zeros(3, 30, 8, dtype=torch.int64)
+    S, P, want = [4, 9, 6], [6, 30, 11], []
+    for i, (s_, p_) in enumerate(zip(S, P)):
+        xi, xli, yi = vo.make_inputs(s_, p_, seed=200 + i)
+        X[i, :s_], Y[i, :p_] = xi[0], yi[0]
+        want.append(vo.inference(sd, cfg, xi, xli, yi, None, top_k=1, kv_cache=True)[0])
+    got = m.inference_batch(X.to(DEV), torch.tensor(S, dtype=torch.int32), Y.to(DEV), P, None, top_k=1)  # batch 1 -> 3
+    assert m._engine is eng0 and eng0.cfg.max_batch >= 3
+    for i in range(3):
+        assert torch.equal(got[i].cpu(), want[i])
+    assert torch.equal(m.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1).cpu(), a)  # and the first request again
+    # bf16: batch-1 engine grows into the batched step (weight packs + fused LayerNorm made at vle_reserve)
+    mb = build_model(cfg, sd, "bf16")
+    mb.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1)
+    e1 = mb._engine
+    ob = mb.inference_batch(X.to(DEV), torch.tensor(S, dtype=torch.int32), Y.to(DEV), P, None, top_k=1)
+    assert mb._engine is e1
+    mb2 = build_model(cfg, sd, "bf16", max_batch=3, max_text=9, max_prompt=30)
+    ref = mb2.inference_batch(X.to(DEV), torch.tensor(S, dtype=torch.int32), Y.to(DEV), P, None, top_k=1)
+    for i in range(3):
+        assert torch.equal(ob[i], ref[i]), "a grown engine and a fresh one of the same capacity disagree"

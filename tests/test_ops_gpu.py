@@ -283,3 +283,28 @@ def test_linear_gemm_tile_policy_knobs(M, N, K, knob):
         assert all(torch.equal(outs[0], o) for o in outs[1:])
         assert (outs[0].double() - (ref + r0.double())).abs().max().item() < 3e-5 * math.sqrt(K / 64) * max(1.0, ref.abs().max().item())
         assert (relu.double() - ref.clamp_min(0)).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
+
+
+def test_skinny_gemm_split_k_handoff_under_memory_pressure():
+    """Stress of the cross-workgroup split-K hand-off of gemm_skinny.hip (write-through partial tiles + vmcnt drain + relaxed
+    ticket, no fences): 150 launches at 2 / 4 / 8 K slices while a second stream saturates HBM with copies, so workgroup
+    arrival order and cache state vary from launch to launch; every result must be bit-identical to the first one of its slice
+    count (the combine sums in slice order), and equal to the un-split kernel up to fp32 summation order."""
+    torch.manual_seed(3)
+    M, N, K = 64, 1024, 4096
+    a = torch.randn(M, K, device=DEV).to(torch.bfloat16)
+    w = (torch.randn(N, K, device=DEV) / math.sqrt(K)).to(torch.bfloat16)
+    bias = torch.randn(N, device=DEV)
+    ref = ops.linear(a, w, bias, ops.EPI_F32, ksplit=1)
+    side = torch.cuda.Stream()
+    big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
+    big2 = torch.empty_like(big)
+    for ks in (2, 4, 8):
+        first = ops.linear(a, w, bias, ops.EPI_F32, ksplit=ks).clone()
+        assert (first - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
+        for it in range(50):
+            with torch.cuda.stream(side):
+                big2.copy_(big)
+            out = ops.linear(a, w, bias, ops.EPI_F32, ksplit=ks)
+            assert torch.equal(out, first), f"split-K x{ks}: launch {it} differs"
+    torch.cuda.synchronize()

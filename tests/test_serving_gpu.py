@@ -72,3 +72,37 @@ def test_slot_api_state_errors():
         eng.slots_harvest([1], [1])  # not finished
     done, gl = eng.slots_step(8)
     assert done[0] == 1 and gl[0] == 0 and gl[1] == 9  # slot 0 stays free; slot 1: first sample + 8 steps
+
+
+def test_sampled_decode_is_per_request_reproducible_across_batch_sizes():
+    """top_k sampling: a request's RNG stream is keyed on (seed, request index, iteration) -- not on the slot or batch position
+    it occupies -- so continuous batching with 2, 3 or 5 slots, any harvest policy, and the dense batch API all return the SAME
+    sampled codes per request; requests that share a slot one after the other draw different streams."""
+    cfg = vo.OracleConfig(d_model=128, nhead=2, num_layers=2, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 5)
+    ins = _requests(7, 4)
+    reqs = [Request(x[0], y[0]) for x, _, y in ins]
+    outs = []
+    for max_batch, spr, hm in [(2, 4, 1), (3, 8, 2), (5, 3, None)]:
+        m = build_model(cfg, sd, "fp32", max_batch=max_batch)
+        cb = ContinuousBatcher(m, max_batch, max_text=8, max_prompt=18, steps_per_round=spr, harvest_min=hm)
+        outs.append([c.cpu() for c in cb.decode(reqs, top_k=5, temperature=0.9, seed=123)])
+    for other in outs[1:]:
+        for i, (a, b) in enumerate(zip(outs[0], other)):
+            assert a.shape == b.shape and torch.equal(a, b), f"request {i}: sampled codes depend on the batch geometry"
+    # the dense batch API draws the same streams (request index = batch position)
+    m = build_model(cfg, sd, "fp32", max_batch=len(ins))
+    S = [int(x.shape[1]) for x, _, _ in ins]
+    P = [int(y.shape[1]) for _, _, y in ins]
+    X = torch.zeros(len(ins), max(S), dtype=torch.int64); Y = torch.zeros(len(ins), max(P), 8, dtype=torch.int64)
+    for i, (x, _, y) in enumerate(ins):
+        X[i, : S[i]], Y[i, : P[i]] = x[0], y[0]
+    dense = m.inference_batch(X.to(DEV), torch.tensor(S, dtype=torch.int32), Y.to(DEV), P, None, top_k=5, temperature=0.9, seed=123)
+    for i in range(len(ins)):
+        assert torch.equal(dense[i].cpu(), outs[0][i]), f"request {i}: dense batch and continuous batching sample differently"
+    # identical requests get different streams (different request indices), a different seed changes everything
+    same = [reqs[0]] * 4
+    mm = build_model(cfg, sd, "fp32", max_batch=2)
+    got = ContinuousBatcher(mm, 2, max_text=8, max_prompt=18).decode(same, top_k=50, temperature=1.5, seed=7)
+    firsts = [g[:, 0].cpu() for g in got]
+    assert any(f.shape != firsts[0].shape or not torch.equal(f, firsts[0]) for f in firsts[1:])

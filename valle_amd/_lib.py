@@ -39,6 +39,7 @@ SIGNATURES = {
     "vle_ar_prefill": (C.c_int, [_P, _P, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P, C.c_int32]),
     "vle_ar_generate": (C.c_int, [_P, _P, C.c_int32, C.c_float, C.c_uint64, C.c_int32, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P]),
     "vle_nar_decode": (C.c_int, [_P, _P, _I32P, _P, C.c_int64]),
+    "vle_reserve": (C.c_int, [_P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, _P, C.c_int64]),
     "vle_nar_force": (C.c_int, [_P, _P, C.c_int64]),
     "vle_nar_continual": (C.c_int, [_P, _P, _P, C.c_int64, _I32P, _P, C.c_int64, _I32P, C.c_int32, _P, C.c_int64, _I32P]),
     "vle_slots_begin": (C.c_int, [_P, _P]),

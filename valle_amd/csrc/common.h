@@ -254,6 +254,16 @@ __device__ inline void ktrace_end(const KTrace& t, unsigned long long t0, int wa
   p[1] = b;
 }
 
+// RNG stream of one utterance: splitmix64 of (call seed, request index).  The multinomial draw of iteration `it` is
+// Philox(request_seed, it) -- independent of the batch position / slot the utterance happens to occupy, so sampled decodes are
+// reproducible across max_batch and scheduling choices, and two requests that use the same slot one after the other differ.
+__host__ __device__ inline unsigned long long request_seed(unsigned long long seed, unsigned long long request) {
+  unsigned long long z = seed + 0x9E3779B97F4A7C15ull * (request + 1ull);
+  z = (z ^ (z >> 30)) * 0xBF58476D1CE4E5B9ull;
+  z = (z ^ (z >> 27)) * 0x94D049BB133111EBull;
+  return z ^ (z >> 31);
+}
+
 // order-preserving float <-> uint key (for arg-max with lowest-index tie-break and k-th largest)
 __device__ inline uint32_t float_key(float f) {
   uint32_t u = __float_as_uint(f);

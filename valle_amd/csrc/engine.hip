@@ -67,7 +67,9 @@ struct vle_engine {
   std::string err;
   hipStream_t st = nullptr;
   hipEvent_t ev_in = nullptr, ev_out = nullptr, ev_t[6] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-  std::vector<void*> allocs;
+  std::vector<void*> allocs;      // weights and everything that lives as long as the engine
+  std::vector<void*> buf_allocs;  // capacity-dependent buffers (KV cache, activations, traces): vle_reserve frees and re-creates them
+  bool in_buffers = false;        // dev_alloc target
   bool finalized = false;
 
   // ---- host staging of the state dict --------------------------------------------------------
@@ -106,6 +108,8 @@ struct vle_engine {
   int64_t *tokens = nullptr, *sampled = nullptr;  // [max_B][max_G]
   int64_t *text_ids = nullptr, *prompt_codes = nullptr;  // [max_B][max_S], [max_B][max_P + max_G][Q]
   int32_t* forced_len_dev = nullptr;
+  unsigned long long* slot_seed_dev = nullptr;  // [max_B] RNG seed of the request in each slot (slot API)
+  unsigned long long admitted = 0;              // requests admitted since vle_slots_begin
   const int64_t* nar_forced = nullptr; int64_t nar_forced_stride = 0;  // vle_nar_force: consumed by the next NAR call
   int32_t* id_err_dev = nullptr;  // token-id range flag (1 text, 2 prompt / continuation codes, 4 forced tokens): VLE_EINDEX
   hipEvent_t ev_chk = nullptr;
@@ -201,7 +205,7 @@ template <typename T>
 int dev_alloc(vle_engine* e, T** p, size_t count) {
   void* q = nullptr;
   E_HIP(e, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
-  e->allocs.push_back(q);
+  (e->in_buffers ? e->buf_allocs : e->allocs).push_back(q);
   *p = (T*)q;
   return 0;
 }
@@ -441,6 +445,7 @@ extern "C" void vle_destroy(vle_engine* e) {
   }
   for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
   for (void* p : e->allocs) (void)hipFree(p);
+  for (void* p : e->buf_allocs) (void)hipFree(p);
   if (e->tables_host) (void)hipHostFree(e->tables_host);
   if (e->poll_host) (void)hipHostFree(e->poll_host);
   if (e->prog_host) (void)hipHostFree(e->prog_host);
@@ -508,7 +513,7 @@ static int load_layer(vle_engine* e, const std::string& p, LayerW& w, bool adapt
     if ((r = upload_f32(e, &w.g2, t->data(), t->size()))) return r;
     GET(".norm2.bias", d);
     if ((r = upload_f32(e, &w.be2, t->data(), t->size()))) return r;
-    if (e->max_B >= 2 && e->dtype == DT_BF16 && e->d % 256 == 0) {  // the batched step exists: fused-LayerNorm vectors
+    if (e->dtype == DT_BF16 && e->d % 256 == 0) {  // fused-LayerNorm vectors of the batched step (made for every engine: vle_reserve may grow max_batch)
       const auto* wq = find_w(e, p + ".self_attn.in_proj_weight", {3 * d, d});
       const auto* bq = find_w(e, p + ".self_attn.in_proj_bias", {3 * d});
       const auto* w1 = find_w(e, p + ".linear1.weight", {4 * d, d});
@@ -557,6 +562,37 @@ static int fold_adaln(vle_engine* e, const std::string& site, const std::vector<
 
 static int alloc_buffers(vle_engine* e);
 
+// fragment-major copies of the AR decoder's weights for gemm_skinny.hip, made once the batched step exists (max_batch >= 2)
+static int make_weight_packs(vle_engine* e) {
+  const int64_t d = e->d;
+  if (!(e->max_B >= 2 && e->dtype == DT_BF16 && e->d % 256 == 0) || e->ar.empty() || e->ar[0].wqkv_p != nullptr) return 0;
+  const bool was = e->in_buffers;
+  e->in_buffers = false;  // weights
+  int r = 0;
+  auto pack = [&](const void* src, void** dst, int64_t N, int64_t K) -> int {
+    if (!src) return 0;
+    unsigned char* p = nullptr;
+    const size_t bytes = (size_t)((N + 15) / 16 * 16) * K * (e->w8 ? 1 : 2);
+    int rr = dev_alloc(e, &p, bytes);
+    if (rr) return rr;
+    E_LAUNCH(e, launch_pack_w_frag(e->st, src, p, (int)N, (int)K, e->w8 ? 1 : 0));
+    *dst = p;
+    return 0;
+  };
+  for (int l = 0; l < e->L && !r; ++l) {
+    LayerW& w = e->ar[l];
+    if ((r = pack(e->w8 ? w.wqkv8 : w.wqkv, &w.wqkv_p, 3 * d, d))) break;
+    if ((r = pack(e->w8 ? w.wo8 : w.wo, &w.wo_p, d, d))) break;
+    if ((r = pack(e->w8 ? w.w18 : w.w1, &w.w1_p, 4 * d, d))) break;
+    if ((r = pack(e->w8 ? w.w28 : w.w2, &w.w2_p, d, 4 * d))) break;
+  }
+  if (!r) r = pack(e->w8 ? e->ar_predict8 : e->ar_predict, &e->ar_predict_p, V_AR, d);
+  e->in_buffers = was;
+  if (r) return r;
+  E_HIP(e, hipStreamSynchronize(e->st));
+  return 0;
+}
+
 extern "C" int vle_finalize_weights(vle_engine* e) {
   if (!e) return VLE_EINVAL;
   if (e->finalized) return VLE_OK;
@@ -587,7 +623,7 @@ extern "C" int vle_finalize_weights(vle_engine* e) {
   if (e->w8) r = upload_fp8w(e, &e->ar_predict, &e->ar_predict8, &e->ar_predict_s, t->data(), V_AR, d);
   else r = upload_T(e, &e->ar_predict, t->data(), t->size());
   if (r) return r;
-  if (e->max_B >= 2 && e->dtype == DT_BF16 && e->d % 256 == 0) {
+  if (e->dtype == DT_BF16 && e->d % 256 == 0) {
     const auto* ng = find_w(e, "ar_decoder.norm.weight", {d});
     const auto* nb = find_w(e, "ar_decoder.norm.bias", {d});
     if (!ng || !nb) return VLE_EKEY;
@@ -644,28 +680,12 @@ extern "C" int vle_finalize_weights(vle_engine* e) {
   }
   e->host_w.clear();
   e->host_shape.clear();
-  if ((r = alloc_buffers(e))) return r;
-  if (e->max_B >= 2 && e->dtype == DT_BF16 && e->d % 256 == 0) {  // the batch path of the AR step exists: pack its weights
-    auto pack = [&](const void* src, void** dst, int64_t N, int64_t K) -> int {
-      if (!src) return 0;
-      unsigned char* p = nullptr;
-      const size_t bytes = (size_t)((N + 15) / 16 * 16) * K * (e->w8 ? 1 : 2);
-      int rr = dev_alloc(e, &p, bytes);
-      if (rr) return rr;
-      E_LAUNCH(e, launch_pack_w_frag(e->st, src, p, (int)N, (int)K, e->w8 ? 1 : 0));
-      *dst = p;
-      return 0;
-    };
-    for (int l = 0; l < e->L; ++l) {
-      LayerW& w = e->ar[l];
-      if ((r = pack(e->w8 ? w.wqkv8 : w.wqkv, &w.wqkv_p, 3 * d, d))) return r;
-      if ((r = pack(e->w8 ? w.wo8 : w.wo, &w.wo_p, d, d))) return r;
-      if ((r = pack(e->w8 ? w.w18 : w.w1, &w.w1_p, 4 * d, d))) return r;
-      if ((r = pack(e->w8 ? w.w28 : w.w2, &w.w2_p, d, 4 * d))) return r;
-    }
-    if ((r = pack(e->w8 ? e->ar_predict8 : e->ar_predict, &e->ar_predict_p, V_AR, d))) return r;
-    E_HIP(e, hipStreamSynchronize(e->st));
-  }
+  e->in_buffers = true;
+  r = alloc_buffers(e);
+  e->in_buffers = false;
+  if (r) return r;
+  if ((r = make_weight_packs(e))) return r;
+  e->in_buffers = true;  // from here on dev_alloc serves capacity-dependent buffers (traces, diagnostics)
   e->finalized = true;
   return VLE_OK;
 }
@@ -718,9 +738,12 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->dyn_dev, 1))) return r;
   if ((r = dev_alloc(e, &e->tokens, (size_t)B * e->max_G))) return r;
   if ((r = dev_alloc(e, &e->sampled, (size_t)B * e->max_G))) return r;
+  E_HIP(e, hipMemset(e->tokens, 0, (size_t)B * e->max_G * sizeof(int64_t)));
+  E_HIP(e, hipMemset(e->sampled, 0, (size_t)B * e->max_G * sizeof(int64_t)));
   if ((r = dev_alloc(e, &e->text_ids, (size_t)B * e->max_S))) return r;
   if ((r = dev_alloc(e, &e->prompt_codes, (size_t)B * (e->max_P + e->max_G) * 8))) return r;
   if ((r = dev_alloc(e, &e->forced_len_dev, B))) return r;
+  if ((r = dev_alloc(e, &e->slot_seed_dev, B))) return r;
   if ((r = dev_alloc(e, &e->id_err_dev, 4))) return r;
   E_HIP(e, hipMemset(e->id_err_dev, 0, 4 * sizeof(int32_t)));
   const int64_t R = e->max_rows;
@@ -914,6 +937,7 @@ int enqueue_ar_sample(vle_engine* e, int first, const int32_t* slot_map = nullpt
   a.slot_map = slot_map; a.id_err = e->id_err_dev;
   if (!first) a.kt = e->next_kt();
   if (e->opt_host_prog && !slot_map) a.host_prog = e->prog_dev;
+  if (e->slot_mode) a.slot_seed = e->slot_seed_dev;
   if (use_mfma_skinny(e) && use_fuse_ln(e)) a.lnp = ln_producer(e, e->ar[0].g1);
   a.tokens = e->tokens; a.g_stride = e->max_G; a.sampled = e->sampled;
   a.audio_emb = e->ar_audio_emb; a.pe = e->pe; a.alpha_audio = e->alphas + 1; a.x = e->x_step; a.ctx_max = e->ctx_max;
@@ -1627,6 +1651,7 @@ extern "C" int vle_slots_begin(vle_engine* e, void* stream) {
   e->B = e->max_B;
   e->nsplit = e->opt_nsplit > 0 ? e->opt_nsplit : choose_nsplit(e, e->B);
   e->slot_mode = true;
+  e->admitted = 0;
   e->have_prefill = e->have_gen = false;
   e->S_len.assign(e->max_B, 0);
   e->P_len.assign(e->max_B, 0);
@@ -1726,7 +1751,8 @@ extern "C" int vle_slots_prefill(vle_engine* e, void* stream, int32_t n, const i
     (void)leave(e, stream);
     return e->fail(VLE_EINDEX, kIdErrMsg);
   }
-  E_LAUNCH(e, launch_slot_state_init(st, e->state_dev, e->max_B, d_slots, d_kv, d_ap, d_cap, n));
+  E_LAUNCH(e, launch_slot_state_init(st, e->state_dev, e->max_B, d_slots, d_kv, d_ap, d_cap, n, e->slot_seed_dev, seed, e->admitted));
+  e->admitted += (unsigned long long)n;
 
   PrefillEmbedArgs pa{};
   pa.text = e->text_ids; pa.s_stride = e->max_S; pa.prompt = e->prompt_codes; pa.p_stride = e->max_P + e->max_G; pa.Q = e->Q;
@@ -1828,6 +1854,74 @@ extern "C" int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const i
   if ((r = finish_nar_timing(e))) return r;
   for (int i = 0; i < n; ++i) e->S_len[slots[i]] = 0;  // the slot is free again
   return leave(e, stream);
+}
+
+// Grow the engine's capacities in place: weights (and their packed / quantised copies) stay on the device, only the
+// capacity-dependent buffers are re-created.  `pe` (HOST fp32 [pe_rows][d], the SinePositionalEmbedding table built by the
+// caller like valle/modules/embedding.py:75-91) is needed when the position range grows; null = the engine's own restatement.
+extern "C" int vle_reserve(vle_engine* e, int32_t max_batch, int32_t max_text, int32_t max_prompt, int32_t max_gen, const float* pe,
+                           int64_t pe_rows) {
+  if (!e) return VLE_EINVAL;
+  if (max_batch < 1 || max_text < 1 || max_prompt < 0 || max_gen < 0) return e->fail(VLE_EINVAL, "bad capacity");
+  const int nB = std::max(e->max_B, (int)max_batch), nS = std::max(e->max_S, (int)max_text), nP = std::max(e->max_P, (int)max_prompt);
+  int nG = std::max(e->max_G, max_gen > 0 ? (int)max_gen : 0);
+  nG = std::max(nG, 16 * nS + 1);
+  if (!e->finalized) {  // nothing allocated yet
+    e->max_B = nB; e->max_S = nS; e->max_P = nP; e->max_G = nG;
+    e->cfg.max_batch = nB; e->cfg.max_text = nS; e->cfg.max_prompt = nP; e->cfg.max_gen = nG;
+    e->ctx_max = nS + nP + 1 + nG;
+    e->max_pos = std::max(nS, nP + 1 + nG) + 1;
+    e->max_rows = (int64_t)nB * (nS + nP + 1 + nG);
+    return VLE_OK;
+  }
+  if (nB == e->max_B && nS == e->max_S && nP == e->max_P && nG == e->max_G) return VLE_OK;
+  E_HIP(e, hipSetDevice(e->cfg.device));
+  E_HIP(e, hipStreamSynchronize(e->st));
+  for (auto& kv : e->graphs) {
+    if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
+    if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+  }
+  e->graphs.clear();
+  for (void* p : e->buf_allocs) (void)hipFree(p);
+  e->buf_allocs.clear();
+  if (e->tables_host) (void)hipHostFree(e->tables_host);
+  if (e->poll_host) (void)hipHostFree(e->poll_host);
+  if (e->prog_host) (void)hipHostFree(e->prog_host);
+  e->tables_host = e->poll_host = e->prog_host = nullptr;
+  e->trace_ar = nullptr; e->trace_ar_cap = 0; e->trace_nar = nullptr; e->ktrace_buf = nullptr;
+  e->have_prefill = e->have_gen = false;
+  e->slot_mode = false;
+  const int old_pos = e->max_pos;
+  e->max_B = nB; e->max_S = nS; e->max_P = nP; e->max_G = nG;
+  e->cfg.max_batch = nB; e->cfg.max_text = nS; e->cfg.max_prompt = nP; e->cfg.max_gen = nG;
+  e->ctx_max = nS + nP + 1 + nG;
+  e->max_pos = std::max(nS, nP + 1 + nG) + 1;
+  e->max_rows = (int64_t)nB * (nS + nP + 1 + nG);
+  int r;
+  if (e->max_pos > old_pos) {  // a longer sinusoid table (the old one stays allocated until vle_destroy: a few MB)
+    std::vector<float> tab;
+    if (pe != nullptr && pe_rows >= e->max_pos) tab.assign(pe, pe + (size_t)e->max_pos * e->d);
+    else build_pe(tab, e->max_pos, e->d);
+    e->in_buffers = false;
+    r = upload_f32(e, &e->pe, tab.data(), tab.size());
+    e->in_buffers = true;
+    if (r) return r;
+  }
+  e->in_buffers = true;
+  if ((r = alloc_buffers(e))) return r;
+  if ((r = make_weight_packs(e))) return r;
+  if (e->opt_trace_nar && e->Q > 1) {
+    float* p = nullptr;
+    if ((r = dev_alloc(e, &p, (size_t)(e->Q - 1) * e->max_B * e->max_G * NUM_AUDIO_TOKENS))) return r;
+    e->trace_nar = p;
+  }
+  if (e->opt_ktrace) {
+    unsigned long long* p = nullptr;
+    if ((r = dev_alloc(e, &p, (size_t)KT_STEPS * KT_KERNELS * KT_WAVES * 4))) return r;
+    e->ktrace_buf = p;
+    (void)hipMemset(e->ktrace_buf, 0xFF, (size_t)KT_STEPS * KT_KERNELS * KT_WAVES * 4 * sizeof(unsigned long long));
+  }
+  return VLE_OK;
 }
 
 extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {

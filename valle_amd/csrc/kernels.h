@@ -239,6 +239,7 @@ struct ArSampleArgs {
   float* x;                                // [B][d] next step's input
   int ctx_max;
   const int32_t* slot_map = nullptr;       // slot API: block i serves utterance slot_map[i] (B = number of listed slots)
+  const unsigned long long* slot_seed = nullptr;  // slot API: RNG seed of the request each slot holds (null: request_seed(dyn.seed, b))
   int32_t* id_err = nullptr;               // |= 4 when a forced token is outside the audio vocabulary (it is replaced by 0)
   KTrace kt;
   LnProducer lnp;                          // batched step with fused LayerNorm: also emit bf16(x * gamma) + group statistics
@@ -249,7 +250,8 @@ struct ArSampleArgs {
 int launch_ar_sample(hipStream_t st, const ArSampleArgs& a);
 // slot API (continuous batching): per-slot AR state of newly admitted utterances; rows of X scattered to slot rows
 int launch_slot_state_init(hipStream_t st, int32_t* state, int max_B, const int32_t* slots, const int32_t* kv_len,
-                           const int32_t* audio_pos, const int32_t* cap, int n);
+                           const int32_t* audio_pos, const int32_t* cap, int n, unsigned long long* slot_seed = nullptr,
+                           unsigned long long seed = 0, unsigned long long first_request = 0);
 // fragment-major copy of W[N][K] (bf16 or fp8 codes) for gemm_skinny.hip; dst holds ceil(N/16)*16*K elements
 int launch_pack_w_frag(hipStream_t st, const void* src, void* dst, int N, int K, int fp8);
 int launch_scatter_rows(hipStream_t st, const float* src, const int32_t* src_rows, float* dst, const int32_t* dst_rows, int rows, int d);

@@ -85,10 +85,12 @@ int launch_codes_set_first(hipStream_t st, const int64_t* first_cb, int64_t fc_s
 // ---- slot API (continuous batching) -----------------------------------------------------------------
 // AR state of newly admitted utterances: [kv_len | audio_pos | n_gen | done | cap | iter][max_B]
 __global__ void slot_state_init_kernel(int32_t* state, int max_B, const int32_t* slots, const int32_t* kv_len,
-                                       const int32_t* audio_pos, const int32_t* cap, int n) {
+                                       const int32_t* audio_pos, const int32_t* cap, int n, unsigned long long* slot_seed,
+                                       unsigned long long seed, unsigned long long first_request) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   if (i >= n) return;
   const int b = slots[i];
+  if (slot_seed != nullptr) slot_seed[b] = request_seed(seed, first_request + (unsigned long long)i);  // RNG stream of the REQUEST, not of the slot
   state[0 * max_B + b] = kv_len[i];
   state[1 * max_B + b] = audio_pos[i];
   state[2 * max_B + b] = 0;
@@ -98,9 +100,11 @@ __global__ void slot_state_init_kernel(int32_t* state, int max_B, const int32_t*
 }
 
 int launch_slot_state_init(hipStream_t st, int32_t* state, int max_B, const int32_t* slots, const int32_t* kv_len,
-                           const int32_t* audio_pos, const int32_t* cap, int n) {
+                           const int32_t* audio_pos, const int32_t* cap, int n, unsigned long long* slot_seed, unsigned long long seed,
+                           unsigned long long first_request) {
   if (n <= 0) return 0;
-  hipLaunchKernelGGL(slot_state_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, state, max_B, slots, kv_len, audio_pos, cap, n);
+  hipLaunchKernelGGL(slot_state_init_kernel, dim3((n + 63) / 64), dim3(64), 0, st, state, max_B, slots, kv_len, audio_pos, cap, n,
+                     slot_seed, seed, first_request);
   return 0;
 }
 

@@ -160,7 +160,8 @@ __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
       total += wave_tot[i];
     }
     const float excl = base + incl - local;
-    const float u = philox_uniform(dyn.seed, (uint32_t)it, (uint32_t)b);
+    const unsigned long long rseed = a.slot_seed != nullptr ? a.slot_seed[b] : request_seed(dyn.seed, (unsigned long long)b);
+    const float u = philox_uniform(rseed, (uint32_t)it, 0u);
     const float target = u * total;
     int cand = 0x7fffffff;
     float run = excl;
@@ -202,6 +203,7 @@ __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
       a.s.kv_len[b] = kvl;
       a.s.audio_pos[b] = ap;
     } else {
+      if (n < (int)a.g_stride) a.sampled[(int64_t)b * a.g_stride + n] = sample;  // the stopping iteration's own draw (e.g. EOS), for the hooks
       a.s.done[b] = 1;
       atomicAdd(a.s.done_count, 1);
     }

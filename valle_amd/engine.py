@@ -100,6 +100,17 @@ class Engine:
         _lib.check(self.lib.vle_load_tensor(self.h, b"position.pe", C.c_void_p(pe.data_ptr()), shape, 2), self.h)
         _lib.check(self.lib.vle_finalize_weights(self.h), self.h)
 
+    def reserve(self, max_batch: int, max_text: int, max_prompt: int, max_gen: int = 0):
+        """Grow capacities in place (vle_reserve): the weights stay on the device, buffers are re-created."""
+        c = self.cfg
+        nb, ns, npp = max(c.max_batch, max_batch), max(c.max_text, max_text), max(c.max_prompt, max_prompt)
+        ng = max(c.max_gen_eff(), max_gen, 16 * ns + 1)
+        new = EngineConfig(**{**c.__dict__, "max_batch": nb, "max_text": ns, "max_prompt": npp, "max_gen": ng})
+        pe = sine_pe(new.max_pos(), c.d_model).contiguous()
+        _lib.check(self.lib.vle_reserve(self.h, nb, ns, npp, ng, C.c_void_p(pe.data_ptr()), pe.shape[0]), self.h)
+        self.cfg = new
+        self._B, self._gen_lens = 0, []
+
     def set_option(self, name: str, value: int):
         _lib.check(self.lib.vle_set_option(self.h, name.encode(), int(value)), self.h)
 

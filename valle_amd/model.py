@@ -129,8 +129,12 @@ class VALLE(nn.Module):
         need_gen = max(gen_len, 16 * text_len + 1)
         if self._engine is not None:
             c = self._engine.cfg
-            if (self._engine_key == (dev.index or 0, self.engine_dtype) and c.max_batch >= batch and c.max_text >= text_len
-                    and c.max_prompt >= prompt_len and c.max_gen_eff() >= need_gen):
+            if self._engine_key == (dev.index or 0, self.engine_dtype):
+                if not (c.max_batch >= batch and c.max_text >= text_len and c.max_prompt >= prompt_len and c.max_gen_eff() >= need_gen):
+                    # a capacity grew: re-create the buffers only, the weights stay on the device (vle_reserve)
+                    self._engine.reserve(batch, text_len, prompt_len, need_gen)
+                    c = self._engine.cfg
+                    self.max_text, self.max_prompt, self.max_batch, self.max_gen = c.max_text, c.max_prompt, c.max_batch, c.max_gen
                 return self._engine
             self._invalidate()
         max_text = max(self.max_text, text_len)

@@ -5,7 +5,9 @@ The reference's caller decodes one utterance at a time (valle/bin/infer.py:223-2
 valle.py:1044-1048) leaves its slot at the next scheduling round -- its 7 NAR stages run then -- and a waiting request is
 prefilled into the free slot while the other slots keep decoding.  Every arithmetic step is the engine's
 (vle_slots_prefill / vle_slots_step / vle_slots_harvest); this module only decides WHICH utterance sits in which slot.
-What an utterance decodes to is independent of its batch mates (greedy: token-identical to ``VALLE.inference``).
+What an utterance decodes to is independent of its batch mates: greedy decodes are token-identical to ``VALLE.inference``,
+and sampled decodes draw from an RNG stream keyed on (seed, request index, iteration) -- not on the slot -- so they do not
+depend on ``max_batch`` / scheduling either and equal ``VALLE.inference_batch`` with the same seed.
 """
 from __future__ import annotations
 

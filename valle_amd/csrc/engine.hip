@@ -145,6 +145,7 @@ struct vle_engine {
   bool opt_gs_xf = true;            // option "gs_xf": AR-step activations of the gemm_skinny path in the fragment-major layout
   int opt_gs_target = 0;            // option "gs_target_wgs": workgroups the split-K of gemm_skinny aims for (0 = 256)
   void* gs_ws = nullptr;            // split-K tickets + partial tiles of gemm_skinny (zeroed once)
+  int opt_gs_dbg = 0;               // option "gs_dbg": timing diagnostics of gemm_skinny (1 = no X loads, 2 = no W loads)
   int opt_gs_rot = 0;               // option "gs_rot": gemm_skinny workgroups walk X in rotated orders (A/B knob)
   bool opt_gs_fuse_ln = true;       // option "gs_fuse_ln": LayerNorm folded into the gemm_skinny launches (no LayerNorm kernels in the step)
   float* ln_stats = nullptr;        // [64][d / 16][2] group statistics of the residual rows (kernels.h LnProducer)
@@ -921,7 +922,7 @@ int enqueue_ar_logits(vle_engine* e, bool fused = false) {
       }
       g.x = xn; g.w = e->w8 ? e->ar_predict8 : e->ar_predict; g.wscale = e->w8 ? e->ar_predict_s : nullptr; g.M = e->B; g.N = V_AR;
       if (e->opt_gs_wpack && e->ar_predict_p) { g.w = e->ar_predict_p; g.w_packed = 1; } g.K = e->d; g.epi = GS_EPI_F32; g.out = e->logits;
-      g.kt = e->next_kt(); g.rot = e->opt_gs_rot;
+      g.kt = e->next_kt(); g.rot = e->opt_gs_rot; g.dbg = e->opt_gs_dbg;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
     } else {
       E_LAUNCH(e, launch_gemm(st, e->dtype, xn, e->ar_predict, nullptr, e->logits, nullptr, e->B, V_AR, e->d, EPI_F32));
@@ -980,7 +981,7 @@ int enqueue_ar_step(vle_engine* e) {
         g.w_packed = wpk ? 1 : 0;
         if (wpk) g.w = w.wqkv_p;
         g.q_out = e->q_step; g.k_cache = kc; g.v_cache = vc; g.kv_len = e->S.kv_len; g.ctx_max = e->ctx_max; g.nhead = e->H; g.dh = e->dh;
-        g.kt = e->next_kt(); g.rot = e->opt_gs_rot;
+        g.kt = e->next_kt(); g.rot = e->opt_gs_rot; g.dbg = e->opt_gs_dbg;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       const bool direct = e->nsplit == 1;  // one block holds a whole (utterance, head): it normalises itself
@@ -997,7 +998,7 @@ int enqueue_ar_step(vle_engine* e) {
         g.lnc = LnConsumer();
         g.x = e->att_step; g.w = g.w_packed ? w.wo_p : (e->w8 ? w.wo8 : w.wo); g.wscale = e->w8 ? w.so : nullptr; g.bias = w.bo; g.N = d; g.K = d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         if (fuse) g.lnp = ln_producer(e, w.g2);  // the residual it completes is read by this layer's norm2 next
-        g.kt = e->next_kt(); g.rot = e->opt_gs_rot;
+        g.kt = e->next_kt(); g.rot = e->opt_gs_rot; g.dbg = e->opt_gs_dbg;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
         g.lnp = LnProducer();
       }
@@ -1012,7 +1013,7 @@ int enqueue_ar_step(vle_engine* e) {
         if (fuse) {
           g.lnc = lnc; g.lnc.wg = w.wg_1; g.bias = w.wb_1;
         }
-        g.kt = e->next_kt(); g.rot = e->opt_gs_rot;
+        g.kt = e->next_kt(); g.rot = e->opt_gs_rot; g.dbg = e->opt_gs_dbg;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
         g.lnc = LnConsumer();
       }
@@ -1021,7 +1022,7 @@ int enqueue_ar_step(vle_engine* e) {
         g.x_xf = xf ? 1 : 0; g.out_xf = 0;
         g.x = e->hT_step; g.w = g.w_packed ? w.w2_p : (e->w8 ? w.w28 : w.w2); g.wscale = e->w8 ? w.s2 : nullptr; g.bias = w.b2; g.N = d; g.K = 4 * d; g.epi = GS_EPI_RESID; g.resid = e->x_step;
         if (fuse) g.lnp = ln_producer(e, l + 1 < e->L ? e->ar[l + 1].g1 : e->ar_norm_g);  // next layer's norm1, or the final norm
-        g.kt = e->next_kt(); g.rot = e->opt_gs_rot;
+        g.kt = e->next_kt(); g.rot = e->opt_gs_rot; g.dbg = e->opt_gs_dbg;
         E_LAUNCH(e, launch_gemm_skinny(st, g));
         g.lnp = LnProducer();
       }
@@ -1961,10 +1962,11 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal" || n == "gs_fuse_ln" || n == "gs_rot") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal" || n == "gs_fuse_ln" || n == "gs_rot" || n == "gs_dbg") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
     else if (n == "gs_fuse_ln") e->opt_gs_fuse_ln = value != 0;
     else if (n == "gs_rot") e->opt_gs_rot = (int)value;
+    else if (n == "gs_dbg") e->opt_gs_dbg = (int)value;
     else if (n == "gs_xf") e->opt_gs_xf = value != 0;
     else if (n == "gs_wpack") e->opt_gs_wpack = value != 0;
     else if (n == "w8_temporal") e->opt_w8_temporal = (int)value;

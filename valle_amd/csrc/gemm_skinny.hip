@@ -236,7 +236,10 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int c = min(c0 + g, chunks - 1);  // clamped: a short last round re-reads its final chunk, unused below
-      if (a.w_packed) {  // fragment-major copy (misc.hip pack_w_frag_kernel): one contiguous 1 KB per fragment load
+      if (a.dbg & 2) {  // timing diagnostic: no W traffic
+        wv[g][0] = gs_u32x4{0x3c003c00u, 0x3c003c00u, 0x3c003c00u, 0x3c003c00u};
+        wv[g][1] = wv[g][0];
+      } else if (a.w_packed) {  // fragment-major copy (misc.hip pack_w_frag_kernel): one contiguous 1 KB per fragment load
         const int64_t cc = (int64_t)blockIdx.x * (K >> 6) + (kbeg >> 6) + c;
         if constexpr (W8) {
           wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(reinterpret_cast<const unsigned char*>(a.w) + cc * 1024 + lane * 16));
@@ -253,6 +256,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
       }
 #pragma unroll
       for (int i = 0; i < MF; ++i) {
+        if (a.dbg & 1) {  // timing diagnostic (option "gs_dbg"): no X traffic -- results are meaningless
+          xv[g][i][0] = gs_u32x4{0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+          xv[g][i][1] = xv[g][i][0];
+          continue;
+        }
         xv[g][i][0] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 0) * MF + fi(i)) * 512 : xp[i] + c * 64);
         xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 1) * MF + fi(i)) * 512 : xp[i] + c * 64 + SSTEP);
       }

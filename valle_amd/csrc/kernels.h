@@ -84,6 +84,7 @@ struct GemmSkinnyArgs {
   LnProducer lnp;
   LnConsumer lnc;
   KTrace kt;  // diagnostic timeline (option "ktrace")
+  int dbg = 0;  // timing diagnostics (option "gs_dbg"): 1 = no X loads, 2 = no W loads (results meaningless)
   int rot = 0;  // rotate the order in which a workgroup walks X by its index (option "gs_rot")
   const void* x = nullptr;     // bf16 [M][K]
   const void* w = nullptr;     // bf16 [N][K]

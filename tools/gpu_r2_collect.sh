@@ -17,6 +17,11 @@ for SET in "FETCH_SIZE" "WRITE_SIZE"; do
   (cd /tmp && rm -rf /tmp/pmc_run && timeout 400 rocprofv3 --pmc $SET --kernel-trace -d /tmp/pmc_run -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-graph --no-c3 > $GRAFT_REPO_ROOT/$D/pmc_$SET.log 2>&1); echo "pmc $SET rc=$?"
   python tools/pmc_summary.py /tmp/pmc_run/p_counter_collection.csv $D/pmc_${SET}_by_kernel.csv
 done
+for SET in "FETCH_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
+  TAG=$(echo $SET | tr ' ' '+')
+  (cd /tmp && rm -rf /tmp/pmc_run && timeout 400 rocprofv3 --pmc $SET --kernel-trace -d /tmp/pmc_run -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --batch 64 --steps 1 --warmup 0 --cpu-frames 0 --no-graph > $GRAFT_REPO_ROOT/$D/pmc_b64_$TAG.log 2>&1); echo "pmc b64 $TAG rc=$?"
+  python tools/pmc_summary.py /tmp/pmc_run/p_counter_collection.csv $D/b64_pmc_${TAG}_by_kernel.csv
+done
 timeout 600 python tools/ktrace_step.py --out $D/ktrace_b1 > $D/ktrace_b1.log 2>&1; echo "ktrace b1 rc=$?"
 timeout 600 python tools/ktrace_step.py --out $D/ktrace_b64 --spg 8 --batch 64 > $D/ktrace_b64.log 2>&1; echo "ktrace b64 rc=$?"
 timeout 120 tools/bin/ubench_edges > $D/ubench_edges.json 2> $D/ubench_edges.err; echo "edges rc=$?"

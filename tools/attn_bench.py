@@ -37,14 +37,18 @@ def main():
     for name, B, N, H, dh, causal in [("C2 NAR", 1, 1025, 16, 64, False), ("C3 NAR", 64, 1025, 16, 64, False), ("C3 prefill", 64, 272, 16, 64, True),
                                       ("C5 share NAR", 32, 1025, 16, 96, False)]:
         row = []
-        for tag, knobs in [("v1", dict(attn_v2=0)), ("v2 no-xcd", dict(attn_v2=2, attn_xcd=0)), ("v2", dict(attn_v2=2, attn_xcd=1)),
-                           ("v2 q128", dict(attn_v2=2, attn_xcd=1, attn_q128=1)), ("default policy", dict(attn_v2=1))]:
+        for tag, knobs in [("v1", dict(attn_v2=0)), ("v2 pad32 exact-max", dict(attn_v2=2, attn_mode=1, attn_defer=0)),
+                           ("v2 pad32", dict(attn_v2=2, attn_mode=1)), ("v2 dma exact-max", dict(attn_v2=2, attn_mode=2, attn_defer=0)),
+                           ("v2 dma", dict(attn_v2=2, attn_mode=2)), ("v2 pad32 q128", dict(attn_v2=2, attn_mode=1, attn_q128=1)),
+                           ("v2 dma q128", dict(attn_v2=2, attn_mode=2, attn_q128=1)), ("default policy", dict(attn_v2=1))]:
+            if tag != "default policy":
+                ops.tune("attn_q128", 0)
             for k, v in knobs.items():
                 ops.tune(k, v)
             ms, tf = bench(B, N, H, dh, causal)
             row.append(f"{tag}: {ms:7.3f} ms {tf:6.1f} TF")
-            ops.tune("attn_v2", 1); ops.tune("attn_xcd", 1); ops.tune("attn_q128", 0)
-        print(f"{name:13s} B={B:3d} N={N} H={H} dh={dh} c={int(causal)}  " + " | ".join(row), flush=True)
+            ops.tune("attn_v2", 1); ops.tune("attn_xcd", 1); ops.tune("attn_q128", -1); ops.tune("attn_mode", 2); ops.tune("attn_defer", 8)
+        print(f"{name:13s} B={B:3d} N={N} H={H} dh={dh} c={int(causal)}\n    " + "\n    ".join(row), flush=True)
 
 
 if __name__ == "__main__":

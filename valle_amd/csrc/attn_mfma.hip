@@ -38,13 +38,15 @@ __device__ inline int am_vpos(int key) {  // slot of key (0..63) inside a V^T ro
 
 // QW = 16-query fragments per wave: 1 (64 queries per block) or 2 (128: every K / V fragment read from LDS feeds two
 // MFMAs and the K/V tiles are re-read from L2 half as often -- for the batched passes, where there are blocks to spare).
-template <int DH, int QW>
+// PAD = bytes of padding per LDS row: 16 (round 1) makes two lanes of a ds_read_b128 lane group share a bank, 32 is conflict-free
+// for every head size (see attn_mfma2.hip, MODE 0 / 1).
+template <int DH, int QW, int PAD>
 __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict__ qkv, bf16_t* __restrict__ out,
                                                         const int32_t* __restrict__ seq_off,
                                                         const int32_t* __restrict__ text_len, int d, int nhead, int causal) {
   constexpr int NV = DH / 8;           // 16-byte vectors per K/V row
-  constexpr int KSTR = DH * 2 + 16;    // bytes per K row in LDS (one vector of padding: bank spread)
-  constexpr int VSTR = 64 * 2 + 16;    // bytes per V^T row
+  constexpr int KSTR = DH * 2 + PAD;   // bytes per K row in LDS
+  constexpr int VSTR = 64 * 2 + PAD;   // bytes per V^T row
   constexpr int NLD = 64 * NV / 256;   // staged vectors per thread per tile (K and V each)
   constexpr int KS = DH / 32, EB = DH / 16;
   __shared__ __attribute__((aligned(16))) unsigned char smem[64 * KSTR + DH * VSTR];
@@ -215,14 +217,18 @@ int launch_attention_mfma(hipStream_t st, const void* qkv, void* out, const int3
   if (d % 8 != 0) return 1;
   const int qw = g_attn_qw == 2 ? 2 : 1;
   const dim3 grid((max_len + 64 * qw - 1) / (64 * qw), nhead, B), block(256);
-#define VLE_AM(DH)                                                                                                            \
-  do {                                                                                                                        \
-    if (qw == 2)                                                                                                              \
-      hipLaunchKernelGGL((attn_mfma_kernel<DH, 2>), grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)out, seq_off, text_len, d, \
-                         nhead, causal);                                                                                      \
-    else                                                                                                                      \
-      hipLaunchKernelGGL((attn_mfma_kernel<DH, 1>), grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)out, seq_off, text_len, d, \
-                         nhead, causal);                                                                                      \
+#define VLE_AMP(DH, QW, PAD)                                                                                                  \
+  hipLaunchKernelGGL((attn_mfma_kernel<DH, QW, PAD>), grid, block, 0, st, (const bf16_t*)qkv, (bf16_t*)out, seq_off, text_len, d, \
+                     nhead, causal)
+#define VLE_AM(DH)                            \
+  do {                                        \
+    if (qw == 2) {                            \
+      if (g_attn_mode == 0) VLE_AMP(DH, 2, 16); \
+      else VLE_AMP(DH, 2, 32);                \
+    } else {                                  \
+      if (g_attn_mode == 0) VLE_AMP(DH, 1, 16); \
+      else VLE_AMP(DH, 1, 32);                \
+    }                                         \
   } while (0)
   switch (dh) {
     case 32: VLE_AM(32); break;
@@ -232,6 +238,7 @@ int launch_attention_mfma(hipStream_t st, const void* qkv, void* out, const int3
     default: return 1;
   }
 #undef VLE_AM
+#undef VLE_AMP
   return 0;
 }
 #undef AM_GLOAD

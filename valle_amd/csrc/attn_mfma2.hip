@@ -68,15 +68,32 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__
   }
 }
 
-template <int DH, int QW, bool XCD_REMAP>
+template <int N>
+__device__ inline void a2_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+// MODE 0: tiles staged through registers (global -> VGPR -> ds_write_b128), rows padded by 16 bytes (round 2's first layout: a
+//         ds_read_b128 is served in lane groups {0-3, 12-15, 20-27}, {4-11, 16-19, 28-31}, ... (MI355X_MICROARCH.md, LDS table): with a
+//         row stride of 2 DH + 16 bytes two lanes of a group share a bank -- 8 LDS cycles per fragment read instead of 4);
+// MODE 1: same staging, rows padded by 32 bytes: conflict-free for every head size (stride = 32 mod 64 bytes);
+// MODE 2: tiles go global -> LDS by LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction: no VGPR round trip, no
+//         ds_write_b128 at ~13 cycles each), dense rows, 16-byte slots XOR-swizzled on the DMA source address and on the ds_read
+//         side (key = row mod (vectors per row)): conflict-free; two buffers, tile t+1 in flight while tile t is multiplied,
+//         counted-free wait (vmcnt(0): the only loads in the loop are the DMA pieces) + raw s_barrier per tile.  DH 64 / 128.
+template <int DH, int QW, int MODE>
 __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                     const int32_t* __restrict__ seq_off, const int32_t* __restrict__ text_len, int d,
-                                                    int nhead, int causal, int64_t rp) {
+                                                    int nhead, int causal, int64_t rp, int xcd_remap, float defer_exp2) {
+  constexpr bool GLDS = MODE == 2;
+  static_assert(!GLDS || DH == 64 || DH == 128, "LDS-DMA layout: 8 or 16 vectors per K row");
   constexpr int NV = DH / 8;           // 16-byte vectors per K row
-  constexpr int KSTR = DH * 2 + 16;    // bytes per K row in LDS (one vector of padding: bank spread)
-  constexpr int VSTR = 64 * 2 + 16;    // bytes per V^T row
+  constexpr int PAD = GLDS ? 0 : (MODE == 1 ? 32 : 16);
+  constexpr int KSTR = DH * 2 + PAD;   // bytes per K row in LDS
+  constexpr int VSTR = 64 * 2 + PAD;   // bytes per V^T row
   constexpr int NLD = 64 * NV / 256;   // staged vectors per thread per tile (K and V^T each): DH / 32
   constexpr int KS = DH / 32, EB = DH / 16;
+  constexpr int KSWZ = GLDS ? NV - 1 : 0, VSWZ = GLDS ? 7 : 0;  // slot ^= row & mask
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (64 * KSTR + DH * VSTR)];
 
   // XCD-aware block order (block L runs on XCD L % 8, each with its own 4 MB L2): the query blocks of one (sequence, head) read
@@ -87,7 +104,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
     const int gx = gridDim.x, gy = gridDim.y;
     const int nb = gx * gy * (int)gridDim.z;
     int L = ((int)blockIdx.z * gy + (int)blockIdx.y) * gx + (int)blockIdx.x;
-    if (XCD_REMAP) {
+    if (xcd_remap) {
       const int q = nb / 8, r = nb % 8, xcd = L % 8, idx = L / 8;
       L = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
     }
@@ -146,8 +163,31 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
       *reinterpret_cast<a2_u32x4*>(buf + 64 * KSTR + e * VSTR + vec * 16) = vreg[i];
     }
   };
+  // LDS-DMA staging (MODE 2): a tile is NV pieces of K (piece q: K-tile vectors 64 q .. 64 q + 63 in row-major order, i.e. rows
+  // 64 q / NV ..) and DH / 8 pieces of V^T; wave w issues pieces w, w + 4, ...; lane l of a piece lands at LDS offset 16 l, so the
+  // swizzle is applied to WHAT the lane fetches: slot s of row r holds vector s ^ (r & mask)
+  const int wv = __builtin_amdgcn_readfirstlane(w);  // provably wave-uniform (LDS base of the DMA goes through M0)
+  auto dma = [&](int kt0, unsigned char* buf) {
+#pragma unroll
+    for (int i = 0; i < NV / 4; ++i) {
+      const int idx = (i * 4 + w) * 64 + lane;
+      const int row = idx / NV, slot = idx % NV;
+      const bf16_t* src = base + (int64_t)min(kt0 + row, len - 1) * d3 + d + ((slot ^ (row & KSWZ)) * 8);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + (i * 4 + wv) * 1024), 16, 0, 0);
+    }
+#pragma unroll
+    for (int i = 0; i < DH / 32; ++i) {
+      const int idx = (i * 4 + w) * 64 + lane;
+      const int e = idx >> 3, slot = idx & 7;
+      const bf16_t* src = vbase + (int64_t)e * rp + kt0 + ((slot ^ (e & VSWZ)) * 8);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(buf + 64 * KSTR + (i * 4 + wv) * 1024), 16, 0, 0);
+    }
+  };
 
   const float sl2 = 1.4426950408889634f / sqrtf((float)DH);  // log2(e) / sqrt(dh)
+  const float defer = defer_exp2 / sl2;                       // threshold on raw scores
   float m[QW], l[QW];  // m: running max of the RAW scores of the row (shared by its 4 lanes); l: this lane's part of the row sum
   a2_f32x4 o[QW][EB];
 #pragma unroll
@@ -161,14 +201,23 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
   // (Measured and rejected: issuing the scores of tile t+1 ahead of the softmax of tile t -- K ring one tile ahead of the V^T
   //  ring -- 365 -> 328 TF/s at the C3 NAR shape: the extra score registers cost more occupancy than the overlap returns.)
   const int ntile = (kmax + 63) >> 6;
-  gload(0);
-  lstore(smem);
-  __syncthreads();
-  if (ntile > 1) gload(64);
+  if constexpr (GLDS) {
+    dma(0, smem);
+  } else {
+    gload(0);
+    lstore(smem);
+    __syncthreads();
+    if (ntile > 1) gload(64);
+  }
   for (int t = 0; t < ntile; ++t) {
     const int kt0 = t * 64;
     const unsigned char* Ks = smem + (t & 1) * BUF;
     const unsigned char* Vt = Ks + 64 * KSTR;
+    if constexpr (GLDS) {
+      a2_wait_vm<0>();                 // this wave's pieces of tile t landed (and, at t = 0, its Q fragments)
+      __builtin_amdgcn_s_barrier();    // everyone's did; everyone finished reading tile t-1
+      if (t + 1 < ntile) dma(kt0 + 64, smem + ((t + 1) & 1) * BUF);  // into tile t-1's buffer, in flight under this tile's math
+    }
 
     // ---- S^T = K Q^T: one K fragment read feeds the QW query fragments ---------------------------------
     a2_f32x4 s[QW][4];
@@ -178,7 +227,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
       for (int f = 0; f < QW; ++f) s[f][kb] = a2_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const a2_bf16x8 a = *reinterpret_cast<const a2_bf16x8*>(Ks + (kb * 16 + c) * KSTR + (ks * 4 + g) * 16);
+        const a2_bf16x8 a = *reinterpret_cast<const a2_bf16x8*>(Ks + (kb * 16 + c) * KSTR + (((ks * 4 + g) ^ (c & KSWZ)) * 16));
 #pragma unroll
         for (int f = 0; f < QW; ++f) s[f][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[f][ks], s[f][kb], 0, 0, 0);
       }
@@ -195,30 +244,33 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
           for (int r = 0; r < 4; ++r)
             if (kt0 + kb * 16 + g * 4 + r >= klim[f]) s[f][kb][r] = A2_NEG;
       }
+      // this lane's maximum over its 16 keys of the row; m[f] is the row's reference, shared by its 4 lanes
       float mt = fmaxf(fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3])),
                        fmaxf(fmaxf(s[f][1][0], s[f][1][1]), fmaxf(s[f][1][2], s[f][1][3])));
       mt = fmaxf(mt, fmaxf(fmaxf(fmaxf(s[f][2][0], s[f][2][1]), fmaxf(s[f][2][2], s[f][2][3])),
                            fmaxf(fmaxf(s[f][3][0], s[f][3][1]), fmaxf(s[f][3][2], s[f][3][3]))));
-      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
-      if (!__all(mt <= m[f])) {  // some row's maximum grew: rescale (alpha = 1 exactly for the rows whose maximum did not)
+      // Deferred maximum: as long as no score of the wave exceeds its row's reference by more than `defer` (raw-score units;
+      // 8 in the exp2 domain => P <= 256, nothing for bf16 P / fp32 sums) the reference stays: no cross-lane reduction, no
+      // rescale.  Softmax does not depend on the reference (O and l carry the same factor); defer = 0 is the exact-maximum form.
+      if (!__all(mt <= m[f] + defer)) {  // wave-uniform; always taken on the first tile (m = -1e30)
+        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
+        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
         const float mn = fmaxf(m[f], mt);
-        const float alpha = __builtin_amdgcn_exp2f((m[f] - mn) * sl2);
+        const float alpha = __builtin_amdgcn_exp2f((m[f] - mn) * sl2);  // 1 exactly for the rows whose maximum did not grow
         m[f] = mn;
         l[f] *= alpha;
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb) o[f][eb] *= alpha;
       }
       const float nm = -m[f] * sl2;
-      float rowsum = 0.f;
+      float ps[4];
 #pragma unroll
-      for (int kb = 0; kb < 4; ++kb)
+      for (int kb = 0; kb < 4; ++kb) {
 #pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const float p = __builtin_amdgcn_exp2f(fmaf(s[f][kb][r], sl2, nm));  // masked scores: exp2(-1e30 * sl2 + ...) = 0
-          s[f][kb][r] = p;
-          rowsum += p;
-        }
+        for (int r = 0; r < 4; ++r) s[f][kb][r] = __builtin_amdgcn_exp2f(fmaf(s[f][kb][r], sl2, nm));  // masked: exp2(-1e30 sl2 + ..) = 0
+        ps[kb] = (s[f][kb][0] + s[f][kb][1]) + (s[f][kb][2] + s[f][kb][3]);
+      }
+      const float rowsum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
       l[f] += rowsum;
 #pragma unroll
       for (int j = 0; j < 2; ++j)
@@ -230,17 +282,19 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
     for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const a2_bf16x8 a = *reinterpret_cast<const a2_bf16x8*>(Vt + (eb * 16 + c) * VSTR + (j * 32 + g * 8) * 2);
+        const a2_bf16x8 a = *reinterpret_cast<const a2_bf16x8*>(Vt + (eb * 16 + c) * VSTR + (((j * 4 + g) ^ (c & VSWZ)) * 16));
 #pragma unroll
         for (int f = 0; f < QW; ++f) o[f][eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[f][j], o[f][eb], 0, 0, 0);
       }
 
     // ---- tile t+1 (in registers since the previous iteration) -> the other buffer; tile t+2 -> registers -------
-    if (t + 1 < ntile) {
-      lstore(smem + ((t + 1) & 1) * BUF);  // last read during iteration t-1, i.e. before the barrier that ended it
-      if (t + 2 < ntile) gload(kt0 + 128);
+    if constexpr (!GLDS) {
+      if (t + 1 < ntile) {
+        lstore(smem + ((t + 1) & 1) * BUF);  // last read during iteration t-1, i.e. before the barrier that ended it
+        if (t + 2 < ntile) gload(kt0 + 128);
+      }
+      __syncthreads();  // tile t+1 visible; everyone is done reading tile t
     }
-    __syncthreads();  // tile t+1 visible; everyone is done reading tile t
   }
 
 #pragma unroll
@@ -293,8 +347,12 @@ int attn2_reserve(int64_t rows, int B, int d) {
 
 int g_attn_v2 = 1;    // "attn_v2": 0 = round 1's kernel (attn_mfma.hip) for A/B
 int g_attn_xcd = 1;   // "attn_xcd": XCD-aware block order (A/B)
-int g_attn_q128 = 0;  // "attn_q128": 128-query blocks: 0 never (measured: 64-query blocks win at every shape of the engine), 1 always,
-                      // -1 = for sequences longer than 384
+int g_attn_mode = 2;  // "attn_mode": tile staging of attn2_kernel -- 0 registers + 16-byte row padding (round 2's first layout), 1 registers +
+                      // 32-byte padding (conflict-free), 2 LDS-DMA + XOR swizzle where the head size allows (64 / 128), else 1
+int g_attn_defer = 8; // "attn_defer": deferred-maximum threshold of attn2_kernel in exp2-domain units (0 = exact running maximum)
+int g_attn_q128 = -1; // "attn_q128": 128-query blocks (each K / V^T fragment read from LDS feeds two MFMAs): 0 never, 1 always, -1 (default) =
+                      // on the un-masked passes with at least 1024 such blocks (4 per CU) -- measured (tools/attn_bench.py): C3 NAR 461 -> 474
+                      // TF/s, C5's dh 96 368 -> 438; a single sequence (144 blocks) and the causal prefill are faster with 64
 
 // returns 0 = launched, 1 = not covered (caller uses attn_mfma.hip / the generic kernel), < 0 error.  `rows` = packed rows of qkv.
 int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int32_t* seq_off, const int32_t* text_len, int B,
@@ -313,16 +371,17 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
   const int64_t rp = rows + 128 * (int64_t)(B + 1) + 64;  // >= every sequence's last padded column
   const int64_t rp8 = rp & ~(int64_t)7;                    // row pitch: a multiple of 8 elements (16-byte vectors)
   const dim3 pgrid((max_len + 63) / 64, nhead, B), block(256);
-  const bool q128 = g_attn_q128 < 0 ? max_len > 384 : g_attn_q128 != 0;  // short sequences: 64-query blocks (less masked work, more blocks)
+  const bool q128 = g_attn_q128 < 0 ? (!causal && (int64_t)B * nhead * ((max_len + 127) / 128) >= 1024) : g_attn_q128 != 0;
   const dim3 grid(q128 ? (max_len + 127) / 128 : (max_len + 63) / 64, nhead, B);
-#define VLE_A2K(DH, QW)                                                                                                              \
-  do {                                                                                                                               \
-    if (g_attn_xcd)                                                                                                                  \
-      hipLaunchKernelGGL((attn2_kernel<DH, QW, true>), grid, block, 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, seq_off, \
-                         text_len, d, nhead, causal, rp8);                                                                           \
-    else                                                                                                                             \
-      hipLaunchKernelGGL((attn2_kernel<DH, QW, false>), grid, block, 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, seq_off, \
-                         text_len, d, nhead, causal, rp8);                                                                           \
+#define VLE_A2M(DH, QW, MODE)                                                                                                      \
+  hipLaunchKernelGGL((attn2_kernel<DH, QW, MODE>), grid, block, 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, seq_off, \
+                     text_len, d, nhead, causal, rp8, g_attn_xcd, (float)g_attn_defer)
+#define VLE_A2K(DH, QW)                                  \
+  do {                                                   \
+    if (mode == 2) {                                     \
+      if constexpr (DH == 64 || DH == 128) VLE_A2M(DH, QW, 2); \
+    } else if (mode == 1) VLE_A2M(DH, QW, 1);            \
+    else VLE_A2M(DH, QW, 0);                             \
   } while (0)
 #define VLE_A2(DH)                                                                                                              \
   do {                                                                                                                          \
@@ -330,6 +389,7 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
     if (q128) VLE_A2K(DH, 2);                                                                                                   \
     else VLE_A2K(DH, 1);                                                                                                        \
   } while (0)
+  const int mode = (g_attn_mode == 2 && !(dh == 64 || dh == 128)) ? 1 : g_attn_mode;
   switch (dh) {
     case 32: VLE_A2(32); break;
     case 64: VLE_A2(64); break;
@@ -338,6 +398,7 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
     default: return 1;
   }
 #undef VLE_A2
+#undef VLE_A2M
 #undef VLE_A2K
   return 0;
 }

@@ -34,6 +34,10 @@ def bench(B, N, nhead, dh, causal, reps=10):
 
 
 def main():
+    if "--quick" in sys.argv:  # one shape, the default policy, few launches: the target of a rocprofv3 --pmc pass
+        ms, tf = bench(64, 1025, 16, 64, False, reps=3)
+        print(f"C3 NAR default policy: {ms:7.3f} ms {tf:6.1f} TF")
+        return
     for name, B, N, H, dh, causal in [("C2 NAR", 1, 1025, 16, 64, False), ("C3 NAR", 64, 1025, 16, 64, False), ("C3 prefill", 64, 272, 16, 64, True),
                                       ("C5 share NAR", 32, 1025, 16, 96, False)]:
         row = []

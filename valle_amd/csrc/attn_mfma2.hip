@@ -27,6 +27,7 @@ namespace vle {
 typedef __bf16 a2_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 a2_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float a2_f32x4 __attribute__((ext_vector_type(4)));
+typedef float a2_f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int a2_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float A2_NEG = -1e30f;
@@ -129,6 +130,9 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
     if (qvalid[f]) kfull = min(kfull, klim[f]);
   }
   const int kmax = causal ? max(S, min(q0 + 64 * QW, len)) : len;      // block-wide bound
+  const int wq0 = __builtin_amdgcn_readfirstlane(q0 + w * QW * 16);     // first query row of this wave
+  const bool wave_live = wq0 < len;                                      // wave-uniform
+  const int kmax_w = causal ? max(S, min(wq0 + QW * 16, len)) : len;     // keys any row of this wave can see
   const int d3 = 3 * d;
   const bf16_t* base = qkv + (int64_t)off * d3 + h * DH;
   const bf16_t* vbase = vt + (int64_t)h * DH * rp + a2_vt_start(off, b);
@@ -172,7 +176,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
     for (int i = 0; i < NV / 4; ++i) {
       const int idx = (i * 4 + w) * 64 + lane;
       const int row = idx / NV, slot = idx % NV;
-      const bf16_t* src = base + (int64_t)min(kt0 + row, len - 1) * d3 + d + ((slot ^ (row & KSWZ)) * 8);
+      const bf16_t* src = base + (__umul24((unsigned)min(kt0 + row, len - 1), (unsigned)d3) + (unsigned)(d + ((slot ^ (row & KSWZ)) * 8)));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(buf + (i * 4 + wv) * 1024), 16, 0, 0);
     }
@@ -219,6 +223,9 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
       if (t + 1 < ntile) dma(kt0 + 64, smem + ((t + 1) & 1) * BUF);  // into tile t-1's buffer, in flight under this tile's math
     }
 
+    // a wave whose query rows all lie beyond the sequence (the ragged last block: N = 1025 leaves ONE row for a block of 64 / 128)
+    // or whose rows see none of this tile's keys (causal) only stages tiles and meets the barriers
+    if (wave_live && kt0 < kmax_w) {
     // ---- S^T = K Q^T: one K fragment read feeds the QW query fragments ---------------------------------
     a2_f32x4 s[QW][4];
 #pragma unroll
@@ -238,11 +245,12 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
 #pragma unroll
     for (int f = 0; f < QW; ++f) {
       if (!all_visible) {
+        const int rel = klim[f] - kt0 - g * 4;  // key kt0 + 16 kb + 4 g + r is visible iff 16 kb + r < rel (compile-time left side)
 #pragma unroll
         for (int kb = 0; kb < 4; ++kb)
 #pragma unroll
           for (int r = 0; r < 4; ++r)
-            if (kt0 + kb * 16 + g * 4 + r >= klim[f]) s[f][kb][r] = A2_NEG;
+            if (kb * 16 + r >= rel) s[f][kb][r] = A2_NEG;
       }
       // this lane's maximum over its 16 keys of the row; m[f] is the row's reference, shared by its 4 lanes
       float mt = fmaxf(fmaxf(fmaxf(s[f][0][0], s[f][0][1]), fmaxf(s[f][0][2], s[f][0][3])),
@@ -262,12 +270,16 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb) o[f][eb] *= alpha;
       }
-      const float nm = -m[f] * sl2;
+      const a2_f32x2 nm2 = {-m[f] * sl2, -m[f] * sl2}, sl22 = {sl2, sl2};
       float ps[4];
 #pragma unroll
       for (int kb = 0; kb < 4; ++kb) {
-#pragma unroll
-        for (int r = 0; r < 4; ++r) s[f][kb][r] = __builtin_amdgcn_exp2f(fmaf(s[f][kb][r], sl2, nm));  // masked: exp2(-1e30 sl2 + ..) = 0
+        // pairs of scores: one v_pk_fma_f32 scales two (the VALU port, not the MFMA pipe, bounds this kernel: ~6 VALU per MFMA)
+        const a2_f32x2 t0 = a2_f32x2{s[f][kb][0], s[f][kb][1]} * sl22 + nm2, t1 = a2_f32x2{s[f][kb][2], s[f][kb][3]} * sl22 + nm2;
+        s[f][kb][0] = __builtin_amdgcn_exp2f(t0[0]);  // masked scores: exp2(-1e30 sl2 + ..) = 0
+        s[f][kb][1] = __builtin_amdgcn_exp2f(t0[1]);
+        s[f][kb][2] = __builtin_amdgcn_exp2f(t1[0]);
+        s[f][kb][3] = __builtin_amdgcn_exp2f(t1[1]);
         ps[kb] = (s[f][kb][0] + s[f][kb][1]) + (s[f][kb][2] + s[f][kb][3]);
       }
       const float rowsum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
@@ -286,6 +298,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
 #pragma unroll
         for (int f = 0; f < QW; ++f) o[f][eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[f][j], o[f][eb], 0, 0, 0);
       }
+    }  // wave_live
 
     // ---- tile t+1 (in registers since the previous iteration) -> the other buffer; tile t+2 -> registers -------
     if constexpr (!GLDS) {

@@ -36,6 +36,7 @@ namespace vle {
 typedef __bf16 g8_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 g8_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float g8_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int g8_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int G8_HALF = 128 * 128;       // bytes of one half-tile (128 rows x 64 bf16)
 constexpr int G8_BUF = 4 * G8_HALF;      // A-top, A-bot, B-left, B-right
@@ -58,7 +59,7 @@ __device__ inline int g8_key(int row) {
 template <int EPI, bool STAGGER, int SWZ>
 __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                        const float* __restrict__ bias, void* __restrict__ out_,
-                                                       float* __restrict__ resid, int64_t M, int N, int K, int GC) {
+                                                       float* __restrict__ resid, int64_t M, int N, int K, int GC, int dbg) {
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G8_BUF];  // the ONLY LDS object (a second one makes
                                                                            // hipcc drain vmcnt before every ds_read)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -172,7 +173,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
     __builtin_amdgcn_sched_barrier(0);
   };
 
-  const int KT = K / 64;
+  const int KT = (dbg & 2) ? 2 : K / 64;  // diagnostic (g8_dbg bit 1): prologue + two K-tiles + epilogue only
   // Issue schedule (one half-tile per phase, in order of first use, into a half whose last read lies >= 2 phases back,
   // so it also holds when the two wave groups are half a phase apart):
   //   phase 1: A-bot of tile t+1      phase 2: B-right of tile t+1     (other buffer)
@@ -221,6 +222,86 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
   if (STAGGER && wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the last barrier of waves 4-7
 
   // ---- epilogue: lane (fg, fr) holds C[m = .. + 16 i + fr][n = .. + 16 j + 4 fg + r], r = 0..3 -----------------
+  // Through LDS (free once the last K-tile is consumed): written straight from the fragments, a store instruction covers 16 rows x
+  // 32 bytes (8-byte pieces of 16 different rows) and the store tail costs 20-50 % of the kernel (diagnostic knob g8_dbg = 1:
+  // QKV 960 -> 1243 TF/s, out-proj 560 -> 1090 without the stores).  Staged as a row-major image, every global access is a whole
+  // row of the tile: 512 bytes of bf16 (two rows per wave-instruction) or 1 KB of fp32 (one row), 16 bytes per lane.
+  //   bf16 image  [256][256]: 16-byte chunk c of row r at chunk c ^ (r & 7), its 8-byte halves swapped when (r >> 3) & 1 --
+  //               conflict-free for the fragment writes (ds_write_b64: 16 rows of one column chunk) and the row reads;
+  //   fp32 image  [128][256], one row half of the tile per pass: chunk c of row r at c ^ (r & 7) (ds_write_b128 groups of 8 rows).
+  if (!(dbg & 4)) {
+    unsigned char* const E = smem;
+    if constexpr (EPI == EPI_STORE || EPI == EPI_RELU) {
+#pragma unroll
+      for (int a = 0; a < 2; ++a)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = a * 128 + wr * 64 + i * 16 + fr;
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int c = b * 16 + wc * 4 + j * 2 + (fg >> 1);
+              g8_f32x4 v = acc[a][b][i][j] + bias4[b][j];
+              if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              }
+              g8_bf16x4 o4;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o4[r] = (__bf16)v[r];
+              *reinterpret_cast<g8_bf16x4*>(E + row * 512 + ((c ^ (fr & 7)) << 4) + (((fg & 1) ^ (fr >> 3)) << 3)) = o4;
+            }
+        }
+      __syncthreads();
+      bf16_t* const outp = reinterpret_cast<bf16_t*>(out_);
+      const int l = lane & 31;
+#pragma unroll
+      for (int it = 0; it < 16; ++it) {
+        const int r = wave * 32 + it * 2 + (lane >> 5);
+        g8_u32x4 v = *reinterpret_cast<const g8_u32x4*>(E + r * 512 + ((l ^ (r & 7)) << 4));
+        if ((r >> 3) & 1) v = g8_u32x4{v[2], v[3], v[0], v[1]};
+        const int64_t m = m0 + r;
+        if (m < M && !(dbg & 1)) *reinterpret_cast<g8_u32x4*>(outp + m * N + n0 + l * 8) = v;
+      }
+    } else {
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (a == 1) __syncthreads();  // the rows of pass 0 have been read
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wr * 64 + i * 16 + fr;
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int c = b * 32 + wc * 8 + j * 4 + fg;
+              *reinterpret_cast<g8_f32x4*>(E + row * 1024 + ((c ^ (fr & 7)) << 4)) = acc[a][b][i][j] + bias4[b][j];
+            }
+        }
+        float* const base = (EPI == EPI_RESID ? resid : reinterpret_cast<float*>(out_)) + n0 + lane * 4;
+        g8_f32x4 old[16];
+        if constexpr (EPI == EPI_RESID) {  // the 16 rows' old values: requested before the barrier
+#pragma unroll
+          for (int it = 0; it < 16; ++it) {
+            const int64_t m = m0 + a * 128 + wave * 16 + it;
+            old[it] = *reinterpret_cast<const g8_f32x4*>(base + (m < M ? m : M - 1) * N);
+          }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < 16; ++it) {
+          const int r = wave * 16 + it;
+          g8_f32x4 v = *reinterpret_cast<const g8_f32x4*>(E + r * 1024 + ((lane ^ (r & 7)) << 4));
+          if constexpr (EPI == EPI_RESID) v = old[it] + v;
+          const int64_t m = m0 + a * 128 + r;
+          if (m < M && !(dbg & 1)) *reinterpret_cast<g8_f32x4*>(base + m * N) = v;
+        }
+      }
+    }
+    return;
+  }
+  // ---- legacy epilogue (g8_dbg bit 2): stores straight from the fragments ------------------------------------------------------
 #pragma unroll
   for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -233,6 +314,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
         for (int j = 0; j < 2; ++j) {
           const int n = n0 + b * 128 + wc * 32 + j * 16 + fg * 4;
           g8_f32x4 v = acc[a][b][i][j] + bias4[b][j];
+          if ((dbg & 1) && v[0] != 1.2345e30f) continue;  // diagnostic (g8_dbg bit 0): no epilogue stores
           if constexpr (EPI == EPI_RELU) {
 #pragma unroll
             for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
@@ -252,6 +334,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
     }
 }
 
+int g_g8_dbg = 0;       // "g8_dbg": diagnostics -- 1 no epilogue stores, 2 two K-tiles only (what do prologue / epilogue cost?), 4 legacy epilogue
 int g_g8_colgroup = 0;  // "g8_colgroup": column tiles per group of the tile order (0 / 1 = row-major)
 int g_g8_stagger = 1;  // "g8_stagger": waves 4-7 half a phase behind waves 0-3 (measured +7-10 %: 905 -> 970 TF/s); 0 = lock step
 
@@ -262,7 +345,7 @@ int launch_gemm_8ph(hipStream_t st, const void* A, const void* W, const float* b
   const dim3 grid(N / 256, (unsigned)((M + 255) / 256)), block(512);
   const bf16_t* a = (const bf16_t*)A;
   const bf16_t* w = (const bf16_t*)W;
-#define VLE_G8(E, ST, SW) hipLaunchKernelGGL((gemm_8ph_kernel<E, ST, SW>), grid, block, 0, st, a, w, bias, out, resid, M, N, K, g_g8_colgroup)
+#define VLE_G8(E, ST, SW) hipLaunchKernelGGL((gemm_8ph_kernel<E, ST, SW>), grid, block, 0, st, a, w, bias, out, resid, M, N, K, g_g8_colgroup, g_g8_dbg)
 #define VLE_G8E(ST, SW)                           \
   switch (epi) {                                  \
     case EPI_STORE: VLE_G8(EPI_STORE, ST, SW); break; \

@@ -278,6 +278,13 @@ int vle_op_linear_fp8(void* stream, const void* a8, const float* a_scale, const 
                       void* out, float* resid, int64_t M, int32_t N, int32_t K, int epilogue);
 int vle_op_cross_entropy(void* stream, const float* logits, const int64_t* targets, float* loss, int32_t* hit, int64_t rows, int32_t V,
                          int32_t ignore_index, int32_t topk);
+/* topk_sampling (valle/models/valle.py:1287-1302; top_k_top_p_filtering :1242-1284 with top_p = 1.0) of each row of
+ * logits [f32, rows x V], V <= 1280: divide by `temperature` (if != 1), keep the top_k largest (ties at the k-th value kept;
+ * top_k <= 0 or >= V keeps all, top_k == 1 is the arg-max), softmax, draw samples[row] (int64) with
+ * u = Philox4x32-10(request seed of (seed, row), step) -- the stream of request `row` of vle_ar_generate(seed) at AR step `step`.
+ * argmax [int64, rows] (nullable) receives the arg-max of the raw row (lowest index among ties): the stop rule :1044-1048 needs both. */
+int vle_op_topk_sample(void* stream, const float* logits, int64_t rows, int32_t V, int32_t top_k, float temperature, uint64_t seed,
+                       uint32_t step, int64_t* samples, int64_t* argmax);
 /* AdaptiveLayerNorm.forward (transformer.py:93-108) as an affine fold: with wb = project_layer(stage_emb)
  * [f32, 2d] = [w ; b] and the inner norm's (g, be): gamma_out = w * g, beta_out = w * be + b, so that
  * vle_op_layernorm(x, gamma_out, beta_out) == w * LayerNorm(x) + b (the fold vle_finalize_weights applies). */

@@ -41,6 +41,16 @@ CASES = {
     "tiny_noshare": dict(cfg=dict(d_model=64, nhead=1, num_layers=1, prefix_mode=1, share_embedding=False), S=4, P=6, ar_stride=8),
     "tiny_continual": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=1), S=7, P=40, mode="continual"),
     "tiny_continual_pm0": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=0), S=7, P=31, mode="continual"),
+    # constructor options outside the fused engine's shape (post-norm layers, prenets, a different NAR width: the reference's own
+    # smoke test runs them, valle/tests/valle_test.py:106-133) -- decoded by the block-module path of valle_amd/model.py
+    "opt_postnorm_prenet_pm1": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, norm_first=False, add_prenet=True, prefix_mode=1), S=6, P=10, ar_stride=8),
+    "opt_postnorm_prenet_half_bos_pm0": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, norm_first=False, add_prenet=True, prefix_mode=0,
+                                                      nar_scale_factor=0.5, prepend_bos=True), S=5, P=9, ar_stride=8),
+    "opt_prenorm_prenet_pm1": dict(cfg=dict(d_model=64, nhead=2, num_layers=2, add_prenet=True, prefix_mode=1), S=6, P=10, ar_stride=8),
+    "opt_postnorm_pm2_enroll": dict(cfg=dict(d_model=128, nhead=4, num_layers=2, norm_first=False, prefix_mode=2), S=9, P=14, enroll=4, ar_stride=8),
+    "opt_scale2_pm1": dict(cfg=dict(d_model=64, nhead=2, num_layers=1, nar_scale_factor=2.0, prefix_mode=1), S=5, P=8, ar_stride=8),
+    "opt_postnorm_prenet_continual": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, norm_first=False, add_prenet=True, prefix_mode=1), S=7, P=40,
+                                          mode="continual"),
     "small_dh64": dict(cfg=dict(d_model=128, nhead=2, num_layers=2, prefix_mode=1), S=12, P=30, ar_stride=8),
     "small_dh96": dict(cfg=dict(d_model=192, nhead=2, num_layers=2, prefix_mode=1), S=10, P=20, ar_stride=8),
     # BASELINE.json configs[0]: dim256-L6-h4, S=47, P=225 -> G=753 (the CPU-runnable plumbing case)

@@ -50,9 +50,27 @@ class OracleConfig:
     prepend_bos: bool = False
     num_quantizers: int = 8
 
+    # NAR sizes, valle.py:83, :235, :241
+    @property
+    def nar_d_model(self) -> int:
+        return int(self.d_model * self.nar_scale_factor)
+
+    @property
+    def nar_nhead(self) -> int:
+        return int(self.nhead * self.nar_scale_factor)
+
+    @property
+    def nar_num_layers(self) -> int:
+        return int(self.num_layers * self.nar_scale_factor)
+
+    @property
+    def fused_shape(self) -> bool:
+        """The production shape the fused HIP engine runs (pre-norm, no prenet, one width); the other constructor
+        combinations decode through the block modules (valle_amd/model.py)."""
+        return self.norm_first and not self.add_prenet and self.nar_scale_factor == 1.0
+
     def check_supported(self):
-        # production shape only; the oracle mirrors what the engine runs natively
-        assert self.norm_first and not self.add_prenet and self.nar_scale_factor == 1.0
+        assert self.nar_d_model > 0 and self.nar_nhead > 0 and self.nar_num_layers > 0 and self.nar_d_model % self.nar_nhead == 0
 
 
 # --------------------------------------------------------------------------------------
@@ -61,14 +79,36 @@ class OracleConfig:
 def state_dict_spec(cfg: OracleConfig) -> "OrderedDict[str, tuple]":
     """Key -> shape, exactly the reference's ``state_dict()`` (valle.py:85-279)."""
     d, L, Q = cfg.d_model, cfg.num_layers, cfg.num_quantizers
+    nd, nL = cfg.nar_d_model, cfg.nar_num_layers
     s: "OrderedDict[str, tuple]" = OrderedDict()
     s["ar_text_embedding.word_embeddings.weight"] = (NUM_TEXT_TOKENS, d)
-    s["nar_text_embedding.word_embeddings.weight"] = (NUM_TEXT_TOKENS, d)
+    s["nar_text_embedding.word_embeddings.weight"] = (NUM_TEXT_TOKENS, nd)
     s["ar_audio_embedding.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1 + int(cfg.prepend_bos), d)
+
+    def prenets(prefix, w):  # valle.py:100-125 / :183-216: nn.Sequential indices of the modules that own parameters
+        for conv, bn in ((1, 2), (5, 6), (9, 10)):
+            s[f"{prefix}_text_prenet.{conv}.weight"] = (w, w, 5)
+            s[f"{prefix}_text_prenet.{conv}.bias"] = (w,)
+            s[f"{prefix}_text_prenet.{bn}.weight"] = (w,)
+            s[f"{prefix}_text_prenet.{bn}.bias"] = (w,)
+            s[f"{prefix}_text_prenet.{bn}.running_mean"] = (w,)
+            s[f"{prefix}_text_prenet.{bn}.running_var"] = (w,)
+            s[f"{prefix}_text_prenet.{bn}.num_batches_tracked"] = ()
+        s[f"{prefix}_text_prenet.14.weight"] = (w, w)
+        s[f"{prefix}_text_prenet.14.bias"] = (w,)
+        s[f"{prefix}_audio_prenet.0.weight"] = (256, w)
+        s[f"{prefix}_audio_prenet.0.bias"] = (256,)
+        s[f"{prefix}_audio_prenet.3.weight"] = (256, 256)
+        s[f"{prefix}_audio_prenet.3.bias"] = (256,)
+        s[f"{prefix}_audio_prenet.6.weight"] = (w, 256)
+        s[f"{prefix}_audio_prenet.6.bias"] = (w,)
+
+    if cfg.add_prenet:
+        prenets("ar", d)
     s["ar_text_position.alpha"] = (1,)
     s["ar_audio_position.alpha"] = (1,)
 
-    def layer(prefix, adaptive):
+    def layer(prefix, adaptive, d):
         s[f"{prefix}.self_attn.in_proj_weight"] = (3 * d, d)
         s[f"{prefix}.self_attn.in_proj_bias"] = (3 * d,)
         s[f"{prefix}.self_attn.out_proj.weight"] = (d, d)
@@ -88,26 +128,30 @@ def state_dict_spec(cfg: OracleConfig) -> "OrderedDict[str, tuple]":
                 s[f"{prefix}.{n}.bias"] = (d,)
 
     for l in range(L):
-        layer(f"ar_decoder.layers.{l}", False)
-    s["ar_decoder.norm.weight"] = (d,)
-    s["ar_decoder.norm.bias"] = (d,)
+        layer(f"ar_decoder.layers.{l}", False, d)
+    if cfg.norm_first:  # norm=LayerNorm(d) if norm_first else None, valle.py:151
+        s["ar_decoder.norm.weight"] = (d,)
+        s["ar_decoder.norm.bias"] = (d,)
     s["ar_predict_layer.weight"] = (NUM_AUDIO_TOKENS + 1, d)
     if Q > 1:
-        s["nar_audio_embeddings.0.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1, d)
+        s["nar_audio_embeddings.0.word_embeddings.weight"] = (NUM_AUDIO_TOKENS + 1, nd)
         for j in range(1, Q):
-            s[f"nar_audio_embeddings.{j}.word_embeddings.weight"] = (NUM_AUDIO_TOKENS, d)
+            s[f"nar_audio_embeddings.{j}.word_embeddings.weight"] = (NUM_AUDIO_TOKENS, nd)
+        if cfg.add_prenet:
+            prenets("nar", nd)
         s["nar_text_position.alpha"] = (1,)
         s["nar_audio_position.alpha"] = (1,)
-        for l in range(L):
-            layer(f"nar_decoder.layers.{l}", True)
-        s["nar_decoder.norm.project_layer.weight"] = (2 * d, d)
-        s["nar_decoder.norm.project_layer.bias"] = (2 * d,)
-        s["nar_decoder.norm.norm.weight"] = (d,)
-        s["nar_decoder.norm.norm.bias"] = (d,)
+        for l in range(nL):
+            layer(f"nar_decoder.layers.{l}", True, nd)
+        if cfg.norm_first:  # valle.py:242-246
+            s["nar_decoder.norm.project_layer.weight"] = (2 * nd, nd)
+            s["nar_decoder.norm.project_layer.bias"] = (2 * nd,)
+            s["nar_decoder.norm.norm.weight"] = (nd,)
+            s["nar_decoder.norm.norm.bias"] = (nd,)
         for i in range(Q - 1):
-            s[f"nar_predict_layers.{i}.weight"] = (NUM_AUDIO_TOKENS, d)
+            s[f"nar_predict_layers.{i}.weight"] = (NUM_AUDIO_TOKENS, nd)
         for i in range(Q - 1):
-            s[f"nar_stage_embeddings.{i}.word_embeddings.weight"] = (1, d)
+            s[f"nar_stage_embeddings.{i}.word_embeddings.weight"] = (1, nd)
     return s
 
 
@@ -126,7 +170,19 @@ def make_state_dict(cfg: OracleConfig, seed: int = 0) -> "OrderedDict[str, torch
     sd: "OrderedDict[str, torch.Tensor]" = OrderedDict()
     for key, shape in spec.items():
         g = torch.Generator().manual_seed(_key_seed(seed, key))
-        if key.endswith("alpha"):
+        if key.endswith("num_batches_tracked"):  # BatchNorm1d buffer (int64 scalar; unused in eval mode)
+            sd[key] = torch.tensor(100, dtype=torch.int64)
+            continue
+        if key.endswith("running_mean"):
+            t = 0.1 * torch.randn(shape, generator=g)
+        elif key.endswith("running_var"):
+            t = 0.5 + torch.rand(shape, generator=g)
+        elif "_prenet." in key and len(shape) == 1 and key.endswith("weight"):  # BatchNorm1d affine
+            t = 1.0 + 0.1 * torch.randn(shape, generator=g)
+        elif "_prenet." in key and len(shape) == 3:  # Conv1d (out, in, k): nn.Conv1d's default bound 1 / sqrt(in * k)
+            a = 1.0 / math.sqrt(shape[1] * shape[2])
+            t = (torch.rand(shape, generator=g) * 2 - 1) * a
+        elif key.endswith("alpha"):
             t = 1.0 + 0.25 * torch.rand(shape, generator=g) if key.startswith("ar_") else torch.ones(shape)
         elif "word_embeddings" in key:
             t = torch.randn(shape, generator=g)
@@ -243,9 +299,13 @@ def mha(sd, prefix: str, x, nhead: int, attn_mask: Optional[torch.Tensor], kv_st
     return _lin(o, sd[f"{prefix}.out_proj.weight"], sd[f"{prefix}.out_proj.bias"], act_fp8)
 
 
-def encoder_layer(sd, prefix: str, x, nhead: int, attn_mask, stage_emb, kv_state=None, act_fp8: bool = False):
-    """TransformerEncoderLayer.forward, pre-norm branch (transformer.py:296-302):
-    x += SA(norm1(x)); x += W2 relu(W1 norm2(x) + b1) + b2 (ReLU: transformer.py:187, :333)."""
+def encoder_layer(sd, prefix: str, x, nhead: int, attn_mask, stage_emb, kv_state=None, act_fp8: bool = False, norm_first: bool = True):
+    """TransformerEncoderLayer.forward (transformer.py:296-308).  Pre-norm: x += SA(norm1(x)); x += W2 relu(W1 norm2(x) + b1) + b2;
+    post-norm: x = norm1(x + SA(x)); x = norm2(x + FFN(x))  (ReLU: transformer.py:187, :333)."""
+    if not norm_first:  # :303-308
+        x = norm_site(sd, f"{prefix}.norm1", x + mha(sd, f"{prefix}.self_attn", x, nhead, attn_mask, kv_state, act_fp8), stage_emb)
+        h = F.relu(_lin(x, sd[f"{prefix}.linear1.weight"], sd[f"{prefix}.linear1.bias"], act_fp8))
+        return norm_site(sd, f"{prefix}.norm2", x + _lin(h, sd[f"{prefix}.linear2.weight"], sd[f"{prefix}.linear2.bias"], act_fp8), stage_emb)
     x = x + mha(sd, f"{prefix}.self_attn", norm_site(sd, f"{prefix}.norm1", x, stage_emb), nhead, attn_mask, kv_state, act_fp8)
     h = F.relu(_lin(norm_site(sd, f"{prefix}.norm2", x, stage_emb), sd[f"{prefix}.linear1.weight"], sd[f"{prefix}.linear1.bias"], act_fp8))
     x = x + _lin(h, sd[f"{prefix}.linear2.weight"], sd[f"{prefix}.linear2.bias"], act_fp8)
@@ -254,16 +314,37 @@ def encoder_layer(sd, prefix: str, x, nhead: int, attn_mask, stage_emb, kv_state
 
 def encoder(sd, prefix: str, cfg: OracleConfig, x, attn_mask=None, stage_emb=None, kv_states=None, layer_states=None,
             act_fp8: bool = False):
-    """TransformerEncoder.forward (transformer.py:363-406): L layers, then the final norm
-    (LayerNorm for AR, valle.py:151; AdaptiveLayerNorm(nn.LayerNorm) for NAR, valle.py:242-244)."""
-    for l in range(cfg.num_layers):
+    """TransformerEncoder.forward (transformer.py:363-406): the layers, then -- for norm_first models only -- the final norm
+    (LayerNorm for AR, valle.py:151; AdaptiveLayerNorm(nn.LayerNorm) for NAR, valle.py:242-246).  The NAR decoder has
+    int(L * scale) layers of int(h * scale) heads (valle.py:235, :241)."""
+    nar = prefix.startswith("nar_")
+    for l in range(cfg.nar_num_layers if nar else cfg.num_layers):
         x = encoder_layer(
-            sd, f"{prefix}.layers.{l}", x, cfg.nhead, attn_mask, stage_emb,
-            None if kv_states is None else kv_states[l], act_fp8,
+            sd, f"{prefix}.layers.{l}", x, cfg.nar_nhead if nar else cfg.nhead, attn_mask, stage_emb,
+            None if kv_states is None else kv_states[l], act_fp8, cfg.norm_first,
         )
         if layer_states is not None:
             layer_states.append(x.clone())
-    return norm_site(sd, f"{prefix}.norm", x, stage_emb)
+    return norm_site(sd, f"{prefix}.norm", x, stage_emb) if cfg.norm_first else x
+
+
+def text_prenet(sd, prefix: str, x: torch.Tensor) -> torch.Tensor:
+    """{ar,nar}_text_prenet (valle.py:100-116): 3 x [Conv1d(k 5, padding "same") -> BatchNorm1d (eval: running statistics)
+    -> ReLU -> Dropout (identity)] over time, then Linear.  x (T, d) -> (T, d)."""
+    h = x.t()[None]  # Transpose(): (1, d, T)
+    for conv, bn in ((1, 2), (5, 6), (9, 10)):
+        h = F.conv1d(h, sd[f"{prefix}.{conv}.weight"], sd[f"{prefix}.{conv}.bias"], padding=2)
+        h = F.batch_norm(h, sd[f"{prefix}.{bn}.running_mean"], sd[f"{prefix}.{bn}.running_var"], sd[f"{prefix}.{bn}.weight"],
+                         sd[f"{prefix}.{bn}.bias"], False, 0.1, 1e-5)
+        h = F.relu(h)
+    return F.linear(h[0].t(), sd[f"{prefix}.14.weight"], sd[f"{prefix}.14.bias"])
+
+
+def audio_prenet(sd, prefix: str, y: torch.Tensor) -> torch.Tensor:
+    """{ar,nar}_audio_prenet (valle.py:118-126): Linear(d, 256) ReLU Linear(256, 256) ReLU Linear(256, d), per frame."""
+    h = F.relu(F.linear(y, sd[f"{prefix}.0.weight"], sd[f"{prefix}.0.bias"]))
+    h = F.relu(F.linear(h, sd[f"{prefix}.3.weight"], sd[f"{prefix}.3.bias"]))
+    return F.linear(h, sd[f"{prefix}.6.weight"], sd[f"{prefix}.6.bias"])
 
 
 def prefix_lm_mask(S: int, T: int) -> torch.Tensor:
@@ -307,7 +388,16 @@ def ar_decode(
     assert torch.all(x_lens > 0)  # :991
     S = int(x_lens.max())
     x = token_embedding(sd, "ar_text_embedding", x_ids[0])  # :994
-    x = sine_position(x, sd["ar_text_position.alpha"])  # :997 (prenet = Identity, :124-126)
+    if cfg.add_prenet:
+        x = text_prenet(sd, "ar_text_prenet", x)  # :996 (Identity without add_prenet, :124-126)
+    x = sine_position(x, sd["ar_text_position.alpha"])  # :997
+
+    def audio_in(ids, start=0):  # :1013-1015
+        e = token_embedding(sd, "ar_audio_embedding", ids)
+        if cfg.add_prenet:
+            e = audio_prenet(sd, "ar_audio_prenet", e)
+        return sine_position(e, sd["ar_audio_position.alpha"], start=start)
+
     P = prompts.shape[1]
     y = prompts[0, :, 0]  # :1005
     if cfg.prepend_bos:
@@ -317,13 +407,13 @@ def ar_decode(
     n_cached_audio = 0
     while True:
         if not kv_cache:
-            y_pos = sine_position(token_embedding(sd, "ar_audio_embedding", y), sd["ar_audio_position.alpha"])  # :1013-1015
+            y_pos = audio_in(y)  # :1013-1015
             xy_pos = torch.cat([x, y_pos], 0)  # :1016
             mask = prefix_lm_mask(S, y.shape[0]).to(x.device)  # :1018-1033
             xy_dec = encoder(sd, "ar_decoder", cfg, xy_pos, attn_mask=mask)  # :1035-1038
         else:
             new = y[n_cached_audio:]
-            y_pos = sine_position(token_embedding(sd, "ar_audio_embedding", new), sd["ar_audio_position.alpha"], start=n_cached_audio)
+            y_pos = audio_in(new, n_cached_audio)
             if n_cached_audio == 0:
                 inp = torch.cat([x, y_pos], 0)
                 mask = prefix_lm_mask(S, y.shape[0]).to(x.device)
@@ -371,12 +461,16 @@ def nar_decode(sd, cfg: OracleConfig, text_ids, y0, prompts, prefix_len, enroll_
         enrolled_len = int(enroll_x_lens.max())
         text = torch.cat([text[:1], text[enrolled_len - 1 :]], 0)
     S = text.shape[0]
-    x = sine_position(token_embedding(sd, "nar_text_embedding", text), sd["nar_text_position.alpha"])  # :1081-1083
+    x = token_embedding(sd, "nar_text_embedding", text)  # :1081
+    if cfg.add_prenet:
+        x = text_prenet(sd, "nar_text_prenet", x)  # :1082
+    x = sine_position(x, sd["nar_text_position.alpha"])  # :1083
     if cfg.prefix_mode != 0:
         for j in range(1, Q):  # :1110-1113
             y_emb[:prefix_len] += token_embedding(sd, f"nar_audio_embeddings.{j}", prompts[:, j])
     for i in range(Q - 1):  # :1085 / :1115
-        y_pos = sine_position(y_emb, sd["nar_audio_position.alpha"])  # :1121-1122
+        y_pos = audio_prenet(sd, "nar_audio_prenet", y_emb) if cfg.add_prenet else y_emb  # :1121
+        y_pos = sine_position(y_pos, sd["nar_audio_position.alpha"])  # :1122
         xy_pos = torch.cat([x, y_pos], 0)  # :1123
         stage = sd[f"nar_stage_embeddings.{i}.word_embeddings.weight"]  # (1, d)  :1126
         xy_dec = encoder(sd, "nar_decoder", cfg, xy_pos, attn_mask=None, stage_emb=stage, act_fp8=act_fp8)  # :1125-1127
@@ -508,8 +602,11 @@ def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum",
             yb = codes[b, :, 0]
             targets = torch.cat([yb[1:], torch.tensor([NUM_AUDIO_TOKENS])]) if not bos else torch.cat([yb, torch.tensor([NUM_AUDIO_TOKENS])])  # pad_y_eos :322-333
             inputs = yb if not bos else F.pad(yb, (1, 0), value=NUM_AUDIO_TOKENS + 1)
-            xe = sine_position(token_embedding(sd, "ar_text_embedding", x[b]), sd["ar_text_position.alpha"])  # :827-829
-            ye = sine_position(token_embedding(sd, "ar_audio_embedding", inputs), sd["ar_audio_position.alpha"])  # :861-863
+            xe, ye = token_embedding(sd, "ar_text_embedding", x[b]), token_embedding(sd, "ar_audio_embedding", inputs)
+            if cfg.add_prenet:
+                xe, ye = text_prenet(sd, "ar_text_prenet", xe), audio_prenet(sd, "ar_audio_prenet", ye)  # :828, :862
+            xe = sine_position(xe, sd["ar_text_position.alpha"])  # :827-829
+            ye = sine_position(ye, sd["ar_audio_position.alpha"])  # :861-863
             mask = prefix_lm_mask(S, inputs.shape[0])  # :833-859 without padding
             dec = encoder(sd, "ar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=mask)  # :867-872
             logits = F.linear(dec[S:], sd["ar_predict_layer.weight"])  # :873
@@ -532,7 +629,10 @@ def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum",
         hits, kept = torch.zeros(()), torch.zeros(())
         for b in range(N):
             y0 = codes[b, :, 0]
-            xe = sine_position(token_embedding(sd, "nar_text_embedding", x[b]), sd["nar_text_position.alpha"])  # :897-899
+            xe = token_embedding(sd, "nar_text_embedding", x[b])
+            if cfg.add_prenet:
+                xe = text_prenet(sd, "nar_text_prenet", xe)  # :898
+            xe = sine_position(xe, sd["nar_text_position.alpha"])  # :897-899
             y_emb = token_embedding(sd, "nar_audio_embeddings.0", y0).clone()  # _prepare_prompts :335-393
             if cfg.prefix_mode == 0:
                 for j in range(1, nar_stage):
@@ -543,7 +643,7 @@ def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum",
                     if j < nar_stage:
                         y_emb[P:] += token_embedding(sd, f"nar_audio_embeddings.{j}", codes[b, P:, j])
             targets = codes[b, P:, nar_stage]  # :906, :916-917
-            ye = sine_position(y_emb, sd["nar_audio_position.alpha"])  # :919-920
+            ye = sine_position(audio_prenet(sd, "nar_audio_prenet", y_emb) if cfg.add_prenet else y_emb, sd["nar_audio_position.alpha"])  # :919-920
             stage = sd[f"nar_stage_embeddings.{nar_stage - 1}.word_embeddings.weight"]
             dec = encoder(sd, "nar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=None, stage_emb=stage)  # :922-926
             logits = F.linear(dec[S + P:], sd[f"nar_predict_layers.{nar_stage - 1}.weight"])  # :927-932

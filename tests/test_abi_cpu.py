@@ -43,10 +43,23 @@ def test_state_dict_contract_same_keys_shapes_and_tying(kw):
         assert m.nar_predict_layers[0].weight is m.nar_audio_embeddings[2].weight
 
 
-def test_unsupported_constructor_combinations_raise():
-    for kw in (dict(norm_first=False), dict(add_prenet=True), dict(nar_scale_factor=0.5)):
-        with pytest.raises(NotImplementedError):
-            valle_amd.VALLE(64, 4, 2, **kw)
+def test_constructor_combinations_outside_the_fused_shape():
+    """post-norm / prenet / nar_scale_factor != 1 (valle/tests/valle_test.py:106-133 builds them): the reference's state-dict
+    keys and shapes, decoded by the block modules -- the fused engine refuses them."""
+    for kw in (dict(norm_first=False), dict(add_prenet=True), dict(nar_scale_factor=0.5), dict(norm_first=False, add_prenet=True, nar_scale_factor=2.0)):
+        m = valle_amd.VALLE(64, 4, 2, prefix_mode=1, **kw)
+        assert not m.fused
+        cfg = vo.OracleConfig(d_model=64, nhead=4, num_layers=2, prefix_mode=1, **kw)
+        spec = vo.state_dict_spec(cfg)  # == the reference's key order (asserted against it in oracle/make_golden.py)
+        got = m.state_dict()
+        assert list(got.keys()) == list(spec.keys())
+        for k, shape in spec.items():
+            assert tuple(got[k].shape) == tuple(shape), k
+        m.load_state_dict(vo.make_state_dict(cfg, 0), strict=True)
+        with pytest.raises(RuntimeError):
+            m.engine_for(1, 4, 4)
+    with pytest.raises(NotImplementedError):
+        valle_amd.VALLE(64, 4, 2, norm_first=False, engine_dtype="fp8")
 
 
 def test_no_cpu_path():

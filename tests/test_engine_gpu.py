@@ -15,7 +15,7 @@ from oracle import valle_oracle as vo  # noqa: E402
 from tests.golden_util import list_cases, load_case  # noqa: E402
 
 DEV = "cuda:0"
-SMALL = [c for c in list_cases() if not c.startswith("c1_") and not c.startswith("c2_")]
+SMALL = [c for c in list_cases() if not c.startswith(("c1_", "c2_", "opt_"))]  # opt_*: tests/test_options_gpu.py (block-module decode)
 
 
 def build_model(cfg, sd, dtype="fp32", **kw):
@@ -290,8 +290,8 @@ def test_reference_assertions_and_unsupported_configs():
         m.inference(x[0].to(DEV), xl.to(DEV), y.to(DEV), None)  # x.ndim != 2 (valle.py:986)
     with pytest.raises(AssertionError):
         m.inference(x.to(DEV), xl.to(DEV), torch.cat([y, y]).to(DEV), None)  # batch != 1 (valle.py:989)
-    with pytest.raises(NotImplementedError):
-        valle_amd.VALLE(64, 4, 1, norm_first=False)
+    with pytest.raises(RuntimeError):
+        valle_amd.VALLE(64, 4, 1, norm_first=False).engine_for(1, 4, 4)  # post-norm decodes through the block modules
 
 
 @pytest.mark.parametrize("top_k,temperature", [(5, 0.8), (40, 1.3), (-100, 1.0)])

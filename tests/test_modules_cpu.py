@@ -58,8 +58,7 @@ def test_classify_attn_mask():
 
 
 def test_configurations_outside_the_decode_path_raise():
-    with pytest.raises(NotImplementedError):
-        M.TransformerEncoderLayer(64, 4, norm_first=False)
+    assert not M.TransformerEncoderLayer(64, 4, norm_first=False).norm_first  # post-norm layers are implemented
     with pytest.raises(NotImplementedError):
         M.TransformerEncoderLayer(64, 4, norm_first=True, activation=F.gelu)
     with pytest.raises(NotImplementedError):

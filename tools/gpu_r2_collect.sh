@@ -25,4 +25,7 @@ done
 timeout 600 python tools/ktrace_step.py --out $D/ktrace_b1 > $D/ktrace_b1.log 2>&1; echo "ktrace b1 rc=$?"
 timeout 600 python tools/ktrace_step.py --out $D/ktrace_b64 --spg 8 --batch 64 > $D/ktrace_b64.log 2>&1; echo "ktrace b64 rc=$?"
 timeout 120 tools/bin/ubench_edges > $D/ubench_edges.json 2> $D/ubench_edges.err; echo "edges rc=$?"
-timeout 300 python tools/attn_bench.py > $D/attn_bench.log 2>&1; tail -n 4 $D/attn_bench.log
+timeout 300 python tools/attn_bench.py > $D/attn_bench.log 2>&1; grep -E "^C|default" $D/attn_bench.log
+timeout 300 python tools/gemm_bench.py > $D/gemm_bench.log 2>&1; tail -n 12 $D/gemm_bench.log
+timeout 120 tools/bin/ubench_l2keep > $D/ubench_l2keep.json 2> $D/ubench_l2keep.err; echo "l2keep rc=$?"
+timeout 200 tools/bin/ubench_prefetch > $D/ubench_prefetch.json 2> $D/ubench_prefetch.err; echo "prefetch rc=$?"

@@ -250,6 +250,10 @@ struct ArSampleArgs {
   int32_t* host_prog = nullptr;
 };
 int launch_ar_sample(hipStream_t st, const ArSampleArgs& a);
+// stand-alone topk_sampling (valle.py:1287-1302) per row of logits[rows][V]: out[row] = draw with Philox(request_seed(seed, row), it),
+// argmax_out[row] (nullable) = arg-max of the raw row
+int launch_topk_sample_rows(hipStream_t st, const float* logits, int64_t rows, int V, int top_k, float temperature, unsigned long long seed,
+                            unsigned it, int64_t* out, int64_t* argmax_out);
 // slot API (continuous batching): per-slot AR state of newly admitted utterances; rows of X scattered to slot rows
 int launch_slot_state_init(hipStream_t st, int32_t* state, int max_B, const int32_t* slots, const int32_t* kv_len,
                            const int32_t* audio_pos, const int32_t* cap, int n, unsigned long long* slot_seed = nullptr,

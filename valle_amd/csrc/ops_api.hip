@@ -183,6 +183,15 @@ extern "C" int vle_op_cross_entropy(void* stream, const float* logits, const int
   return op_done(launch_cross_entropy((hipStream_t)stream, logits, targets, loss, hit, rows, V, ignore_index, topk), "vle_op_cross_entropy");
 }
 
+extern "C" int vle_op_topk_sample(void* stream, const float* logits, int64_t rows, int32_t V, int32_t top_k, float temperature, uint64_t seed,
+                                  uint32_t step, int64_t* samples, int64_t* argmax) {
+  if (!logits || !samples || rows < 0 || V < 1) return op_fail("vle_op_topk_sample: bad argument");
+  if (!(temperature > 0.f)) return op_fail("vle_op_topk_sample: temperature must be positive");
+  const int r = launch_topk_sample_rows((hipStream_t)stream, logits, rows, V, top_k, temperature, seed, step, samples, argmax);
+  if (r == -2) return op_fail("vle_op_topk_sample: V must be <= 1280 (the audio vocabulary is 1025)");
+  return op_done(r, "vle_op_topk_sample");
+}
+
 extern "C" int vle_op_quantize_rows_fp8(void* stream, const void* x_bf16, void* q_out, float* scale_out, int64_t rows, int32_t K) {
   if (!x_bf16 || !q_out || !scale_out || rows < 0 || K < 512) return op_fail("vle_op_quantize_rows_fp8: bad argument");
   const int r = launch_quantize_rows_fp8((hipStream_t)stream, x_bf16, q_out, scale_out, rows, K);

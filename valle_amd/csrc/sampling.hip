@@ -58,6 +58,145 @@ __device__ inline int block_sum_i(int v, int* red) {
   return r;
 }
 
+// topk_sampling (valle/models/valle.py:1287-1302) of ONE row held by the block as SAMP_PER logits per thread: temperature, top-k
+// filter (ties at the k-th value kept, :1259-1260), softmax, inverse-CDF draw with u = Philox(rseed, it).  Block-wide: every thread
+// of the SAMP_T-thread block calls it; returns the drawn index (arg-max when top_k == 1).
+struct SampScratch {
+  unsigned long long* red64;
+  int* redi;
+  float* redf;
+  float* wave_tot;
+};
+__device__ inline int sample_row(const float (&raw)[SAMP_PER], int V, int top_k, float temperature, unsigned long long rseed, uint32_t it,
+                                 int argmax, const SampScratch& sh) {
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  unsigned long long* const red64 = sh.red64;
+  int* const redi = sh.redi;
+  float* const redf = sh.redf;
+  float* const wave_tot = sh.wave_tot;
+  int sample = argmax;
+  if (top_k != 1) {
+    float sc[SAMP_PER];
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) sc[j] = temperature != 1.0f ? raw[j] / temperature : raw[j];
+    uint32_t thr_key = 0u;  // keep keys >= thr_key
+    if (top_k > 1 && top_k < V) {
+      // k-th largest via bitwise binary search on the order-preserving key:
+      // largest K with count(key >= K) >= top_k.  Ties at the k-th value are all kept, like
+      // `logits < topk(logits, k)[0][..., -1]` (valle.py:1259-1260).
+      uint32_t cur = 0u;
+      for (int bit = 31; bit >= 0; --bit) {
+        const uint32_t cand = cur | (1u << bit);
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < SAMP_PER; ++j) cnt += (tid * SAMP_PER + j < V) && (float_key(sc[j]) >= cand);
+        cnt = block_sum_i(cnt, redi);
+        if (cnt >= top_k) cur = cand;
+      }
+      thr_key = cur;
+    }
+    // softmax over kept entries (max = global max, always kept)
+    float m = -INFINITY;
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) m = fmaxf(m, sc[j]);
+    m = wave_max(m);
+    __syncthreads();
+    if (lane == 0) redf[w] = m;
+    __syncthreads();
+    m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
+    float p[SAMP_PER];
+    float local = 0.f;
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) {
+      const int idx = tid * SAMP_PER + j;
+      const bool keep = idx < V && float_key(sc[j]) >= thr_key;
+      p[j] = keep ? expf(sc[j] - m) : 0.f;
+      local += p[j];
+    }
+    // block-wide exclusive prefix of `local` (inclusive wave scan + per-wave totals)
+    float incl = local;
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+      const float t = __shfl_up(incl, o, 64);
+      if (lane >= o) incl += t;
+    }
+    __syncthreads();
+    if (lane == 63) wave_tot[w] = incl;
+    __syncthreads();
+    float base = 0.f, total = 0.f;
+#pragma unroll
+    for (int i = 0; i < SAMP_T / 64; ++i) {
+      if (i < w) base += wave_tot[i];
+      total += wave_tot[i];
+    }
+    const float excl = base + incl - local;
+    const float u = philox_uniform(rseed, it, 0u);
+    const float target = u * total;
+    int cand = 0x7fffffff;
+    float run = excl;
+#pragma unroll
+    for (int j = 0; j < SAMP_PER; ++j) {
+      const int idx = tid * SAMP_PER + j;
+      run += p[j];
+      if (p[j] > 0.f && run > target && cand == 0x7fffffff) cand = idx;
+    }
+    // first index whose inclusive cumulative mass exceeds the target
+    const unsigned long long ck = block_max_u64((unsigned long long)(0x7fffffff - cand), red64);
+    const int pick = 0x7fffffff - (int)ck;
+    sample = pick == 0x7fffffff ? argmax : pick;
+  }
+
+  return sample;
+}
+
+// arg-max of the row (highest value; among equal values the LOWEST index, torch.argmax's convention) from the per-thread logits
+__device__ inline int argmax_row(const float (&raw)[SAMP_PER], int V, unsigned long long* red64) {
+  const int tid = threadIdx.x;
+  unsigned long long best = 0ull;
+#pragma unroll
+  for (int j = 0; j < SAMP_PER; ++j) {
+    const int idx = tid * SAMP_PER + j;
+    if (idx < V) {
+      const unsigned long long key = ((unsigned long long)float_key(raw[j]) << 32) | (unsigned)(0x7fffffff - idx);
+      best = key > best ? key : best;
+    }
+  }
+  best = block_max_u64(best, red64);
+  return 0x7fffffff - (int)(best & 0xffffffffu);
+}
+
+// ---- stand-alone operator: one block per row of logits[rows][V] (V <= SAMP_T * SAMP_PER): out[row] = topk_sampling draw --------
+__global__ __launch_bounds__(SAMP_T) void topk_sample_rows_kernel(const float* __restrict__ logits, int V, int top_k, float temperature,
+                                                                  unsigned long long seed, unsigned it, int64_t* __restrict__ out,
+                                                                  int64_t* __restrict__ argmax_out) {
+  __shared__ unsigned long long red64[SAMP_T / 64];
+  __shared__ int redi[SAMP_T / 64];
+  __shared__ float redf[SAMP_T / 64];
+  __shared__ float wave_tot[SAMP_T / 64];
+  const int row = blockIdx.x, tid = threadIdx.x;
+  const float* lg = logits + (int64_t)row * V;
+  float raw[SAMP_PER];
+#pragma unroll
+  for (int j = 0; j < SAMP_PER; ++j) {
+    const int idx = tid * SAMP_PER + j;
+    raw[j] = idx < V ? lg[idx] : -INFINITY;
+  }
+  const int am = argmax_row(raw, V, red64);
+  const int smp = sample_row(raw, V, top_k, temperature, request_seed(seed, (unsigned long long)row), it, am, SampScratch{red64, redi, redf, wave_tot});
+  if (tid == 0) {
+    out[row] = smp;
+    if (argmax_out) argmax_out[row] = am;
+  }
+}
+
+int launch_topk_sample_rows(hipStream_t st, const float* logits, int64_t rows, int V, int top_k, float temperature, unsigned long long seed,
+                            unsigned it, int64_t* out, int64_t* argmax_out) {
+  if (rows <= 0) return 0;
+  if (V <= 0 || V > SAMP_T * SAMP_PER || rows > 0x7fffffff) return -2;
+  hipLaunchKernelGGL(topk_sample_rows_kernel, dim3((unsigned)rows), dim3(SAMP_T), 0, st, logits, V, top_k, temperature, seed, it, out, argmax_out);
+  return 0;
+}
+
 __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
   __shared__ unsigned long long red64[SAMP_T / 64];
   __shared__ int redi[SAMP_T / 64];
@@ -104,78 +243,8 @@ __global__ __launch_bounds__(SAMP_T) void ar_sample_kernel(ArSampleArgs a) {
   best = block_max_u64(best, red64);
   const int argmax = 0x7fffffff - (int)(best & 0xffffffffu);
 
-  int sample = argmax;
-  if (dyn.top_k != 1) {
-    float sc[SAMP_PER];
-#pragma unroll
-    for (int j = 0; j < SAMP_PER; ++j) sc[j] = dyn.temperature != 1.0f ? raw[j] / dyn.temperature : raw[j];
-    uint32_t thr_key = 0u;  // keep keys >= thr_key
-    if (dyn.top_k > 1 && dyn.top_k < V) {
-      // k-th largest via bitwise binary search on the order-preserving key:
-      // largest K with count(key >= K) >= top_k.  Ties at the k-th value are all kept, like
-      // `logits < topk(logits, k)[0][..., -1]` (valle.py:1259-1260).
-      uint32_t cur = 0u;
-      for (int bit = 31; bit >= 0; --bit) {
-        const uint32_t cand = cur | (1u << bit);
-        int cnt = 0;
-#pragma unroll
-        for (int j = 0; j < SAMP_PER; ++j) cnt += (tid * SAMP_PER + j < V) && (float_key(sc[j]) >= cand);
-        cnt = block_sum_i(cnt, redi);
-        if (cnt >= dyn.top_k) cur = cand;
-      }
-      thr_key = cur;
-    }
-    // softmax over kept entries (max = global max, always kept)
-    float m = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < SAMP_PER; ++j) m = fmaxf(m, sc[j]);
-    m = wave_max(m);
-    __syncthreads();
-    if (lane == 0) redf[w] = m;
-    __syncthreads();
-    m = fmaxf(fmaxf(redf[0], redf[1]), fmaxf(redf[2], redf[3]));
-    float p[SAMP_PER];
-    float local = 0.f;
-#pragma unroll
-    for (int j = 0; j < SAMP_PER; ++j) {
-      const int idx = tid * SAMP_PER + j;
-      const bool keep = idx < V && float_key(sc[j]) >= thr_key;
-      p[j] = keep ? expf(sc[j] - m) : 0.f;
-      local += p[j];
-    }
-    // block-wide exclusive prefix of `local` (inclusive wave scan + per-wave totals)
-    float incl = local;
-#pragma unroll
-    for (int o = 1; o < 64; o <<= 1) {
-      const float t = __shfl_up(incl, o, 64);
-      if (lane >= o) incl += t;
-    }
-    __syncthreads();
-    if (lane == 63) wave_tot[w] = incl;
-    __syncthreads();
-    float base = 0.f, total = 0.f;
-#pragma unroll
-    for (int i = 0; i < SAMP_T / 64; ++i) {
-      if (i < w) base += wave_tot[i];
-      total += wave_tot[i];
-    }
-    const float excl = base + incl - local;
-    const unsigned long long rseed = a.slot_seed != nullptr ? a.slot_seed[b] : request_seed(dyn.seed, (unsigned long long)b);
-    const float u = philox_uniform(rseed, (uint32_t)it, 0u);
-    const float target = u * total;
-    int cand = 0x7fffffff;
-    float run = excl;
-#pragma unroll
-    for (int j = 0; j < SAMP_PER; ++j) {
-      const int idx = tid * SAMP_PER + j;
-      run += p[j];
-      if (p[j] > 0.f && run > target && cand == 0x7fffffff) cand = idx;
-    }
-    // first index whose inclusive cumulative mass exceeds the target
-    const unsigned long long ck = block_max_u64((unsigned long long)(0x7fffffff - cand), red64);
-    const int pick = 0x7fffffff - (int)ck;
-    sample = pick == 0x7fffffff ? argmax : pick;
-  }
+  const unsigned long long rseed = a.slot_seed != nullptr ? a.slot_seed[b] : request_seed(dyn.seed, (unsigned long long)b);
+  const int sample = sample_row(raw, V, dyn.top_k, dyn.temperature, rseed, (uint32_t)it, argmax, SampScratch{red64, redi, redf, wave_tot});
 
   if (tid == 0) {
     ktrace_end(a.kt, kt0, (int)blockIdx.x);  // before a.s.iter moves on: the stamp lands in this step's slot

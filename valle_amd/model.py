@@ -7,8 +7,11 @@ backed by the HIP engine.  ``bin/infer.py`` of the reference works unchanged whe
 The module tree is built from the HIP-backed block modules of ``modules.py`` under the reference's
 attribute names, so that ``load_state_dict(ckpt["model"], strict=True)`` (valle/bin/infer.py:135-138)
 accepts a reference checkpoint and ``model.ar_decoder(...)`` / ``model.nar_decoder(...)`` keep the
-reference's block-level call surface; ``inference()`` itself drives the fused engine.  Only the production shape runs (norm_first, no prenet,
-nar_scale_factor = 1); other combinations raise -- there is no PyTorch fallback.
+reference's block-level call surface.  For the production shape (norm_first, no prenet, nar_scale_factor = 1) ``inference()``
+drives the fused, KV-cached, graph-captured engine; the other constructor combinations of the reference (post-norm layers,
+prenets, a NAR decoder of a different width: valle/tests/valle_test.py:106-133 runs them) decode through the same HIP block
+modules in the reference's own loop structure (one full-sequence pass per AR step, valle.py:1012-1057) -- slower, still HIP
+kernels only: there is no PyTorch or CPU fallback.
 """
 from __future__ import annotations
 
@@ -27,16 +30,23 @@ NUM_AUDIO_TOKENS = 1024  # valle/models/macros.py:5
 
 
 # the block modules (reference names, reference state-dict keys, HIP forward): modules.py
-from .modules import (AdaptiveLayerNorm, LayerNorm, SinePositionalEmbedding, TokenEmbedding, TransformerEncoder,  # noqa: E402
-                      TransformerEncoderLayer, set_compute_dtype)
+from .modules import (AdaptiveLayerNorm, AudioPrenet, LayerNorm, SinePositionalEmbedding, TextPrenet, TokenEmbedding,  # noqa: E402
+                      TransformerEncoder, TransformerEncoderLayer, set_compute_dtype)
 
 
-def _decoder(d: int, nhead: int, num_layers: int, adaptive: bool) -> TransformerEncoder:
-    """valle/models/valle.py:141-152 (AR) / :232-245 (NAR): pre-norm layers, FFN 4d, final (Adaptive)LayerNorm."""
-    layer = TransformerEncoderLayer(d, nhead, dim_feedforward=d * 4, dropout=0.1, batch_first=True, norm_first=True,
+def _decoder(d: int, nhead: int, num_layers: int, adaptive: bool, norm_first: bool = True) -> TransformerEncoder:
+    """valle/models/valle.py:141-152 (AR) / :232-246 (NAR): FFN 4d; the final (Adaptive)LayerNorm only for pre-norm layers."""
+    layer = TransformerEncoderLayer(d, nhead, dim_feedforward=d * 4, dropout=0.1, batch_first=True, norm_first=norm_first,
                                     adaptive_layer_norm=adaptive)
-    norm = AdaptiveLayerNorm(d, norm=LayerNorm(d)) if adaptive else LayerNorm(d)
+    norm = None if not norm_first else (AdaptiveLayerNorm(d, norm=LayerNorm(d)) if adaptive else LayerNorm(d))
     return TransformerEncoder(layer, num_layers=num_layers, norm=norm)
+
+
+def _request_seed_base(seed: int, b: int) -> int:
+    """ops.topk_sample draws row r from the stream of request r of ``seed``; the block path samples one row (r = 0) per step, so
+    utterance b of a batch passes the seed whose request-0 stream is request b's: identical to the engine for b = 0 (the
+    reference's batch-1 case), distinct deterministic streams for the others."""
+    return seed if b == 0 else (seed * 0x9E3779B97F4A7C15 + b) & (2**64 - 1)
 
 
 class VALLE(nn.Module):
@@ -64,13 +74,15 @@ class VALLE(nn.Module):
         **kwargs,
     ):
         super().__init__()
-        if not norm_first or add_prenet or nar_scale_factor != 1.0:
-            raise NotImplementedError(
-                "the HIP engine runs the production shape only (norm_first=True, add_prenet=False, "
-                "nar_scale_factor=1.0); there is no PyTorch fallback"
-            )
         assert num_quantizers >= 1
         d = d_model
+        nd = int(d_model * nar_scale_factor)                                       # valle.py:83
+        nar_heads, nar_layers = int(nhead * nar_scale_factor), int(num_layers * nar_scale_factor)  # :235, :241
+        # the fused engine implements the production shape; every other combination decodes through the block modules
+        self.fused = bool(norm_first) and not add_prenet and nar_scale_factor == 1.0
+        if not self.fused and engine_dtype == "fp8":
+            raise NotImplementedError("engine_dtype='fp8' (fp8 activations) exists only in the fused engine's packed passes")
+        self.norm_first, self.add_prenet, self.nar_scale_factor = bool(norm_first), bool(add_prenet), float(nar_scale_factor)
         self.d_model, self.num_heads, self.num_layers = d_model, nhead, num_layers
         self.prefix_mode, self.num_quantizers = prefix_mode, num_quantizers
         self.ar_audio_prepend_bos = prepend_bos
@@ -79,21 +91,25 @@ class VALLE(nn.Module):
         self.max_text, self.max_prompt, self.max_gen, self.use_graph = max_text, max_prompt, max_gen, use_graph
 
         self.ar_text_embedding = TokenEmbedding(d, NUM_TEXT_TOKENS)
-        self.nar_text_embedding = TokenEmbedding(d, NUM_TEXT_TOKENS)
+        self.nar_text_embedding = TokenEmbedding(nd, NUM_TEXT_TOKENS)
         self.ar_audio_embedding = TokenEmbedding(d, NUM_AUDIO_TOKENS + 1 + int(prepend_bos))
+        self.ar_text_prenet = TextPrenet(d) if add_prenet else nn.Identity()      # valle.py:99-126
+        self.ar_audio_prenet = AudioPrenet(d) if add_prenet else nn.Identity()
         self.ar_text_position = SinePositionalEmbedding(d, dropout=0.1, scale=False, alpha=True)
         self.ar_audio_position = SinePositionalEmbedding(d, dropout=0.1, scale=False, alpha=True)
-        self.ar_decoder = _decoder(d, nhead, num_layers, adaptive=False)
+        self.ar_decoder = _decoder(d, nhead, num_layers, adaptive=False, norm_first=norm_first)
         self.ar_predict_layer = nn.Linear(d, NUM_AUDIO_TOKENS + 1, bias=False)
         if num_quantizers > 1:
             self.nar_audio_embeddings = nn.ModuleList(
-                [TokenEmbedding(d, NUM_AUDIO_TOKENS + 1)] + [TokenEmbedding(d, NUM_AUDIO_TOKENS) for _ in range(num_quantizers - 1)]
+                [TokenEmbedding(nd, NUM_AUDIO_TOKENS + 1)] + [TokenEmbedding(nd, NUM_AUDIO_TOKENS) for _ in range(num_quantizers - 1)]
             )
-            self.nar_text_position = SinePositionalEmbedding(d, dropout=0.0, scale=False, alpha=False)
-            self.nar_audio_position = SinePositionalEmbedding(d, dropout=0.1, scale=False, alpha=False)
-            self.nar_decoder = _decoder(d, nhead, num_layers, adaptive=True)
-            self.nar_predict_layers = nn.ModuleList([nn.Linear(d, NUM_AUDIO_TOKENS, bias=False) for _ in range(num_quantizers - 1)])
-            self.nar_stage_embeddings = nn.ModuleList([TokenEmbedding(d, 1) for _ in range(num_quantizers - 1)])
+            self.nar_text_prenet = TextPrenet(nd) if add_prenet else nn.Identity()   # valle.py:182-219
+            self.nar_audio_prenet = AudioPrenet(nd) if add_prenet else nn.Identity()
+            self.nar_text_position = SinePositionalEmbedding(nd, dropout=0.0, scale=False, alpha=False)
+            self.nar_audio_position = SinePositionalEmbedding(nd, dropout=0.1, scale=False, alpha=False)
+            self.nar_decoder = _decoder(nd, nar_heads, nar_layers, adaptive=True, norm_first=norm_first)
+            self.nar_predict_layers = nn.ModuleList([nn.Linear(nd, NUM_AUDIO_TOKENS, bias=False) for _ in range(num_quantizers - 1)])
+            self.nar_stage_embeddings = nn.ModuleList([TokenEmbedding(nd, 1) for _ in range(num_quantizers - 1)])
             if share_embedding:
                 for j in range(0, num_quantizers - 2):  # valle.py:268-271
                     self.nar_predict_layers[j].weight = self.nar_audio_embeddings[j + 2].weight
@@ -123,6 +139,9 @@ class VALLE(nn.Module):
 
     def engine_for(self, batch: int, text_len: int, prompt_len: int, gen_len: int = 0) -> Engine:
         """Engine sized for the request (rebuilt only when a capacity grows)."""
+        if not self.fused:
+            raise RuntimeError("this constructor combination (post-norm / prenet / nar_scale_factor != 1) decodes through the block "
+                               "modules; the fused engine implements the production shape only")
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("the HIP engine needs the model on a ROCm device: call .to('cuda') first (no CPU path)")
@@ -191,6 +210,8 @@ class VALLE(nn.Module):
         B = x.shape[0]
         xl = [int(v) for v in x_lens.tolist()]
         yl = [int(v) for v in y_lens]
+        if not self.fused:
+            return self._inference_blocks(x, xl, y, yl, enroll_x_lens, top_k, temperature, seed, max_new)
         eng = self.engine_for(B, max(xl), max(yl))
         dev = eng.device
         if seed is None:
@@ -226,11 +247,110 @@ class VALLE(nn.Module):
         assert torch.all(x_lens > 0)
         assert self.num_quantizers == 8
         T = y.shape[1]
+        if not self.fused:
+            P = min(int(T * 0.5), 3 * 75)  # valle.py:1173
+            dev = self._block_device()
+            S = int(x_lens.max())
+            return self._nar_blocks(x.to(dev, torch.int64)[:, :S], y.to(dev, torch.int64)[:, :, 0], y.to(dev, torch.int64)[:, :P], P,
+                                    1 if self.prefix_mode in (2, 4) else self.prefix_mode, None)
         eng = self.engine_for(1, int(x_lens.max()), T, T)
         dev = eng.device
         codes, gl = eng.continual(x.to(dev, torch.int64), [int(x_lens.max())], y.to(dev, torch.int64), [T])
         return codes[:, : gl[0]]
 
+
+    # ---- the same decode written on the block modules (constructor combinations outside the fused engine's shape) -----------
+    def _block_device(self) -> torch.device:
+        dev = next(self.parameters()).device
+        if dev.type != "cuda":
+            raise RuntimeError("the HIP operators need the model on a ROCm device: call .to('cuda') first (no CPU path)")
+        if self.training:
+            raise NotImplementedError("decode runs in eval mode: call .eval() first (dropout / BatchNorm statistics)")
+        return dev
+
+    def _predict(self, dec: TransformerEncoder, h2d: torch.Tensor, weight: torch.Tensor) -> torch.Tensor:
+        """nn.Linear(d, V, bias=False) (valle.py:153-155, 248-253) on the GEMM path, fp32 logits."""
+        from . import ops
+
+        return ops.linear(h2d.to(dec._tdtype()).contiguous(), dec._w(weight), None, epilogue=ops.EPI_F32)
+
+    def _inference_blocks(self, x, xl, y, yl, enroll_x_lens, top_k, temperature, seed, max_new) -> List[torch.Tensor]:
+        """valle.py:993-1137 per utterance, every tensor operation a HIP operator of modules.py / ops.py: like the reference, each
+        AR step re-runs the whole [text; audio] sequence through ``ar_decoder`` (no KV cache on this path)."""
+        from . import ops
+
+        dev = self._block_device()
+        if seed is None:
+            seed = 0 if top_k == 1 else int(torch.randint(0, 2**62, (1,)).item())
+        bos = int(self.ar_audio_prepend_bos)
+        outs = []
+        for b in range(x.shape[0]):
+            S, P = xl[b], yl[b]
+            text = x[b:b + 1, :S].to(dev, torch.int64)
+            prompts = y[b:b + 1, :P, : self.num_quantizers].to(dev, torch.int64)
+            xe = self.ar_text_position(self.ar_text_prenet(self.ar_text_embedding(text)))            # :994-997
+            yy = prompts[..., 0]
+            if bos:
+                yy = torch.nn.functional.pad(yy, (1, 0), value=NUM_AUDIO_TOKENS + 1)                  # :1006-1007
+            n_gen = 0
+            while True:
+                ye = self.ar_audio_position(self.ar_audio_prenet(self.ar_audio_embedding(yy)))       # :1013-1015
+                T = yy.shape[1]
+                i = torch.arange(S + T, device=dev)
+                allowed = i[None, :] < torch.maximum(i[:, None] + 1, torch.tensor(S, device=dev))    # prefix-LM mask, :1018-1033
+                h, _ = self.ar_decoder((torch.cat([xe, ye], dim=1), None), mask=~allowed)             # :1035-1038
+                logits = self._predict(self.ar_decoder, h[0, -1:], self.ar_predict_layer.weight)      # :1039
+                # request b's RNG stream at step n_gen: what vle_ar_generate(seed) draws for this utterance
+                smp, am = ops.topk_sample(logits, top_k, temperature, seed=_request_seed_base(seed, b), step=n_gen)  # :1040-1042
+                smp_i, am_i = int(smp[0]), int(am[0])
+                stop = am_i == NUM_AUDIO_TOKENS or smp_i == NUM_AUDIO_TOKENS or (yy.shape[1] - P) > S * 16  # :1044-1048
+                if max_new and n_gen >= max_new:
+                    stop = True
+                if stop:
+                    if P == yy.shape[1]:
+                        if x.shape[0] == 1:
+                            raise SyntaxError("well trained model shouldn't reach here.")               # :1049-1052
+                    print(f"VALL-E EOS [{P} -> {yy.shape[1]}]")                                        # :1054
+                    break
+                yy = torch.cat([yy, smp.view(1, 1)], dim=1)                                            # :1057
+                n_gen += 1
+            y0 = yy[:, bos:]
+            en = None
+            if self.prefix_mode in (2, 4):
+                assert enroll_x_lens is not None, "prefix_mode 2/4 needs enroll_x_lens (valle.py:1068-1079)"
+                el = [int(v) for v in enroll_x_lens.tolist()]
+                en = el[b] if len(el) > 1 else el[0]
+            outs.append(self._nar_blocks(text, y0, prompts, P, self.prefix_mode, en)[0])
+        return outs
+
+    def _nar_blocks(self, text, y0, prompts, P: int, prefix_mode: int, enrolled_len) -> torch.Tensor:
+        """The seven NAR stages, valle.py:1059-1137 (and continual()'s :1176-1238): text (1, S) ids, y0 (1, P + G) first-codebook
+        stream, prompts (1, P, Q) -> codes (1, G, Q)."""
+        Q = self.num_quantizers
+        codes = [y0[:, P:]]                                                                           # :1059
+        if Q == 1 or y0.shape[1] == P:  # (an utterance of a batch that stopped at its first step: no frames)
+            return torch.stack(codes * (1 if Q == 1 else Q), dim=-1)
+        if prefix_mode in (2, 4):                                                                      # :1068-1079
+            text = torch.cat([text[:, :1], text[:, enrolled_len - 1:]], dim=1)
+        S = text.shape[1]
+        xe = self.nar_text_position(self.nar_text_prenet(self.nar_text_embedding(text)))              # :1081-1083
+        y_emb = self.nar_audio_embeddings[0](y0).clone()                                              # :1064-1066
+        if prefix_mode != 0:
+            for j in range(1, Q):                                                                      # :1110-1113
+                y_emb[:, :P] += self.nar_audio_embeddings[j](prompts[..., j])
+        for i in range(Q - 1):                                                                         # :1085 / :1115
+            ye = self.nar_audio_position(self.nar_audio_prenet(y_emb))                                 # :1121-1122
+            h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), self.nar_stage_embeddings[i].weight))  # :1125-1127
+            logits = self._predict(self.nar_decoder, h[0, S + P:], self.nar_predict_layers[i].weight)  # :1128
+            from . import ops
+
+            samples = ops.topk_sample(logits, 1)[1][None]                                              # arg-max, :1130
+            codes.append(samples)
+            if i < Q - 2:                                                                              # :1133 / :1103
+                if prefix_mode == 0:
+                    y_emb[:, :P] += self.nar_audio_embeddings[i + 1](prompts[..., i + 1])              # :1104-1107
+                y_emb[:, P:] += self.nar_audio_embeddings[i + 1](samples)                              # :1108 / :1134
+        return torch.stack(codes, dim=-1)                                                              # :1136-1137
 
     # ---- VALLE.forward (valle/models/valle.py:762-959), teacher-forced, eval mode ----------------------------
     @torch.no_grad()
@@ -284,8 +404,8 @@ class VALLE(nn.Module):
             else:
                 inputs, targets = y0, torch.cat([y0[:, 1:], eos], dim=1)
             Ta = inputs.shape[1]
-            xe = self.ar_text_position(self.ar_text_embedding(x))                    # :827-829
-            ye = self.ar_audio_position(self.ar_audio_embedding(inputs))             # :861-863
+            xe = self.ar_text_position(self.ar_text_prenet(self.ar_text_embedding(x)))            # :827-829
+            ye = self.ar_audio_position(self.ar_audio_prenet(self.ar_audio_embedding(inputs)))     # :861-863
             i = torch.arange(S + Ta, device=dev)
             allowed = i[None, :] < torch.maximum(i[:, None] + 1, torch.tensor(S, device=dev))  # prefix-LM mask, :833-859
             h, _ = self.ar_decoder((torch.cat([xe, ye], dim=1), None), mask=~allowed)  # :867-872
@@ -309,7 +429,7 @@ class VALLE(nn.Module):
                     int_low = int(0.25 * T)
                     prefix_len = min(int(torch.randint(int_low, int_low * 2, size=()).item()), 225)  # :348-350
                 P = int(prefix_len)
-            xe = self.nar_text_position(self.nar_text_embedding(x))                  # :897-899
+            xe = self.nar_text_position(self.nar_text_prenet(self.nar_text_embedding(x)))         # :897-899
             x_emb = xe
             y_emb = self.nar_audio_embeddings[0](codes[..., 0])                      # _prepare_prompts :335-393
             if self.prefix_mode == 0:
@@ -321,7 +441,7 @@ class VALLE(nn.Module):
                     if j < nar_stage:
                         y_emb[:, P:] += self.nar_audio_embeddings[j](codes[:, P:, j])
             targets = codes[:, P:, nar_stage].reshape(-1)                            # :906, :916-917
-            ye = self.nar_audio_position(y_emb)                                      # :919-920
+            ye = self.nar_audio_position(self.nar_audio_prenet(y_emb))                             # :919-920
             h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), self.nar_stage_embeddings[nar_stage - 1].weight))  # :922-926
             logits = predict(h[:, S + P:].reshape(N * (T - P), -1), self.nar_predict_layers[nar_stage - 1].weight)  # :927-932
             loss_rows, hit = ops.cross_entropy_rows(logits, targets, ignore_index=NUM_AUDIO_TOKENS, topk=10)

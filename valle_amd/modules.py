@@ -16,8 +16,9 @@ modules (it drives the fused, KV-cached, graph-captured engine); they are the pe
 the same kernels, checked against the reference's modules in tests/test_modules_gpu.py.
 
 Only what the decode path uses is implemented; everything else raises ``NotImplementedError``:
-pre-norm layers (``norm_first=True``), ReLU, self-attention with ``attn_mask`` either ``None`` or the
-prefix-LM / causal pattern of valle.py:1019-1033, no key-padding, eval mode (dropout = identity).
+pre-norm and post-norm layers, ReLU, self-attention with ``attn_mask`` either ``None`` or the
+prefix-LM / causal pattern of valle.py:1019-1033, no key-padding, eval mode (dropout = identity; BatchNorm1d of
+the prenets on its running statistics).
 """
 from __future__ import annotations
 
@@ -139,6 +140,77 @@ class SinePositionalEmbedding(_HipModule):
         if xin.shape[-1] != self.dim_model:
             xin = xin.expand(*xin.shape[:-1], self.dim_model)
         return ops.sine_positional(xin.to(torch.float32), self.pe[0], self.alpha.detach(), self.x_scale)
+
+
+# ---- valle/models/valle.py: prenets ----------------------------------------------------------------------
+class Transpose(nn.Identity):
+    """valle/models/valle.py:38-42, (N, T, D) -> (N, D, T).  A place holder inside the prenet containers below (their
+    forward works time-major and never calls it); kept so that the nn.Sequential indices -- the state-dict keys -- match."""
+
+    def forward(self, input: Tensor) -> Tensor:
+        return input.transpose(1, 2)
+
+
+class TextPrenet(nn.Sequential):
+    """``{ar,nar}_text_prenet`` (valle/models/valle.py:100-116, 183-206): 3 x [Conv1d(d, d, 5, padding="same") -> BatchNorm1d ->
+    ReLU -> Dropout(0.5)] over time, then Linear(d, d).  Same children at the same indices as the reference (parameters and
+    BatchNorm buffers keep their keys: 1, 2, 5, 6, 9, 10, 14).  Eval mode only.  Each conv block is ONE fp32 GEMM: the five
+    taps of the zero-padded, time-major signal are the K dimension (window rows of 5 d contiguous values), BatchNorm's running
+    statistics and affine are folded into the conv's weight and bias, ReLU is the GEMM epilogue."""
+
+    def __init__(self, d: int):
+        blocks = []
+        for _ in range(3):
+            blocks += [nn.Conv1d(d, d, kernel_size=5, padding="same"), nn.BatchNorm1d(d), nn.ReLU(), nn.Dropout(0.5)]
+        super().__init__(Transpose(), *blocks, Transpose(), nn.Linear(d, d))
+        self.d = d
+
+    def _folded(self, conv: nn.Conv1d, bn: nn.BatchNorm1d):
+        cache = self.__dict__.setdefault("_fold", {})
+        key = id(conv)
+        ver = tuple((t._version, t.data_ptr()) for t in (conv.weight, conv.bias, bn.weight, bn.bias, bn.running_mean, bn.running_var))
+        hit = cache.get(key)
+        if hit is not None and hit[0] == ver:
+            return hit[1], hit[2]
+        # parameter preparation (once per weight version), in fp64: y = (conv(x) + b - mean) * g / sqrt(var + eps) + beta
+        sc = bn.weight.detach().double() / torch.sqrt(bn.running_var.detach().double() + bn.eps)
+        w = (conv.weight.detach().double() * sc[:, None, None]).permute(0, 2, 1).reshape(self.d, 5 * self.d)  # [out][tap * d + in]
+        b = (conv.bias.detach().double() - bn.running_mean.detach().double()) * sc + bn.bias.detach().double()
+        w, b = w.float().contiguous(), b.float().contiguous()
+        cache[key] = (ver, w, b)
+        return w, b
+
+    def forward(self, x: Tensor) -> Tensor:
+        _need_device(x, "TextPrenet")
+        if self.training:
+            raise NotImplementedError("the prenets run in eval mode only (BatchNorm running statistics, no dropout)")
+        N, T, d = x.shape
+        h = x.to(torch.float32)
+        for conv_i, bn_i in ((1, 2), (5, 6), (9, 10)):
+            w, b = self._folded(self[conv_i], self[bn_i])
+            hp = torch.nn.functional.pad(h, (0, 0, 2, 2))                       # zero "same" padding along time (data movement)
+            win = hp.unfold(1, 5, 1).permute(0, 1, 3, 2).reshape(N * T, 5 * d)  # row t = taps t .. t+4, each d values
+            h = ops.linear(win.contiguous(), w, b, epilogue=ops.EPI_RELU).view(N, T, d)
+        lin = self[14]
+        return ops.linear(h.reshape(N * T, d), lin.weight.detach(), lin.bias.detach(), epilogue=ops.EPI_F32).view(N, T, d)
+
+
+class AudioPrenet(nn.Sequential):
+    """``{ar,nar}_audio_prenet`` (valle/models/valle.py:118-126, 207-215): Linear(d, 256) ReLU Dropout Linear(256, 256) ReLU
+    Dropout Linear(256, d) per frame (keys 0, 3, 6): three fp32 GEMMs."""
+
+    def __init__(self, d: int):
+        super().__init__(nn.Linear(d, 256), nn.ReLU(), nn.Dropout(0.25), nn.Linear(256, 256), nn.ReLU(), nn.Dropout(0.25), nn.Linear(256, d))
+
+    def forward(self, y: Tensor) -> Tensor:
+        _need_device(y, "AudioPrenet")
+        if self.training:
+            raise NotImplementedError("the prenets run in eval mode only")
+        shape = y.shape
+        h = y.to(torch.float32).reshape(-1, shape[-1]).contiguous()
+        h = ops.linear(h, self[0].weight.detach(), self[0].bias.detach(), epilogue=ops.EPI_RELU)
+        h = ops.linear(h, self[3].weight.detach(), self[3].bias.detach(), epilogue=ops.EPI_RELU)
+        return ops.linear(h, self[6].weight.detach(), self[6].bias.detach(), epilogue=ops.EPI_F32).view(shape)
 
 
 # ---- valle/modules/transformer.py: norms -------------------------------------------------------------
@@ -308,9 +380,10 @@ class MultiheadAttention(_HipModule):
 
 # ---- valle/modules/transformer.py: encoder -----------------------------------------------------------
 class TransformerEncoderLayer(_HipModule):
-    """valle/modules/transformer.py:178-334, pre-norm branch (:296-302):
-    ``x += SA(norm1(x)); x += W2 relu(W1 norm2(x) + b1) + b2`` -- six launches per layer: LayerNorm,
-    QKV GEMM, attention, out-proj GEMM (+residual), LayerNorm, FFN1 GEMM (+ReLU), FFN2 GEMM (+residual)."""
+    """valle/modules/transformer.py:178-334.  Pre-norm branch (:296-302):
+    ``x += SA(norm1(x)); x += W2 relu(W1 norm2(x) + b1) + b2`` -- LayerNorm, QKV GEMM, attention, out-proj GEMM
+    (+residual), LayerNorm, FFN1 GEMM (+ReLU), FFN2 GEMM (+residual).  Post-norm branch (:303-308):
+    ``x = norm1(x + SA(x)); x = norm2(x + FFN(x))`` -- the same kernels, the norms after the residual GEMMs."""
 
     def __init__(self, d_model: int, nhead: int, dim_feedforward: int = 2048, dropout: float = 0.1,
                  activation: Union[str, Callable[[Tensor], Tensor]] = F.relu, batch_first: bool = False, norm_first: bool = False,
@@ -318,8 +391,6 @@ class TransformerEncoderLayer(_HipModule):
                  linear1_feedforward_cls=nn.Linear, linear2_feedforward_cls=nn.Linear, layer_norm_cls=LayerNorm,
                  layer_norm_eps: float = 1e-5, adaptive_layer_norm=False) -> None:
         super().__init__()
-        if not norm_first:
-            raise NotImplementedError("post-norm layers are outside the decode path (VALL-E is trained with norm_first=True)")
         if not (activation is F.relu or activation == "relu" or isinstance(activation, nn.ReLU)):
             raise NotImplementedError("only ReLU is fused in the FFN1 epilogue (VALL-E passes no activation: transformer.py:187)")
         if linear1_feedforward_cls is not nn.Linear or linear2_feedforward_cls is not nn.Linear or layer_norm_cls is not LayerNorm:
@@ -365,6 +436,8 @@ class TransformerEncoderLayer(_HipModule):
         xb = x if self.batch_first else x.transpose(0, 1)
         B, T, d = xb.shape
         res = xb.to(torch.float32).reshape(B * T, d).clone()  # fp32 residual stream; the GEMM epilogues add into it
+        if not self.norm_first:
+            return self._post_norm(res, B, T, d, src_mask, stage_embedding, is_src_tuple)
         xn = self._n(self.norm1, res, stage_embedding)
         att = self.self_attn._attend(xn, B, T, src_mask)
         sa = self.self_attn
@@ -373,6 +446,28 @@ class TransformerEncoderLayer(_HipModule):
         h = ops.linear(xn, self._w(self.linear1.weight), self.linear1.bias.detach(), epilogue=ops.EPI_RELU)
         ops.linear(h, self._w(self.linear2.weight), self.linear2.bias.detach(), epilogue=ops.EPI_RESID, resid=res)
         out = res.view(B, T, d)
+        if not self.batch_first:
+            out = out.transpose(0, 1)
+        return (out, stage_embedding) if is_src_tuple else out
+
+
+    def _n32(self, norm, x2: Tensor, stage_embedding) -> Tensor:
+        if isinstance(norm, AdaptiveLayerNorm):
+            return norm._norm(x2, stage_embedding, torch.float32)
+        assert stage_embedding is None
+        return norm._norm(x2, torch.float32)
+
+    def _post_norm(self, res: Tensor, B: int, T: int, d: int, src_mask, stage_embedding, is_src_tuple: bool):
+        """transformer.py:303-308: x = norm1(x + SA(x)); x = norm2(x + W2 relu(W1 x + b1) + b2)."""
+        sa = self.self_attn
+        tdt = self._tdtype()
+        att = sa._attend(res if tdt == torch.float32 else res.to(tdt), B, T, src_mask)
+        ops.linear(att, sa._w(sa.out_proj.weight), sa.out_proj.bias.detach(), epilogue=ops.EPI_RESID, resid=res)  # res = x + SA(x)
+        x1 = self._n32(self.norm1, res, stage_embedding)                                                       # the new residual stream
+        x1c = x1 if tdt == torch.float32 else self._n(self.norm1, res, stage_embedding)                         # ... in the GEMM's element type
+        h = ops.linear(x1c, self._w(self.linear1.weight), self.linear1.bias.detach(), epilogue=ops.EPI_RELU)
+        ops.linear(h, self._w(self.linear2.weight), self.linear2.bias.detach(), epilogue=ops.EPI_RESID, resid=x1)  # x1 += FFN(x1)
+        out = self._n32(self.norm2, x1, stage_embedding).view(B, T, d)
         if not self.batch_first:
             out = out.transpose(0, 1)
         return (out, stage_embedding) if is_src_tuple else out

@@ -252,6 +252,21 @@ def cross_entropy_rows(logits: torch.Tensor, targets: torch.Tensor, ignore_index
     return loss, hit
 
 
+def topk_sample(logits: torch.Tensor, top_k: int = -100, temperature: float = 1.0, seed: int = 0, step: int = 0):
+    """``topk_sampling(logits, top_k, top_p=1.0, temperature)`` (valle/models/valle.py:1287-1302) per row of fp32 ``logits``
+    (rows, V): returns (samples, argmax), both int64 (rows,).  Row r draws from the RNG stream of request r of seed ``seed``
+    at AR step ``step`` (the engine's own streams: a block-level decode loop samples what ``vle_ar_generate`` would)."""
+    lib = _lib.load()
+    assert logits.dim() == 2 and logits.dtype == torch.float32
+    logits = logits.contiguous()
+    rows, V = logits.shape
+    samples = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    argmax = torch.empty(rows, dtype=torch.int64, device=logits.device)
+    _lib.check(lib.vle_op_topk_sample(_st(logits), _p(logits), rows, V, int(top_k), float(temperature), int(seed) & (2**64 - 1),
+                                      int(step) & 0xFFFFFFFF, _p(samples), _p(argmax)))
+    return samples, argmax
+
+
 def quantize_rows_fp8(x: torch.Tensor):
     """Per-row activation quantiser of engine mode FP8: x bf16 (rows, K) -> (codes uint8 (rows, K) e4m3fn, scale fp32 (rows,))."""
     lib = _lib.load()

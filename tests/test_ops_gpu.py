@@ -153,8 +153,11 @@ def test_attention_mfma_long(nhead, dh, lens, text_lens, causal, v2, qw, mode, q
     ops.tune("attn_q128", q128)
     ops.tune("attn_defer", defer)
     try:
-        _attention_mfma_long(nhead, dh, lens, text_lens, causal)
+        for ring in ((2, 4) if (v2 == 2 and mode == 2) else (0,)):  # LDS ring depth of the LDS-DMA staging (0 = by launch size)
+            ops.tune("attn_ring", ring)
+            _attention_mfma_long(nhead, dh, lens, text_lens, causal)
     finally:
+        ops.tune("attn_ring", 0)
         ops.tune("attn_qw", 0)
         ops.tune("attn_v2", 1)
         ops.tune("attn_mode", 2)

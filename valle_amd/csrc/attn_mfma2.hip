@@ -82,7 +82,10 @@ __device__ inline void a2_wait_vm() {
 //         ds_write_b128 at ~13 cycles each), dense rows, 16-byte slots XOR-swizzled on the DMA source address and on the ds_read
 //         side (key = row mod (vectors per row)): conflict-free; two buffers, tile t+1 in flight while tile t is multiplied,
 //         counted-free wait (vmcnt(0): the only loads in the loop are the DMA pieces) + raw s_barrier per tile.  DH 64 / 128.
-template <int DH, int QW, int MODE>
+//         NS = ring depth: 2 (one tile in flight under the current one's math).  4 (three tiles ahead, counted vmcnt) is a
+//         measured dead end kept as knob "attn_ring": one 1025-row sequence (272 blocks, nobody else to hide the DMA latency)
+//         runs 17.1 us per launch either way, the batched passes lose occupancy (C3 NAR shape 451 -> 338 TF/s).
+template <int DH, int QW, int MODE, int NS = 2>
 __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                     const int32_t* __restrict__ seq_off, const int32_t* __restrict__ text_len, int d,
                                                     int nhead, int causal, int64_t rp, int xcd_remap, float defer_exp2) {
@@ -95,7 +98,9 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
   constexpr int NLD = 64 * NV / 256;   // staged vectors per thread per tile (K and V^T each): DH / 32
   constexpr int KS = DH / 32, EB = DH / 16;
   constexpr int KSWZ = GLDS ? NV - 1 : 0, VSWZ = GLDS ? 7 : 0;  // slot ^= row & mask
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * (64 * KSTR + DH * VSTR)];
+  static_assert(NS == 2 || (GLDS && NS == 4), "deeper rings exist for the LDS-DMA staging only");
+  constexpr int NPW = NV / 4 + DH / 32;  // DMA pieces per wave per tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (64 * KSTR + DH * VSTR)];
 
   // XCD-aware block order (block L runs on XCD L % 8, each with its own 4 MB L2): the query blocks of one (sequence, head) read
   // the same K / V -- give every XCD a CONTIGUOUS run of the (b, h, query-block) order so that they meet in one L2 instead of
@@ -206,7 +211,9 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
   //  ring -- 365 -> 328 TF/s at the C3 NAR shape: the extra score registers cost more occupancy than the overlap returns.)
   const int ntile = (kmax + 63) >> 6;
   if constexpr (GLDS) {
-    dma(0, smem);
+#pragma unroll
+    for (int p = 0; p < NS - 1; ++p)
+      if (p < ntile) dma(p * 64, smem + p * BUF);
   } else {
     gload(0);
     lstore(smem);
@@ -215,12 +222,20 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
   }
   for (int t = 0; t < ntile; ++t) {
     const int kt0 = t * 64;
-    const unsigned char* Ks = smem + (t & 1) * BUF;
+    const unsigned char* Ks = smem + (t & (NS - 1)) * BUF;
     const unsigned char* Vt = Ks + 64 * KSTR;
     if constexpr (GLDS) {
-      a2_wait_vm<0>();                 // this wave's pieces of tile t landed (and, at t = 0, its Q fragments)
+      // this wave's pieces of tile t landed (and, at t = 0, its Q fragments): at most the pieces of the younger tiles in flight
+      if constexpr (NS == 2) {
+        a2_wait_vm<0>();
+      } else {
+        const int younger = min(NS - 2, ntile - 1 - t);
+        if (younger >= 2) a2_wait_vm<2 * NPW>();
+        else if (younger == 1) a2_wait_vm<NPW>();
+        else a2_wait_vm<0>();
+      }
       __builtin_amdgcn_s_barrier();    // everyone's did; everyone finished reading tile t-1
-      if (t + 1 < ntile) dma(kt0 + 64, smem + ((t + 1) & 1) * BUF);  // into tile t-1's buffer, in flight under this tile's math
+      if (t + NS - 1 < ntile) dma(kt0 + 64 * (NS - 1), smem + ((t + NS - 1) & (NS - 1)) * BUF);  // into tile t-1's buffer
     }
 
     // a wave whose query rows all lie beyond the sequence (the ragged last block: N = 1025 leaves ONE row for a block of 64 / 128)
@@ -362,6 +377,7 @@ int g_attn_v2 = 1;    // "attn_v2": 0 = round 1's kernel (attn_mfma.hip) for A/B
 int g_attn_xcd = 1;   // "attn_xcd": XCD-aware block order (A/B)
 int g_attn_mode = 2;  // "attn_mode": tile staging of attn2_kernel -- 0 registers + 16-byte row padding (round 2's first layout), 1 registers +
                       // 32-byte padding (conflict-free), 2 LDS-DMA + XOR swizzle where the head size allows (64 / 128), else 1
+int g_attn_ring = 0;  // "attn_ring": LDS ring depth of the LDS-DMA staging: 0 / 2 = two buffers, 4 = four (A/B knob, see attn2_kernel)
 int g_attn_defer = 8; // "attn_defer": deferred-maximum threshold of attn2_kernel in exp2-domain units (0 = exact running maximum)
 int g_attn_q128 = -1; // "attn_q128": 128-query blocks (each K / V^T fragment read from LDS feeds two MFMAs): 0 never, 1 always, -1 (default) =
                       // on the un-masked passes with at least 1024 such blocks (4 per CU) -- measured (tools/attn_bench.py): C3 NAR 461 -> 474
@@ -386,15 +402,18 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
   const dim3 pgrid((max_len + 63) / 64, nhead, B), block(256);
   const bool q128 = g_attn_q128 < 0 ? (!causal && (int64_t)B * nhead * ((max_len + 127) / 128) >= 1024) : g_attn_q128 != 0;
   const dim3 grid(q128 ? (max_len + 127) / 128 : (max_len + 63) / 64, nhead, B);
-#define VLE_A2M(DH, QW, MODE)                                                                                                      \
-  hipLaunchKernelGGL((attn2_kernel<DH, QW, MODE>), grid, block, 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, seq_off, \
+#define VLE_A2M(DH, QW, MODE, NS)                                                                                                  \
+  hipLaunchKernelGGL((attn2_kernel<DH, QW, MODE, NS>), grid, block, 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, seq_off, \
                      text_len, d, nhead, causal, rp8, g_attn_xcd, (float)g_attn_defer)
 #define VLE_A2K(DH, QW)                                  \
   do {                                                   \
     if (mode == 2) {                                     \
-      if constexpr (DH == 64 || DH == 128) VLE_A2M(DH, QW, 2); \
-    } else if (mode == 1) VLE_A2M(DH, QW, 1);            \
-    else VLE_A2M(DH, QW, 0);                             \
+      if constexpr (DH == 64 || (DH == 128 && QW == 1)) { \
+        if (ring4) VLE_A2M(DH, QW, 2, 4);                \
+        else VLE_A2M(DH, QW, 2, 2);                      \
+      } else if constexpr (DH == 128) VLE_A2M(DH, QW, 2, 2); \
+    } else if (mode == 1) VLE_A2M(DH, QW, 1, 2);         \
+    else VLE_A2M(DH, QW, 0, 2);                          \
   } while (0)
 #define VLE_A2(DH)                                                                                                              \
   do {                                                                                                                          \
@@ -403,6 +422,9 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
     else VLE_A2K(DH, 1);                                                                                                        \
   } while (0)
   const int mode = (g_attn_mode == 2 && !(dh == 64 || dh == 128)) ? 1 : g_attn_mode;
+  const int64_t nblocks = (int64_t)grid.x * grid.y * grid.z;
+  const bool ring4 = g_attn_ring == 4;
+  (void)nblocks;
   switch (dh) {
     case 32: VLE_A2(32); break;
     case 64: VLE_A2(64); break;

@@ -1987,8 +1987,8 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     g_attn_qw = (int)value;
     return VLE_OK;
   }
-  if (n == "attn_v2" || n == "attn_xcd" || n == "attn_q128" || n == "attn_mode" || n == "attn_defer") {
-    (n == "attn_v2" ? g_attn_v2 : n == "attn_xcd" ? g_attn_xcd : n == "attn_q128" ? g_attn_q128 : n == "attn_mode" ? g_attn_mode : g_attn_defer) = (int)value;
+  if (n == "attn_v2" || n == "attn_xcd" || n == "attn_q128" || n == "attn_mode" || n == "attn_defer" || n == "attn_ring") {
+    (n == "attn_v2" ? g_attn_v2 : n == "attn_xcd" ? g_attn_xcd : n == "attn_q128" ? g_attn_q128 : n == "attn_mode" ? g_attn_mode : n == "attn_defer" ? g_attn_defer : g_attn_ring) = (int)value;
     return VLE_OK;
   }
   if (n == "glds_swz" || n == "glds_8ph" || n == "g8_stagger" || n == "g8_colgroup") {

@@ -239,6 +239,11 @@ int vle_op_linear_skinny(void* stream, int dtype, const float* x, const float* g
 int vle_op_attention(void* stream, int dtype, const void* qkv, void* out, const int32_t* seq_off_dev,
                      const int32_t* text_len_dev, int32_t B, int32_t max_len, int32_t d, int32_t nhead, int causal);
 
+/* Cross-attention of VALL-F's decoder layers (valle/modules/transformer.py:582-597, MultiheadAttention.forward(x, mem, mem),
+ * valle/modules/activation.py:199-431): q [Tq x d] (the projected, un-scaled queries), kv [S x 2d] = [K | V] rows of the memory
+ * (text) sequence, heads = contiguous d / nhead slices (<= 128), no mask; out [Tq x d]; dtype VLE_DTYPE_F32 / _BF16 for all three. */
+int vle_op_cross_attention(void* stream, int dtype, const void* q, const void* kv, void* out, int32_t Tq, int32_t S, int32_t d,
+                           int32_t nhead);
 /* The same attention for ONE new query per utterance against the head-major KV cache
  * [B][H][ctx_max][dh] (element type T): the last row of F.multi_head_attention_forward under the
  * prefix-LM mask of valle.py:1019-1033 (the new token sees cache slots 0 .. kv_len[b]).  The reference

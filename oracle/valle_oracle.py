@@ -49,6 +49,7 @@ class OracleConfig:
     nar_scale_factor: float = 1.0
     prepend_bos: bool = False
     num_quantizers: int = 8
+    model: str = "valle"  # "valle" (decoder-only: text is a prefix of the sequence) | "vallf" (text is cross-attention memory, valle.py:50-710)
 
     # NAR sizes, valle.py:83, :235, :241
     @property
@@ -67,9 +68,10 @@ class OracleConfig:
     def fused_shape(self) -> bool:
         """The production shape the fused HIP engine runs (pre-norm, no prenet, one width); the other constructor
         combinations decode through the block modules (valle_amd/model.py)."""
-        return self.norm_first and not self.add_prenet and self.nar_scale_factor == 1.0
+        return self.model == "valle" and self.norm_first and not self.add_prenet and self.nar_scale_factor == 1.0
 
     def check_supported(self):
+        assert self.model in ("valle", "vallf")
         assert self.nar_d_model > 0 and self.nar_nhead > 0 and self.nar_num_layers > 0 and self.nar_d_model % self.nar_nhead == 0
 
 
@@ -113,11 +115,16 @@ def state_dict_spec(cfg: OracleConfig) -> "OrderedDict[str, tuple]":
         s[f"{prefix}.self_attn.in_proj_bias"] = (3 * d,)
         s[f"{prefix}.self_attn.out_proj.weight"] = (d, d)
         s[f"{prefix}.self_attn.out_proj.bias"] = (d,)
+        if cfg.model == "vallf":  # TransformerDecoderLayer, transformer.py:442-450
+            s[f"{prefix}.multihead_attn.in_proj_weight"] = (3 * d, d)
+            s[f"{prefix}.multihead_attn.in_proj_bias"] = (3 * d,)
+            s[f"{prefix}.multihead_attn.out_proj.weight"] = (d, d)
+            s[f"{prefix}.multihead_attn.out_proj.bias"] = (d,)
         s[f"{prefix}.linear1.weight"] = (4 * d, d)
         s[f"{prefix}.linear1.bias"] = (4 * d,)
         s[f"{prefix}.linear2.weight"] = (d, 4 * d)
         s[f"{prefix}.linear2.bias"] = (d,)
-        for n in ("norm1", "norm2"):
+        for n in ("norm1", "norm2", "norm3") if cfg.model == "vallf" else ("norm1", "norm2"):
             if adaptive:
                 s[f"{prefix}.{n}.project_layer.weight"] = (2 * d, d)
                 s[f"{prefix}.{n}.project_layer.bias"] = (2 * d,)
@@ -347,6 +354,123 @@ def audio_prenet(sd, prefix: str, y: torch.Tensor) -> torch.Tensor:
     return F.linear(h, sd[f"{prefix}.6.weight"], sd[f"{prefix}.6.bias"])
 
 
+def cross_mha(sd, prefix: str, x, mem, nhead: int):
+    """MultiheadAttention.forward(x, mem, mem) (valle/modules/activation.py:199-431 -> F.multi_head_attention_forward): queries
+    from the first d rows of the packed in-proj, keys / values of ``mem`` from the other 2 d, no mask.  x (T, d), mem (S, d)."""
+    T, d = x.shape
+    S = mem.shape[0]
+    dh = d // nhead
+    w, b = sd[f"{prefix}.in_proj_weight"], sd[f"{prefix}.in_proj_bias"]
+    q = F.linear(x, w[:d], b[:d]).view(T, nhead, dh).transpose(0, 1)
+    k = F.linear(mem, w[d: 2 * d], b[d: 2 * d]).view(S, nhead, dh).transpose(0, 1)
+    v = F.linear(mem, w[2 * d:], b[2 * d:]).view(S, nhead, dh).transpose(0, 1)
+    p = torch.softmax(torch.matmul(q, k.transpose(1, 2)) / math.sqrt(dh), dim=-1)
+    o = torch.matmul(p, v).transpose(0, 1).reshape(T, d)
+    return F.linear(o, sd[f"{prefix}.out_proj.weight"], sd[f"{prefix}.out_proj.bias"])
+
+
+def decoder_layer(sd, prefix: str, x, mem, nhead: int, tgt_mask, stage_emb, norm_first: bool):
+    """TransformerDecoderLayer.forward (valle/modules/transformer.py:520-575): self-attention, cross-attention over the
+    memory, FFN; pre-norm (:544-556) or post-norm (:557-571)."""
+    n = lambda i, t: norm_site(sd, f"{prefix}.norm{i}", t, stage_emb)  # noqa: E731
+    ff = lambda t: F.linear(F.relu(F.linear(t, sd[f"{prefix}.linear1.weight"], sd[f"{prefix}.linear1.bias"])),  # noqa: E731
+                            sd[f"{prefix}.linear2.weight"], sd[f"{prefix}.linear2.bias"])
+    if norm_first:
+        x = x + mha(sd, f"{prefix}.self_attn", n(1, x), nhead, tgt_mask)
+        x = x + cross_mha(sd, f"{prefix}.multihead_attn", n(2, x), mem, nhead)
+        return x + ff(n(3, x))
+    x = n(1, x + mha(sd, f"{prefix}.self_attn", x, nhead, tgt_mask))
+    x = n(2, x + cross_mha(sd, f"{prefix}.multihead_attn", x, mem, nhead))
+    return n(3, x + ff(x))
+
+
+def decoder(sd, prefix: str, cfg: OracleConfig, tgt, mem, tgt_mask=None, stage_emb=None):
+    """nn.TransformerDecoder.forward of torch 1.13 (the reference's pin, README.md:31): each layer on the previous output and the
+    memory, then the final norm if there is one (valle.py:141-152, 232-246).  (torch >= 2's container rejects the reference's
+    tuple inputs, SURVEY.md 8c: the goldens come from the reference's own layers under this loop, oracle/make_golden.py.)"""
+    nar = prefix.startswith("nar_")
+    x = tgt
+    for l in range(cfg.nar_num_layers if nar else cfg.num_layers):
+        x = decoder_layer(sd, f"{prefix}.layers.{l}", x, mem, cfg.nar_nhead if nar else cfg.nhead, tgt_mask, stage_emb, cfg.norm_first)
+    return norm_site(sd, f"{prefix}.norm", x, stage_emb) if cfg.norm_first else x
+
+
+def vallf_ar_decode(sd, cfg: OracleConfig, x_ids, x_lens, prompts, top_k=-100, temperature=1.0, max_new=None, trace=None, generator=None):
+    """VALLF.inference's AR loop, valle.py:593-652: the text is the decoder's MEMORY, the audio stream its causal target."""
+    assert x_ids.ndim == 2 and x_lens.ndim == 1 and prompts.ndim == 3 and prompts.shape[0] == 1  # :591-594
+    assert torch.all(x_lens > 0)
+    S = int(x_lens.max())
+    x = token_embedding(sd, "ar_text_embedding", x_ids[0])  # :599
+    if cfg.add_prenet:
+        x = text_prenet(sd, "ar_text_prenet", x)
+    x = sine_position(x, sd["ar_text_position.alpha"])  # :601
+    P = prompts.shape[1]
+    y = prompts[0, :, 0]  # :610
+    if cfg.prepend_bos:
+        y = F.pad(y, (1, 0), value=NUM_AUDIO_TOKENS + 1)  # :611-612
+    bos = int(cfg.prepend_bos)
+    while True:
+        e = token_embedding(sd, "ar_audio_embedding", y)  # :615-617
+        if cfg.add_prenet:
+            e = audio_prenet(sd, "ar_audio_prenet", e)
+        y_pos = sine_position(e, sd["ar_audio_position.alpha"])
+        T = y.shape[0]
+        tgt_mask = torch.triu(torch.ones(T, T, dtype=torch.bool), diagonal=1)  # :619-624
+        y_dec = decoder(sd, "ar_decoder", cfg, y_pos, x, tgt_mask=tgt_mask)  # :626-632
+        logits = F.linear(y_dec[-1:], sd["ar_predict_layer.weight"])  # :633
+        if trace is not None:
+            trace.setdefault("ar_logits", []).append(logits[0].clone())
+        samples = topk_sampling(logits.clone(), top_k, temperature, generator)  # :634-636
+        n_gen = T - bos - P
+        stop = (int(torch.argmax(logits, dim=-1)[0]) == NUM_AUDIO_TOKENS or int(samples[0, 0]) == NUM_AUDIO_TOKENS
+                or (T - P) > S * 16)  # :638-642
+        if max_new is not None and n_gen >= max_new:
+            stop = True
+        if stop:
+            if P == T:
+                raise SyntaxError("well trained model shouldn't reach here.")  # :643-646
+            break
+        y = torch.cat([y, samples[0]], 0)  # :651
+    return y[None]
+
+
+def vallf_nar_decode(sd, cfg: OracleConfig, text_ids, y0, prompts, prefix_len, enroll_x_lens=None, trace=None):
+    """VALLF.inference's NAR stages, valle.py:653-710: like VALL-E's, but the decoder runs over the audio stream only and
+    attends to the text through cross-attention."""
+    Q = cfg.num_quantizers
+    codes = [y0[prefix_len:]]  # :653
+    if Q == 1:
+        return torch.stack(codes, dim=-1)[None]
+    y_emb = token_embedding(sd, "nar_audio_embeddings.0", y0).clone()  # :658-660
+    text = text_ids
+    if cfg.prefix_mode in (2, 4):  # :661-671
+        enrolled_len = int(enroll_x_lens.max())
+        text = torch.cat([text[:1], text[enrolled_len - 1:]], 0)
+    x = token_embedding(sd, "nar_text_embedding", text)  # :673-675
+    if cfg.add_prenet:
+        x = text_prenet(sd, "nar_text_prenet", x)
+    x = sine_position(x, sd["nar_text_position.alpha"])
+    if cfg.prefix_mode != 0:
+        for j in range(1, Q):  # :677-681
+            y_emb[:prefix_len] += token_embedding(sd, f"nar_audio_embeddings.{j}", prompts[:, j])
+    for i in range(Q - 1):  # :683-705
+        y_pos = audio_prenet(sd, "nar_audio_prenet", y_emb) if cfg.add_prenet else y_emb
+        y_pos = sine_position(y_pos, sd["nar_audio_position.alpha"])
+        stage = sd[f"nar_stage_embeddings.{i}.word_embeddings.weight"]
+        y_dec = decoder(sd, "nar_decoder", cfg, y_pos, x, tgt_mask=None, stage_emb=stage)  # :691-697
+        logits = F.linear(y_dec[prefix_len:], sd[f"nar_predict_layers.{i}.weight"])  # :698
+        if trace is not None:
+            trace.setdefault("nar_logits", []).append(logits.clone())
+        samples = torch.argmax(logits, dim=-1)  # :699
+        codes.append(samples)
+        if i < Q - 2:  # :701 (``if i < 6``)
+            if cfg.prefix_mode == 0:
+                y_emb[:prefix_len] += token_embedding(sd, f"nar_audio_embeddings.{i + 1}", prompts[:, i + 1])
+            y_emb[prefix_len:] += token_embedding(sd, f"nar_audio_embeddings.{i + 1}", samples)
+    assert len(codes) == Q
+    return torch.stack(codes, dim=-1)[None]
+
+
 def prefix_lm_mask(S: int, T: int) -> torch.Tensor:
     """valle.py:1018-1033: [[0_{SxS} | 1_{SxT}], [0_{TxS} | triu(1)_{TxT}]], True = blocked."""
     top = F.pad(torch.zeros(S, S, dtype=torch.bool), (0, T), value=True)
@@ -495,6 +619,10 @@ def inference(
     """VALLE.inference, valle/models/valle.py:961-1137.  x (1,S) int64, x_lens (1,) int32,
     y (1,P,Q) int64 -> (1,G,Q) int64."""
     cfg.check_supported()
+    if cfg.model == "vallf":  # VALLF.inference, valle.py:566-710 (no incremental mode: the literal loop only)
+        assert not act_fp8 and force_tokens is None
+        yy = vallf_ar_decode(sd, cfg, x, x_lens, y, top_k, temperature, max_new, trace, generator)
+        return vallf_nar_decode(sd, cfg, x[0], yy[0, int(cfg.prepend_bos):], y[0], y.shape[1], enroll_x_lens, trace)
     assert not act_fp8 or kv_cache, "act_fp8 models the engine's packed prefill + single-row steps: needs kv_cache=True"
     yy = ar_decode(sd, cfg, x, x_lens, y, top_k, temperature, kv_cache, force_tokens, max_new, trace, generator, act_fp8)
     P = y.shape[1]

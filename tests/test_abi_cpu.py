@@ -83,6 +83,12 @@ def test_get_model_surface():
                       prefix_mode=1, share_embedding=True, scale_factor=1.0, prepend_bos=False, num_quantizers=8)
     m = valle_amd.get_model(p)
     assert isinstance(m, valle_amd.VALLE) and m.num_quantizers == 8
-    p.model_name = "VALL-F"
+    p.model_name = "VALL-F"  # valle/models/__init__.py:99-111
+    f = valle_amd.get_model(p)
+    assert isinstance(f, valle_amd.VALLF) and not f.fused
+    cfg = vo.OracleConfig(d_model=64, nhead=4, num_layers=2, prefix_mode=1, model="vallf")
+    assert list(f.state_dict().keys()) == list(vo.state_dict_spec(cfg).keys())  # the reference's keys (multihead_attn, norm3)
+    f.load_state_dict(vo.make_state_dict(cfg, 0), strict=True)
+    p.model_name = "Transformer"
     with pytest.raises(NotImplementedError):
         valle_amd.get_model(p)

@@ -15,7 +15,7 @@ from oracle import valle_oracle as vo  # noqa: E402
 from tests.golden_util import list_cases, load_case  # noqa: E402
 
 DEV = "cuda:0"
-SMALL = [c for c in list_cases() if not c.startswith(("c1_", "c2_", "opt_"))]  # opt_*: tests/test_options_gpu.py (block-module decode)
+SMALL = [c for c in list_cases() if not c.startswith(("c1_", "c2_", "opt_", "vallf_"))]  # opt_* / vallf_*: tests/test_options_gpu.py (block-module decode)
 
 
 def build_model(cfg, sd, dtype="fp32", **kw):

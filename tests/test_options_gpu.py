@@ -1,7 +1,7 @@
 """GPU: the constructor combinations outside the fused engine's shape -- post-norm layers (valle/modules/transformer.py:303-308),
-prenets (valle/models/valle.py:99-126, 182-219), a NAR decoder of another width (nar_scale_factor, :83, :235, :241) -- decoded
-by the HIP block modules (valle_amd/model.py ``_inference_blocks``) against the UNMODIFIED reference's outputs
-(tests/golden/opt_*.npz, made by oracle/make_golden.py) and against the oracle."""
+prenets (valle/models/valle.py:99-126, 182-219), a NAR decoder of another width (nar_scale_factor, :83, :235, :241) -- and VALL-F
+(cross-attention decoders, valle.py:50-710), decoded by the HIP block modules (valle_amd/model.py ``_inference_blocks``) against
+the reference's outputs (tests/golden/opt_*.npz, vallf_*.npz, made by oracle/make_golden.py) and against the oracle."""
 import numpy as np
 import pytest
 import torch
@@ -15,11 +15,11 @@ from oracle import valle_oracle as vo  # noqa: E402
 from tests.golden_util import list_cases, load_case  # noqa: E402
 
 DEV = "cuda:0"
-OPT = [c for c in list_cases() if c.startswith("opt_")]
+OPT = [c for c in list_cases() if c.startswith(("opt_", "vallf_"))]
 
 
 def build(cfg, sd, dtype="fp32"):
-    m = valle_amd.VALLE(cfg.d_model, cfg.nhead, cfg.num_layers, norm_first=cfg.norm_first, add_prenet=cfg.add_prenet,
+    m = (valle_amd.VALLF if cfg.model == "vallf" else valle_amd.VALLE)(cfg.d_model, cfg.nhead, cfg.num_layers, norm_first=cfg.norm_first, add_prenet=cfg.add_prenet,
                         prefix_mode=cfg.prefix_mode, share_embedding=cfg.share_embedding, nar_scale_factor=cfg.nar_scale_factor,
                         prepend_bos=cfg.prepend_bos, num_quantizers=cfg.num_quantizers, engine_dtype=dtype)
     m.load_state_dict(sd, strict=True)
@@ -35,7 +35,7 @@ def run(m, case, **kw):
 
 
 def test_golden_cases_exist():
-    assert len(OPT) >= 6
+    assert len([c for c in OPT if c.startswith("opt_")]) >= 6 and len([c for c in OPT if c.startswith("vallf_")]) >= 3
 
 
 @pytest.mark.parametrize("name", OPT)
@@ -181,3 +181,48 @@ def test_batch_api_on_option_models():
     assert torch.equal(outs[0].cpu(), case["codes"][0])
     want1 = vo.inference(case["sd"], case["cfg"], x2, xl2, y2, None, top_k=1, kv_cache=True)
     assert torch.equal(outs[1].cpu(), want1[0])
+
+
+@pytest.mark.parametrize("dtype,tol", [("fp32", 2e-5), ("bf16", 0.04)])
+@pytest.mark.parametrize("norm_first", [True, False])
+@pytest.mark.parametrize("adaptive", [False, True])
+def test_decoder_layer_matches_oracle(dtype, tol, norm_first, adaptive):
+    """TransformerDecoderLayer (self-attention + cross-attention over the memory + FFN, valle/modules/transformer.py:409-616) against
+    the oracle's restatement, pre- and post-norm, plain and adaptive norms."""
+    d, h, T, S = 128, 4, 29, 11
+    cfg = vo.OracleConfig(d_model=d, nhead=h, num_layers=1, norm_first=norm_first, model="vallf")
+    sd = vo.make_state_dict(cfg, 6)
+    prefix = "nar_decoder.layers.0" if adaptive else "ar_decoder.layers.0"
+    layer = M.TransformerDecoderLayer(d, h, dim_feedforward=4 * d, batch_first=True, norm_first=norm_first, adaptive_layer_norm=adaptive)
+    layer.load_state_dict({k[len(prefix) + 1:]: v for k, v in sd.items() if k.startswith(prefix + ".")}, strict=True)
+    layer = M.set_compute_dtype(layer.to(DEV).eval(), dtype)
+    g = torch.Generator().manual_seed(8)
+    x, mem = torch.randn(T, d, generator=g), torch.randn(S, d, generator=g)
+    stage = sd["nar_stage_embeddings.1.word_embeddings.weight"] if adaptive else None
+    mask = torch.triu(torch.ones(T, T, dtype=torch.bool), diagonal=1)
+    want = vo.decoder_layer(sd, prefix, x, mem, h, mask, stage, norm_first)
+    got = layer((x[None].to(DEV), None if stage is None else stage.to(DEV)), mem[None].to(DEV), tgt_mask=mask.to(DEV))[0][0].cpu()
+    assert (got - want).abs().max().item() < tol * max(1.0, want.abs().max().item())
+
+
+@pytest.mark.parametrize("dt", [torch.float32, torch.bfloat16])
+@pytest.mark.parametrize("nhead,dh", [(4, 16), (2, 64), (3, 96), (2, 128)])
+def test_cross_attention_operator(nhead, dh, dt):
+    d, T, S = nhead * dh, 37, 23
+    g = torch.Generator().manual_seed(12)
+    q, kv = torch.randn(T, d, generator=g).to(dt), torch.randn(S, 2 * d, generator=g).to(dt)
+    got = ops.cross_attention(q.to(DEV), kv.to(DEV), nhead).cpu().double()
+    qd, k, v = q.double().view(T, nhead, dh), kv[:, :d].double().view(S, nhead, dh), kv[:, d:].double().view(S, nhead, dh)
+    p = torch.softmax(torch.einsum("thd,shd->hts", qd, k) / dh ** 0.5, dim=-1)
+    want = torch.einsum("hts,shd->thd", p, v).reshape(T, d)
+    assert (got - want).abs().max().item() < (2e-6 if dt == torch.float32 else 0.02)
+
+
+def test_vallf_surface():
+    case = load_case("vallf_prenorm_pm1")
+    m = build(case["cfg"], case["sd"], "fp32")
+    assert isinstance(m, valle_amd.VALLF) and not m.fused
+    with pytest.raises(NotImplementedError):
+        m.continual(case["x"].to(DEV), case["x_lens"].to(DEV), case["y"].to(DEV))
+    with pytest.raises(RuntimeError):
+        m.engine_for(1, 4, 4)

@@ -73,6 +73,7 @@ SIGNATURES = {
     "vle_op_quantize_rows_fp8": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32]),
     "vle_op_linear_fp8": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_cross_entropy": (C.c_int, [_P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
+    "vle_op_cross_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vle_op_topk_sample": (C.c_int, [_P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_float, C.c_uint64, C.c_uint32, _P, _P]),
     "vle_op_adaln_fold": (C.c_int, [_P, _P, _P, _P, _P, _P, C.c_int32]),
 }

@@ -114,4 +114,57 @@ int launch_cross_entropy(hipStream_t st, const float* logits, const int64_t* tar
   return 0;
 }
 
+// ---- cross-attention of VALL-F's TransformerDecoderLayer._mha_block (valle/modules/transformer.py:582-597 ->
+// MultiheadAttention.forward(x, mem, mem), activation.py:199-431): out[t][h] = softmax(q[t][h] . K[:, h]^T / sqrt(dh)) V[:, h], no
+// mask (the decode path runs one un-padded utterance: memory_key_padding_mask is all False, valle.py:604, :626-632).
+// q [Tq][d], kv [S][2 d] = [K | V] rows of the memory (text) sequence, heads = contiguous dh-slices.  One wave per (query row,
+// head): lane l owns elements l and l + 64 of the head (dh <= 128); per key one 64-lane DPP reduction for the score and an
+// online-softmax update of the lane's two output elements.  The text side is short (S <= a few hundred) and VALL-F is not the
+// production model: a plain exact kernel, fp32 arithmetic, no tiling.
+template <typename T>
+__global__ __launch_bounds__(256) void cross_attention_kernel(const T* __restrict__ q, const T* __restrict__ kv, T* __restrict__ out, int Tq,
+                                                              int S, int d, int dh) {
+  const int lane = threadIdx.x & 63;
+  const int t = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int h = blockIdx.y;
+  if (t >= Tq) return;  // wave-uniform
+  const bool a0 = lane < dh, a1 = lane + 64 < dh;
+  const T* qp = q + (int64_t)t * d + h * dh;
+  const float scale = 1.0f / sqrtf((float)dh);
+  const float q0 = a0 ? Elem<T>::to_f32(qp[lane]) * scale : 0.f, q1 = a1 ? Elem<T>::to_f32(qp[lane + 64]) * scale : 0.f;
+  float m = -INFINITY, l = 0.f, o0 = 0.f, o1 = 0.f;
+  for (int j = 0; j < S; ++j) {
+    const T* kp = kv + (int64_t)j * 2 * d + h * dh;
+    float part = 0.f;
+    if (a0) part = q0 * Elem<T>::to_f32(kp[lane]);
+    if (a1) part = fmaf(q1, Elem<T>::to_f32(kp[lane + 64]), part);
+    const float sc = wave_sum_dpp(part);  // the same value in every lane
+    const float mn = fmaxf(m, sc);
+    const float alpha = __expf(m - mn), p = __expf(sc - mn);  // first key: alpha = exp(-inf) = 0
+    l = l * alpha + p;
+    const T* vp = kp + d;
+    if (a0) o0 = fmaf(p, Elem<T>::to_f32(vp[lane]), o0 * alpha);
+    if (a1) o1 = fmaf(p, Elem<T>::to_f32(vp[lane + 64]), o1 * alpha);
+    m = mn;
+  }
+  const float inv = 1.0f / l;
+  T* op = out + (int64_t)t * d + h * dh;
+  if (a0) store_elem<T>(op + lane, o0 * inv);
+  if (a1) store_elem<T>(op + lane + 64, o1 * inv);
+}
+
+int launch_cross_attention(hipStream_t st, int dtype, const void* q, const void* kv, void* out, int Tq, int S, int d, int nhead) {
+  if (Tq <= 0) return 0;
+  if (S <= 0 || nhead <= 0 || d % nhead != 0 || d / nhead > 128) return -1;
+  const dim3 grid((unsigned)((Tq + 3) / 4), (unsigned)nhead), block(256);
+  if (dtype == DT_F32)
+    hipLaunchKernelGGL((cross_attention_kernel<float>), grid, block, 0, st, (const float*)q, (const float*)kv, (float*)out, Tq, S, d, d / nhead);
+  else if (dtype == DT_BF16)
+    hipLaunchKernelGGL((cross_attention_kernel<bf16_t>), grid, block, 0, st, (const bf16_t*)q, (const bf16_t*)kv, (bf16_t*)out, Tq, S, d,
+                       d / nhead);
+  else
+    return -1;
+  return 0;
+}
+
 }  // namespace vle

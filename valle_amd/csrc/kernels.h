@@ -249,6 +249,8 @@ struct ArSampleArgs {
   // polls these words instead of putting a D2H copy + event on the stream after every graph replay.
   int32_t* host_prog = nullptr;
 };
+// VALL-F cross-attention (block API): q [Tq x d], kv [S x 2d] = [K | V] of the memory sequence, no mask; dtype DT_F32 / DT_BF16
+int launch_cross_attention(hipStream_t st, int dtype, const void* q, const void* kv, void* out, int Tq, int S, int d, int nhead);
 int launch_ar_sample(hipStream_t st, const ArSampleArgs& a);
 // stand-alone topk_sampling (valle.py:1287-1302) per row of logits[rows][V]: out[row] = draw with Philox(request_seed(seed, row), it),
 // argmax_out[row] (nullable) = arg-max of the raw row

@@ -130,6 +130,14 @@ extern "C" int vle_op_attention(void* stream, int dtype, const void* qkv, void* 
                  "vle_op_attention");
 }
 
+extern "C" int vle_op_cross_attention(void* stream, int dtype, const void* q, const void* kv, void* out, int32_t Tq, int32_t S, int32_t d,
+                                      int32_t nhead) {
+  if (!q || !kv || !out || Tq < 0 || S < 1 || nhead < 1 || d % nhead) return op_fail("vle_op_cross_attention: bad argument");
+  const int r = launch_cross_attention((hipStream_t)stream, dtype, q, kv, out, Tq, S, d, nhead);
+  if (r == -1) return op_fail("vle_op_cross_attention: head size must be <= 128, dtype f32 or bf16");
+  return op_done(r, "vle_op_cross_attention");
+}
+
 extern "C" int vle_op_decode_attention(void* stream, int dtype, const float* q, const void* k_cache, const void* v_cache,
                                        const int32_t* kv_len_dev, float* workspace, float* out, int32_t B, int32_t nhead,
                                        int32_t dh, int32_t ctx_max, int32_t nsplit) {

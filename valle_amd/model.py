@@ -31,7 +31,7 @@ NUM_AUDIO_TOKENS = 1024  # valle/models/macros.py:5
 
 # the block modules (reference names, reference state-dict keys, HIP forward): modules.py
 from .modules import (AdaptiveLayerNorm, AudioPrenet, LayerNorm, SinePositionalEmbedding, TextPrenet, TokenEmbedding,  # noqa: E402
-                      TransformerEncoder, TransformerEncoderLayer, set_compute_dtype)
+                      TransformerDecoder, TransformerDecoderLayer, TransformerEncoder, TransformerEncoderLayer, set_compute_dtype)
 
 
 def _decoder(d: int, nhead: int, num_layers: int, adaptive: bool, norm_first: bool = True) -> TransformerEncoder:
@@ -40,6 +40,15 @@ def _decoder(d: int, nhead: int, num_layers: int, adaptive: bool, norm_first: bo
                                     adaptive_layer_norm=adaptive)
     norm = None if not norm_first else (AdaptiveLayerNorm(d, norm=LayerNorm(d)) if adaptive else LayerNorm(d))
     return TransformerEncoder(layer, num_layers=num_layers, norm=norm)
+
+
+def _cross_decoder(d: int, nhead: int, num_layers: int, adaptive: bool, norm_first: bool = True) -> TransformerDecoder:
+    """VALL-F's decoders (valle/models/valle.py:141-152, 232-246 with decoder_cls = nn.TransformerDecoder, decoder_layer_cls =
+    TransformerDecoderLayer): self-attention over the audio stream, cross-attention over the text."""
+    layer = TransformerDecoderLayer(d, nhead, dim_feedforward=d * 4, dropout=0.1, batch_first=True, norm_first=norm_first,
+                                    adaptive_layer_norm=adaptive)
+    norm = None if not norm_first else (AdaptiveLayerNorm(d, norm=LayerNorm(d)) if adaptive else LayerNorm(d))
+    return TransformerDecoder(layer, num_layers=num_layers, norm=norm)
 
 
 def _request_seed_base(seed: int, b: int) -> int:
@@ -51,6 +60,9 @@ def _request_seed_base(seed: int, b: int) -> int:
 
 class VALLE(nn.Module):
     """HIP-backed VALL-E (valle/models/valle.py:722-1238)."""
+
+    _decoder_factory = staticmethod(_decoder)
+    _eos_name = "VALL-E"
 
     def __init__(
         self,
@@ -79,7 +91,7 @@ class VALLE(nn.Module):
         nd = int(d_model * nar_scale_factor)                                       # valle.py:83
         nar_heads, nar_layers = int(nhead * nar_scale_factor), int(num_layers * nar_scale_factor)  # :235, :241
         # the fused engine implements the production shape; every other combination decodes through the block modules
-        self.fused = bool(norm_first) and not add_prenet and nar_scale_factor == 1.0
+        self.fused = type(self)._decoder_factory is _decoder and bool(norm_first) and not add_prenet and nar_scale_factor == 1.0
         if not self.fused and engine_dtype == "fp8":
             raise NotImplementedError("engine_dtype='fp8' (fp8 activations) exists only in the fused engine's packed passes")
         self.norm_first, self.add_prenet, self.nar_scale_factor = bool(norm_first), bool(add_prenet), float(nar_scale_factor)
@@ -97,7 +109,7 @@ class VALLE(nn.Module):
         self.ar_audio_prenet = AudioPrenet(d) if add_prenet else nn.Identity()
         self.ar_text_position = SinePositionalEmbedding(d, dropout=0.1, scale=False, alpha=True)
         self.ar_audio_position = SinePositionalEmbedding(d, dropout=0.1, scale=False, alpha=True)
-        self.ar_decoder = _decoder(d, nhead, num_layers, adaptive=False, norm_first=norm_first)
+        self.ar_decoder = self._decoder_factory(d, nhead, num_layers, adaptive=False, norm_first=norm_first)
         self.ar_predict_layer = nn.Linear(d, NUM_AUDIO_TOKENS + 1, bias=False)
         if num_quantizers > 1:
             self.nar_audio_embeddings = nn.ModuleList(
@@ -107,7 +119,7 @@ class VALLE(nn.Module):
             self.nar_audio_prenet = AudioPrenet(nd) if add_prenet else nn.Identity()
             self.nar_text_position = SinePositionalEmbedding(nd, dropout=0.0, scale=False, alpha=False)
             self.nar_audio_position = SinePositionalEmbedding(nd, dropout=0.1, scale=False, alpha=False)
-            self.nar_decoder = _decoder(nd, nar_heads, nar_layers, adaptive=True, norm_first=norm_first)
+            self.nar_decoder = self._decoder_factory(nd, nar_heads, nar_layers, adaptive=True, norm_first=norm_first)
             self.nar_predict_layers = nn.ModuleList([nn.Linear(nd, NUM_AUDIO_TOKENS, bias=False) for _ in range(num_quantizers - 1)])
             self.nar_stage_embeddings = nn.ModuleList([TokenEmbedding(nd, 1) for _ in range(num_quantizers - 1)])
             if share_embedding:
@@ -295,11 +307,7 @@ class VALLE(nn.Module):
             n_gen = 0
             while True:
                 ye = self.ar_audio_position(self.ar_audio_prenet(self.ar_audio_embedding(yy)))       # :1013-1015
-                T = yy.shape[1]
-                i = torch.arange(S + T, device=dev)
-                allowed = i[None, :] < torch.maximum(i[:, None] + 1, torch.tensor(S, device=dev))    # prefix-LM mask, :1018-1033
-                h, _ = self.ar_decoder((torch.cat([xe, ye], dim=1), None), mask=~allowed)             # :1035-1038
-                logits = self._predict(self.ar_decoder, h[0, -1:], self.ar_predict_layer.weight)      # :1039
+                logits = self._predict(self.ar_decoder, self._ar_last_hidden(xe, ye), self.ar_predict_layer.weight)  # :1016-1039
                 # request b's RNG stream at step n_gen: what vle_ar_generate(seed) draws for this utterance
                 smp, am = ops.topk_sample(logits, top_k, temperature, seed=_request_seed_base(seed, b), step=n_gen)  # :1040-1042
                 smp_i, am_i = int(smp[0]), int(am[0])
@@ -310,7 +318,7 @@ class VALLE(nn.Module):
                     if P == yy.shape[1]:
                         if x.shape[0] == 1:
                             raise SyntaxError("well trained model shouldn't reach here.")               # :1049-1052
-                    print(f"VALL-E EOS [{P} -> {yy.shape[1]}]")                                        # :1054
+                    print(f"{self._eos_name} EOS [{P} -> {yy.shape[1]}]")                              # :1054
                     break
                 yy = torch.cat([yy, smp.view(1, 1)], dim=1)                                            # :1057
                 n_gen += 1
@@ -322,6 +330,20 @@ class VALLE(nn.Module):
                 en = el[b] if len(el) > 1 else el[0]
             outs.append(self._nar_blocks(text, y0, prompts, P, self.prefix_mode, en)[0])
         return outs
+
+    def _ar_last_hidden(self, xe: torch.Tensor, ye: torch.Tensor) -> torch.Tensor:
+        """Decoder output of the LAST audio position, (1, d): [text; audio] through the decoder-only stack under the prefix-LM mask
+        (valle.py:1016-1038)."""
+        S, T = xe.shape[1], ye.shape[1]
+        i = torch.arange(S + T, device=xe.device)
+        allowed = i[None, :] < torch.maximum(i[:, None] + 1, torch.tensor(S, device=xe.device))       # :1018-1033
+        h, _ = self.ar_decoder((torch.cat([xe, ye], dim=1), None), mask=~allowed)                     # :1035-1038
+        return h[0, -1:]
+
+    def _nar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, stage_weight: torch.Tensor, P: int) -> torch.Tensor:
+        """Decoder outputs of the generated frames, (G, d) (valle.py:1123-1128)."""
+        h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), stage_weight))
+        return h[0, xe.shape[1] + P:]
 
     def _nar_blocks(self, text, y0, prompts, P: int, prefix_mode: int, enrolled_len) -> torch.Tensor:
         """The seven NAR stages, valle.py:1059-1137 (and continual()'s :1176-1238): text (1, S) ids, y0 (1, P + G) first-codebook
@@ -340,8 +362,8 @@ class VALLE(nn.Module):
                 y_emb[:, :P] += self.nar_audio_embeddings[j](prompts[..., j])
         for i in range(Q - 1):                                                                         # :1085 / :1115
             ye = self.nar_audio_position(self.nar_audio_prenet(y_emb))                                 # :1121-1122
-            h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), self.nar_stage_embeddings[i].weight))  # :1125-1127
-            logits = self._predict(self.nar_decoder, h[0, S + P:], self.nar_predict_layers[i].weight)  # :1128
+            logits = self._predict(self.nar_decoder, self._nar_hidden(xe, ye, self.nar_stage_embeddings[i].weight, P),
+                                   self.nar_predict_layers[i].weight)                               # :1123-1128
             from . import ops
 
             samples = ops.topk_sample(logits, 1)[1][None]                                              # arg-max, :1130
@@ -453,6 +475,33 @@ class VALLE(nn.Module):
         return ((x_emb, codes), total_loss, metrics)
 
 
+class VALLF(VALLE):
+    """VALL-F (valle/models/valle.py:50-710): the same embeddings, prenets, predict layers and NAR scheme as VALL-E, but the
+    decoders are ``nn.TransformerDecoder`` stacks -- the text is their cross-attention MEMORY, the audio stream their (causal,
+    for AR) target.  Decoded by the HIP block modules in the reference's loop (one full pass per AR step, :613-651); the
+    state-dict keys are the reference's (``...multihead_attn...``, ``norm3``).  Not the production model: there is no fused
+    engine path, ``continual()`` does not exist in the reference's VALLF, and the teacher-forced ``forward()`` is not carried."""
+
+    _decoder_factory = staticmethod(_cross_decoder)
+    _eos_name = "VALL-F"
+
+    def _ar_last_hidden(self, xe: torch.Tensor, ye: torch.Tensor) -> torch.Tensor:
+        T = ye.shape[1]
+        tgt_mask = torch.triu(torch.ones(T, T, device=ye.device, dtype=torch.bool), diagonal=1)        # valle.py:619-624
+        h, _ = self.ar_decoder((ye, None), xe, tgt_mask=tgt_mask, memory_mask=None)                    # :626-632
+        return h[0, -1:]
+
+    def _nar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, stage_weight: torch.Tensor, P: int) -> torch.Tensor:
+        h, _ = self.nar_decoder((ye, stage_weight), xe, tgt_mask=None, memory_mask=None)               # :691-697
+        return h[0, P:]                                                                               # :698
+
+    def continual(self, *a, **k):
+        raise NotImplementedError("VALLF has no continual() (valle/models/valle.py: it is defined on VALLE only)")
+
+    def forward(self, *a, **k):
+        raise NotImplementedError("VALL-F's teacher-forced forward (valle.py:395-564) is not carried; decode with inference()")
+
+
 # ---- valle/models/__init__.py surface ---------------------------------------------------------------
 def _str2bool(v):
     return str(v).lower() in ("1", "true", "yes", "y", "t")
@@ -476,13 +525,13 @@ def add_model_arguments(parser: argparse.ArgumentParser):
 
 
 def get_model(params) -> nn.Module:
-    """valle/models/__init__.py:98-136 for --model-name vall-e|valle.  VALL-F and the debug
-    Transformer-TTS are outside this engine's scope."""
+    """valle/models/__init__.py:98-136 for --model-name vall-e|valle (:112-124) and vall-f|vallf (:99-111); the debug
+    Transformer-TTS (:125-134) is outside this package's scope."""
     name = str(params.model_name).lower()
-    if name not in ("vall-e", "valle"):
-        raise NotImplementedError(f"model_name={params.model_name!r}: only VALL-E is implemented by the HIP engine")
+    if name not in ("vall-e", "valle", "vall-f", "vallf"):
+        raise NotImplementedError(f"model_name={params.model_name!r}: VALL-E and VALL-F are implemented (the debug Transformer-TTS is not)")
     get = params.get if hasattr(params, "get") else lambda k, dflt=None: getattr(params, k, dflt)
-    return VALLE(
+    return (VALLF if name in ("vall-f", "vallf") else VALLE)(
         params.decoder_dim,
         params.nhead,
         params.num_decoder_layers,

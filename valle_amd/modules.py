@@ -352,8 +352,10 @@ class MultiheadAttention(_HipModule):
     def forward(self, query: Tensor, key: Tensor, value: Tensor, key_padding_mask: Optional[Tensor] = None,
                 need_weights: bool = True, attn_mask: Optional[Tensor] = None, average_attn_weights: bool = True):
         _need_device(query, "MultiheadAttention")
-        if not (key is query and value is query):
-            raise NotImplementedError("only self-attention (query is key is value) is on the decode path")
+        if key is not query:
+            return self._cross_forward(query, key, value, key_padding_mask, need_weights, attn_mask)
+        if value is not query:
+            raise NotImplementedError("self-attention with a separate value tensor is not on the decode path")
         if key_padding_mask is not None and bool(key_padding_mask.any()):
             raise NotImplementedError("key_padding_mask: the decode path runs unpadded sequences")
         if need_weights:
@@ -376,6 +378,44 @@ class MultiheadAttention(_HipModule):
         if unbatched:
             out = out.squeeze(0 if self.batch_first else 1)
         return out, None
+
+
+def _mha_cross_forward(self, query: Tensor, key: Tensor, value: Tensor, key_padding_mask, need_weights, attn_mask):
+    """MultiheadAttention.forward(x, mem, mem): VALL-F's ``multihead_attn`` (valle/modules/transformer.py:582-597): queries
+    projected by the first d rows of the packed in-proj, keys / values of the memory by the other 2 d (activation.py:128-130),
+    un-masked softmax(Q K^T / sqrt(dh)) V per head (``vle_op_cross_attention``), out_proj."""
+    if value is not key:
+        raise NotImplementedError("cross-attention with different key and value tensors is not on the decode path")
+    if attn_mask is not None:
+        raise NotImplementedError("memory_mask: VALL-F passes None (valle.py:629)")
+    if key_padding_mask is not None and bool(key_padding_mask.any()):
+        raise NotImplementedError("memory_key_padding_mask: the decode path runs unpadded sequences")
+    if need_weights:
+        raise NotImplementedError("need_weights=True is not produced (transformer.py:594 calls with need_weights=False)")
+    if self.training and self.dropout > 0:
+        raise NotImplementedError("dropout (training) is outside the decode path")
+    x, mem = query, key
+    unbatched = x.dim() == 2
+    if unbatched:
+        x, mem = x.unsqueeze(0 if self.batch_first else 1), mem.unsqueeze(0 if self.batch_first else 1)
+    if not self.batch_first:
+        x, mem = x.transpose(0, 1), mem.transpose(0, 1)
+    B, T, d = x.shape
+    S = mem.shape[1]
+    tdt = self._tdtype()
+    w, b = self._w(self.in_proj_weight), self.in_proj_bias.detach()
+    q = ops.linear(x.reshape(B * T, d).to(tdt).contiguous(), w[:d], b[:d])
+    kv = ops.linear(mem.reshape(B * S, d).to(tdt).contiguous(), w[d:], b[d:])
+    att = torch.cat([ops.cross_attention(q[i * T:(i + 1) * T], kv[i * S:(i + 1) * S], self.num_heads) for i in range(B)], dim=0)
+    out = ops.linear(att, self._w(self.out_proj.weight), self.out_proj.bias.detach(), epilogue=ops.EPI_F32).view(B, T, d)
+    if not self.batch_first:
+        out = out.transpose(0, 1)
+    if unbatched:
+        out = out.squeeze(0 if self.batch_first else 1)
+    return out, None
+
+
+MultiheadAttention._cross_forward = _mha_cross_forward
 
 
 # ---- valle/modules/transformer.py: encoder -----------------------------------------------------------
@@ -500,6 +540,122 @@ class TransformerEncoder(_HipModule):
         output = src
         for mod in self.layers:
             output = mod(output, src_mask=mask, src_key_padding_mask=src_key_padding_mask)
+        if self.norm is not None:
+            output = self.norm(output)
+        return output
+
+
+# ---- valle/modules/transformer.py: decoder (VALL-F) ---------------------------------------------------
+class TransformerDecoderLayer(_HipModule):
+    """valle/modules/transformer.py:409-616: self-attention over the (audio) target, cross-attention over the (text) memory, FFN;
+    pre-norm (:544-556) or post-norm (:557-571); plain or adaptive LayerNorms norm1..3.  The same kernels as the encoder layer
+    plus ``vle_op_cross_attention``; the residual stream stays fp32 and the residual GEMM epilogues add into it."""
+
+    def __init__(self, d_model: int, nhead: int, dim_feedforward: int = 2048, dropout: float = 0.1,
+                 activation: Union[str, Callable[[Tensor], Tensor]] = F.relu, linear1_self_attention_cls=nn.Linear,
+                 linear2_self_attention_cls=nn.Linear, linear1_feedforward_cls=nn.Linear, linear2_feedforward_cls=nn.Linear,
+                 batch_first: bool = False, norm_first: bool = False, device=None, dtype=None, layer_norm_cls=LayerNorm,
+                 layer_norm_eps: float = 1e-5, adaptive_layer_norm=False) -> None:
+        super().__init__()
+        if not (activation is F.relu or activation == "relu" or isinstance(activation, nn.ReLU)):
+            raise NotImplementedError("only ReLU is fused in the FFN1 epilogue")
+        if linear1_feedforward_cls is not nn.Linear or linear2_feedforward_cls is not nn.Linear or layer_norm_cls is not LayerNorm:
+            raise NotImplementedError("scaled linears / BasicNorm (scaling.py) are outside the decode path")
+        mk = lambda: MultiheadAttention(d_model, nhead, dropout=dropout, batch_first=batch_first, linear1_cls=linear1_self_attention_cls,  # noqa: E731
+                                        linear2_cls=linear2_self_attention_cls, device=device)
+        self.self_attn = mk()
+        self.multihead_attn = mk()
+        self.linear1 = nn.Linear(d_model, dim_feedforward, device=device)
+        self.dropout = nn.Dropout(dropout)
+        self.linear2 = nn.Linear(dim_feedforward, d_model, device=device)
+        self.norm_first = norm_first
+        self.batch_first = batch_first
+        self.dropout1, self.dropout2, self.dropout3 = nn.Dropout(dropout), nn.Dropout(dropout), nn.Dropout(dropout)
+        self.activation = F.relu
+        norms = [LayerNorm(d_model, eps=layer_norm_eps, device=device) for _ in range(3)]
+        if adaptive_layer_norm:
+            norms = [AdaptiveLayerNorm(d_model, n) for n in norms]
+        self.norm1, self.norm2, self.norm3 = norms
+
+    def _n(self, norm, x2: Tensor, stage_embedding, out_dtype: torch.dtype) -> Tensor:
+        if isinstance(norm, AdaptiveLayerNorm):
+            return norm._norm(x2, stage_embedding, out_dtype)
+        assert stage_embedding is None
+        return norm._norm(x2, out_dtype)
+
+    def _cross(self, xq: Tensor, mem_kv: Tensor, B: int, T: int, S: int) -> Tensor:
+        """xq (B*T, d) in the compute dtype -> cross-attention output before out_proj; mem_kv (B*S, 2d) projected memory."""
+        ca = self.multihead_attn
+        d = xq.shape[1]
+        q = ops.linear(xq, ca._w(ca.in_proj_weight)[:d], ca.in_proj_bias.detach()[:d])
+        return torch.cat([ops.cross_attention(q[i * T:(i + 1) * T], mem_kv[i * S:(i + 1) * S], ca.num_heads) for i in range(B)], dim=0)
+
+    def forward(self, tgt, memory: Tensor, tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None, memory_key_padding_mask: Optional[Tensor] = None):
+        x, stage_embedding = tgt, None
+        tgt_is_tuple = isinstance(tgt, tuple)
+        if tgt_is_tuple:
+            x, stage_embedding = tgt
+        _need_device(x, "TransformerDecoderLayer")
+        if memory_mask is not None:
+            raise NotImplementedError("memory_mask: VALL-F passes None (valle.py:629)")
+        for pm in (tgt_key_padding_mask, memory_key_padding_mask):
+            if pm is not None and bool(pm.to(torch.bool).any()):
+                raise NotImplementedError("key_padding_mask: the decode path runs unpadded sequences")
+        if self.training and self.dropout.p > 0:
+            raise NotImplementedError("dropout (training) is outside the decode path")
+        xb = x if self.batch_first else x.transpose(0, 1)
+        mb = memory if self.batch_first else memory.transpose(0, 1)
+        B, T, d = xb.shape
+        S = mb.shape[1]
+        tdt = self._tdtype()
+        sa, ca = self.self_attn, self.multihead_attn
+        lin = lambda a, w, b, **k: ops.linear(a, self._w(w), b.detach(), **k)  # noqa: E731
+        # the memory's keys / values: rows d .. 3d of the packed in-proj (activation.py:128-130)
+        mem_kv = ops.linear(mb.reshape(B * S, d).to(tdt).contiguous(), ca._w(ca.in_proj_weight)[d:], ca.in_proj_bias.detach()[d:])
+        res = xb.to(torch.float32).reshape(B * T, d).clone()
+        if self.norm_first:  # :544-556
+            att = sa._attend(self._n(self.norm1, res, stage_embedding, tdt), B, T, tgt_mask)
+            lin(att, sa.out_proj.weight, sa.out_proj.bias, epilogue=ops.EPI_RESID, resid=res)
+            catt = self._cross(self._n(self.norm2, res, stage_embedding, tdt), mem_kv, B, T, S)
+            lin(catt, ca.out_proj.weight, ca.out_proj.bias, epilogue=ops.EPI_RESID, resid=res)
+            h = lin(self._n(self.norm3, res, stage_embedding, tdt), self.linear1.weight, self.linear1.bias, epilogue=ops.EPI_RELU)
+            lin(h, self.linear2.weight, self.linear2.bias, epilogue=ops.EPI_RESID, resid=res)
+            out = res
+        else:  # :557-571
+            cast = (lambda t: t) if tdt == torch.float32 else (lambda t: t.to(tdt))
+            att = sa._attend(cast(res), B, T, tgt_mask)
+            lin(att, sa.out_proj.weight, sa.out_proj.bias, epilogue=ops.EPI_RESID, resid=res)
+            x1 = self._n(self.norm1, res, stage_embedding, torch.float32)
+            catt = self._cross(cast(x1), mem_kv, B, T, S)
+            lin(catt, ca.out_proj.weight, ca.out_proj.bias, epilogue=ops.EPI_RESID, resid=x1)
+            x2 = self._n(self.norm2, x1, stage_embedding, torch.float32)
+            h = lin(cast(x2), self.linear1.weight, self.linear1.bias, epilogue=ops.EPI_RELU)
+            lin(h, self.linear2.weight, self.linear2.bias, epilogue=ops.EPI_RESID, resid=x2)
+            out = self._n(self.norm3, x2, stage_embedding, torch.float32)
+        out = out.view(B, T, d)
+        if not self.batch_first:
+            out = out.transpose(0, 1)
+        return (out, stage_embedding) if tgt_is_tuple else out
+
+
+class TransformerDecoder(_HipModule):
+    """The container VALL-F builds its decoders with -- ``nn.TransformerDecoder`` of torch 1.13 (the reference's pin,
+    README.md:31; valle/models/valle.py:141-152): N deep-copied layers, each called with the previous output and the memory,
+    then the optional final norm.  Same attribute names (``layers``, ``num_layers``, ``norm``), hence the same state-dict keys."""
+
+    def __init__(self, decoder_layer, num_layers, norm=None):
+        super().__init__()
+        self.layers = _get_clones(decoder_layer, num_layers)
+        self.num_layers = num_layers
+        self.norm = norm
+
+    def forward(self, tgt, memory: Tensor, tgt_mask: Optional[Tensor] = None, memory_mask: Optional[Tensor] = None,
+                tgt_key_padding_mask: Optional[Tensor] = None, memory_key_padding_mask: Optional[Tensor] = None):
+        output = tgt
+        for mod in self.layers:
+            output = mod(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask, tgt_key_padding_mask=tgt_key_padding_mask,
+                         memory_key_padding_mask=memory_key_padding_mask)
         if self.norm is not None:
             output = self.norm(output)
         return output

@@ -119,6 +119,17 @@ def attention(qkv: torch.Tensor, seq_off: torch.Tensor, text_len: torch.Tensor, 
     return out
 
 
+def cross_attention(q: torch.Tensor, kv: torch.Tensor, nhead: int) -> torch.Tensor:
+    """softmax(q K^T / sqrt(dh)) V per head, no mask: q (Tq, d), kv (S, 2d) = [K | V] of the memory sequence (VALL-F's
+    ``multihead_attn``, valle/modules/transformer.py:582-597); fp32 or bf16, output like q."""
+    lib = _lib.load()
+    q, kv = q.contiguous(), kv.contiguous()
+    assert q.dim() == 2 and kv.dim() == 2 and kv.shape[1] == 2 * q.shape[1] and q.dtype == kv.dtype
+    out = torch.empty_like(q)
+    _lib.check(lib.vle_op_cross_attention(_st(q), _dt(q), _p(q), _p(kv), _p(out), q.shape[0], kv.shape[0], q.shape[1], int(nhead)))
+    return out
+
+
 def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: torch.Tensor, nsplit: int = 1,
                      merged: bool = True):
     """One new query per utterance against the head-major KV cache.

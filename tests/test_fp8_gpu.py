@@ -32,7 +32,16 @@ def test_activation_quantiser_bit_identical_to_torch_float8(rows, K):
 
 @pytest.mark.parametrize("M,N,K", [(1025, 3072, 1024), (300, 1024, 4096), (16, 1536, 1536), (4100, 4096, 1024), (129, 1028, 512)])
 @pytest.mark.parametrize("epi", [ops.EPI_STORE, ops.EPI_RELU, ops.EPI_RESID, ops.EPI_F32])
-def test_fp8_gemm_equals_product_of_dequantised_operands(M, N, K, epi):
+@pytest.mark.parametrize("staged", [1, 0])  # epilogue through LDS as whole rows (default) / straight from the fragments (knob glds_epi)
+def test_fp8_gemm_equals_product_of_dequantised_operands(M, N, K, epi, staged):
+    ops.tune("glds_epi", staged)
+    try:
+        _fp8_gemm_case(M, N, K, epi)
+    finally:
+        ops.tune("glds_epi", 1)
+
+
+def _fp8_gemm_case(M, N, K, epi):
     g = torch.Generator().manual_seed(M * 7 + N)
     a = (torch.randn(M, K, generator=g) * 1.7).to(torch.bfloat16)
     w = torch.randn(N, K, generator=g) * 0.05

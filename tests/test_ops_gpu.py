@@ -259,7 +259,7 @@ def test_linear_split_k_tickets(M, N, K, ksplit, epi):
 
 
 @pytest.mark.parametrize("M,N,K", [(17408, 1024, 1024), (1041, 4096, 1024), (300, 1025, 1024), (130, 256, 256), (4100, 3072, 1536), (2049, 1024, 4096)])
-@pytest.mark.parametrize("knob", ["glds_swz", "glds_prio", "glds_8ph", "glds_8ph+g8_stagger", "glds_8ph+glds_swz", "glds_8ph+g8_stagger+glds_swz", "glds_8ph+g8_stagger+g8_colgroup", "glds_8ph+g8_stagger+g8_dbg"])  # listed = 1 (g8_colgroup: 4; g8_dbg: 4 = stores straight from the fragments instead of the LDS-staged epilogue), others 0
+@pytest.mark.parametrize("knob", ["glds_swz", "glds_prio", "glds_epi", "glds_swz+glds_epi", "glds_8ph", "glds_8ph+g8_stagger", "glds_8ph+glds_swz", "glds_8ph+g8_stagger+glds_swz", "glds_8ph+g8_stagger+g8_colgroup", "glds_8ph+g8_stagger+g8_dbg"])  # listed = 1 (g8_colgroup: 4; g8_dbg: 4 = stores straight from the fragments instead of the LDS-staged epilogue), others 0
 def test_linear_gemm_tile_policy_knobs(M, N, K, knob):
     """The A/B variants of the 8-wave GEMM tiles (alternative LDS slot key, s_setprio) compute the same product."""
     a = _rand(M, K, seed=70).to(torch.bfloat16)
@@ -267,7 +267,9 @@ def test_linear_gemm_tile_policy_knobs(M, N, K, knob):
     bias = _rand(N, seed=72) * 0.1
     ref = a.double() @ w.double().t() + bias.double()
     knobs = knob.split("+")
-    defaults = {"glds_swz": 0, "glds_prio": 0, "glds_8ph": -1, "g8_stagger": 1, "g8_colgroup": 0, "g8_dbg": 0}
+    # glds_epi: 1 (default) = gemm_glds.hip's epilogue staged through LDS, 0 = stores straight from the fragments -- the variants
+    # that do not list it run the legacy epilogue and must still equal `base` (staged) bit for bit
+    defaults = {"glds_swz": 0, "glds_prio": 0, "glds_epi": 1, "glds_8ph": -1, "g8_stagger": 1, "g8_colgroup": 0, "g8_dbg": 0}
 
     def tune(on):
         for k, dflt in defaults.items():

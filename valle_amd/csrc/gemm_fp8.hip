@@ -36,7 +36,7 @@ template <int BM, int BN, int EPI, int NW>
 __global__ __launch_bounds__(NW * 64) void gemm_fp8_kernel(const unsigned char* __restrict__ A, const float* __restrict__ sa,
                                                            const unsigned char* __restrict__ W, const float* __restrict__ sw,
                                                            const float* __restrict__ bias, void* __restrict__ out_,
-                                                           float* __restrict__ resid, int64_t M, int N, int K) {
+                                                           float* __restrict__ resid, int64_t M, int N, int K, int g_glds_epi_dev) {
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int STAGES = (4 * STAGE_BYTES <= 144 * 1024) ? 4 : 3;
   constexpr int D = STAGES - 1;
@@ -163,6 +163,64 @@ __global__ __launch_bounds__(NW * 64) void gemm_fp8_kernel(const unsigned char* 
     }
   }
 
+  // Tiles inside N: epilogue staged through LDS as a swizzled row-major image and written as whole rows -- gemm_glds.hip's
+  // epilogue with the two scale factors applied on the way in (see there for the layout and why).
+  if (n0 + BN <= N && g_glds_epi_dev) {
+    constexpr bool F32OUT = EPI == EPI_RESID || EPI == EPI_F32;
+    constexpr int ES = F32OUT ? 4 : 2, RB = BN * ES, CPR = RB / 16, RPI = 64 / CPR, IT = BM / NW / RPI;
+    static_assert(BM * RB <= STAGES * STAGE_BYTES && (BM / NW) % RPI == 0, "epilogue image must fit the LDS ring");
+    __syncthreads();
+    unsigned char* const E = smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wm0 + i * 16 + fr, col = wn0 + j * 16 + fg * 4;
+        g8_f32x4 v = acc[i][j] * (sw4[j] * sa1[i]) + bias4[j];  // the two scales are powers of two: exact
+        if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if constexpr (F32OUT) {
+          *reinterpret_cast<g8_f32x4*>(E + row * RB + (((col >> 2) ^ (fr & 7)) << 4)) = v;
+        } else {
+          g8_bf16x4 o4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o4[r] = (__bf16)v[r];
+          *reinterpret_cast<g8_bf16x4*>(E + row * RB + (((col >> 3) ^ (fr & 7)) << 4) + ((((col >> 2) & 1) ^ (fr >> 3)) << 3)) = o4;
+        }
+      }
+    const int l = lane % CPR, rsub = lane / CPR;
+    g8_f32x4 old[EPI == EPI_RESID ? IT : 1];
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int64_t m = m0 + wave * (BM / NW) + it * RPI + rsub;
+        old[it] = *reinterpret_cast<const g8_f32x4*>(resid + (m < M ? m : M - 1) * N + n0 + l * 4);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int r = wave * (BM / NW) + it * RPI + rsub;
+      const int64_t m = m0 + r;
+      g8_i32x4 v = *reinterpret_cast<const g8_i32x4*>(E + r * RB + ((l ^ (r & 7)) << 4));
+      if constexpr (!F32OUT) {
+        if ((r >> 3) & 1) v = g8_i32x4{v[2], v[3], v[0], v[1]};
+      }
+      if (m < M) {
+        if constexpr (EPI == EPI_RESID) {
+          const g8_f32x4 f = g8_f32x4{__int_as_float(v[0]), __int_as_float(v[1]), __int_as_float(v[2]), __int_as_float(v[3])};
+          *reinterpret_cast<g8_f32x4*>(resid + m * N + n0 + l * 4) = old[it] + f;
+        } else if constexpr (EPI == EPI_F32) {
+          *reinterpret_cast<g8_i32x4*>(reinterpret_cast<float*>(out_) + m * N + n0 + l * 4) = v;
+        } else {
+          *reinterpret_cast<g8_i32x4*>(reinterpret_cast<bf16_t*>(out_) + m * N + n0 + l * 8) = v;
+        }
+      }
+    }
+    return;
+  }
   const bool full = m0 + BM <= M && n0 + BN <= N;
   if constexpr (EPI == EPI_RESID) {
     g8_f32x4 old[FM][FN];
@@ -220,7 +278,7 @@ template <int BM, int BN, int NW>
 static int g8_launch(hipStream_t st, const unsigned char* A, const float* sa, const unsigned char* W, const float* sw, const float* bias,
                      void* out, float* resid, int64_t M, int N, int K, int epi) {
   const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM)), block(NW * 64);
-#define VLE_G8(E) hipLaunchKernelGGL((gemm_fp8_kernel<BM, BN, E, NW>), grid, block, 0, st, A, sa, W, sw, bias, out, resid, M, N, K)
+#define VLE_G8(E) hipLaunchKernelGGL((gemm_fp8_kernel<BM, BN, E, NW>), grid, block, 0, st, A, sa, W, sw, bias, out, resid, M, N, K, g_glds_epi)
   switch (epi) {
     case EPI_STORE: VLE_G8(EPI_STORE); break;
     case EPI_RELU: VLE_G8(EPI_RELU); break;

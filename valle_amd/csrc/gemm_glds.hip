@@ -23,6 +23,7 @@ namespace vle {
 
 typedef __bf16 gg_bf16x8 __attribute__((ext_vector_type(8)));
 typedef float gg_f32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int gg_u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 gg_bf16x4 __attribute__((ext_vector_type(4)));
 
 template <int N>
@@ -42,7 +43,7 @@ __device__ inline int gg_key(int row) {
 template <int BM, int BN, int EPI, int NW, bool PRIO = false, int SWZ = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const float* __restrict__ bias, void* __restrict__ out_,
-                                                        float* __restrict__ resid, int64_t M, int N, int K) {
+                                                        float* __restrict__ resid, int64_t M, int N, int K, int glds_legacy_epilogue) {
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int STAGES = (4 * STAGE_BYTES <= 144 * 1024) ? 4 : 3;
   constexpr int D = STAGES - 1;                 // k-steps in flight
@@ -183,8 +184,72 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   }
 
   // epilogue.  The MFMAs above compute C^T (W fragment as the A operand), so lane (fg, fr) holds
-  // C[m = 16 i + fr][n = 16 j + 4 fg + r], r = 0..3: four CONSECUTIVE columns of one row -> one 8-byte
-  // (bf16) or 16-byte (fp32) access per fragment instead of four scattered 2-byte stores.  N % 4 == 0.
+  // C[m = 16 i + fr][n = 16 j + 4 fg + r], r = 0..3: four CONSECUTIVE columns of one row.
+  //
+  // Tiles that lie inside N go through LDS (free once the last k-step is consumed; measured on gemm_8ph.hip, which does the
+  // same: a store instruction issued from the fragments covers 16 rows x 32 bytes and that store tail cost 20-50 % of the
+  // kernel).  The tile is written as a row-major image -- 16-byte chunk c of row r at chunk c ^ (r & 7), and for 2-byte
+  // elements the two 8-byte halves of a chunk swapped when (r >> 3) & 1: conflict-free for the fragment writes -- and read back
+  // as whole rows: every global access is BN x element-size contiguous bytes of one output row, 16 bytes per lane; the
+  // residual's old values are loaded in that row form too (requested before the barrier).
+  if (n0 + BN <= N && !glds_legacy_epilogue) {
+    constexpr bool F32OUT = EPI == EPI_RESID || EPI == EPI_F32;
+    constexpr int ES = F32OUT ? 4 : 2, RB = BN * ES, CPR = RB / 16, RPI = 64 / CPR, IT = BM / NW / RPI;
+    static_assert(BM * RB <= STAGES * STAGE_BYTES && (BM / NW) % RPI == 0, "epilogue image must fit the LDS ring");
+    __syncthreads();  // every wave has consumed the last k-step
+    unsigned char* const E = smem;
+#pragma unroll
+    for (int i = 0; i < FM; ++i)
+#pragma unroll
+      for (int j = 0; j < FN; ++j) {
+        const int row = wm0 + i * 16 + fr, col = wn0 + j * 16 + fg * 4;
+        gg_f32x4 v = acc[i][j] + bias4[j];
+        if constexpr (EPI == EPI_RELU) {
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+        }
+        if constexpr (F32OUT) {
+          *reinterpret_cast<gg_f32x4*>(E + row * RB + (((col >> 2) ^ (fr & 7)) << 4)) = v;
+        } else {
+          gg_bf16x4 o4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o4[r] = (__bf16)v[r];  // v_cvt_pk_bf16_f32: round-to-nearest-even
+          *reinterpret_cast<gg_bf16x4*>(E + row * RB + (((col >> 3) ^ (fr & 7)) << 4) + ((((col >> 2) & 1) ^ (fr >> 3)) << 3)) = o4;
+        }
+      }
+    const int l = lane % CPR, rsub = lane / CPR;
+    gg_f32x4 old[EPI == EPI_RESID ? IT : 1];
+    if constexpr (EPI == EPI_RESID) {
+#pragma unroll
+      for (int it = 0; it < IT; ++it) {
+        const int64_t m = m0 + wave * (BM / NW) + it * RPI + rsub;
+        old[it] = *reinterpret_cast<const gg_f32x4*>(resid + (m < M ? m : M - 1) * N + n0 + l * 4);
+      }
+    }
+    __syncthreads();
+#pragma unroll
+    for (int it = 0; it < IT; ++it) {
+      const int r = wave * (BM / NW) + it * RPI + rsub;
+      const int64_t m = m0 + r;
+      gg_u32x4 v = *reinterpret_cast<const gg_u32x4*>(E + r * RB + ((l ^ (r & 7)) << 4));
+      if constexpr (!F32OUT) {
+        if ((r >> 3) & 1) v = gg_u32x4{v[2], v[3], v[0], v[1]};
+      }
+      if (m < M) {
+        if constexpr (EPI == EPI_RESID) {
+          const gg_f32x4 f = gg_f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+          *reinterpret_cast<gg_f32x4*>(resid + m * N + n0 + l * 4) = old[it] + f;
+        } else if constexpr (EPI == EPI_F32) {
+          *reinterpret_cast<gg_u32x4*>(reinterpret_cast<float*>(out_) + m * N + n0 + l * 4) = v;
+        } else {
+          *reinterpret_cast<gg_u32x4*>(reinterpret_cast<bf16_t*>(out_) + m * N + n0 + l * 8) = v;
+        }
+      }
+    }
+    return;
+  }
+  // Tiles that reach beyond N (and the A/B knob "glds_epi" = 0): straight from the fragments -- one 8-byte (bf16) or 16-byte
+  // (fp32) access per fragment.  N % 4 == 0.
   // Values are finished in one straight-line block (a single wait for the bias / residual loads);
   // the conditional blocks contain only the memory instructions, so no store waits for another.
   const bool full = m0 + BM <= M && n0 + BN <= N;  // block-uniform: no per-element bounds checks
@@ -247,6 +312,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
 int g_glds_big = -1;
 int g_glds_8ph = -1;  // "glds_8ph": 0 = never gemm_8ph.hip, -1 = from 128 full 256 x 256 tiles (measured: ahead of the 256 x 128
                       // tile from there on, 463 vs 401 TF/s at 128 tiles, 970 vs 740 at 4112), n > 0 = from n tiles
+int g_glds_epi = 1;   // "glds_epi": 1 = epilogue staged through LDS (whole-row stores), 0 = stores straight from the fragments (A/B knob)
 int g_glds_swz = 0;   // "glds_swz": 1 = slot key (row >> 1) & 7 on the 8-wave tiles (A/B knob)
 int g_glds_prio = 0;  // "glds_prio": s_setprio(1) around the MFMA cluster of the 8-wave tiles (A/B knob)
 int g_glds_w8 = 1;  // "glds_w8": 8-wave workgroups on the 128-row tiles as well (batch-1 NAR 12.0 -> 10.0 ms); 0 = 4 waves
@@ -258,11 +324,11 @@ static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const flo
 #define VLE_GG(E)                                                                                                       \
   do {                                                                                                                  \
     if (NW == 8 && g_glds_swz)                                                                                          \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, (NW == 8) ? 1 : 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, (NW == 8) ? 1 : 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0); \
     else if (NW == 8 && g_glds_prio)                                                                                    \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, (NW == 8), 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K); \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, (NW == 8), 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0); \
     else                                                                                                                \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K);  \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0);  \
   } while (0)
   switch (epi) {
     case EPI_STORE: VLE_GG(EPI_STORE); break;

@@ -160,6 +160,7 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
                            int max_len, int64_t rows, int d, int nhead, int causal);
 int attn2_reserve(int64_t rows, int B, int d);
 extern int g_g8_dbg;
+extern int g_glds_epi;
 extern int g_attn_v2, g_attn_xcd, g_attn_q128, g_attn_mode, g_attn_defer, g_attn_ring;
 // copy K,V of packed prefill rows into the cache: cache[b][h][pos][e]
 int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache, void* v_cache, const int32_t* row_seq,

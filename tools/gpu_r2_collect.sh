@@ -26,6 +26,11 @@ timeout 600 python tools/ktrace_step.py --out $D/ktrace_b1 > $D/ktrace_b1.log 2>
 timeout 600 python tools/ktrace_step.py --out $D/ktrace_b64 --spg 8 --batch 64 > $D/ktrace_b64.log 2>&1; echo "ktrace b64 rc=$?"
 timeout 120 tools/bin/ubench_edges > $D/ubench_edges.json 2> $D/ubench_edges.err; echo "edges rc=$?"
 timeout 300 python tools/attn_bench.py > $D/attn_bench.log 2>&1; grep -E "^C|default" $D/attn_bench.log
+for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_ACTIVE_INST_VALU" "SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE" "SQ_INST_CYCLES_VMEM SQ_WAIT_INST_LDS SQ_INSTS_MFMA SQ_INSTS_SALU"; do
+  TAG=$(echo $SET | tr ' ' '+')
+  (cd /tmp && rm -rf /tmp/pmc_run && timeout 200 rocprofv3 --pmc $SET --kernel-trace -d /tmp/pmc_run -o p --output-format csv -- python $GRAFT_REPO_ROOT/tools/attn_bench.py --quick > $GRAFT_REPO_ROOT/$D/pmc_attn_$TAG.log 2>&1); echo "pmc attn $TAG rc=$?"
+  python tools/pmc_summary.py /tmp/pmc_run/p_counter_collection.csv $D/attn_pmc_${TAG}.csv
+done
 timeout 300 python tools/gemm_bench.py > $D/gemm_bench.log 2>&1; tail -n 12 $D/gemm_bench.log
 timeout 120 tools/bin/ubench_l2keep > $D/ubench_l2keep.json 2> $D/ubench_l2keep.err; echo "l2keep rc=$?"
 timeout 200 tools/bin/ubench_prefetch > $D/ubench_prefetch.json 2> $D/ubench_prefetch.err; echo "prefetch rc=$?"

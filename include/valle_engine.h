@@ -264,6 +264,8 @@ int vle_op_attn_out_proj(void* stream, int dtype, const float* workspace, const 
 /* TokenEmbedding.forward (valle/modules/embedding.py:43-47): out[f32, n x d] = table[f32, V x d][ids[i64, n]].
  * ids must lie in [0, V) (like nn.Embedding on a device, no range check on the hot path). */
 int vle_op_token_embedding(void* stream, const int64_t* ids, const float* table, float* out, int64_t n, int32_t d);
+/* inout[r] += table[ids[r]]: `y_emb += nar_audio_embeddings[j](codes)` of the NAR prompt / stage update (valle.py:1104-1113, 1134) */
+int vle_op_token_embedding_add(void* stream, const int64_t* ids, const float* table, float* inout, int64_t n, int32_t d);
 /* SinePositionalEmbedding.forward (embedding.py:93-97): out[b][t] = x[b][t] * x_scale + alpha[0] * pe[t];
  * x/out f32 [B x T x d], pe f32 [>= T x d] (built as embedding.py:75-91), alpha f32 DEVICE scalar. */
 int vle_op_sine_positional(void* stream, const float* x, const float* pe, const float* alpha_dev, float x_scale, float* out,

@@ -63,6 +63,7 @@ SIGNATURES = {
     "vle_op_decode_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vle_op_attn_out_proj": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vle_op_token_embedding": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32]),
+    "vle_op_token_embedding_add": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32]),
     "vle_op_sine_positional": (C.c_int, [_P, _P, _P, _P, C.c_float, _P, C.c_int64, C.c_int32, C.c_int32]),
     "vle_codec_create": (C.c_int, [C.c_int32, C.c_int32, C.POINTER(_P)]),
     "vle_codec_load_tensor": (C.c_int, [_P, C.c_char_p, _P, C.POINTER(C.c_int64), C.c_int]),

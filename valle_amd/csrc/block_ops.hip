@@ -20,6 +20,28 @@ __global__ __launch_bounds__(BO_NW * 64) void token_embedding_kernel(const int64
   for (int i = lane; i < (d >> 2); i += 64) dst[i] = src[i];
 }
 
+// out[r][:] += table[ids[r]][:]  -- the accumulating form: "y_emb += embedding(codes)" of the NAR prompt / stage update
+// (valle/models/valle.py:1104-1113, 1134)
+__global__ __launch_bounds__(BO_NW * 64) void token_embedding_add_kernel(const int64_t* __restrict__ ids, const float* __restrict__ table,
+                                                                          float* __restrict__ out, int64_t n, int d) {
+  const int lane = threadIdx.x & 63;
+  const int64_t r = (int64_t)blockIdx.x * BO_NW + (threadIdx.x >> 6);
+  if (r >= n) return;
+  const float4* src = reinterpret_cast<const float4*>(table + ids[r] * (int64_t)d);
+  float4* dst = reinterpret_cast<float4*>(out + r * (int64_t)d);
+  for (int i = lane; i < (d >> 2); i += 64) {
+    const float4 a = dst[i], b = src[i];
+    dst[i] = make_float4(a.x + b.x, a.y + b.y, a.z + b.z, a.w + b.w);
+  }
+}
+
+int launch_token_embedding_add(hipStream_t st, const int64_t* ids, const float* table, float* out, int64_t n, int d) {
+  if (n <= 0) return 0;
+  if (d % 4) return -1;
+  hipLaunchKernelGGL(token_embedding_add_kernel, dim3((unsigned)((n + BO_NW - 1) / BO_NW)), dim3(BO_NW * 64), 0, st, ids, table, out, n, d);
+  return 0;
+}
+
 int launch_token_embedding(hipStream_t st, const int64_t* ids, const float* table, float* out, int64_t n, int d) {
   if (n <= 0) return 0;
   if (d % 4) return -1;

@@ -24,6 +24,7 @@ int launch_gather_rows(hipStream_t st, const float* src, const int32_t* row_map,
 int launch_layernorm_xf(hipStream_t st, const float* x, const float* gamma, const float* beta, void* out, int rows, int d, int w8);
 // block_ops.hip: stand-alone forms of ops the engine runs fused (block API, SURVEY.md 8b seam B3)
 int launch_token_embedding(hipStream_t st, const int64_t* ids, const float* table, float* out, int64_t n, int d);
+int launch_token_embedding_add(hipStream_t st, const int64_t* ids, const float* table, float* out, int64_t n, int d);  // out += table[ids]
 int launch_sine_positional(hipStream_t st, const float* x, const float* pe, const float* alpha, float x_scale, float* out,
                            int64_t B, int T, int d);
 int launch_adaln_fold(hipStream_t st, const float* wb, const float* g, const float* be, float* gamma_out, float* beta_out, int d);

@@ -175,6 +175,11 @@ extern "C" int vle_op_token_embedding(void* stream, const int64_t* ids, const fl
   return op_done(launch_token_embedding((hipStream_t)stream, ids, table, out, n, d), "vle_op_token_embedding");
 }
 
+extern "C" int vle_op_token_embedding_add(void* stream, const int64_t* ids, const float* table, float* inout, int64_t n, int32_t d) {
+  if (!ids || !table || !inout || n < 0 || d < 4 || d % 4) return op_fail("vle_op_token_embedding_add: bad argument");
+  return op_done(launch_token_embedding_add((hipStream_t)stream, ids, table, inout, n, d), "vle_op_token_embedding_add");
+}
+
 extern "C" int vle_op_sine_positional(void* stream, const float* x, const float* pe, const float* alpha_dev, float x_scale, float* out,
                                       int64_t B, int32_t T, int32_t d) {
   if (!x || !pe || !alpha_dev || !out || B < 0 || T < 1 || d < 4 || d % 4) return op_fail("vle_op_sine_positional: bad argument");

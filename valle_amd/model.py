@@ -348,6 +348,8 @@ class VALLE(nn.Module):
     def _nar_blocks(self, text, y0, prompts, P: int, prefix_mode: int, enrolled_len) -> torch.Tensor:
         """The seven NAR stages, valle.py:1059-1137 (and continual()'s :1176-1238): text (1, S) ids, y0 (1, P + G) first-codebook
         stream, prompts (1, P, Q) -> codes (1, G, Q)."""
+        from . import ops
+
         Q = self.num_quantizers
         codes = [y0[:, P:]]                                                                           # :1059
         if Q == 1 or y0.shape[1] == P:  # (an utterance of a batch that stopped at its first step: no frames)
@@ -359,19 +361,17 @@ class VALLE(nn.Module):
         y_emb = self.nar_audio_embeddings[0](y0).clone()                                              # :1064-1066
         if prefix_mode != 0:
             for j in range(1, Q):                                                                      # :1110-1113
-                y_emb[:, :P] += self.nar_audio_embeddings[j](prompts[..., j])
+                self.nar_audio_embeddings[j].add_to(y_emb[0, :P], prompts[0, :, j])
         for i in range(Q - 1):                                                                         # :1085 / :1115
             ye = self.nar_audio_position(self.nar_audio_prenet(y_emb))                                 # :1121-1122
             logits = self._predict(self.nar_decoder, self._nar_hidden(xe, ye, self.nar_stage_embeddings[i].weight, P),
                                    self.nar_predict_layers[i].weight)                               # :1123-1128
-            from . import ops
-
             samples = ops.topk_sample(logits, 1)[1][None]                                              # arg-max, :1130
             codes.append(samples)
             if i < Q - 2:                                                                              # :1133 / :1103
                 if prefix_mode == 0:
-                    y_emb[:, :P] += self.nar_audio_embeddings[i + 1](prompts[..., i + 1])              # :1104-1107
-                y_emb[:, P:] += self.nar_audio_embeddings[i + 1](samples)                              # :1108 / :1134
+                    self.nar_audio_embeddings[i + 1].add_to(y_emb[0, :P], prompts[0, :, i + 1])        # :1104-1107
+                self.nar_audio_embeddings[i + 1].add_to(y_emb[0, P:], samples[0])                      # :1108 / :1134
         return torch.stack(codes, dim=-1)                                                              # :1136-1137
 
     # ---- VALLE.forward (valle/models/valle.py:762-959), teacher-forced, eval mode ----------------------------
@@ -456,12 +456,13 @@ class VALLE(nn.Module):
             y_emb = self.nar_audio_embeddings[0](codes[..., 0])                      # _prepare_prompts :335-393
             if self.prefix_mode == 0:
                 for j in range(1, nar_stage):
-                    y_emb = y_emb + self.nar_audio_embeddings[j](codes[..., j])
+                    self.nar_audio_embeddings[j].add_to(y_emb, codes[..., j])
             else:
                 for j in range(1, self.num_quantizers):
-                    y_emb[:, :P] += self.nar_audio_embeddings[j](codes[:, :P, j])
-                    if j < nar_stage:
-                        y_emb[:, P:] += self.nar_audio_embeddings[j](codes[:, P:, j])
+                    for n in range(N):  # row ranges of one utterance are contiguous
+                        self.nar_audio_embeddings[j].add_to(y_emb[n, :P], codes[n, :P, j])
+                        if j < nar_stage:
+                            self.nar_audio_embeddings[j].add_to(y_emb[n, P:], codes[n, P:, j])
             targets = codes[:, P:, nar_stage].reshape(-1)                            # :906, :916-917
             ye = self.nar_audio_position(self.nar_audio_prenet(y_emb))                             # :919-920
             h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), self.nar_stage_embeddings[nar_stage - 1].weight))  # :922-926

@@ -103,6 +103,12 @@ class TokenEmbedding(_HipModule):
             raise NotImplementedError("dropout (training) is outside the decode path")
         return ops.token_embedding(x.to(self.word_embeddings.weight.device, torch.int64), self.word_embeddings.weight.detach())
 
+    def add_to(self, inout: Tensor, x: Tensor) -> Tensor:
+        """``inout += self(x)`` in one kernel (no reference counterpart as a method: it is ``y_emb[...] += embedding_layer(codes)``,
+        valle.py:1104-1113, 1134); ``inout`` a contiguous fp32 view of whole rows."""
+        _need_device(self.word_embeddings.weight, "TokenEmbedding")
+        return ops.token_embedding_add(inout, x.to(self.word_embeddings.weight.device, torch.int64), self.word_embeddings.weight.detach())
+
 
 def sine_pe_table(length: int, dim_model: int) -> Tensor:
     """The reference's table, built by the same fp32 torch ops (embedding.py:75-91), (length, d) on the host."""
@@ -349,6 +355,40 @@ class MultiheadAttention(_HipModule):
         tl = torch.full((B,), text_len, dtype=torch.int32, device=xn.device)
         return ops.attention(qkv, seq_off, tl, self.num_heads, causal)
 
+    def _cross_forward(self, query: Tensor, key: Tensor, value: Tensor, key_padding_mask, need_weights, attn_mask):
+        """MultiheadAttention.forward(x, mem, mem): VALL-F's ``multihead_attn`` (valle/modules/transformer.py:582-597): queries
+        projected by the first d rows of the packed in-proj, keys / values of the memory by the other 2 d (activation.py:128-130),
+        un-masked softmax(Q K^T / sqrt(dh)) V per head (``vle_op_cross_attention``), out_proj."""
+        if value is not key:
+            raise NotImplementedError("cross-attention with different key and value tensors is not on the decode path")
+        if attn_mask is not None:
+            raise NotImplementedError("memory_mask: VALL-F passes None (valle.py:629)")
+        if key_padding_mask is not None and bool(key_padding_mask.any()):
+            raise NotImplementedError("memory_key_padding_mask: the decode path runs unpadded sequences")
+        if need_weights:
+            raise NotImplementedError("need_weights=True is not produced (transformer.py:594 calls with need_weights=False)")
+        if self.training and self.dropout > 0:
+            raise NotImplementedError("dropout (training) is outside the decode path")
+        x, mem = query, key
+        unbatched = x.dim() == 2
+        if unbatched:
+            x, mem = x.unsqueeze(0 if self.batch_first else 1), mem.unsqueeze(0 if self.batch_first else 1)
+        if not self.batch_first:
+            x, mem = x.transpose(0, 1), mem.transpose(0, 1)
+        B, T, d = x.shape
+        S = mem.shape[1]
+        tdt = self._tdtype()
+        w, b = self._w(self.in_proj_weight), self.in_proj_bias.detach()
+        q = ops.linear(x.reshape(B * T, d).to(tdt).contiguous(), w[:d], b[:d])
+        kv = ops.linear(mem.reshape(B * S, d).to(tdt).contiguous(), w[d:], b[d:])
+        att = torch.cat([ops.cross_attention(q[i * T:(i + 1) * T], kv[i * S:(i + 1) * S], self.num_heads) for i in range(B)], dim=0)
+        out = ops.linear(att, self._w(self.out_proj.weight), self.out_proj.bias.detach(), epilogue=ops.EPI_F32).view(B, T, d)
+        if not self.batch_first:
+            out = out.transpose(0, 1)
+        if unbatched:
+            out = out.squeeze(0 if self.batch_first else 1)
+        return out, None
+
     def forward(self, query: Tensor, key: Tensor, value: Tensor, key_padding_mask: Optional[Tensor] = None,
                 need_weights: bool = True, attn_mask: Optional[Tensor] = None, average_attn_weights: bool = True):
         _need_device(query, "MultiheadAttention")
@@ -379,43 +419,6 @@ class MultiheadAttention(_HipModule):
             out = out.squeeze(0 if self.batch_first else 1)
         return out, None
 
-
-def _mha_cross_forward(self, query: Tensor, key: Tensor, value: Tensor, key_padding_mask, need_weights, attn_mask):
-    """MultiheadAttention.forward(x, mem, mem): VALL-F's ``multihead_attn`` (valle/modules/transformer.py:582-597): queries
-    projected by the first d rows of the packed in-proj, keys / values of the memory by the other 2 d (activation.py:128-130),
-    un-masked softmax(Q K^T / sqrt(dh)) V per head (``vle_op_cross_attention``), out_proj."""
-    if value is not key:
-        raise NotImplementedError("cross-attention with different key and value tensors is not on the decode path")
-    if attn_mask is not None:
-        raise NotImplementedError("memory_mask: VALL-F passes None (valle.py:629)")
-    if key_padding_mask is not None and bool(key_padding_mask.any()):
-        raise NotImplementedError("memory_key_padding_mask: the decode path runs unpadded sequences")
-    if need_weights:
-        raise NotImplementedError("need_weights=True is not produced (transformer.py:594 calls with need_weights=False)")
-    if self.training and self.dropout > 0:
-        raise NotImplementedError("dropout (training) is outside the decode path")
-    x, mem = query, key
-    unbatched = x.dim() == 2
-    if unbatched:
-        x, mem = x.unsqueeze(0 if self.batch_first else 1), mem.unsqueeze(0 if self.batch_first else 1)
-    if not self.batch_first:
-        x, mem = x.transpose(0, 1), mem.transpose(0, 1)
-    B, T, d = x.shape
-    S = mem.shape[1]
-    tdt = self._tdtype()
-    w, b = self._w(self.in_proj_weight), self.in_proj_bias.detach()
-    q = ops.linear(x.reshape(B * T, d).to(tdt).contiguous(), w[:d], b[:d])
-    kv = ops.linear(mem.reshape(B * S, d).to(tdt).contiguous(), w[d:], b[d:])
-    att = torch.cat([ops.cross_attention(q[i * T:(i + 1) * T], kv[i * S:(i + 1) * S], self.num_heads) for i in range(B)], dim=0)
-    out = ops.linear(att, self._w(self.out_proj.weight), self.out_proj.bias.detach(), epilogue=ops.EPI_F32).view(B, T, d)
-    if not self.batch_first:
-        out = out.transpose(0, 1)
-    if unbatched:
-        out = out.squeeze(0 if self.batch_first else 1)
-    return out, None
-
-
-MultiheadAttention._cross_forward = _mha_cross_forward
 
 
 # ---- valle/modules/transformer.py: encoder -----------------------------------------------------------

@@ -175,6 +175,22 @@ def token_embedding(ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
     return out
 
 
+def token_embedding_add(inout: torch.Tensor, ids: torch.Tensor, table: torch.Tensor) -> torch.Tensor:
+    """``inout += table[ids]`` in place (``y_emb[:, :P] += nar_audio_embeddings[j](codes)``, valle.py:1104-1113, 1134): inout fp32
+    (..., d) CONTIGUOUS (a view of whole rows is fine), ids int64 with one id per row."""
+    lib = _lib.load()
+    assert inout.dtype == torch.float32 and inout.is_contiguous() and ids.dtype == torch.int64 and table.dtype == torch.float32
+    ids, table = ids.contiguous(), table.contiguous()
+    d = table.shape[1]
+    assert inout.shape[-1] == d and inout.numel() == ids.numel() * d
+    if ids.numel():
+        lo, hi = torch.aminmax(ids)
+        if int(lo) < 0 or int(hi) >= table.shape[0]:
+            raise IndexError(f"token id out of range for an embedding table of {table.shape[0]} rows: min {int(lo)}, max {int(hi)}")
+    _lib.check(lib.vle_op_token_embedding_add(_st(table), _p(ids), _p(table), _p(inout), ids.numel(), d))
+    return inout
+
+
 def sine_positional(x: torch.Tensor, pe: torch.Tensor, alpha: torch.Tensor, x_scale: float = 1.0) -> torch.Tensor:
     """SinePositionalEmbedding.forward (embedding.py:93-97): x * x_scale + alpha * pe[:T]; x fp32 (B, T, d), pe (>=T, d)."""
     lib = _lib.load()

@@ -306,6 +306,10 @@ static int g1_dispatch_rpw(hipStream_t st, const SkinnyArgs& a) {
     int rpw = 1;
     if (a.pro != PRO_ATTN) {
       if (a.N >= 4096 && NCH <= 2) rpw = 4;
+      // N = 3 x 1024 k (the QKV GEMV at d = 1024 k): 3 rows per wave give exactly k workgroups per CU.  With 2 rows per wave
+      // 384 workgroups leave half the CUs with two and half with one, and the launch ends 1.4 us after its first wave does
+      // (profiles/r02_ktrace_b1_timeline.csv, end_spread); measured 253.4 -> 251.1 us per step (tools/ar_tune.py qkv_rpw3)
+      else if (a.N % 3 == 0 && (a.N / 3) % 1024 == 0) rpw = 3;
       else if (a.N >= 2048) rpw = 2;
     }
     if (a.rpw_override > 0) rpw = a.rpw_override;
@@ -314,6 +318,7 @@ static int g1_dispatch_rpw(hipStream_t st, const SkinnyArgs& a) {
     switch (rpw) {
       case 1: return g1_dispatch_pe<T, NCH, 1>(st, a);
       case 2: return g1_dispatch_pe<T, NCH, 2>(st, a);
+      case 3: return g1_dispatch_pe<T, NCH, 3>(st, a);
       case 4:
         if constexpr (NCH <= 2) return g1_dispatch_pe<T, NCH, 4>(st, a);
         return g1_dispatch_pe<T, NCH, 2>(st, a);

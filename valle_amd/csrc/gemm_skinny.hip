@@ -328,31 +328,28 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   }
   if (wave >= MF) return;
   if (ln_in) {
-    // merge the row's 16-column groups in slot order (Chan et al.: mean / M2 of a union; every group has 16 elements), then
-    // the four quarters held by lanes fg = 0..3 with formulas symmetric in the two halves, so all four lanes agree bitwise
-    float mean = lst[0][0], m2 = lst[0][1], cnt = 16.f;
+    // merge the row's 16-column groups (mean_g, M2_g = sum (x - mean_g)^2).  Every group has 16 elements, so the union is
+    //   mean = average of the group means,   M2 = sum_g M2_g + 16 sum_g (mean_g - mean)^2
+    // (Chan et al. for equal counts): two short passes over the lane's quarter of the slots, no divisions, no dependent chain of
+    // running means (the general pairwise update cost ~15 instructions per group on the epilogue's critical path).  Fixed order,
+    // and the cross-lane sums over fg = 0..3 are commutative pairwise adds: all four lanes of a row agree bitwise.
+    float msum = 0.f;
 #pragma unroll
-    for (int j = 0; j < LN_MAXQ; ++j) {
+    for (int j = 0; j < LN_MAXQ; ++j)
+      if (j < ln_nq) msum += lst[j][0] + lst[j][2];
+    msum += __shfl_xor(msum, 16, 64);
+    msum += __shfl_xor(msum, 32, 64);
+    const float cnt = 16.f * (float)a.lnc.nslots;  // = K of the producer's rows
+    const float mean = msum / (float)a.lnc.nslots;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j)
       if (j < ln_nq) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h) {
-          if (j == 0 && h == 0) continue;
-          const float mb = lst[j][2 * h], qb = lst[j][2 * h + 1];
-          const float delta = mb - mean, tot = cnt + 16.f;
-          mean = fmaf(delta, 16.f / tot, mean);
-          m2 += qb + delta * delta * (cnt * 16.f / tot);
-          cnt = tot;
-        }
+        const float d0 = lst[j][0] - mean, d1 = lst[j][2] - mean;
+        m2 += (lst[j][1] + lst[j][3]) + 16.f * (d0 * d0 + d1 * d1);
       }
-    }
-#pragma unroll
-    for (int o = 16; o <= 32; o <<= 1) {
-      const float mo = __shfl_xor(mean, o, 64), qo = __shfl_xor(m2, o, 64);
-      const float delta = mo - mean;
-      mean = 0.5f * (mean + mo);
-      m2 = (m2 + qo) + delta * delta * (cnt * 0.5f);
-      cnt *= 2.f;
-    }
+    m2 += __shfl_xor(m2, 16, 64);
+    m2 += __shfl_xor(m2, 32, 64);
     const float rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
     if constexpr (W8) v = v * scale4;
     v = (v - mean * wg4) * rstd + bias4;  // bias4 = wb = W beta + bias

@@ -150,8 +150,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
           s[f][kb][r] = v;
           mt = fmaxf(mt, v);
         }
-      mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-      mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+      mt = rows4_max(mt);
       const float mn = fmaxf(m[f], mt);
       const float alpha = __builtin_amdgcn_exp2f(m[f] - mn);
       m[f] = mn;
@@ -191,8 +190,7 @@ __global__ __launch_bounds__(256) void attn_mfma_kernel(const bf16_t* __restrict
 #pragma unroll
   for (int f = 0; f < QW; ++f) {
     float lf = l[f];
-    lf += __shfl_xor(lf, 16, 64);
-    lf += __shfl_xor(lf, 32, 64);
+    lf = rows4_sum(lf);
     if (qvalid[f]) {
       const float inv = 1.0f / lf;
       bf16_t* op = out + (int64_t)(off + qrow[f]) * d + h * DH + g * 4;

@@ -276,8 +276,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
       // 8 in the exp2 domain => P <= 256, nothing for bf16 P / fp32 sums) the reference stays: no cross-lane reduction, no
       // rescale.  Softmax does not depend on the reference (O and l carry the same factor); defer = 0 is the exact-maximum form.
       if (!__all(mt <= m[f] + defer)) {  // wave-uniform; always taken on the first tile (m = -1e30)
-        mt = fmaxf(mt, __shfl_xor(mt, 16, 64));
-        mt = fmaxf(mt, __shfl_xor(mt, 32, 64));
+        mt = rows4_max(mt);
         const float mn = fmaxf(m[f], mt);
         const float alpha = __builtin_amdgcn_exp2f((m[f] - mn) * sl2);  // 1 exactly for the rows whose maximum did not grow
         m[f] = mn;
@@ -328,8 +327,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
 #pragma unroll
   for (int f = 0; f < QW; ++f) {
     float lf = l[f];
-    lf += __shfl_xor(lf, 16, 64);
-    lf += __shfl_xor(lf, 32, 64);
+    lf = rows4_sum(lf);
     if (qvalid[f]) {
       const float inv = 1.0f / lf;
       bf16_t* op = out + (int64_t)(off + qrow[f]) * d + h * DH + g * 4;

@@ -204,6 +204,24 @@ __device__ inline float row16_max_dpp(float v) {
 __device__ inline float readlane_f32(float v, int l) {
   return __builtin_bit_cast(float, __builtin_amdgcn_readlane(__builtin_bit_cast(int, v), l));
 }
+// Sum / max of v over the 4 lanes {l, l ^ 16, l ^ 32, l ^ 48} (the four 16-lane rows of the wave), the same value in all
+// four: gfx950's v_permlane16_swap / v_permlane32_swap instead of two ds_bpermute round trips through the LDS (~100 cycles
+// each, on the epilogue's critical path of every batched AR GEMM).  swap(x, x) leaves {own, partner} (in either order) in the
+// two results; add and max are commutative, so the partners agree bitwise.
+typedef unsigned permlane_u32x2 __attribute__((ext_vector_type(2)));
+__device__ inline float rows4_sum(float v) {
+  permlane_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(r[0]) + __uint_as_float(r[1]);
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+__device__ inline float rows4_max(float v) {
+  permlane_u32x2 r = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+  r = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+
 __device__ inline float wave_sum_dpp(float v) {
   v = row16_sum_dpp(v);
   return (readlane_f32(v, 0) + readlane_f32(v, 16)) + (readlane_f32(v, 32) + readlane_f32(v, 48));

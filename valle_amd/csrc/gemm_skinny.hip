@@ -91,18 +91,14 @@ __device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, i
 #pragma unroll
         for (int r = 0; r < 4; ++r) o4[r] = (__bf16)(x4[r] * gamma4[r]);
         *reinterpret_cast<gs_bf16x4*>(reinterpret_cast<bf16_t*>(a.lnp.xg_out) + xf_index(m, ncol, a.lnp.MF, a.lnp.w8 != 0)) = o4;
-        float s = (x4[0] + x4[1]) + (x4[2] + x4[3]);
-        s += __shfl_xor(s, 16, 64);
-        s += __shfl_xor(s, 32, 64);
-        const float mean = s * (1.0f / 16.0f);
+        const float mean = rows4_sum((x4[0] + x4[1]) + (x4[2] + x4[3])) * (1.0f / 16.0f);
         float q = 0.f;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const float t = x4[r] - mean;
           q = fmaf(t, t, q);
         }
-        q += __shfl_xor(q, 16, 64);
-        q += __shfl_xor(q, 32, 64);
+        q = rows4_sum(q);
         if ((threadIdx.x & 63) < 16) {
           typedef float gs_f32x2 __attribute__((ext_vector_type(2)));
           *reinterpret_cast<gs_f32x2*>(a.lnp.stats_out + ((int64_t)m * (N >> 4) + (ncol >> 4)) * 2) = gs_f32x2{mean, q};
@@ -337,8 +333,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
 #pragma unroll
     for (int j = 0; j < LN_MAXQ; ++j)
       if (j < ln_nq) msum += lst[j][0] + lst[j][2];
-    msum += __shfl_xor(msum, 16, 64);
-    msum += __shfl_xor(msum, 32, 64);
+    msum = rows4_sum(msum);
     const float cnt = 16.f * (float)a.lnc.nslots;  // = K of the producer's rows
     const float mean = msum / (float)a.lnc.nslots;
     float m2 = 0.f;
@@ -348,8 +343,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
         const float d0 = lst[j][0] - mean, d1 = lst[j][2] - mean;
         m2 += (lst[j][1] + lst[j][3]) + 16.f * (d0 * d0 + d1 * d1);
       }
-    m2 += __shfl_xor(m2, 16, 64);
-    m2 += __shfl_xor(m2, 32, 64);
+    m2 = rows4_sum(m2);
     const float rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
     if constexpr (W8) v = v * scale4;
     v = (v - mean * wg4) * rstd + bias4;  // bias4 = wb = W beta + bias

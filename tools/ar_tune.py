@@ -31,18 +31,16 @@ def main():
     Y = torch.stack([synth_inputs(b)[1] for b in range(B)]).to(dev)
     variants = [
         ("default", {}),
-        ("ns4_nk4", {"nsplit": 4, "attn_nk": 4}),
-        ("ns4_nk8", {"nsplit": 4, "attn_nk": 8}),
-        ("ns8_nk4", {"nsplit": 8, "attn_nk": 4}),
-        ("ns2_nk8", {"nsplit": 2, "attn_nk": 8}),
-        ("qkv_rpw3", {"gemv1_rpw_qkv": 3}),
-        ("qkv_rpw1", {"gemv1_rpw_qkv": 1}),
-        ("qkv_rpw4", {"gemv1_rpw_qkv": 4}),
+        ("ns2_nk4", {"nsplit": 2, "attn_nk": 4}),
+        ("qkv_rpw2", {"gemv1_rpw_qkv": 2}),
+        ("ffn1_rpw2", {"gemv1_rpw_ffn1": 2}),
+        ("ffn1_rpw1", {"gemv1_rpw_ffn1": 1}),
+        ("ffn1_rpw3", {"gemv1_rpw_ffn1": 3}),
     ]
     res = {name: [] for name, _ in variants}
     for r in range(args.rounds):
         for name, opts in variants:
-            for k in ("nsplit", "gemv1_rpw", "gemv1_rpw_qkv", "no_gemv1", "attn_nk", "steps_per_graph"):
+            for k in ("nsplit", "gemv1_rpw", "gemv1_rpw_qkv", "gemv1_rpw_ffn1", "no_gemv1", "attn_nk", "steps_per_graph"):
                 eng.set_option(k, 0)
             for k, v in opts.items():
                 eng.set_option(k, v)

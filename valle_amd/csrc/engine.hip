@@ -157,6 +157,7 @@ struct vle_engine {
   int opt_spg = 0;            // option "steps_per_graph": overrides cfg.steps_per_graph when > 0
   int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
   int opt_rpw_qkv = 0;        // option "gemv1_rpw_qkv": the same for the QKV GEMV only
+  int opt_rpw_ffn1 = 0;       // option "gemv1_rpw_ffn1": ... for the FFN1 GEMV only
   std::vector<hipEvent_t> prof_pool;
   size_t prof_used = 0;
   std::vector<int> prof_tags;
@@ -354,7 +355,7 @@ int choose_nsplit(const vle_engine* e, int B) {
 int launch_ar_linear(vle_engine* e, const SkinnyArgs& a) {
   if (a.B == 1 && !e->opt_no_gemv1) {
     SkinnyArgs t = a;
-    t.rpw_override = (a.epi == SEPI_QKV && e->opt_rpw_qkv > 0) ? e->opt_rpw_qkv : e->opt_rpw;
+    t.rpw_override = (a.epi == SEPI_QKV && e->opt_rpw_qkv > 0) ? e->opt_rpw_qkv : (a.epi == SEPI_RELU && e->opt_rpw_ffn1 > 0) ? e->opt_rpw_ffn1 : e->opt_rpw;
     t.kt = e->next_kt();
     if (e->w8 && a.w8 != nullptr) {  // FP8W: stream the e4m3fn codes; shapes gemv1 lacks fall through to bf16(W')
       t.w = a.w8;
@@ -1963,7 +1964,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "gemv1_rpw_qkv" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal" || n == "gs_fuse_ln" || n == "gs_rot" || n == "gs_dbg") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "gemv1_rpw_qkv" || n == "gemv1_rpw_ffn1" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal" || n == "gs_fuse_ln" || n == "gs_rot" || n == "gs_dbg") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
     else if (n == "gs_fuse_ln") e->opt_gs_fuse_ln = value != 0;
     else if (n == "gs_rot") e->opt_gs_rot = (int)value;
@@ -1976,6 +1977,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     else if (n == "attn_nk") e->opt_nk = (int)value;
     else if (n == "steps_per_graph") e->opt_spg = (int)value;
     else if (n == "gemv1_rpw_qkv") e->opt_rpw_qkv = (int)value;
+    else if (n == "gemv1_rpw_ffn1") e->opt_rpw_ffn1 = (int)value;
     else e->opt_rpw = (int)value;
     (void)hipStreamSynchronize(e->st);
     for (auto& kv : e->graphs) {

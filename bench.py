@@ -32,7 +32,7 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 S_TEXT, P_PROMPT = 47, 225  # 47 phonemes, 3 s x 75 Hz prompt
-PMC_STEP_BYTES = 352_700_000  # (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the 62 kernels of one AR step, mean context (round 2 PMC pass)
+PMC_STEP_BYTES = 352_200_000  # (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the 62 kernels of one AR step, mean context (round 2 PMC pass)
 
 
 def synth_inputs(index: int, S: int = S_TEXT, P: int = P_PROMPT):

@@ -71,6 +71,20 @@ CASES = {
 }
 
 
+# VALL-F builds its decoders with torch's nn.TransformerDecoder (valle.py:141); the container of torch >= 2 rejects the
+# reference's tuple inputs and passes keywords its layers do not take.  For the VALL-F fixtures ONLY the
+# container's forward is replaced, from outside, by the loop of torch 1.13.1 (the reference's pin, README.md:31): each layer
+# on (output, memory), then the norm.  Every layer, norm, embedding and the inference / forward code are the reference's own.
+def dec_forward_113(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, **_):
+    output = tgt
+    for mod in self.layers:
+        output = mod(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask, tgt_key_padding_mask=tgt_key_padding_mask,
+                     memory_key_padding_mask=memory_key_padding_mask)
+    if self.norm is not None:
+        output = self.norm(output)
+    return output
+
+
 def build_reference(vm, cfg: vo.OracleConfig, sd):
     p = AttributeDict(
         model_name="vall-f" if cfg.model == "vallf" else "valle", decoder_dim=cfg.d_model, nhead=cfg.nhead, num_decoder_layers=cfg.num_layers,
@@ -108,23 +122,9 @@ def run_case(vm, name: str, spec: dict):
         for i, layer in enumerate(model.nar_predict_layers):
             hooks.append(layer.register_forward_hook(lambda m, a, out, i=i: nar_logits.__setitem__(i, out.detach().clone()[0])))
 
-    # VALL-F builds its decoders with torch's nn.TransformerDecoder (valle.py:141); the container of torch >= 2 rejects the
-    # reference's tuple inputs and passes keywords its layers do not take.  For these fixtures ONLY the
-    # container's forward is replaced, from outside, by the loop of torch 1.13.1 (the reference's pin, README.md:31): each layer
-    # on (output, memory), then the norm.  Every layer, norm, embedding and the inference loop itself are the reference's own.
     orig_dec_forward = torch.nn.TransformerDecoder.forward
-
-    def dec_forward_113(self, tgt, memory, tgt_mask=None, memory_mask=None, tgt_key_padding_mask=None, memory_key_padding_mask=None, **_):
-        output = tgt
-        for mod in self.layers:
-            output = mod(output, memory, tgt_mask=tgt_mask, memory_mask=memory_mask, tgt_key_padding_mask=tgt_key_padding_mask,
-                         memory_key_padding_mask=memory_key_padding_mask)
-        if self.norm is not None:
-            output = self.norm(output)
-        return output
-
     if cfg.model == "vallf":
-        torch.nn.TransformerDecoder.forward = dec_forward_113
+        torch.nn.TransformerDecoder.forward = dec_forward_113  # see its comment: torch 1.13's container loop, nothing else
     ref_valle.topk_sampling = spy
     t0 = time.time()
     try:

@@ -16,7 +16,7 @@ import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import valle_oracle as vo  # noqa: E402
-from oracle.make_golden import build_reference  # noqa: E402
+from oracle.make_golden import build_reference, dec_forward_113  # noqa: E402
 from oracle.ref_import import import_reference  # noqa: E402
 
 OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden", "forward")
@@ -26,6 +26,10 @@ CASES = {
     "fwd_pm0_n2": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=0), N=2, S=6, T=17, train_stage=0, seed=5),
     "fwd_pm1_ar_only": dict(cfg=dict(d_model=128, nhead=2, num_layers=2, prefix_mode=1), N=2, S=9, T=30, train_stage=1, seed=7),
     "fwd_pm1_nar_only": dict(cfg=dict(d_model=128, nhead=2, num_layers=2, prefix_mode=1), N=3, S=5, T=40, train_stage=2, seed=11),
+    # VALLF.forward (valle.py:395-564) under torch 1.13's nn.TransformerDecoder loop (oracle/make_golden.py dec_forward_113)
+    "fwd_vallf_pm1_n2": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=1, model="vallf"), N=2, S=6, T=20, train_stage=0, seed=17),
+    "fwd_vallf_postnorm_prenet_pm0": dict(cfg=dict(d_model=64, nhead=2, num_layers=1, prefix_mode=0, norm_first=False, add_prenet=True, model="vallf"),
+                                          N=1, S=5, T=15, train_stage=0, seed=19),
     "fwd_pm0_bos": dict(cfg=dict(d_model=64, nhead=4, num_layers=1, prefix_mode=0, prepend_bos=True), N=1, S=5, T=13, train_stage=0, seed=13),
 }
 
@@ -59,8 +63,14 @@ def main():
             return emb, plen
 
         model._prepare_prompts = spy
-        with torch.no_grad():
-            _, loss, metrics = model(x, xl, y, yl, reduction="sum", train_stage=spec["train_stage"])
+        orig_fwd = torch.nn.TransformerDecoder.forward
+        if cfg.model == "vallf":
+            torch.nn.TransformerDecoder.forward = dec_forward_113
+        try:
+            with torch.no_grad():
+                _, loss, metrics = model(x, xl, y, yl, reduction="sum", train_stage=spec["train_stage"])
+        finally:
+            torch.nn.TransformerDecoder.forward = orig_fwd
         out = dict(loss=np.float64(float(loss)), N=np.int32(spec["N"]), S=np.int32(spec["S"]), T=np.int32(spec["T"]),
                    seed=np.int32(spec["seed"]), train_stage=np.int32(spec["train_stage"]),
                    nar_stage=np.int32(drawn.get("nar_stage", -1)), prefix_len=np.int32(drawn.get("prefix_len", -1)),

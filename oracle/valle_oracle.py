@@ -735,9 +735,13 @@ def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum",
                 xe, ye = text_prenet(sd, "ar_text_prenet", xe), audio_prenet(sd, "ar_audio_prenet", ye)  # :828, :862
             xe = sine_position(xe, sd["ar_text_position.alpha"])  # :827-829
             ye = sine_position(ye, sd["ar_audio_position.alpha"])  # :861-863
-            mask = prefix_lm_mask(S, inputs.shape[0])  # :833-859 without padding
-            dec = encoder(sd, "ar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=mask)  # :867-872
-            logits = F.linear(dec[S:], sd["ar_predict_layer.weight"])  # :873
+            if cfg.model == "vallf":  # VALLF.forward, valle.py:474-489: the text is the memory, the audio a causal target
+                Ta = inputs.shape[0]
+                dec = decoder(sd, "ar_decoder", cfg, ye, xe, tgt_mask=torch.triu(torch.ones(Ta, Ta, dtype=torch.bool), diagonal=1))
+            else:
+                mask = prefix_lm_mask(S, inputs.shape[0])  # :833-859 without padding
+                dec = encoder(sd, "ar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=mask)[S:]  # :867-872
+            logits = F.linear(dec, sd["ar_predict_layer.weight"])  # :873
             if trace is not None:
                 trace.setdefault("ar_logits", []).append(logits.clone())
             ar_loss = ar_loss + F.cross_entropy(logits, targets, reduction="sum")  # :875
@@ -773,8 +777,11 @@ def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum",
             targets = codes[b, P:, nar_stage]  # :906, :916-917
             ye = sine_position(audio_prenet(sd, "nar_audio_prenet", y_emb) if cfg.add_prenet else y_emb, sd["nar_audio_position.alpha"])  # :919-920
             stage = sd[f"nar_stage_embeddings.{nar_stage - 1}.word_embeddings.weight"]
-            dec = encoder(sd, "nar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=None, stage_emb=stage)  # :922-926
-            logits = F.linear(dec[S + P:], sd[f"nar_predict_layers.{nar_stage - 1}.weight"])  # :927-932
+            if cfg.model == "vallf":  # valle.py:537-544: cross-attention to the text
+                dec = decoder(sd, "nar_decoder", cfg, ye, xe, tgt_mask=None, stage_emb=stage)[P:]
+            else:
+                dec = encoder(sd, "nar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=None, stage_emb=stage)[S + P:]  # :922-926
+            logits = F.linear(dec, sd[f"nar_predict_layers.{nar_stage - 1}.weight"])  # :927-932
             if trace is not None:
                 trace.setdefault("nar_logits", []).append(logits.clone())
             nar_loss = nar_loss + F.cross_entropy(logits, targets, reduction="sum")  # :936-942 (no padded targets here)

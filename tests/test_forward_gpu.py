@@ -17,8 +17,9 @@ DEV = "cuda:0"
 @pytest.mark.parametrize("dtype,rtol", [("fp32", 2e-5), ("bf16", 5e-3)])
 def test_forward_loss_matches_reference(name, dtype, rtol):
     z, cfg, sd, x, xl, y, yl, kw = load_forward_case(name)
-    m = valle_amd.VALLE(cfg.d_model, cfg.nhead, cfg.num_layers, prefix_mode=cfg.prefix_mode, prepend_bos=cfg.prepend_bos,
-                        engine_dtype=dtype)
+    cls = valle_amd.VALLF if cfg.model == "vallf" else valle_amd.VALLE  # VALLF.forward, valle.py:395-564
+    m = cls(cfg.d_model, cfg.nhead, cfg.num_layers, norm_first=cfg.norm_first, add_prenet=cfg.add_prenet, prefix_mode=cfg.prefix_mode,
+            prepend_bos=cfg.prepend_bos, engine_dtype=dtype)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
     (_, codes), loss, metrics = m(x.to(DEV), xl.to(DEV), y.to(DEV), yl.to(DEV), reduction="sum", **kw)

@@ -345,6 +345,19 @@ class VALLE(nn.Module):
         h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), stage_weight))
         return h[0, xe.shape[1] + P:]
 
+    def _fwd_ar_hidden(self, xe: torch.Tensor, ye: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced AR pass over a batch: decoder outputs of the audio positions, (N, Ta, d) (valle.py:833-872)."""
+        S, T = xe.shape[1], ye.shape[1]
+        i = torch.arange(S + T, device=xe.device)
+        allowed = i[None, :] < torch.maximum(i[:, None] + 1, torch.tensor(S, device=xe.device))       # prefix-LM mask
+        h, _ = self.ar_decoder((torch.cat([xe, ye], dim=1), None), mask=~allowed)
+        return h[:, S:]
+
+    def _fwd_nar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, stage_weight: torch.Tensor) -> torch.Tensor:
+        """Teacher-forced NAR pass: decoder outputs of the audio positions, (N, T, d) (valle.py:922-926)."""
+        h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), stage_weight))
+        return h[:, xe.shape[1]:]
+
     def _nar_blocks(self, text, y0, prompts, P: int, prefix_mode: int, enrolled_len) -> torch.Tensor:
         """The seven NAR stages, valle.py:1059-1137 (and continual()'s :1176-1238): text (1, S) ids, y0 (1, P + G) first-codebook
         stream, prompts (1, P, Q) -> codes (1, G, Q)."""
@@ -428,10 +441,7 @@ class VALLE(nn.Module):
             Ta = inputs.shape[1]
             xe = self.ar_text_position(self.ar_text_prenet(self.ar_text_embedding(x)))            # :827-829
             ye = self.ar_audio_position(self.ar_audio_prenet(self.ar_audio_embedding(inputs)))     # :861-863
-            i = torch.arange(S + Ta, device=dev)
-            allowed = i[None, :] < torch.maximum(i[:, None] + 1, torch.tensor(S, device=dev))  # prefix-LM mask, :833-859
-            h, _ = self.ar_decoder((torch.cat([xe, ye], dim=1), None), mask=~allowed)  # :867-872
-            logits = predict(h[:, S:].reshape(N * Ta, -1), self.ar_predict_layer.weight)  # :873
+            logits = predict(self._fwd_ar_hidden(xe, ye).reshape(N * Ta, -1), self.ar_predict_layer.weight)  # :833-873
             loss_rows, hit = ops.cross_entropy_rows(logits, targets.reshape(-1), ignore_index=-100, topk=10)
             total_loss = total_loss + loss_rows.sum()                                 # :875 (no ignore_index)
             kept = targets.reshape(-1) != NUM_AUDIO_TOKENS                           # the metric ignores EOS targets (:157-163)
@@ -465,8 +475,8 @@ class VALLE(nn.Module):
                             self.nar_audio_embeddings[j].add_to(y_emb[n, P:], codes[n, P:, j])
             targets = codes[:, P:, nar_stage].reshape(-1)                            # :906, :916-917
             ye = self.nar_audio_position(self.nar_audio_prenet(y_emb))                             # :919-920
-            h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), self.nar_stage_embeddings[nar_stage - 1].weight))  # :922-926
-            logits = predict(h[:, S + P:].reshape(N * (T - P), -1), self.nar_predict_layers[nar_stage - 1].weight)  # :927-932
+            h = self._fwd_nar_hidden(xe, ye, self.nar_stage_embeddings[nar_stage - 1].weight)                 # :922-926
+            logits = predict(h[:, P:].reshape(N * (T - P), -1), self.nar_predict_layers[nar_stage - 1].weight)   # :927-932
             loss_rows, hit = ops.cross_entropy_rows(logits, targets, ignore_index=NUM_AUDIO_TOKENS, topk=10)
             total_loss = total_loss + loss_rows.sum() * (total_length / (total_length - P * N))  # :936-943
             kept = hit >= 0
@@ -481,7 +491,8 @@ class VALLF(VALLE):
     decoders are ``nn.TransformerDecoder`` stacks -- the text is their cross-attention MEMORY, the audio stream their (causal,
     for AR) target.  Decoded by the HIP block modules in the reference's loop (one full pass per AR step, :613-651); the
     state-dict keys are the reference's (``...multihead_attn...``, ``norm3``).  Not the production model: there is no fused
-    engine path, ``continual()`` does not exist in the reference's VALLF, and the teacher-forced ``forward()`` is not carried."""
+    engine path and ``continual()`` does not exist in the reference's VALLF; ``forward()`` (the teacher-forced scoring pass,
+    valle.py:395-564) is VALLE's with the two decoder passes replaced (same scope: eval mode, unpadded batches, prefix_mode 0 / 1)."""
 
     _decoder_factory = staticmethod(_cross_decoder)
     _eos_name = "VALL-F"
@@ -496,11 +507,18 @@ class VALLF(VALLE):
         h, _ = self.nar_decoder((ye, stage_weight), xe, tgt_mask=None, memory_mask=None)               # :691-697
         return h[0, P:]                                                                               # :698
 
+    def _fwd_ar_hidden(self, xe: torch.Tensor, ye: torch.Tensor) -> torch.Tensor:
+        T = ye.shape[1]
+        tgt_mask = torch.triu(torch.ones(T, T, device=ye.device, dtype=torch.bool), diagonal=1)        # valle.py:474-480
+        h, _ = self.ar_decoder((ye, None), xe, tgt_mask=tgt_mask, memory_mask=None)                    # :481-488
+        return h
+
+    def _fwd_nar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, stage_weight: torch.Tensor) -> torch.Tensor:
+        h, _ = self.nar_decoder((ye, stage_weight), xe, tgt_mask=None, memory_mask=None)               # :537-544
+        return h
+
     def continual(self, *a, **k):
         raise NotImplementedError("VALLF has no continual() (valle/models/valle.py: it is defined on VALLE only)")
-
-    def forward(self, *a, **k):
-        raise NotImplementedError("VALL-F's teacher-forced forward (valle.py:395-564) is not carried; decode with inference()")
 
 
 # ---- valle/models/__init__.py surface ---------------------------------------------------------------

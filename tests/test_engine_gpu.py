@@ -367,6 +367,51 @@ def test_fused_layernorm_batch_step_matches_layernorm_kernels(B, d, h, L, dtype)
     assert (runs[0][0] - ref_lg[0]).abs().max().item() == 0.0  # step 0 = the prefill's logits: same kernels in both modes
 
 
+@pytest.mark.parametrize("dtype", ["bf16", "fp8w"])
+@pytest.mark.parametrize("fuse_ln", [1, 0])
+@pytest.mark.parametrize("B,d,h,L", [(5, 256, 4, 3), (64, 1024, 16, 2), (33, 1024, 8, 2)])
+def test_attention_with_fused_out_proj_matches_separate_launches(B, d, h, L, dtype, fuse_ln):
+    """Option attn_oproj (a measured dead end kept for A/B -- the step gets SLOWER): the batched step's decode
+    attention launch also does the layer's out-proj + residual (+ the LayerNorm
+    producer): per (utterance, head) partial products with that head's slice of W_o, summed in head order by the utterance's last
+    block (decode_attn.hip AttnOproj).  Against the same engine with the separate out-proj GEMM, teacher-forced on its tokens:
+    the same bf16 products in another summation order -- logits within 1 % of sigma at every step, bit-identical run to run
+    (ragged batch: arrival order of the heads varies), head sizes 64 and 128."""
+    cfg = vo.OracleConfig(d_model=d, nhead=h, num_layers=L, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 23)
+    g = torch.Generator().manual_seed(10)
+    S = torch.randint(3, 9, (B,), generator=g).tolist()
+    P = torch.randint(4, 40, (B,), generator=g).tolist()
+    X = torch.zeros(B, max(S), dtype=torch.int64)
+    Y = torch.zeros(B, max(P), 8, dtype=torch.int64)
+    for b in range(B):
+        x, _, y = vo.make_inputs(S[b], P[b], seed=700 + b)
+        X[b, : S[b]] = x[0]; Y[b, : P[b]] = y[0]
+    X, Y = X.to(DEV), Y.to(DEV)
+    m = build_model(cfg, sd, dtype, max_batch=B)
+    eng = m.engine_for(B, max(S), max(P))
+    eng.set_option("trace_ar_logits", 1)
+    eng.set_option("ignore_eos", 1)
+    eng.set_option("gs_fuse_ln", fuse_ln)
+    n = 12
+    eng.set_option("attn_oproj", 0)
+    eng.prefill(X, S, Y, P)
+    c0, gl = eng.generate(top_k=1, max_new=n)
+    ref_tok, ref_lg = c0[:, :n].clone(), eng.fetch_ar_logits()[:n + 1].clone()
+    runs = []
+    eng.set_option("attn_oproj", 1)
+    for _ in range(3):
+        eng.prefill(X, S, Y, P)
+        eng.generate(top_k=1, forced=ref_tok, forced_lens=[n] * B)
+        runs.append(eng.fetch_ar_logits()[:n + 1].clone())
+    eng.set_option("attn_oproj", 0)
+    assert torch.equal(runs[0], runs[1]) and torch.equal(runs[0], runs[2]), "fused attention + out-proj is not deterministic"
+    sigma = ref_lg.std().item()
+    err = (runs[0] - ref_lg).abs().max().item()
+    assert err <= 0.01 * sigma, (err, sigma)  # measured 0.1-0.5 %
+    assert (runs[0][0] - ref_lg[0]).abs().max().item() == 0.0  # step 0 = the prefill's logits: same kernels in both modes
+
+
 def test_engine_grows_capacities_without_reloading_weights():
     """engine_for() on a bigger request re-creates the buffers in place (vle_reserve) -- same engine object, same weights on the
     device -- and the decodes before / after equal the oracle; a batch-1 engine grows into the batched (fused-LayerNorm) path."""

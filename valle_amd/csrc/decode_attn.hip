@@ -35,12 +35,108 @@ __device__ inline float group_sum(float v) {  // sum over the LPK consecutive la
   return v;
 }
 
-template <typename T, int VEC, int LPK, int NK>
+// ---- optional tail (batched step, one block per (utterance, head)): the out-proj of the layer, fused --------------------------
+// out_proj + residual (valle/modules/activation.py:421, transformer.py:297) of the new token needs all H heads of an utterance,
+// but it is linear in them: every (utterance, head) block multiplies ITS normalised head output (rounded to bf16 like the
+// stand-alone path's X) by its 2 dh-byte slice of every W_o row -- 128 KB from L2, shared by the B blocks of the head -- and
+// publishes the d partial sums; the LAST of an utterance's H blocks (ticket; write-through stores + vmcnt drain, no fences:
+// gemm_skinny.hip's split-K hand-off) adds the H partials in head order (deterministic), bias and the residual, and is the
+// producer of the fused LayerNorm (bf16(x * gamma_next) fragment-major + per-16-column statistics, kernels.h LnProducer).
+// One launch and one boundary less per layer; the W_o reads ride under the other blocks' KV streams.
+struct AttnOproj {
+  const bf16_t* w = nullptr;   // [d][d] row-major bf16 (bf16(W') in FP8W mode)
+  const float* bias = nullptr; // [d]
+  float* resid = nullptr;      // [B][d] fp32, updated in place
+  float* part = nullptr;       // [B][H][d] fp32 partial sums
+  int* cnt = nullptr;          // [B] tickets, zero between launches (self-resetting)
+  LnProducer lnp;
+};
+
+template <int LPKO>
+__device__ inline void attn_oproj_tail(const AttnOproj& fo, const float* sm_on, int b, int h, int nhead, int dh, int d) {
+  __shared__ int s_last;
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  constexpr int RPI = 64 / LPKO;  // W_o rows per wave-load: LPKO lanes x 16 bytes cover the head's dh bf16 of one row
+  const int part_l = lane % LPKO, sub = lane / LPKO;
+  const bool act = part_l * 8 < dh;
+  float ov[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) ov[j] = act ? sm_on[part_l * 8 + j] : 0.f;
+  float* pp = fo.part + ((int64_t)b * nhead + h) * d;
+  const bf16_t* wb = fo.w + h * dh + (act ? part_l * 8 : 0);
+  // a wave owns rows [w * d/4, (w + 1) * d/4) in chunks of 64: load i of a chunk covers rows i * RPI + sub; after the LPKO-lane
+  // butterfly every lane of a group holds its row's sum and lane (part_l == i % LPKO ...) keeps it, so one 256-byte store per chunk
+  const int rows_w = d >> 2;
+  for (int r0 = w * rows_w; r0 < (w + 1) * rows_w; r0 += 64) {
+    float keep = 0.f;
+#pragma unroll
+    for (int i = 0; i < 64 / RPI; ++i) {  // = LPKO loads per chunk
+      const int row = r0 + i * RPI + sub;
+      float wf[8];
+      load_vec16<bf16_t>(wb + (int64_t)row * d, wf);
+      float t = 0.f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) t = fmaf(wf[j], ov[j], t);
+      t = group_sum<LPKO>(act ? t : 0.f);
+      keep = part_l == i ? t : keep;  // lane (sub, part_l = i) keeps row r0 + i * RPI + sub
+    }
+    __hip_atomic_store(pp + r0 + part_l * RPI + sub, keep, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (tid == 0) {
+    const int t = __hip_atomic_fetch_add(fo.cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    s_last = t == nhead - 1;
+    if (t == nhead - 1) __hip_atomic_store(fo.cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-reset (graph replay)
+  }
+  __syncthreads();
+  if (!s_last) return;
+  // ---- last block of the utterance: sum the heads, finish the residual row, feed the next LayerNorm -------------------------------
+  typedef float f32x4_t __attribute__((ext_vector_type(4)));
+  for (int c = tid * 4; c < d; c += 1024) {
+    f32x4_t y = f32x4_t{0.f, 0.f, 0.f, 0.f};
+    for (int hh = 0; hh < nhead; ++hh) {  // fixed order: the sum does not depend on which head finished last
+      const float* ph = fo.part + ((int64_t)b * nhead + hh) * d + c;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) y[r] += __hip_atomic_load(ph + r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    const f32x4_t bias4 = fo.bias ? *reinterpret_cast<const f32x4_t*>(fo.bias + c) : f32x4_t{0.f, 0.f, 0.f, 0.f};
+    float* o = fo.resid + (int64_t)b * d + c;
+    const f32x4_t x4 = *reinterpret_cast<const f32x4_t*>(o) + (y + bias4);
+    *reinterpret_cast<f32x4_t*>(o) = x4;
+    if (fo.lnp.gamma != nullptr) {
+      typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+      typedef float f32x2_t __attribute__((ext_vector_type(2)));
+      const f32x4_t g4 = *reinterpret_cast<const f32x4_t*>(fo.lnp.gamma + c);
+      bf16x4_t o4;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) o4[r] = (__bf16)(x4[r] * g4[r]);
+      *reinterpret_cast<bf16x4_t*>(reinterpret_cast<bf16_t*>(fo.lnp.xg_out) + xf_index(b, c, fo.lnp.MF, fo.lnp.w8 != 0)) = o4;
+      // the 4 consecutive threads tid % 4 = 0..3 hold one 16-column group (d % 16 == 0: they are active together)
+      float sg = (x4[0] + x4[1]) + (x4[2] + x4[3]);
+      sg += dpp_f32<0xB1>(sg);
+      sg += dpp_f32<0x4E>(sg);
+      const float mean = sg * (1.0f / 16.0f);
+      float qg = 0.f;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float t = x4[r] - mean;
+        qg = fmaf(t, t, qg);
+      }
+      qg += dpp_f32<0xB1>(qg);
+      qg += dpp_f32<0x4E>(qg);
+      if ((tid & 3) == 0) *reinterpret_cast<f32x2_t*>(fo.lnp.stats_out + ((int64_t)b * (d >> 4) + (c >> 4)) * 2) = f32x2_t{mean, qg};
+    }
+  }
+}
+
+template <typename T, int VEC, int LPK, int NK, bool FO = false>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ q, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, const int32_t* __restrict__ kv_len,
                                                           float* __restrict__ part_o, float* __restrict__ part_ml, int nhead,
                                                           int dh, int ctx_max, int nsplit, T* __restrict__ out_norm,
-                                                          const int32_t* __restrict__ done, int out_xf, KTrace kt) {
+                                                          const int32_t* __restrict__ done, int out_xf, KTrace kt,
+                                                          AttnOproj fo = AttnOproj()) {
   const unsigned long long kt0 = ktrace_begin(kt);
   constexpr int KPW = 64 / LPK;         // keys per wave-load
   constexpr int WCH = NK * KPW;         // keys per wave per round
@@ -165,6 +261,23 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   __syncthreads();
   if (tid == 0) ktrace_end(kt, kt0, ((int)blockIdx.z * (int)gridDim.y + (int)blockIdx.y) * (int)gridDim.x + (int)blockIdx.x);  // one stamp per block (past the barrier)
   // ---- merge the 4 waves, write the partial -------------------------------------------------------------
+  if constexpr (FO) {
+    __shared__ float sm_on[LPK * VEC];
+    if (tid < dh) {
+      const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+      float o = 0.f, L = 0.f;
+#pragma unroll
+      for (int ww = 0; ww < 4; ++ww) {
+        const float f = __expf(sm_m[ww] - M);
+        o = fmaf(sm_o[ww][tid], f, o);
+        L = fmaf(sm_l[ww], f, L);
+      }
+      sm_on[tid] = bf16_to_f32(f32_to_bf16(o / L));  // the value the stand-alone out-proj GEMM reads as its bf16 X
+    }
+    __syncthreads();
+    attn_oproj_tail<LPK>(fo, sm_on, b, h, nhead, dh, d);
+    return;
+  }
   if (tid < dh || tid == 255) {
     const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
     float f[4];
@@ -250,6 +363,28 @@ int launch_decode_attention(hipStream_t st, int dtype, const float* q, const voi
   if (dtype == DT_F32)
     return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf, kt);
   return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf, kt);
+}
+
+// decode attention + out-proj + residual (+ LayerNorm producer) of the batched step in ONE launch: bf16 cache, one block per
+// (utterance, head) (nsplit = 1), dh % 8 == 0, dh in {32, 64, 128} (a power-of-two group of lanes covers the head), d % 256 == 0.
+// `part` [B][nhead][d] fp32, `cnt` [B] zeroed ints.  Returns 1 when the shape is not covered.
+int launch_decode_attention_oproj(hipStream_t st, const float* q, const void* k_cache, const void* v_cache, const int32_t* kv_len, int B,
+                                  int nhead, int dh, int ctx_max, const int32_t* done, const void* wo_bf16, const float* bias, float* resid,
+                                  float* part, int* cnt, const LnProducer& lnp, KTrace kt) {
+  if (B <= 0) return 0;
+  const int d = nhead * dh;
+  if (!(dh == 32 || dh == 64 || dh == 128) || d % 256 != 0 || !wo_bf16 || !resid || !part || !cnt) return 1;
+  AttnOproj fo;
+  fo.w = (const bf16_t*)wo_bf16; fo.bias = bias; fo.resid = resid; fo.part = part; fo.cnt = cnt; fo.lnp = lnp;
+  const dim3 grid(nhead, 1, B), block(256);
+#define VLE_DAO(LPK)                                                                                                            \
+  hipLaunchKernelGGL((decode_attn_kernel<bf16_t, 8, LPK, 4, true>), grid, block, 0, st, q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, \
+                     kv_len, (float*)nullptr, (float*)nullptr, nhead, dh, ctx_max, 1, (bf16_t*)nullptr, done, 0, kt, fo)
+  if (dh == 32) VLE_DAO(4);
+  else if (dh == 64) VLE_DAO(8);
+  else VLE_DAO(16);
+#undef VLE_DAO
+  return 0;
 }
 
 }  // namespace vle

@@ -149,6 +149,9 @@ struct vle_engine {
   int opt_gs_rot = 0;               // option "gs_rot": gemm_skinny workgroups walk X in rotated orders (A/B knob)
   bool opt_gs_fuse_ln = true;       // option "gs_fuse_ln": LayerNorm folded into the gemm_skinny launches (no LayerNorm kernels in the step)
   float* ln_stats = nullptr;        // [64][d / 16][2] group statistics of the residual rows (kernels.h LnProducer)
+  float* ao_part = nullptr;         // [B][H][d] partial out-proj sums of the fused attention + out-proj launch (decode_attn.hip AttnOproj)
+  int* ao_cnt = nullptr;            // [B] its tickets (zeroed once, self-resetting)
+  bool opt_attn_oproj = false;      // option "attn_oproj": batched step, out-proj folded into the decode-attention launch
   float *wg_pred = nullptr, *wb_pred = nullptr;  // final LayerNorm + ar_predict_layer
   bool opt_ignore_eos = false;  // option "ignore_eos": synthetic-weight benchmarks run every utterance to the length cap
   bool opt_no_gemv1 = false;  // option "no_gemv1": force the generic skinny kernel at batch 1 (A/B measurements)
@@ -729,6 +732,10 @@ static int alloc_buffers(vle_engine* e) {
     E_HIP(e, hipMemset(e->xn_step, 0, Bp * d * es));
     if ((r = dev_alloc(e, &e->ln_stats, (size_t)64 * (d / 16 + 1) * 2))) return r;
     E_HIP(e, hipMemset(e->ln_stats, 0, (size_t)64 * (d / 16 + 1) * 2 * sizeof(float)));
+    if ((r = dev_alloc(e, &e->ao_part, (size_t)B * e->H * d))) return r;
+    if ((r = dev_alloc(e, &p, (size_t)B * sizeof(int)))) return r;
+    E_HIP(e, hipMemset(p, 0, (size_t)B * sizeof(int)));
+    e->ao_cnt = (int*)p;
   }
   if ((r = dev_alloc(e, &e->state_dev, 6 * B + 8))) return r;
   e->S.kv_len = e->state_dev;
@@ -987,13 +994,21 @@ int enqueue_ar_step(vle_engine* e) {
         E_LAUNCH(e, launch_gemm_skinny(st, g));
       }
       const bool direct = e->nsplit == 1;  // one block holds a whole (utterance, head): it normalises itself
-      {
+      bool oproj_done = false;
+      if (e->opt_attn_oproj && direct && e->dtype == DT_BF16 && e->ao_part != nullptr) {  // attention + out-proj + residual in one launch
+        ProfScope ps(e, 1);
+        const int fr = launch_decode_attention_oproj(st, e->q_step, kc, vc, e->S.kv_len, e->B, e->H, e->dh, e->ctx_max, e->S.done, w.wo, w.bo,
+                                                     e->x_step, e->ao_part, e->ao_cnt, fuse ? ln_producer(e, w.g2) : LnProducer(), e->next_kt());
+        if (fr < 0) return e->fail(VLE_EHIP, "launch_decode_attention_oproj failed");
+        oproj_done = fr == 0;
+      }
+      if (!oproj_done) {
         ProfScope ps(e, 1);
         E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
                                             e->ctx_max, e->nsplit, e->opt_nk, direct ? e->att_step : nullptr, e->S.done,
                                             direct ? xfw : 0, e->next_kt()));
       }
-      {
+      if (!oproj_done) {
         ProfScope ps(e, 2);
         if (!direct) E_LAUNCH(e, launch_attn_combine(st, e->dtype, e->part_o, e->part_ml, e->att_step, e->B, e->H, e->dh, e->nsplit));
         g.x_xf = (xf && direct) ? 1 : 0;  // the merge kernel of the split path writes row-major
@@ -1964,7 +1979,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
-  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "gemv1_rpw_qkv" || n == "gemv1_rpw_ffn1" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal" || n == "gs_fuse_ln" || n == "gs_rot" || n == "gs_dbg") {  // change the captured graphs: drop them
+  if (n == "no_gemv1" || n == "gemv1_rpw" || n == "gemv1_rpw_qkv" || n == "gemv1_rpw_ffn1" || n == "attn_oproj" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal" || n == "gs_fuse_ln" || n == "gs_rot" || n == "gs_dbg") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
     else if (n == "gs_fuse_ln") e->opt_gs_fuse_ln = value != 0;
     else if (n == "gs_rot") e->opt_gs_rot = (int)value;
@@ -1978,6 +1993,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     else if (n == "steps_per_graph") e->opt_spg = (int)value;
     else if (n == "gemv1_rpw_qkv") e->opt_rpw_qkv = (int)value;
     else if (n == "gemv1_rpw_ffn1") e->opt_rpw_ffn1 = (int)value;
+    else if (n == "attn_oproj") e->opt_attn_oproj = value != 0;
     else e->opt_rpw = (int)value;
     (void)hipStreamSynchronize(e->st);
     for (auto& kv : e->graphs) {

@@ -172,7 +172,11 @@ int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache,
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
                             int nsplit, int nk_override = 0, void* out_norm = nullptr, const int32_t* done = nullptr,
-                            int out_xf = 0, KTrace kt = KTrace());  // out_xf: out_norm fragment-major (0 no, 1 bf16-W consumer, 2 fp8-W consumer)
+                            int out_xf = 0, KTrace kt = KTrace());
+// the same + the layer's out-proj, residual and LayerNorm producer in one launch (decode_attn.hip AttnOproj); 1 = shape not covered
+int launch_decode_attention_oproj(hipStream_t st, const float* q, const void* k_cache, const void* v_cache, const int32_t* kv_len, int B,
+                                  int nhead, int dh, int ctx_max, const int32_t* done, const void* wo_bf16, const float* bias, float* resid,
+                                  float* part, int* cnt, const LnProducer& lnp, KTrace kt);  // out_xf: out_norm fragment-major (0 no, 1 bf16-W consumer, 2 fp8-W consumer)
 // nk_override: keys per lane per round (0 = auto, 4, 8); out_norm (T [B][d], nsplit == 1 only): write the
 // normalised attention output directly instead of partials
 

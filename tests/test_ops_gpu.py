@@ -139,12 +139,12 @@ def test_attention_rows(nhead, dh, causal, dt):
     (2, 96, [1100], [64]),
 ])
 @pytest.mark.parametrize("causal", [True, False])
-@pytest.mark.parametrize("v2,qw,mode,q128,defer", [(2, 0, 2, 0, 8), (2, 0, 2, 1, 0), (2, 0, 1, 0, 8), (2, 0, 0, 1, 8), (2, 0, 1, 0, 0), (0, 1, 1, 0, 8),
+@pytest.mark.parametrize("v2,qw,mode,q128,defer", [(2, 0, 3, 0, 8), (2, 0, 3, 1, 0), (2, 0, 2, 0, 8), (2, 0, 2, 1, 0), (2, 0, 1, 0, 8), (2, 0, 0, 1, 8), (2, 0, 1, 0, 0), (0, 1, 1, 0, 8),
                                                       (0, 2, 0, 0, 8)])
 def test_attention_mfma_long(nhead, dh, lens, text_lens, causal, v2, qw, mode, q128, defer):
     """bf16 MFMA flash kernels at NAR / prefill lengths (many key tiles, ragged tails, prefix-LM mask): the second-generation
-    kernel (attn_mfma2.hip: V^T pre-pass, double-buffered tiles; tile staging by LDS-DMA + XOR swizzle (mode 2, head sizes 64 /
-    128) or through registers with 32- / 16-byte row padding (mode 1 / 0); 64- and 128-query blocks; deferred (8) or exact (0)
+    kernel (attn_mfma2.hip: double-buffered tiles; tile staging by LDS-DMA + XOR swizzle with a V^T pre-pass (mode 2) or with V
+    row-major and LDS transpose reads (mode 3) (head sizes 64 / 128) or through registers with 32- / 16-byte row padding (mode 1 / 0); 64- and 128-query blocks; deferred (8) or exact (0)
     running maximum) and round 1's (attn_mfma.hip) with 64- and 128-query blocks (knobs attn_v2 / attn_qw / attn_mode / attn_q128 /
     attn_defer)."""
     ops.tune("attn_v2", v2)
@@ -153,14 +153,14 @@ def test_attention_mfma_long(nhead, dh, lens, text_lens, causal, v2, qw, mode, q
     ops.tune("attn_q128", q128)
     ops.tune("attn_defer", defer)
     try:
-        for ring in ((2, 4) if (v2 == 2 and mode == 2) else (0,)):  # LDS ring depth of the LDS-DMA staging (0 = by launch size)
+        for ring in ((2, 4) if (v2 == 2 and mode == 2) else (0,)):  # (mode 3 = mode 2 with V read through ds_read_b64_tr_b16)  # LDS ring depth of the LDS-DMA staging (0 = by launch size)
             ops.tune("attn_ring", ring)
             _attention_mfma_long(nhead, dh, lens, text_lens, causal)
     finally:
         ops.tune("attn_ring", 0)
         ops.tune("attn_qw", 0)
         ops.tune("attn_v2", 1)
-        ops.tune("attn_mode", 2)
+        ops.tune("attn_mode", 3)
         ops.tune("attn_q128", -1)
         ops.tune("attn_defer", 8)
 

@@ -43,7 +43,7 @@ def main():
         row = []
         for tag, knobs in [("v1", dict(attn_v2=0)), ("v2 pad32 exact-max", dict(attn_v2=2, attn_mode=1, attn_defer=0)),
                            ("v2 pad32", dict(attn_v2=2, attn_mode=1)), ("v2 dma exact-max", dict(attn_v2=2, attn_mode=2, attn_defer=0)),
-                           ("v2 dma", dict(attn_v2=2, attn_mode=2, attn_ring=2)), ("v2 dma ring4", dict(attn_v2=2, attn_mode=2, attn_ring=4)), ("v2 pad32 q128", dict(attn_v2=2, attn_mode=1, attn_q128=1)),
+                           ("v2 dma", dict(attn_v2=2, attn_mode=2, attn_ring=2)), ("v2 dma tr-read V", dict(attn_v2=2, attn_mode=3)), ("v2 dma tr-read V q128", dict(attn_v2=2, attn_mode=3, attn_q128=1)), ("v2 pad32 q128", dict(attn_v2=2, attn_mode=1, attn_q128=1)),
                            ("v2 dma q128", dict(attn_v2=2, attn_mode=2, attn_q128=1)), ("default policy", dict(attn_v2=1))]:
             if tag != "default policy":
                 ops.tune("attn_q128", 0)
@@ -51,7 +51,7 @@ def main():
                 ops.tune(k, v)
             ms, tf = bench(B, N, H, dh, causal)
             row.append(f"{tag}: {ms:7.3f} ms {tf:6.1f} TF")
-            ops.tune("attn_v2", 1); ops.tune("attn_xcd", 1); ops.tune("attn_q128", -1); ops.tune("attn_mode", 2); ops.tune("attn_defer", 8); ops.tune("attn_ring", 0)
+            ops.tune("attn_v2", 1); ops.tune("attn_xcd", 1); ops.tune("attn_q128", -1); ops.tune("attn_mode", 3); ops.tune("attn_defer", 8); ops.tune("attn_ring", 0)
         print(f"{name:13s} B={B:3d} N={N} H={H} dh={dh} c={int(causal)}\n    " + "\n    ".join(row), flush=True)
 
 

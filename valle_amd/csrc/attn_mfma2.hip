@@ -28,6 +28,7 @@ typedef __bf16 a2_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 a2_bf16x4 __attribute__((ext_vector_type(4)));
 typedef float a2_f32x4 __attribute__((ext_vector_type(4)));
 typedef float a2_f32x2 __attribute__((ext_vector_type(2)));
+typedef short a2_s16x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int a2_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr float A2_NEG = -1e30f;
@@ -82,6 +83,8 @@ __device__ inline void a2_wait_vm() {
 //         ds_write_b128 at ~13 cycles each), dense rows, 16-byte slots XOR-swizzled on the DMA source address and on the ds_read
 //         side (key = row mod (vectors per row)): conflict-free; two buffers, tile t+1 in flight while tile t is multiplied,
 //         counted-free wait (vmcnt(0): the only loads in the loop are the DMA pieces) + raw s_barrier per tile.  DH 64 / 128.
+// MODE 3: MODE 2 without the V^T pre-pass: V tiles are staged ROW-major exactly like K tiles (same DMA, same swizzle) and the
+//         second MFMA's operand is read with ds_read_b64_tr_b16, gfx950's LDS transpose read (two per fragment: 2 x 4 keys).
 //         NS = ring depth: 2 (one tile in flight under the current one's math).  4 (three tiles ahead, counted vmcnt) is a
 //         measured dead end kept as knob "attn_ring": one 1025-row sequence (272 blocks, nobody else to hide the DMA latency)
 //         runs 17.1 us per launch either way, the batched passes lose occupancy (C3 NAR shape 451 -> 338 TF/s).
@@ -89,8 +92,10 @@ template <int DH, int QW, int MODE, int NS = 2>
 __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                     const int32_t* __restrict__ seq_off, const int32_t* __restrict__ text_len, int d,
                                                     int nhead, int causal, int64_t rp, int xcd_remap, float defer_exp2) {
-  constexpr bool GLDS = MODE == 2;
+  constexpr bool GLDS = MODE >= 2;
+  constexpr bool TRV = MODE == 3;  // V staged ROW-major like K and read through ds_read_b64_tr_b16: no V^T pre-pass
   static_assert(!GLDS || DH == 64 || DH == 128, "LDS-DMA layout: 8 or 16 vectors per K row");
+  static_assert(!TRV || DH == 64 || DH == 128, "transpose-read V: the K-row layout");
   constexpr int NV = DH / 8;           // 16-byte vectors per K row
   constexpr int PAD = GLDS ? 0 : (MODE == 1 ? 32 : 16);
   constexpr int KSTR = DH * 2 + PAD;   // bytes per K row in LDS
@@ -99,8 +104,9 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
   constexpr int KS = DH / 32, EB = DH / 16;
   constexpr int KSWZ = GLDS ? NV - 1 : 0, VSWZ = GLDS ? 7 : 0;  // slot ^= row & mask
   static_assert(NS == 2 || (GLDS && NS == 4), "deeper rings exist for the LDS-DMA staging only");
-  constexpr int NPW = NV / 4 + DH / 32;  // DMA pieces per wave per tile
-  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (64 * KSTR + DH * VSTR)];
+  constexpr int NPW = NV / 4 + (TRV ? NV / 4 : DH / 32);  // DMA pieces per wave per tile
+  constexpr int VBYTES = TRV ? 64 * KSTR : DH * VSTR;      // the V (or V^T) image of a tile
+  __shared__ __attribute__((aligned(16))) unsigned char smem[NS * (64 * KSTR + VBYTES)];
 
   // XCD-aware block order (block L runs on XCD L % 8, each with its own 4 MB L2): the query blocks of one (sequence, head) read
   // the same K / V -- give every XCD a CONTIGUOUS run of the (b, h, query-block) order so that they meet in one L2 instead of
@@ -150,7 +156,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
     for (int ks = 0; ks < KS; ++ks) qf[f][ks] = *reinterpret_cast<const a2_bf16x8*>(qp + ks * 32);
   }
 
-  constexpr int BUF = 64 * KSTR + DH * VSTR;
+  constexpr int BUF = 64 * KSTR + VBYTES;
   a2_u32x4 kreg[NLD], vreg[NLD];
   auto gload = [&](int kt0) {
 #pragma unroll
@@ -185,13 +191,24 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(buf + (i * 4 + wv) * 1024), 16, 0, 0);
     }
+    if constexpr (TRV) {  // V rows exactly like the K rows, 2 d bytes... d elements further along the qkv row
 #pragma unroll
-    for (int i = 0; i < DH / 32; ++i) {
-      const int idx = (i * 4 + w) * 64 + lane;
-      const int e = idx >> 3, slot = idx & 7;
-      const bf16_t* src = vbase + (int64_t)e * rp + kt0 + ((slot ^ (e & VSWZ)) * 8);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(buf + 64 * KSTR + (i * 4 + wv) * 1024), 16, 0, 0);
+      for (int i = 0; i < NV / 4; ++i) {
+        const int idx = (i * 4 + w) * 64 + lane;
+        const int row = idx / NV, slot = idx % NV;
+        const bf16_t* src = base + (__umul24((unsigned)min(kt0 + row, len - 1), (unsigned)d3) + (unsigned)(2 * d + ((slot ^ (row & KSWZ)) * 8)));
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + 64 * KSTR + (i * 4 + wv) * 1024), 16, 0, 0);
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < DH / 32; ++i) {
+        const int idx = (i * 4 + w) * 64 + lane;
+        const int e = idx >> 3, slot = idx & 7;
+        const bf16_t* src = vbase + (int64_t)e * rp + kt0 + ((slot ^ (e & VSWZ)) * 8);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(buf + 64 * KSTR + (i * 4 + wv) * 1024), 16, 0, 0);
+      }
     }
   };
 
@@ -308,7 +325,22 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
     for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
       for (int j = 0; j < 2; ++j) {
-        const a2_bf16x8 a = *reinterpret_cast<const a2_bf16x8*>(Vt + (eb * 16 + c) * VSTR + (((j * 4 + g) ^ (c & VSWZ)) * 16));
+        a2_bf16x8 a;
+        if constexpr (TRV) {
+          // ds_read_b64_tr_b16 (lane map probed on the hardware, tools/ubench_trread.hip): inside a 16-lane group, lane 4 a + b
+          // receives element b of the 4 x u16 at the addresses supplied by lanes a, 4 + a, 8 + a, 12 + a.  Lane c supplies the
+          // 8 bytes of key (k0 + c / 4), head columns 16 eb + 4 (c % 4) .. + 3; it then receives V[k0 + 0..3][16 eb + c]: four
+          // consecutive keys of ITS row of V^T -- the 4-key groups the score MFMA left in this lane (keys 16 kb + 4 g + r).
+          const int key = j * 32 + g * 4 + (c >> 2);  // second read: + 16 (same key & 7 / & 15: same swizzle)
+          const unsigned char* va = Vt + key * KSTR + (((eb * 2 + ((c & 3) >> 1)) ^ (key & KSWZ)) << 4) + ((c & 1) << 3);
+          const a2_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) a2_s16x4*)(va));
+          const a2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) a2_s16x4*)(va + 16 * KSTR));
+          typedef short a2_s16x8 __attribute__((ext_vector_type(8)));
+          const a2_s16x8 both = a2_s16x8{lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+          a = __builtin_bit_cast(a2_bf16x8, both);
+        } else {
+          a = *reinterpret_cast<const a2_bf16x8*>(Vt + (eb * 16 + c) * VSTR + (((j * 4 + g) ^ (c & VSWZ)) * 16));
+        }
 #pragma unroll
         for (int f = 0; f < QW; ++f) o[f][eb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, pf[f][j], o[f][eb], 0, 0, 0);
       }
@@ -373,8 +405,9 @@ int attn2_reserve(int64_t rows, int B, int d) {
 
 int g_attn_v2 = 1;    // "attn_v2": 0 = round 1's kernel (attn_mfma.hip) for A/B
 int g_attn_xcd = 1;   // "attn_xcd": XCD-aware block order (A/B)
-int g_attn_mode = 2;  // "attn_mode": tile staging of attn2_kernel -- 0 registers + 16-byte row padding (round 2's first layout), 1 registers +
-                      // 32-byte padding (conflict-free), 2 LDS-DMA + XOR swizzle where the head size allows (64 / 128), else 1
+int g_attn_mode = 3;  // "attn_mode": tile staging of attn2_kernel -- 0 registers + 16-byte row padding (round 2's first layout), 1 registers +
+                      // 32-byte padding (conflict-free), 2 LDS-DMA + XOR swizzle where the head size allows (64 / 128), else 1;
+                      // 3 = 2 with V staged row-major and read by ds_read_b64_tr_b16 (no V^T pre-pass)
 int g_attn_ring = 0;  // "attn_ring": LDS ring depth of the LDS-DMA staging: 0 / 2 = two buffers, 4 = four (A/B knob, see attn2_kernel)
 int g_attn_defer = 8; // "attn_defer": deferred-maximum threshold of attn2_kernel in exp2-domain units (0 = exact running maximum)
 int g_attn_q128 = -1; // "attn_q128": 128-query blocks (each K / V^T fragment read from LDS feeds two MFMAs): 0 never, 1 always, -1 (default) =
@@ -389,12 +422,19 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
   if (rows <= 0) return 1;
   // measured (tools/attn_bench.py, MI355X): ahead of round 1's kernel on the un-masked NAR passes (C3 shape 305 -> 365 TF/s, C5's
   // dh 96 308 -> 319), behind it on the short causal prefill (120 vs 114) -- g_attn_v2 = 2 forces this kernel for every shape
-  if (g_attn_v2 == 1 && (causal || max_len < 512)) return 1;
-  int r = attn2_reserve(rows, B, d);
-  if (r) return r;
-  int dev = 0;
-  (void)hipGetDevice(&dev);
-  bf16_t* vt = (bf16_t*)g_vt[dev].p;
+  const int mode = (g_attn_mode >= 2 && !(dh == 64 || dh == 128)) ? 1 : g_attn_mode;
+  const bool trv = mode == 3;  // V through LDS transpose reads: no V^T scratch, no pre-pass
+  // ... without the pre-pass it is ahead there too (C3 prefill 128 -> 159 TF/s): the old kernel keeps the short / causal passes only
+  // for the head sizes that still need the pre-pass (32, 96)
+  if (g_attn_v2 == 1 && !trv && (causal || max_len < 512)) return 1;
+  bf16_t* vt = nullptr;
+  if (!trv) {
+    int r = attn2_reserve(rows, B, d);
+    if (r) return r;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    vt = (bf16_t*)g_vt[dev].p;
+  }
   const int64_t rp = rows + 128 * (int64_t)(B + 1) + 64;  // >= every sequence's last padded column
   const int64_t rp8 = rp & ~(int64_t)7;                    // row pitch: a multiple of 8 elements (16-byte vectors)
   const dim3 pgrid((max_len + 63) / 64, nhead, B), block(256);
@@ -405,7 +445,9 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
                      text_len, d, nhead, causal, rp8, g_attn_xcd, (float)g_attn_defer)
 #define VLE_A2K(DH, QW)                                  \
   do {                                                   \
-    if (mode == 2) {                                     \
+    if (mode == 3) {                                     \
+      if constexpr (DH == 64 || DH == 128) VLE_A2M(DH, QW, 3, 2); \
+    } else if (mode == 2) {                              \
       if constexpr (DH == 64 || (DH == 128 && QW == 1)) { \
         if (ring4) VLE_A2M(DH, QW, 2, 4);                \
         else VLE_A2M(DH, QW, 2, 2);                      \
@@ -415,11 +457,10 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
   } while (0)
 #define VLE_A2(DH)                                                                                                              \
   do {                                                                                                                          \
-    hipLaunchKernelGGL((vt_pack_kernel<DH>), pgrid, block, 0, st, (const bf16_t*)qkv, vt, seq_off, d, rp8);                     \
+    if (!trv) hipLaunchKernelGGL((vt_pack_kernel<DH>), pgrid, block, 0, st, (const bf16_t*)qkv, vt, seq_off, d, rp8);       \
     if (q128) VLE_A2K(DH, 2);                                                                                                   \
     else VLE_A2K(DH, 1);                                                                                                        \
   } while (0)
-  const int mode = (g_attn_mode == 2 && !(dh == 64 || dh == 128)) ? 1 : g_attn_mode;
   const int64_t nblocks = (int64_t)grid.x * grid.y * grid.z;
   const bool ring4 = g_attn_ring == 4;
   (void)nblocks;

@@ -70,6 +70,15 @@ __global__ __launch_bounds__(256) void vt_pack_kernel(const bf16_t* __restrict__
   }
 }
 
+// XOR key of the 16-byte slot swizzle of a row of NV slots (LDS-DMA modes): conflict-free for the ds_read_b128 fragment reads
+// AND the ds_read_b64_tr_b16 transpose reads under the lane groups of MI355X_MICROARCH.md's LDS table (checked exhaustively on
+// the host): rows of 8 / 16 slots (dh 64 / 128) row & (NV - 1); rows of 4 / 12 slots (dh 32 / 96) (row >> 1) & 3 -- the key
+// must stay inside an aligned group of 4 slots there, and consecutive rows start half a bank set apart.
+template <int NV>
+__device__ __host__ constexpr int a2_key(int row) {
+  return (NV == 8 || NV == 16) ? (row & (NV - 1)) : ((row >> 1) & 3);
+}
+
 template <int N>
 __device__ inline void a2_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -94,15 +103,14 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
                                                     int nhead, int causal, int64_t rp, int xcd_remap, float defer_exp2) {
   constexpr bool GLDS = MODE >= 2;
   constexpr bool TRV = MODE == 3;  // V staged ROW-major like K and read through ds_read_b64_tr_b16: no V^T pre-pass
-  static_assert(!GLDS || DH == 64 || DH == 128, "LDS-DMA layout: 8 or 16 vectors per K row");
-  static_assert(!TRV || DH == 64 || DH == 128, "transpose-read V: the K-row layout");
+  static_assert(MODE != 2 || DH == 64 || DH == 128, "LDS-DMA of the V^T image: 8 slots per V^T row, 8 or 16 per K row");
   constexpr int NV = DH / 8;           // 16-byte vectors per K row
   constexpr int PAD = GLDS ? 0 : (MODE == 1 ? 32 : 16);
   constexpr int KSTR = DH * 2 + PAD;   // bytes per K row in LDS
   constexpr int VSTR = 64 * 2 + PAD;   // bytes per V^T row
   constexpr int NLD = 64 * NV / 256;   // staged vectors per thread per tile (K and V^T each): DH / 32
   constexpr int KS = DH / 32, EB = DH / 16;
-  constexpr int KSWZ = GLDS ? NV - 1 : 0, VSWZ = GLDS ? 7 : 0;  // slot ^= row & mask
+  constexpr int VSWZ = MODE == 2 ? 7 : 0;  // V^T image of MODE 2: slot ^= row & 7 (K rows: a2_key)
   static_assert(NS == 2 || (GLDS && NS == 4), "deeper rings exist for the LDS-DMA staging only");
   constexpr int NPW = NV / 4 + (TRV ? NV / 4 : DH / 32);  // DMA pieces per wave per tile
   constexpr int VBYTES = TRV ? 64 * KSTR : DH * VSTR;      // the V (or V^T) image of a tile
@@ -187,7 +195,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
     for (int i = 0; i < NV / 4; ++i) {
       const int idx = (i * 4 + w) * 64 + lane;
       const int row = idx / NV, slot = idx % NV;
-      const bf16_t* src = base + (__umul24((unsigned)min(kt0 + row, len - 1), (unsigned)d3) + (unsigned)(d + ((slot ^ (row & KSWZ)) * 8)));
+      const bf16_t* src = base + (__umul24((unsigned)min(kt0 + row, len - 1), (unsigned)d3) + (unsigned)(d + ((slot ^ (GLDS ? a2_key<NV>(row) : 0)) * 8)));
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                        (__attribute__((address_space(3))) void*)(buf + (i * 4 + wv) * 1024), 16, 0, 0);
     }
@@ -196,7 +204,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
       for (int i = 0; i < NV / 4; ++i) {
         const int idx = (i * 4 + w) * 64 + lane;
         const int row = idx / NV, slot = idx % NV;
-        const bf16_t* src = base + (__umul24((unsigned)min(kt0 + row, len - 1), (unsigned)d3) + (unsigned)(2 * d + ((slot ^ (row & KSWZ)) * 8)));
+        const bf16_t* src = base + (__umul24((unsigned)min(kt0 + row, len - 1), (unsigned)d3) + (unsigned)(2 * d + ((slot ^ a2_key<NV>(row)) * 8)));
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
                                          (__attribute__((address_space(3))) void*)(buf + 64 * KSTR + (i * 4 + wv) * 1024), 16, 0, 0);
       }
@@ -266,7 +274,7 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
       for (int f = 0; f < QW; ++f) s[f][kb] = a2_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const a2_bf16x8 a = *reinterpret_cast<const a2_bf16x8*>(Ks + (kb * 16 + c) * KSTR + (((ks * 4 + g) ^ (c & KSWZ)) * 16));
+        const a2_bf16x8 a = *reinterpret_cast<const a2_bf16x8*>(Ks + (kb * 16 + c) * KSTR + (((ks * 4 + g) ^ (GLDS ? a2_key<NV>(c) : 0)) * 16));
 #pragma unroll
         for (int f = 0; f < QW; ++f) s[f][kb] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, qf[f][ks], s[f][kb], 0, 0, 0);
       }
@@ -331,8 +339,8 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
           // receives element b of the 4 x u16 at the addresses supplied by lanes a, 4 + a, 8 + a, 12 + a.  Lane c supplies the
           // 8 bytes of key (k0 + c / 4), head columns 16 eb + 4 (c % 4) .. + 3; it then receives V[k0 + 0..3][16 eb + c]: four
           // consecutive keys of ITS row of V^T -- the 4-key groups the score MFMA left in this lane (keys 16 kb + 4 g + r).
-          const int key = j * 32 + g * 4 + (c >> 2);  // second read: + 16 (same key & 7 / & 15: same swizzle)
-          const unsigned char* va = Vt + key * KSTR + (((eb * 2 + ((c & 3) >> 1)) ^ (key & KSWZ)) << 4) + ((c & 1) << 3);
+          const int key = j * 32 + g * 4 + (c >> 2);  // second read: + 16 (same swizzle key: a2_key has period <= 16)
+          const unsigned char* va = Vt + key * KSTR + (((eb * 2 + ((c & 3) >> 1)) ^ a2_key<NV>(key)) << 4) + ((c & 1) << 3);
           const a2_s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) a2_s16x4*)(va));
           const a2_s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) a2_s16x4*)(va + 16 * KSTR));
           typedef short a2_s16x8 __attribute__((ext_vector_type(8)));
@@ -422,10 +430,10 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
   if (rows <= 0) return 1;
   // measured (tools/attn_bench.py, MI355X): ahead of round 1's kernel on the un-masked NAR passes (C3 shape 305 -> 365 TF/s, C5's
   // dh 96 308 -> 319), behind it on the short causal prefill (120 vs 114) -- g_attn_v2 = 2 forces this kernel for every shape
-  const int mode = (g_attn_mode >= 2 && !(dh == 64 || dh == 128)) ? 1 : g_attn_mode;
+  const int mode = (g_attn_mode == 2 && !(dh == 64 || dh == 128)) ? 1 : g_attn_mode;  // the V^T DMA image exists for 64 / 128 only
   const bool trv = mode == 3;  // V through LDS transpose reads: no V^T scratch, no pre-pass
   // ... without the pre-pass it is ahead there too (C3 prefill 128 -> 159 TF/s): the old kernel keeps the short / causal passes only
-  // for the head sizes that still need the pre-pass (32, 96)
+  // when the pre-pass form is selected (attn_mode <= 2)
   if (g_attn_v2 == 1 && !trv && (causal || max_len < 512)) return 1;
   bf16_t* vt = nullptr;
   if (!trv) {
@@ -446,7 +454,7 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
 #define VLE_A2K(DH, QW)                                  \
   do {                                                   \
     if (mode == 3) {                                     \
-      if constexpr (DH == 64 || DH == 128) VLE_A2M(DH, QW, 3, 2); \
+      VLE_A2M(DH, QW, 3, 2);                             \
     } else if (mode == 2) {                              \
       if constexpr (DH == 64 || (DH == 128 && QW == 1)) { \
         if (ring4) VLE_A2M(DH, QW, 2, 4);                \

@@ -447,3 +447,53 @@ def test_engine_grows_capacities_without_reloading_weights():
     ref = mb2.inference_batch(X.to(DEV), torch.tensor(S, dtype=torch.int32), Y.to(DEV), P, None, top_k=1)
     for i in range(3):
         assert torch.equal(ob[i], ref[i]), "a grown engine and a fresh one of the same capacity disagree"
+
+
+def test_failed_reserve_marks_the_engine_unusable_and_the_model_recovers():
+    """vle_reserve frees the capacity-dependent buffers before it re-allocates; when the re-allocation fails (here: a
+    KV cache of > 1 TB, refused by the very first hipMalloc -- nothing is consumed) the engine must not keep pointers into freed
+    memory: every entry point answers VLE_ESTATE, and VALLE.engine_for drops the handle so the next request builds a new engine."""
+    cfg = vo.OracleConfig(d_model=256, nhead=4, num_layers=2, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 6)
+    m = build_model(cfg, sd, "fp32")
+    x, xl, y = vo.make_inputs(4, 6)
+    want = vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True)
+    assert torch.equal(m.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1).cpu(), want)
+    eng = m._engine
+    with pytest.raises(RuntimeError):
+        eng.reserve(2_000_000, 64, 64)
+    with pytest.raises(RuntimeError, match="unusable|not finalized"):
+        eng.prefill(x.to(DEV), [4], y.to(DEV), [6])
+    with pytest.raises(RuntimeError):
+        eng.reserve(1, 4, 6)
+    # through the model: the failed growth invalidates the engine, the next call rebuilds it
+    m2 = build_model(cfg, sd, "fp32")
+    m2.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1)
+    with pytest.raises(RuntimeError):
+        m2.engine_for(2_000_000, 64, 64)
+    assert m2._engine is None
+    assert torch.equal(m2.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1).cpu(), want)
+
+
+def test_nar_force_is_one_shot_on_every_exit_path():
+    """a vle_nar_force pointer must not survive a failed vle_nar_decode (it is caller-owned memory), and its stride
+    is validated against the generated lengths."""
+    cfg = vo.OracleConfig(d_model=256, nhead=4, num_layers=2, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 6)
+    m = build_model(cfg, sd, "fp32")
+    x, xl, y = vo.make_inputs(4, 6)
+    want = vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True)
+    eng = m.engine_for(1, 4, 6)
+    eng.prefill(x.to(DEV), [4], y.to(DEV), [6])
+    import ctypes as C
+
+    first, lens = eng.generate(top_k=1)
+    G = int(lens[0])
+    assert G >= 2
+    short = torch.zeros(1, G - 1, 8, dtype=torch.int64, device=DEV)  # stride smaller than G: rejected by the C ABI
+    assert eng.lib.vle_nar_force(eng.h, C.c_void_p(short.data_ptr()), G - 1) == 0
+    with pytest.raises(RuntimeError, match="f_stride"):
+        eng.nar()
+    del short
+    codes = eng.nar()  # the rejected pointer was forgotten: an ordinary arg-max decode
+    assert torch.equal(codes[0][:G].cpu(), want[0])

@@ -137,6 +137,23 @@ def test_topk_sample_operator_distribution(top_k, temperature):
         assert counts[int(row.argmax())] == n
 
 
+def test_block_path_seed_matches_the_engine_stream_of_every_batch_position():
+    """model._request_seed_base: the block path samples ONE row per call, so utterance b passes the seed whose
+    request-0 stream is request b's stream of the call seed -- row b of a batched draw (what the fused engine / serving path
+    draw for utterance b) must equal row 0 of the single-row draw with that seed, at every step."""
+    from valle_amd.model import _request_seed_base
+
+    g = torch.Generator().manual_seed(5)
+    logits = (torch.randn(6, 1025, generator=g) * 2.0).to(DEV)
+    for seed in (0, 77, 2**63 + 12345):
+        for step in (0, 3, 400):
+            batch, _ = ops.topk_sample(logits, -100, 1.0, seed=seed, step=step)
+            for b in range(6):
+                one, _ = ops.topk_sample(logits[b : b + 1], -100, 1.0, seed=_request_seed_base(seed, b), step=step)
+                assert int(one[0]) == int(batch[b]), (seed, step, b)
+    assert _request_seed_base(77, 0) == 77
+
+
 def test_sampled_block_decode_is_reproducible_and_seeded():
     case = load_case("opt_prenorm_prenet_pm1")
     m = build(case["cfg"], case["sd"], "fp32")

@@ -382,7 +382,10 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
   }
 }
 
-// ---- V^T scratch: one per device, grown on demand (never during stream capture: attention is not part of the captured AR step)
+// ---- V^T scratch of the PRE-PASS modes (attn_mode <= 2, A/B diagnostics only; the default attn_mode = 3 reads V through LDS
+// transpose reads and never touches it): one per device, reserved lazily by the launcher, grown on demand (never during stream
+// capture: attention is not part of the captured AR step), freed at process exit.  The pre-pass modes are therefore meant for ONE
+// engine per device at a time; the pointer is handed out under the lock.
 namespace {
 struct VtScratch {
   void* p = nullptr;
@@ -392,12 +395,15 @@ std::mutex g_vt_mu;
 VtScratch g_vt[16];
 }  // namespace
 
-int attn2_reserve(int64_t rows, int B, int d) {
+int attn2_reserve(int64_t rows, int B, int d, void** out) {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return -3;
   const size_t need = (size_t)d * (size_t)(rows + 128 * (int64_t)(B + 1) + 64) * 2;
   std::lock_guard<std::mutex> lk(g_vt_mu);
-  if (g_vt[dev].bytes >= need) return 0;
+  if (g_vt[dev].bytes >= need) {
+    if (out) *out = g_vt[dev].p;
+    return 0;
+  }
   if (g_vt[dev].p) {
     if (hipDeviceSynchronize() != hipSuccess) return -3;
     (void)hipFree(g_vt[dev].p);
@@ -408,6 +414,7 @@ int attn2_reserve(int64_t rows, int B, int d) {
   if (hipMemset(p, 0, need) != hipSuccess) return -3;  // columns between sequences are read (and multiplied by P = 0): keep them finite
   g_vt[dev].p = p;
   g_vt[dev].bytes = need;
+  if (out) *out = p;
   return 0;
 }
 
@@ -437,11 +444,10 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
   if (g_attn_v2 == 1 && !trv && (causal || max_len < 512)) return 1;
   bf16_t* vt = nullptr;
   if (!trv) {
-    int r = attn2_reserve(rows, B, d);
+    void* sp = nullptr;
+    int r = attn2_reserve(rows, B, d, &sp);
     if (r) return r;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    vt = (bf16_t*)g_vt[dev].p;
+    vt = (bf16_t*)sp;
   }
   const int64_t rp = rows + 128 * (int64_t)(B + 1) + 64;  // >= every sequence's last padded column
   const int64_t rp8 = rp & ~(int64_t)7;                    // row pitch: a multiple of 8 elements (16-byte vectors)

@@ -71,6 +71,7 @@ struct vle_engine {
   std::vector<void*> buf_allocs;  // capacity-dependent buffers (KV cache, activations, traces): vle_reserve frees and re-creates them
   bool in_buffers = false;        // dev_alloc target
   bool finalized = false;
+  bool broken = false;            // vle_reserve failed half-way: buffers are gone, every entry point refuses (VLE_ESTATE)
 
   // ---- host staging of the state dict --------------------------------------------------------
   std::map<std::string, std::vector<float>> host_w;
@@ -101,6 +102,7 @@ struct vle_engine {
   // ---- buffers ------------------------------------------------------------------------------------
   void *kcache = nullptr, *vcache = nullptr;  // T [L][B][H][ctx_max][dh]
   float *x_step = nullptr, *q_step = nullptr, *h_step = nullptr, *part_o = nullptr, *part_ml = nullptr, *logits = nullptr;
+  float *k_new = nullptr, *v_new = nullptr;  // [B][d] the new token's K / V rows (cache-rounded) of the fused batch-1 QKV + attention launch
   void *xn_step = nullptr, *qkv_step = nullptr, *att_step = nullptr, *hT_step = nullptr;  // batch > 8 path
   int32_t* state_dev = nullptr;  // kv_len, audio_pos, n_gen, done, cap, iter [max_B] each, then done_count
   ArState S{};
@@ -441,6 +443,33 @@ extern "C" int vle_create(const vle_config* c, vle_engine** out) {
   return VLE_OK;
 }
 
+// Free every capacity-dependent buffer and forget its address (vle_reserve re-creates them; vle_destroy ends them).
+static void release_buffers(vle_engine* e) {
+  for (void* p : e->buf_allocs) (void)hipFree(p);
+  e->buf_allocs.clear();
+  if (e->tables_host) (void)hipHostFree(e->tables_host);
+  if (e->poll_host) (void)hipHostFree(e->poll_host);
+  if (e->prog_host) (void)hipHostFree(e->prog_host);
+  e->tables_host = e->poll_host = e->prog_host = nullptr;
+  e->prog_dev = nullptr;
+  e->kcache = e->vcache = nullptr;
+  e->x_step = e->q_step = e->h_step = e->part_o = e->part_ml = e->logits = nullptr;
+  e->k_new = e->v_new = nullptr;
+  e->xn_step = e->qkv_step = e->att_step = e->hT_step = nullptr;
+  e->gs_ws = nullptr; e->ln_stats = nullptr; e->ao_part = nullptr; e->ao_cnt = nullptr;
+  e->state_dev = nullptr; e->S = ArState{}; e->dyn_dev = nullptr;
+  e->tokens = e->sampled = e->text_ids = e->prompt_codes = nullptr;
+  e->forced_len_dev = nullptr; e->slot_seed_dev = nullptr; e->id_err_dev = nullptr;
+  e->X = e->yemb = e->nar_logits = nullptr;
+  e->Xn = e->QKV = e->ATT = e->Hb = nullptr;
+  e->A8 = nullptr; e->a8_scale = nullptr;
+  e->tables_dev = nullptr; e->tables_cap = 0;
+  e->trace_ar = nullptr; e->trace_ar_cap = 0; e->trace_nar = nullptr; e->ktrace_buf = nullptr;
+  e->nar_forced = nullptr; e->nar_forced_stride = 0;
+  e->have_prefill = e->have_gen = false;
+  e->slot_mode = false;
+}
+
 extern "C" void vle_destroy(vle_engine* e) {
   if (!e) return;
   (void)hipSetDevice(e->cfg.device);
@@ -451,10 +480,7 @@ extern "C" void vle_destroy(vle_engine* e) {
   }
   for (hipEvent_t ev : e->prof_pool) (void)hipEventDestroy(ev);
   for (void* p : e->allocs) (void)hipFree(p);
-  for (void* p : e->buf_allocs) (void)hipFree(p);
-  if (e->tables_host) (void)hipHostFree(e->tables_host);
-  if (e->poll_host) (void)hipHostFree(e->poll_host);
-  if (e->prog_host) (void)hipHostFree(e->prog_host);
+  release_buffers(e);
   for (int i = 0; i < 6; ++i)
     if (e->ev_t[i]) (void)hipEventDestroy(e->ev_t[i]);
   if (e->ev_in) (void)hipEventDestroy(e->ev_in);
@@ -474,7 +500,7 @@ extern "C" const char* vle_last_error(const vle_engine* e) {
 
 extern "C" int vle_load_tensor(vle_engine* e, const char* key, const float* data, const int64_t* shape, int ndim) {
   if (!e || !key || !data || !shape || ndim < 1 || ndim > 4) return VLE_EINVAL;
-  if (e->finalized) return e->fail(VLE_ESTATE, "vle_load_tensor after vle_finalize_weights");
+  if (e->finalized || e->broken) return e->fail(VLE_ESTATE, e->broken ? "engine is unusable after a failed vle_reserve: destroy it" : "vle_load_tensor after vle_finalize_weights");
   size_t n = 1;
   for (int i = 0; i < ndim; ++i) n *= (size_t)shape[i];
   e->host_w[key].assign(data, data + n);
@@ -602,6 +628,7 @@ static int make_weight_packs(vle_engine* e) {
 extern "C" int vle_finalize_weights(vle_engine* e) {
   if (!e) return VLE_EINVAL;
   if (e->finalized) return VLE_OK;
+  if (e->broken) return e->fail(VLE_ESTATE, "engine is unusable after a failed vle_reserve: destroy it");
   E_HIP(e, hipSetDevice(e->cfg.device));
   const int64_t d = e->d;
   const std::vector<float>* t;
@@ -766,7 +793,6 @@ static int alloc_buffers(vle_engine* e) {
   e->ATT = p;
   if ((r = dev_alloc(e, &p, (size_t)R * 4 * d * es))) return r;
   e->Hb = p;
-  if (e->dtype == DT_BF16 && attn2_reserve(R, (int)B, (int)d) != 0) return e->fail(VLE_EHIP, "V^T scratch of the attention kernel: allocation failed");
   if (e->a8) {
     if ((r = dev_alloc(e, &e->A8, (size_t)R * 4 * d))) return r;
     if ((r = dev_alloc(e, &e->a8_scale, (size_t)R))) return r;
@@ -780,9 +806,16 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->tables_dev, e->tables_cap))) return r;
   E_HIP(e, hipHostMalloc((void**)&e->tables_host, e->tables_cap * sizeof(int32_t), hipHostMallocDefault));
   E_HIP(e, hipHostMalloc((void**)&e->poll_host, 64 * sizeof(int32_t), hipHostMallocDefault));
-  E_HIP(e, hipHostMalloc((void**)&e->prog_host, 16 * sizeof(int32_t), hipHostMallocMapped));
-  memset(e->prog_host, 0, 16 * sizeof(int32_t));
-  E_HIP(e, hipHostGetDevicePointer((void**)&e->prog_dev, e->prog_host, 0));
+  // progress words the sampling kernel writes while graphs are in flight: they must be COHERENT (fine-grained) host memory or the
+  // host sees nothing until a synchronisation; without a device mapping the AR loop falls back to the event / D2H poll
+  e->prog_dev = nullptr;
+  if (hipHostMalloc((void**)&e->prog_host, 16 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
+    memset(e->prog_host, 0, 16 * sizeof(int32_t));
+    if (hipHostGetDevicePointer((void**)&e->prog_dev, e->prog_host, 0) != hipSuccess) e->prog_dev = nullptr;
+  } else {
+    (void)hipGetLastError();
+    e->prog_host = nullptr;
+  }
   return 0;
 }
 
@@ -946,7 +979,7 @@ int enqueue_ar_sample(vle_engine* e, int first, const int32_t* slot_map = nullpt
   a.s = e->S; a.dyn = e->dyn_dev; a.logits = e->logits; a.V = V_AR; a.B = slot_map ? nslots : e->B; a.d = e->d; a.bos = e->bos; a.first = first;
   a.slot_map = slot_map; a.id_err = e->id_err_dev;
   if (!first) a.kt = e->next_kt();
-  if (e->opt_host_prog && !slot_map) a.host_prog = e->prog_dev;
+  if (e->opt_host_prog && !slot_map) a.host_prog = e->prog_dev;  // null without a coherent mapping (alloc_buffers)
   if (e->slot_mode) a.slot_seed = e->slot_seed_dev;
   if (use_mfma_skinny(e) && use_fuse_ln(e)) a.lnp = ln_producer(e, e->ar[0].g1);
   a.tokens = e->tokens; a.g_stride = e->max_G; a.sampled = e->sampled;
@@ -1129,7 +1162,7 @@ int capture_graph(vle_engine* e, int steps, hipGraphExec_t* out) {
 extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, int64_t s_stride, const int32_t* text_lens,
                               const int64_t* prompt_codes, int64_t p_stride, const int32_t* prompt_lens, int32_t B) {
   if (!e) return VLE_EINVAL;
-  if (!e->finalized) return e->fail(VLE_ESTATE, "weights not finalized");
+  if (!e->finalized) return e->fail(VLE_ESTATE, e->broken ? "engine is unusable after a failed vle_reserve: destroy it" : "weights not finalized");
   if (!text || !text_lens || !prompt_codes || !prompt_lens) return e->fail(VLE_EINVAL, "null argument");
   if (B < 1 || B > e->max_B) return e->fail(VLE_EINVAL, "batch exceeds max_batch");
   for (int b = 0; b < B; ++b) {
@@ -1238,7 +1271,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   if ((r = enter(e, stream))) return r;
   hipStream_t st = e->st;
   const int B = e->B;
-  e->prog_host[0] = e->prog_host[1] = 0;  // enter() synchronised the stream: no kernel is writing them
+  if (e->prog_host) e->prog_host[0] = e->prog_host[1] = 0;  // enter() synchronised the stream: no kernel is writing them
 
   // upper bound on loop iterations (stop rule valle.py:1047): n + bos > 16 S  first holds at n = 16 S + 1 - bos
   int bound = 0;
@@ -1309,7 +1342,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   constexpr int RING = 8, LAG = 3;
   hipEvent_t evs[RING];
   for (int i = 0; i < RING; ++i) evs[i] = nullptr;
-  const bool hostprog = e->opt_host_prog;
+  const bool hostprog = e->opt_host_prog && e->prog_dev != nullptr;  // no coherent mapping: event / D2H poll instead
   if (!hostprog)
     for (int i = 0; i < RING; ++i) E_HIP(e, hipEventCreateWithFlags(&evs[i], hipEventDisableTiming));
   volatile int32_t* hprog = e->prog_host;
@@ -1543,6 +1576,11 @@ static int finish_nar_timing(vle_engine* e) {
 
 extern "C" int vle_nar_decode(vle_engine* e, void* stream, const int32_t* enroll_lens, int64_t* codes, int64_t g_stride) {
   if (!e) return VLE_EINVAL;
+  // vle_nar_force is one-shot: whatever way this call ends (argument errors included) the caller-owned pointer is forgotten
+  struct ForcedGuard {
+    vle_engine* e;
+    ~ForcedGuard() { e->nar_forced = nullptr; e->nar_forced_stride = 0; }
+  } forced_guard{e};
   if (!e->have_gen) return e->fail(VLE_ESTATE, "vle_nar_decode needs vle_ar_generate first");
   if (!codes) return e->fail(VLE_EINVAL, "codes is null");
   const int mode = e->cfg.prefix_mode;
@@ -1555,13 +1593,13 @@ extern "C" int vle_nar_decode(vle_engine* e, void* stream, const int32_t* enroll
       drop[b] = enroll_lens[b] - 2;
     }
   }
-  for (int b = 0; b < e->B; ++b)
+  for (int b = 0; b < e->B; ++b) {
     if (e->G_len[b] > g_stride) return e->fail(VLE_EINVAL, "g_stride smaller than generated length");
+    if (e->nar_forced && e->G_len[b] > e->nar_forced_stride) return e->fail(VLE_EINVAL, "vle_nar_force: f_stride smaller than generated length");
+  }
   int r;
   if ((r = enter(e, stream))) return r;
-  r = run_nar(e, drop, mode, codes, g_stride);
-  e->nar_forced = nullptr;  // one-shot
-  if (r) return r;
+  if ((r = run_nar(e, drop, mode, codes, g_stride))) return r;
   if ((r = finish_nar_timing(e))) return r;
   return leave(e, stream);
 }
@@ -1578,7 +1616,8 @@ extern "C" int vle_nar_continual(vle_engine* e, void* stream, const int64_t* tex
                                  const int64_t* y_codes, int64_t t_stride, const int32_t* y_lens, int32_t B, int64_t* codes,
                                  int64_t g_stride, int32_t* gen_lens) {
   if (!e) return VLE_EINVAL;
-  if (!e->finalized) return e->fail(VLE_ESTATE, "weights not finalized");
+  if (!e->finalized) return e->fail(VLE_ESTATE, e->broken ? "engine is unusable after a failed vle_reserve: destroy it" : "weights not finalized");
+  e->nar_forced = nullptr; e->nar_forced_stride = 0;  // vle_nar_force applies to vle_nar_decode only
   if (e->Q != 8) return e->fail(VLE_EINVAL, "continual() asserts num_quantizers == 8 (valle.py:1160)");
   if (!text || !text_lens || !y_codes || !y_lens || !codes || !gen_lens) return e->fail(VLE_EINVAL, "null argument");
   if (B < 1 || B > e->max_B) return e->fail(VLE_EINVAL, "batch exceeds max_batch");
@@ -1663,7 +1702,7 @@ static int set_dyn(vle_engine* e, int32_t top_k, float temperature, uint64_t see
 
 extern "C" int vle_slots_begin(vle_engine* e, void* stream) {
   if (!e) return VLE_EINVAL;
-  if (!e->finalized) return e->fail(VLE_ESTATE, "weights not finalized");
+  if (!e->finalized) return e->fail(VLE_ESTATE, e->broken ? "engine is unusable after a failed vle_reserve: destroy it" : "weights not finalized");
   int r;
   if ((r = enter(e, stream))) return r;
   e->B = e->max_B;
@@ -1851,6 +1890,7 @@ extern "C" int vle_slots_step(vle_engine* e, void* stream, int32_t nsteps, int32
 extern "C" int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slots, const int32_t* enroll_lens,
                                  int64_t* codes, int64_t g_stride) {
   if (!e) return VLE_EINVAL;
+  e->nar_forced = nullptr; e->nar_forced_stride = 0;  // vle_nar_force applies to vle_nar_decode only
   if (!e->slot_mode) return e->fail(VLE_ESTATE, "vle_slots_harvest needs vle_slots_begin first");
   if (n < 1 || n > e->max_B || !slots || !codes) return e->fail(VLE_EINVAL, "bad argument");
   const int mode = e->cfg.prefix_mode;
@@ -1881,9 +1921,11 @@ extern "C" int vle_reserve(vle_engine* e, int32_t max_batch, int32_t max_text, i
                            int64_t pe_rows) {
   if (!e) return VLE_EINVAL;
   if (max_batch < 1 || max_text < 1 || max_prompt < 0 || max_gen < 0) return e->fail(VLE_EINVAL, "bad capacity");
+  if (e->broken) return e->fail(VLE_ESTATE, "engine is unusable after a failed vle_reserve: destroy it");
   const int nB = std::max(e->max_B, (int)max_batch), nS = std::max(e->max_S, (int)max_text), nP = std::max(e->max_P, (int)max_prompt);
-  int nG = std::max(e->max_G, max_gen > 0 ? (int)max_gen : 0);
-  nG = std::max(nG, 16 * nS + 1);
+  // like vle_create: the 16 * max_text + 1 default (the reference's length cap, valle.py:1047) applies only when the caller
+  // names no generation capacity; an explicit max_gen is never inflated
+  const int nG = std::max(e->max_G, max_gen > 0 ? (int)max_gen : 16 * nS + 1);
   if (!e->finalized) {  // nothing allocated yet
     e->max_B = nB; e->max_S = nS; e->max_P = nP; e->max_G = nG;
     e->cfg.max_batch = nB; e->cfg.max_text = nS; e->cfg.max_prompt = nP; e->cfg.max_gen = nG;
@@ -1900,15 +1942,12 @@ extern "C" int vle_reserve(vle_engine* e, int32_t max_batch, int32_t max_text, i
     if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
   }
   e->graphs.clear();
-  for (void* p : e->buf_allocs) (void)hipFree(p);
-  e->buf_allocs.clear();
-  if (e->tables_host) (void)hipHostFree(e->tables_host);
-  if (e->poll_host) (void)hipHostFree(e->poll_host);
-  if (e->prog_host) (void)hipHostFree(e->prog_host);
-  e->tables_host = e->poll_host = e->prog_host = nullptr;
-  e->trace_ar = nullptr; e->trace_ar_cap = 0; e->trace_nar = nullptr; e->ktrace_buf = nullptr;
-  e->have_prefill = e->have_gen = false;
-  e->slot_mode = false;
+  // From here until the new buffers exist the engine owns nothing capacity-dependent: if any allocation below fails (growing is
+  // exactly when memory runs out) the engine is marked broken -- finalized = false, every entry point answers VLE_ESTATE -- instead
+  // of keeping pointers into freed memory.  The caller destroys it and builds a new one (valle_amd.Engine.reserve does).
+  release_buffers(e);
+  e->finalized = false;
+  e->broken = true;
   const int old_pos = e->max_pos;
   e->max_B = nB; e->max_S = nS; e->max_P = nP; e->max_G = nG;
   e->cfg.max_batch = nB; e->cfg.max_text = nS; e->cfg.max_prompt = nP; e->cfg.max_gen = nG;
@@ -1921,9 +1960,11 @@ extern "C" int vle_reserve(vle_engine* e, int32_t max_batch, int32_t max_text, i
     if (pe != nullptr && pe_rows >= e->max_pos) tab.assign(pe, pe + (size_t)e->max_pos * e->d);
     else build_pe(tab, e->max_pos, e->d);
     e->in_buffers = false;
-    r = upload_f32(e, &e->pe, tab.data(), tab.size());
+    float* new_pe = nullptr;
+    r = upload_f32(e, &new_pe, tab.data(), tab.size());
     e->in_buffers = true;
     if (r) return r;
+    e->pe = new_pe;
   }
   e->in_buffers = true;
   if ((r = alloc_buffers(e))) return r;
@@ -1939,6 +1980,8 @@ extern "C" int vle_reserve(vle_engine* e, int32_t max_batch, int32_t max_text, i
     e->ktrace_buf = p;
     (void)hipMemset(e->ktrace_buf, 0xFF, (size_t)KT_STEPS * KT_KERNELS * KT_WAVES * 4 * sizeof(unsigned long long));
   }
+  e->broken = false;
+  e->finalized = true;
   return VLE_OK;
 }
 

@@ -159,7 +159,7 @@ int launch_attention_mfma(hipStream_t st, const void* qkv, void* out, const int3
 // the packed rows of qkv (sizes the V^T scratch); returns 1 when not covered, < 0 on error
 int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int32_t* seq_off, const int32_t* text_len, int B,
                            int max_len, int64_t rows, int d, int nhead, int causal);
-int attn2_reserve(int64_t rows, int B, int d);
+int attn2_reserve(int64_t rows, int B, int d, void** scratch_out = nullptr);  // pre-pass modes only (attn_mode <= 2)
 extern int g_g8_dbg;
 extern int g_glds_epi;
 extern int g_attn_v2, g_attn_xcd, g_attn_q128, g_attn_mode, g_attn_defer, g_attn_ring;

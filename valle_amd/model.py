@@ -53,9 +53,10 @@ def _cross_decoder(d: int, nhead: int, num_layers: int, adaptive: bool, norm_fir
 
 def _request_seed_base(seed: int, b: int) -> int:
     """ops.topk_sample draws row r from the stream of request r of ``seed``; the block path samples one row (r = 0) per step, so
-    utterance b of a batch passes the seed whose request-0 stream is request b's: identical to the engine for b = 0 (the
-    reference's batch-1 case), distinct deterministic streams for the others."""
-    return seed if b == 0 else (seed * 0x9E3779B97F4A7C15 + b) & (2**64 - 1)
+    utterance b of a batch passes the seed whose request-0 stream IS request b's stream of ``seed``:
+    request_seed(s, r) = mix(s + GOLDEN * (r + 1)) (csrc/common.h), hence request_seed(seed + GOLDEN * b, 0) == request_seed(seed, b).
+    Sampled decodes of the block path therefore draw exactly what the fused engine and the serving path draw for every b."""
+    return (seed + 0x9E3779B97F4A7C15 * b) & (2**64 - 1)
 
 
 class VALLE(nn.Module):
@@ -163,7 +164,13 @@ class VALLE(nn.Module):
             if self._engine_key == (dev.index or 0, self.engine_dtype):
                 if not (c.max_batch >= batch and c.max_text >= text_len and c.max_prompt >= prompt_len and c.max_gen_eff() >= need_gen):
                     # a capacity grew: re-create the buffers only, the weights stay on the device (vle_reserve)
-                    self._engine.reserve(batch, text_len, prompt_len, need_gen)
+                    try:
+                        self._engine.reserve(batch, text_len, prompt_len, need_gen)
+                    except Exception:
+                        # a failed vle_reserve leaves the engine unusable (VLE_ESTATE on every call): drop it, so the next
+                        # request builds a fresh one instead of reusing the broken handle
+                        self._invalidate()
+                        raise
                     c = self._engine.cfg
                     self.max_text, self.max_prompt, self.max_batch, self.max_gen = c.max_text, c.max_prompt, c.max_batch, c.max_gen
                 return self._engine

@@ -261,6 +261,20 @@ int vle_op_decode_attention(void* stream, int dtype, const float* q, const void*
 int vle_op_attn_out_proj(void* stream, int dtype, const float* workspace, const void* w, const float* bias, float* resid,
                          int32_t B, int32_t nhead, int32_t dh, int32_t nsplit);
 
+/* The attention half of ONE utterance's decode step as the batch-1 AR step runs it (two launches; gemv1.hip qkv_attn1_kernel +
+ * the out-proj GEMV with the PRO_ATTN_SELF prologue):  x += out_proj(MHA(LayerNorm(x)))  for the one new token, i.e.
+ * `x + self._sa_block(self.norm1(x))` of valle/modules/transformer.py:296-297 on the last row, with the in-projection
+ * (valle/modules/activation.py:414-421) appending the token's K / V to cache slot kv_len[0] and the softmax running over slots
+ * 0 .. kv_len[0] (prefix-LM mask, valle.py:1019-1033).
+ *   x f32 [d] in/out; gamma / beta f32 [d] (norm1); w_in T [3d][d], b_in f32 [3d]; w_out T [d][d], b_out f32 [d];
+ *   k_cache / v_cache cache type (T; bf16 when T is bf16) [nhead][ctx_max][dh]; kv_len_dev int32 [1] < ctx_max;
+ *   workspace f32 [3 d + nsplit * (d + 2 * nhead)]; nsplit in {4, 8, 16}; dtype VLE_DTYPE_F32 / _BF16.
+ * Shapes the fused launch does not cover (dh not in {64, 128}, d / (64 * vector) not in {1, 2, 4}) fail with VLE_EINVAL: the
+ * engine then takes vle_op_linear_skinny + vle_op_decode_attention + vle_op_attn_out_proj. */
+int vle_op_attn_step1(void* stream, int dtype, float* x, const float* gamma, const float* beta, const void* w_in, const float* b_in,
+                      const void* w_out, const float* b_out, void* k_cache, void* v_cache, const int32_t* kv_len_dev, float* workspace,
+                      int32_t nhead, int32_t dh, int32_t ctx_max, int32_t nsplit);
+
 /* TokenEmbedding.forward (valle/modules/embedding.py:43-47): out[f32, n x d] = table[f32, V x d][ids[i64, n]].
  * ids must lie in [0, V) (like nn.Embedding on a device, no range check on the hot path). */
 int vle_op_token_embedding(void* stream, const int64_t* ids, const float* table, float* out, int64_t n, int32_t d);

@@ -228,6 +228,86 @@ def test_decode_attention(H, dh, ctx_max, kv, nsplit, dt):
     assert (got.double() - want).abs().max().item() < 1e-4
 
 
+# (d, H, dtype): every (chunks per row, head size) instantiation of the fused launch -- fp32 d256 (1 chunk), d1024 (4 chunks: two
+# query-row passes per wave); bf16 d512 / d1024 / d2048; head size 128
+STEP1_SHAPES = [(256, 4, torch.float32), (1024, 16, torch.float32), (512, 8, torch.bfloat16), (1024, 16, torch.bfloat16),
+                (2048, 16, torch.bfloat16), (1024, 8, torch.bfloat16), (512, 4, torch.float32)]
+
+
+@pytest.mark.parametrize("d,H,dt", STEP1_SHAPES)
+@pytest.mark.parametrize("nsplit", [4, 8, 16])
+@pytest.mark.parametrize("kv_len,ctx_max", [(0, 40), (1, 40), (271, 1026), (127, 1026), (128, 1026), (129, 1026), (1025, 1026), (2050, 2100)])
+def test_fused_qkv_attention_step_vs_fp64(d, H, dt, nsplit, kv_len, ctx_max):
+    """vle_op_attn_step1 = the batch-1 AR step's two attention launches (qkv_attn1_kernel: LN1 + QKV GEMV + cache append + decode
+    attention over the OLD keys; out-proj GEMV with the new token's own softmax term merged in its prologue) against the fp64
+    definition  x + out_proj(softmax(q K^T / sqrt(dh)) V)  with K / V = the cache rows 0 .. kv_len-1 plus the new token's
+    (rounded to the cache type).  Also: the cache slot kv_len holds exactly the rounded K / V, no other slot changes."""
+    if nsplit == 16 and d // 64 > 16:
+        pytest.skip("16 splits x 4 chunks of partials do not fit the out-proj GEMV's registers (the engine never asks)")
+    dh = d // H
+    g = torch.Generator().manual_seed(d + kv_len + nsplit)
+    x = torch.randn(d, generator=g) * 1.5 + 0.3
+    gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    w_in = (torch.randn(3 * d, d, generator=g) / math.sqrt(d)).to(dt)
+    b_in = torch.randn(3 * d, generator=g) * 0.1
+    w_out = (torch.randn(d, d, generator=g) / math.sqrt(d)).to(dt)
+    b_out = torch.randn(d, generator=g) * 0.1
+    kc = torch.randn(H, ctx_max, dh, generator=g).to(dt)
+    vc = torch.randn(H, ctx_max, dh, generator=g).to(dt)
+    kc[:, kv_len:] = 50.0   # stale slots: finite, adversarially large
+    vc[:, kv_len:] = -1000.0
+    kc_d, vc_d = kc.clone().to(DEV), vc.clone().to(DEV)
+    got = ops.attn_step1(x.to(DEV), gamma.to(DEV), beta.to(DEV), w_in.to(DEV), b_in.to(DEV), w_out.to(DEV), b_out.to(DEV), kc_d, vc_d,
+                         kv_len, H, nsplit).cpu()
+    xd = x.double()
+    xn = (xd - xd.mean()) / torch.sqrt(xd.var(unbiased=False) + 1e-5) * gamma.double() + beta.double()
+    qkv = w_in.double() @ xn + b_in.double()
+    q, kn, vn = qkv[:d].view(H, dh), qkv[d: 2 * d].view(H, dh), qkv[2 * d:].view(H, dh)
+    kn_r, vn_r = kn.to(dt).double(), vn.to(dt).double()
+    K = torch.cat([kc[:, :kv_len].double(), kn_r[:, None]], dim=1)  # (H, kv_len + 1, dh)
+    V = torch.cat([vc[:, :kv_len].double(), vn_r[:, None]], dim=1)
+    p = torch.softmax(torch.einsum("hd,hkd->hk", q, K) / math.sqrt(dh), dim=-1)
+    att = torch.einsum("hk,hkd->hd", p, V).reshape(d)
+    want = xd + w_out.double() @ att + b_out.double()
+    tol = 2e-4 if dt == torch.float32 else 2e-2  # bf16: the cache-rounding of the new K / V sits on a rounding boundary now and then
+    assert (got.double() - want).abs().max().item() < tol * max(1.0, want.abs().max().item()), (got.double() - want).abs().max().item()
+    # cache append: slot kv_len = the token's K / V in the cache type (one rounding of the fp32 GEMV result), nothing else touched
+    kslot, vslot = kc_d[:, kv_len].cpu().double(), vc_d[:, kv_len].cpu().double()
+    ulp = 1e-5 if dt == torch.float32 else 2.0 ** -7
+    assert (kslot - kn).abs().max().item() <= ulp * max(1.0, kn.abs().max().item())
+    assert (vslot - vn).abs().max().item() <= ulp * max(1.0, vn.abs().max().item())
+    keep = torch.ones(ctx_max, dtype=torch.bool)
+    keep[kv_len] = False
+    assert torch.equal(kc_d[:, keep].cpu(), kc[:, keep]) and torch.equal(vc_d[:, keep].cpu(), vc[:, keep])
+
+
+def test_fused_qkv_attention_step_equals_the_three_launch_path():
+    """The fused pair against the engine's previous three launches (QKV GEMV with cache write, decode attention over slots
+    0 .. kv_len, out-proj with the split merge) on the same operands: equal up to fp32 summation order."""
+    d, H, dt = 1024, 16, torch.bfloat16
+    dh, ctx_max, kv_len = d // H, 1026, 600
+    g = torch.Generator().manual_seed(9)
+    x = torch.randn(d, generator=g)
+    gamma, beta = torch.rand(d, generator=g) + 0.5, torch.randn(d, generator=g) * 0.1
+    w_in = (torch.randn(3 * d, d, generator=g) / math.sqrt(d)).to(dt).to(DEV)
+    b_in = (torch.randn(3 * d, generator=g) * 0.1).to(DEV)
+    w_out = (torch.randn(d, d, generator=g) / math.sqrt(d)).to(dt).to(DEV)
+    b_out = (torch.randn(d, generator=g) * 0.1).to(DEV)
+    kc = torch.randn(H, ctx_max, dh, generator=g).to(dt).to(DEV)
+    vc = torch.randn(H, ctx_max, dh, generator=g).to(dt).to(DEV)
+    k1, v1 = kc.clone(), vc.clone()
+    fused = ops.attn_step1(x.to(DEV), gamma.to(DEV), beta.to(DEV), w_in, b_in, w_out, b_out, k1, v1, kv_len, H, 8)
+    # reference path from stand-alone operators: q / k / v by the LayerNorm-fused GEMV, cache append by hand
+    qkv = ops.linear_skinny(x[None].to(DEV), w_in, b_in, epilogue=0, gamma=gamma.to(DEV), beta=beta.to(DEV))[0]
+    k2, v2 = kc.clone(), vc.clone()
+    k2[:, kv_len] = qkv[d: 2 * d].view(H, dh).to(dt)
+    v2[:, kv_len] = qkv[2 * d:].view(H, dh).to(dt)
+    assert torch.equal(k1, k2) and torch.equal(v1, v2)
+    _, ws = ops.decode_attention(qkv[None, :d].contiguous(), k2[None], v2[None], torch.tensor([kv_len], dtype=torch.int32, device=DEV), nsplit=4)
+    want = ops.attn_out_proj(ws, w_out, b_out, x[None].to(DEV).clone(), H, 4)[0]
+    assert (fused - want).abs().max().item() < 2e-5 * max(1.0, want.abs().max().item())
+
+
 @pytest.mark.parametrize("M,N,K", [(64, 1024, 4096), (64, 1024, 1024), (33, 1025, 1024), (5, 3072, 1024), (64, 1536, 1536)])
 @pytest.mark.parametrize("ksplit", [None, 1, 2, 4, 8])
 @pytest.mark.parametrize("epi", [ops.EPI_RESID, ops.EPI_F32, ops.EPI_RELU])
@@ -299,8 +379,10 @@ def test_linear_gemm_tile_policy_knobs(M, N, K, knob):
         assert (relu.double() - ref.clamp_min(0)).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
 
 
-def test_skinny_gemm_split_k_handoff_under_memory_pressure():
-    """Stress of the cross-workgroup split-K hand-off of gemm_skinny.hip (write-through partial tiles + vmcnt drain + relaxed
+@pytest.mark.parametrize("formal", [0, 1])
+def test_skinny_gemm_split_k_handoff_under_memory_pressure(formal):
+    """`formal` = 1: the same hand-off with explicit agent-scope release / acquire fences around the ticket (knob "gs_formal").
+    Stress of the cross-workgroup split-K hand-off of gemm_skinny.hip (write-through partial tiles + vmcnt drain + relaxed
     ticket, no fences): 150 launches at 2 / 4 / 8 K slices while a second stream saturates HBM with copies, so workgroup
     arrival order and cache state vary from launch to launch; every result must be bit-identical to the first one of its slice
     count (the combine sums in slice order), and equal to the un-split kernel up to fp32 summation order."""
@@ -313,12 +395,16 @@ def test_skinny_gemm_split_k_handoff_under_memory_pressure():
     side = torch.cuda.Stream()
     big = torch.empty(64 << 20, dtype=torch.float32, device=DEV)
     big2 = torch.empty_like(big)
-    for ks in (2, 4, 8):
-        first = ops.linear(a, w, bias, ops.EPI_F32, ksplit=ks).clone()
-        assert (first - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
-        for it in range(50):
-            with torch.cuda.stream(side):
-                big2.copy_(big)
-            out = ops.linear(a, w, bias, ops.EPI_F32, ksplit=ks)
-            assert torch.equal(out, first), f"split-K x{ks}: launch {it} differs"
-    torch.cuda.synchronize()
+    ops.tune("gs_formal", formal)
+    try:
+        for ks in (2, 4, 8):
+            first = ops.linear(a, w, bias, ops.EPI_F32, ksplit=ks).clone()
+            assert (first - ref).abs().max().item() <= 1e-3 * ref.abs().max().item()
+            for it in range(50):
+                with torch.cuda.stream(side):
+                    big2.copy_(big)
+                out = ops.linear(a, w, bias, ops.EPI_F32, ksplit=ks)
+                assert torch.equal(out, first), f"split-K x{ks}: launch {it} differs"
+        torch.cuda.synchronize()
+    finally:
+        ops.tune("gs_formal", 0)

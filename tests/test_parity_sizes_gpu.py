@@ -158,9 +158,10 @@ def _load_fixture(name):
     return z, spec, cfg, shapes, X, Y
 
 
-def _check_forced_batch(eng, z, spec, shapes, X, Y, pre=""):
+def _check_forced_batch(eng, z, spec, shapes, X, Y, pre="", TAU=TAU, fp32_bar=None, mean_bar=None, agree=(0.95, 0.9)):
     """Teacher-force the batch on the oracle's per-utterance histories; compare AR logits at the stored steps, the
-    sampled tokens at safe margins, and the NAR stages (forced) at the stored rows."""
+    sampled tokens at safe margins, and the NAR stages (forced) at the stored rows.  `fp32_bar` (engine mode FP8): also
+    compare with the un-quantised fp32 oracle on the same history (fixture key ar_logits32_f16) at that fraction of sigma."""
     B = len(shapes)
     S = [s for s, _, _ in shapes]
     P = [p for _, p, _ in shapes]
@@ -176,6 +177,7 @@ def _check_forced_batch(eng, z, spec, shapes, X, Y, pre=""):
     sampled = eng.fetch_sampled()
     steps = [int(v) for v in z["ar_steps"]]
     worst, n_tok, n_agree = 0.0, 0, 0
+    mean_sum, mean_n, worst32 = 0.0, 0, 0.0
     for b in range(B):
         G = gl_ref[b]
         if G == 0:
@@ -184,9 +186,16 @@ def _check_forced_batch(eng, z, spec, shapes, X, Y, pre=""):
         for j, stp in enumerate(steps):
             if stp > G:
                 continue
-            d = (lg[stp, b] - torch.from_numpy(z[pre + "ar_logits_f16"][b, j].astype(np.float32))).abs().max().item()
+            dv = (lg[stp, b] - torch.from_numpy(z[pre + "ar_logits_f16"][b, j].astype(np.float32))).abs()
+            d = dv.max().item()
             worst = max(worst, d / sigma)
+            mean_sum += dv.mean().item() / sigma
+            mean_n += 1
             assert d <= TAU * sigma + 2.5e-3, (b, stp, d, sigma)
+            if fp32_bar is not None:
+                d32 = (lg[stp, b] - torch.from_numpy(z[pre + "ar_logits32_f16"][b, j].astype(np.float32))).abs().max().item()
+                worst32 = max(worst32, d32 / sigma)
+                assert d32 <= fp32_bar * sigma + 2.5e-3, (b, stp, d32, sigma)
         margin = torch.from_numpy(z[pre + "ar_margin"][b, :G])
         safe = margin > 2 * TAU * sigma
         assert torch.equal(sampled[b, :G][safe], codes_ref[b, :G, 0][safe]), f"utterance {b}: a safe-margin AR token differs"
@@ -210,9 +219,12 @@ def _check_forced_batch(eng, z, spec, shapes, X, Y, pre=""):
         nar_tok += 7 * G
         nar_agree += int((codes[b, :G, 1:] == codes_ref[b, :G, 1:]).sum())
         off += G
+    if mean_bar is not None:
+        assert mean_sum / max(mean_n, 1) <= mean_bar, (mean_sum / max(mean_n, 1), mean_bar)
+    print(f"forced batch ({pre or 'fp32-weights'}): mean AR |dlogit|/sigma {mean_sum / max(mean_n, 1):.4f}; vs the un-quantised fp32 oracle worst {worst32:.4f}")
     print(f"forced batch ({pre or 'fp32-weights'}): worst AR |dlogit|/sigma {worst:.4f}; AR argmax agreement {n_agree / max(n_tok, 1):.4f}; "
           f"NAR agreement {nar_agree / max(nar_tok, 1):.4f}")
-    assert n_agree / max(n_tok, 1) > 0.95 and nar_agree / max(nar_tok, 1) > 0.9
+    assert n_agree / max(n_tok, 1) > agree[0] and nar_agree / max(nar_tok, 1) > agree[1]
 
 
 @pytest.fixture(scope="module")
@@ -246,6 +258,25 @@ def test_c3_batch64_distinct_bf16_batch_path_teacher_forced(c3_fixture):
     _check_forced_batch(eng, z, spec, shapes, X, Y)
 
 
+@pytest.fixture(scope="module")
+def c3_long_fixture():
+    z, spec, cfg, shapes, X, Y = _load_fixture("c3_b64_long")
+    sd = vo.make_state_dict(cfg, int(z["wseed"]))
+    return z, spec, cfg, shapes, X, Y, sd
+
+
+def test_c3_batch64_long_context_bf16_batch_path_teacher_forced(c3_long_fixture):
+    """the bf16 BATCH path (gemm_skinny.hip + decode attention at 64 utterances) at the contexts
+    BASELINE configs[2] is quoted on -- S 40..55, P 200..225, 320 forced steps, contexts 240..600 -- each utterance against
+    ITS OWN oracle call over its whole history (AR logits at 8 stored steps incl. the last, every sampled token at safe
+    margins, the 7 NAR stages over 560..600 rows)."""
+    z, spec, cfg, shapes, X, Y, sd = c3_long_fixture
+    B = len(shapes)
+    m = build_model(cfg, sd, "bf16", max_batch=B)
+    eng = m.engine_for(B, X.shape[1], Y.shape[1], gen_len=int(z["max_new"]))
+    _check_forced_batch(eng, z, spec, shapes, X, Y)
+
+
 # ------------------------------------------------------------------------------------------------------------------------
 # C5 architecture (d1536-L24-h16, dh 96): bf16 and FP8W whole-model parity
 # ------------------------------------------------------------------------------------------------------------------------
@@ -256,16 +287,33 @@ def c5_fixture():
     return z, spec, cfg, shapes, X, Y, sd
 
 
-@pytest.mark.parametrize("dtype,pre", [("bf16", ""), ("fp8w", "w8_")])
+# Engine mode FP8 at depth 24.  Activation quantisation is lossy by construction, and at 24 layers it is the dominant error: the
+# ORACLE with the per-row e4m3fn activation quantisation (act_fp8=True on W') is itself 21.7 % of sigma (max; 4.1 % mean) away
+# from the un-quantised fp32 oracle on the same history (fixture: a8_ar_logits_f16 vs a8_ar_logits32_f16); the 5 % / 15 % figures
+# of tests/test_fp8_gpu.py were calibrated on 2-layer models, where they hold.  Against the quantising oracle the engine cannot
+# be as close as the other modes either: every e4m3fn rounding decision (spacing 2^-3 relative) that the engine's bf16-level
+# upstream noise flips moves an activation by a whole fp8 step, and 4 x 24 quantised Linears feed the logits (measured on
+# MI355X: 10.2 % of sigma max at the prefill's logits; mean printed by the test).  Bars at this depth: engine vs the quantising
+# oracle 15 % max / 3 % mean (the stated fp8-activation tolerance); engine vs the plain fp32 oracle: the oracle's own 21.7 % + 15 %.
+# FP8W (fp8 WEIGHTS, bf16 activations -- BASELINE configs[4]'s weight format) stays at the 5 % bar above.
+FP8_C5_TAU, FP8_C5_MEAN = 0.15, 0.03
+FP8_C5_FP32_BAR = 0.217 + FP8_C5_TAU
+
+
+@pytest.mark.parametrize("dtype,pre", [("bf16", ""), ("fp8w", "w8_"), ("fp8", "a8_")])
 def test_c5_architecture_whole_model_teacher_forced(c5_fixture, dtype, pre):
     """BASELINE.json configs[4] architecture: the bf16 engine against the oracle on the fp32 weights, the FP8W engine
-    against the oracle on W' = e4m3fn-representable weights (oracle.fp8w_state_dict); batch of 3 (batch path) and
-    utterance 0 alone (batch-1 GEMV path)."""
+    against the oracle on W' = e4m3fn-representable weights (oracle.fp8w_state_dict), and engine mode FP8 (fp8 MFMA GEMMs on
+    per-row-quantised activations in prefill / NAR, FP8W AR step) against the oracle that applies the same quantisation to W'
+    AND against the plain fp32 oracle; batch of 3 (batch path) and utterance 0 alone (batch-1 GEMV path)."""
     z, spec, cfg, shapes, X, Y, sd = c5_fixture
     B = len(shapes)
     m = build_model(cfg, sd, dtype, max_batch=B)
     eng = m.engine_for(B, X.shape[1], Y.shape[1])
-    _check_forced_batch(eng, z, spec, shapes, X, Y, pre)
+    if dtype == "fp8":
+        _check_forced_batch(eng, z, spec, shapes, X, Y, pre, TAU=FP8_C5_TAU, fp32_bar=FP8_C5_FP32_BAR, mean_bar=FP8_C5_MEAN, agree=(0.8, 0.8))
+    else:
+        _check_forced_batch(eng, z, spec, shapes, X, Y, pre)
     # utterance 0 alone: the batch-1 kernels (gemv1.hip; fp8 GEMV in FP8W mode)
     S0, P0, _ = shapes[0]
     G0 = int(z[pre + "gen_lens"][0])

@@ -21,6 +21,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=3)
     ap.add_argument("--dtype", default="bf16")
     ap.add_argument("--batch", type=int, default=1)
+    ap.add_argument("--variants", nargs="*", default=None, help="e.g. qkv_attn=0 qa_nsplit=4,steps_per_graph=16")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -31,17 +32,21 @@ def main():
     Y = torch.stack([synth_inputs(b)[1] for b in range(B)]).to(dev)
     variants = [
         ("default", {}),
-        ("ns2_nk4", {"nsplit": 2, "attn_nk": 4}),
-        ("qkv_rpw2", {"gemv1_rpw_qkv": 2}),
-        ("ffn1_rpw2", {"gemv1_rpw_ffn1": 2}),
-        ("ffn1_rpw1", {"gemv1_rpw_ffn1": 1}),
-        ("ffn1_rpw3", {"gemv1_rpw_ffn1": 3}),
+        ("unfused_qkv_attn", {"qkv_attn": 0}),
+        ("fused_ns4", {"qa_nsplit": 4}),
+        ("fused_ns16", {"qa_nsplit": 16}),
+        ("spg16", {"steps_per_graph": 16}),
     ]
+    if args.variants:
+        variants = [("default", {})] + [(v, dict((kv.split("=")[0], int(kv.split("=")[1])) for kv in v.split(","))) for v in args.variants]
     res = {name: [] for name, _ in variants}
     for r in range(args.rounds):
         for name, opts in variants:
             for k in ("nsplit", "gemv1_rpw", "gemv1_rpw_qkv", "gemv1_rpw_ffn1", "no_gemv1", "attn_nk", "steps_per_graph"):
                 eng.set_option(k, 0)
+            eng.set_option("qkv_attn", 1)
+            eng.set_option("qa_nsplit", 8)
+            eng.set_option("g1_shared", 1)
             for k, v in opts.items():
                 eng.set_option(k, v)
             for rep in range(2):  # first pass (re)captures the graph

@@ -17,7 +17,9 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import bench  # noqa: E402
 import valle_amd  # noqa: E402
 
-NAMES = ["qkv(LN1+in_proj+KV write)", "decode_attention", "out_proj(merge+resid)", "ffn1(LN2+relu)", "ffn2(+resid)"]
+NAMES5 = ["qkv(LN1+in_proj+KV write)", "decode_attention", "out_proj(merge+resid)", "ffn1(LN2+relu)", "ffn2(+resid)"]
+# batch 1 with the fused launch (engine option qkv_attn = 1, the default): 4 launches per layer
+NAMES4 = ["qkv+attention(LN1+in_proj+KV write+old keys)", "out_proj(merge+own key+resid)", "ffn1(LN2+relu)", "ffn2(+resid)"]
 
 
 def main():
@@ -29,6 +31,7 @@ def main():
     ap.add_argument("--d-model", type=int, default=1024)
     ap.add_argument("--layers", type=int, default=12)
     ap.add_argument("--opt", action="append", default=[])
+    ap.add_argument("--kpl", type=int, default=0, help="launches per layer (0 = 4 at batch 1 unless --opt qkv_attn=0, else 5)")
     args = ap.parse_args()
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
@@ -64,7 +67,9 @@ def main():
     eng.set_option("ktrace", 1)  # re-arm (clears the buffer)
     tm = run(28)
     kt = eng.fetch_ktrace().double() * 0.01  # us
-    nk = 5 * L + 2
+    KPL = args.kpl or (4 if (B == 1 and "qkv_attn=0" not in args.opt and args.d_model // 16 in (64, 128)) else 5)
+    NAMES = NAMES4 if KPL == 4 else NAMES5
+    nk = KPL * L + 2
     assert nk <= 64 or B == 1, 'the trace holds 64 kernels per step'
     nk = min(nk, 64)
     steps = list(range(9, 25))  # two whole 8-step graph replays, away from both ends
@@ -82,7 +87,7 @@ def main():
             ph1 += float(cur[3] - cur[0])
             ph2 += float(cur[5] - cur[3])
         n = len(steps)
-        name = NAMES[k % 5] if k < 5 * L else ("final_LN+predict" if k == 5 * L else "sample+stop+embed")
+        name = NAMES[k % KPL] if k < KPL * L else ("final_LN+predict" if k == KPL * L else "sample+stop+embed")
         rows.append((k, name, gap / n, ramp / n, body / n, spread / n, ph1 / n, ph2 / n))
         f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
         f[0] += 1; f[1] += gap / n; f[2] += body / n; f[3] += ramp / n

@@ -60,6 +60,7 @@ SIGNATURES = {
     "vle_op_linear_fp8w": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int, _P, C.c_int32]),
     "vle_op_linear_skinny": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int]),
+    "vle_op_attn_step1": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vle_op_decode_attention": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vle_op_attn_out_proj": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     "vle_op_token_embedding": (C.c_int, [_P, _P, _P, _P, C.c_int64, C.c_int32]),

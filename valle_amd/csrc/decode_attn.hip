@@ -49,6 +49,7 @@ struct AttnOproj {
   float* resid = nullptr;      // [B][d] fp32, updated in place
   float* part = nullptr;       // [B][H][d] fp32 partial sums
   int* cnt = nullptr;          // [B] tickets, zero between launches (self-resetting)
+  int formal = 0;              // g_gs_formal at launch
   LnProducer lnp;
 };
 
@@ -85,7 +86,12 @@ __device__ inline void attn_oproj_tail(const AttnOproj& fo, const float* sm_on, 
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   if (tid == 0) {
+    if (fo.formal) {  // "gs_formal": explicit release / acquire around the ticket (gemm_skinny.hip explains both forms)
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     const int t = __hip_atomic_fetch_add(fo.cnt + b, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (fo.formal) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
     s_last = t == nhead - 1;
     if (t == nhead - 1) __hip_atomic_store(fo.cnt + b, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-reset (graph replay)
   }
@@ -375,7 +381,7 @@ int launch_decode_attention_oproj(hipStream_t st, const float* q, const void* k_
   const int d = nhead * dh;
   if (!(dh == 32 || dh == 64 || dh == 128) || d % 256 != 0 || !wo_bf16 || !resid || !part || !cnt) return 1;
   AttnOproj fo;
-  fo.w = (const bf16_t*)wo_bf16; fo.bias = bias; fo.resid = resid; fo.part = part; fo.cnt = cnt; fo.lnp = lnp;
+  fo.w = (const bf16_t*)wo_bf16; fo.bias = bias; fo.resid = resid; fo.part = part; fo.cnt = cnt; fo.lnp = lnp; fo.formal = g_gs_formal;
   const dim3 grid(nhead, 1, B), block(256);
 #define VLE_DAO(LPK)                                                                                                            \
   hipLaunchKernelGGL((decode_attn_kernel<bf16_t, 8, LPK, 4, true>), grid, block, 0, st, q, (const bf16_t*)k_cache, (const bf16_t*)v_cache, \

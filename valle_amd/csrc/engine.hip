@@ -160,6 +160,8 @@ struct vle_engine {
   int opt_nsplit = 0;         // option "nsplit": 0 = chosen per batch
   int opt_nk = 0;             // option "attn_nk": keys per lane per round of the decode attention (0 auto, 4, 8)
   int opt_spg = 0;            // option "steps_per_graph": overrides cfg.steps_per_graph when > 0
+  int opt_qkv_attn = 1;       // option "qkv_attn": batch 1, QKV GEMV + decode attention in one launch (gemv1.hip qkv_attn1_kernel)
+  int opt_qa_nsplit = 8;      // option "qa_nsplit": KV splits per head of that launch (4, 8, 16)
   int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
   int opt_rpw_qkv = 0;        // option "gemv1_rpw_qkv": the same for the QKV GEMV only
   int opt_rpw_ffn1 = 0;       // option "gemv1_rpw_ffn1": ... for the FFN1 GEMV only
@@ -195,6 +197,7 @@ namespace {
     if (_r != hipSuccess) {                                                                      \
       char _b[512];                                                                              \
       snprintf(_b, sizeof(_b), "HIP error %d (%s) at %s:%d: %s", (int)_r, hipGetErrorString(_r), __FILE__, __LINE__, #expr); \
+      (void)hipGetLastError(); /* reported through the C ABI: do not leave it for the caller's next runtime check (torch) */ \
       return (e)->fail(VLE_EHIP, _b);                                                            \
     }                                                                                            \
   } while (0)
@@ -739,6 +742,8 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->x_step, B * d))) return r;
   if ((r = dev_alloc(e, &e->q_step, B * d))) return r;
   if ((r = dev_alloc(e, &e->h_step, B * 4 * d))) return r;
+  if ((r = dev_alloc(e, &e->k_new, B * d))) return r;
+  if ((r = dev_alloc(e, &e->v_new, B * d))) return r;
   if ((r = dev_alloc(e, &e->part_o, (size_t)B * e->H * 16 * e->dh))) return r;
   if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
   if ((r = dev_alloc(e, &e->logits, B * V_AR))) return r;
@@ -1078,7 +1083,32 @@ int enqueue_ar_step(vle_engine* e) {
       }
       continue;
     }
-    if (sk) {
+    // batch 1: LN1 + QKV GEMV + KV write + decode attention over the old keys in ONE launch; the out-proj prologue below merges
+    // the new token's own term (gemv1.hip qkv_attn1_kernel / PRO_ATTN_SELF).  Shapes it lacks take the two launches.
+    bool fused_qa = false;
+    if (sk && e->B == 1 && e->opt_qkv_attn && !e->opt_no_gemv1) {
+      const bool codes = e->w8 && w.wqkv8 != nullptr;
+      const int qdt = codes ? DT_FP8W : e->dtype;
+      if (qkv_attn1_supports(qdt, d, e->H, e->dh) && (e->opt_qa_nsplit == 4 || e->opt_qa_nsplit == 8 || e->opt_qa_nsplit == 16)) {
+        ProfScope ps(e, 0);
+        QkvAttnArgs q;
+        q.w = codes ? w.wqkv8 : w.wqkv; q.wscale = codes ? w.sqkv : nullptr; q.bias = w.bqkv;
+        q.x = e->x_step; q.gamma = w.g1; q.beta = w.be1; q.q_out = e->q_step; q.k_new = e->k_new; q.v_new = e->v_new;
+        q.k_cache = kc; q.v_cache = vc; q.kv_len = e->S.kv_len; q.part_o = e->part_o; q.part_ml = e->part_ml;
+        q.d = d; q.nhead = e->H; q.dh = e->dh; q.ctx_max = e->ctx_max; q.nsplit = e->opt_qa_nsplit;
+        if (codes) {
+          const int64_t w8_bytes = (int64_t)e->L * 12 * e->d * e->d + (int64_t)V_AR * e->d;
+          q.temporal = e->opt_w8_temporal >= 0 ? e->opt_w8_temporal : (w8_bytes <= (int64_t)192 << 20 ? 1 : 0);
+        }
+        q.kt = e->next_kt();
+        const int fr = launch_qkv_attn1(st, qdt, q);
+        if (fr < 0) return e->fail(VLE_EHIP, "launch_qkv_attn1 failed");
+        fused_qa = fr == 0;
+      }
+    }
+    if (fused_qa) {
+      // nothing: both launches are done
+    } else if (sk) {
       ProfScope ps(e, 0);
       SkinnyArgs a;
       a.w = w.wqkv; a.w8 = w.wqkv8; a.wscale = w.sqkv; a.bias = w.bqkv; a.N = 3 * d; a.K = d; a.B = e->B; a.pro = PRO_LN; a.epi = SEPI_QKV;
@@ -1091,7 +1121,7 @@ int enqueue_ar_step(vle_engine* e) {
       E_LAUNCH(e, launch_gemm(st, e->dtype, e->xn_step, w.wqkv, w.bqkv, e->qkv_step, nullptr, e->B, 3 * d, d, EPI_STORE));
       E_LAUNCH(e, launch_qkv_split(st, e->dtype, e->qkv_step, e->q_step, kc, vc, e->S.kv_len, e->B, d, e->H, e->ctx_max));
     }
-    {
+    if (!fused_qa) {
       ProfScope ps(e, 1);
       E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
                                           e->ctx_max, e->nsplit, e->opt_nk, nullptr, e->B > 1 ? e->S.done : nullptr, 0, e->next_kt()));
@@ -1102,6 +1132,9 @@ int enqueue_ar_step(vle_engine* e) {
         SkinnyArgs a;
         a.w = w.wo; a.w8 = w.wo8; a.wscale = w.so; a.bias = w.bo; a.N = d; a.K = d; a.B = e->B; a.pro = PRO_ATTN; a.epi = SEPI_RESID;
         a.part_o = e->part_o; a.part_ml = e->part_ml; a.nsplit = e->nsplit; a.nhead = e->H; a.dh = e->dh; a.resid = e->x_step;
+        if (fused_qa) {  // the partials exclude the new token: merge its own term here
+          a.pro = PRO_ATTN_SELF; a.nsplit = e->opt_qa_nsplit; a.q_self = e->q_step; a.k_self = e->k_new; a.v_self = e->v_new;
+        }
         E_LAUNCH(e, launch_ar_linear(e, a));
       }
       {
@@ -2022,6 +2055,17 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
+  if (n == "qkv_attn" || n == "qa_nsplit") {  // changes the captured graphs: drop them
+    if (n == "qa_nsplit" && !(value == 4 || value == 8 || value == 16)) return e->fail(VLE_EINVAL, "qa_nsplit must be 4, 8 or 16");
+    (n == "qkv_attn" ? e->opt_qkv_attn : e->opt_qa_nsplit) = (int)value;
+    (void)hipStreamSynchronize(e->st);
+    for (auto& kv : e->graphs) {
+      if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
+      if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+    }
+    e->graphs.clear();
+    return VLE_OK;
+  }
   if (n == "no_gemv1" || n == "gemv1_rpw" || n == "gemv1_rpw_qkv" || n == "gemv1_rpw_ffn1" || n == "attn_oproj" || n == "attn_nk" || n == "steps_per_graph" || n == "no_gemm_skinny" || n == "gs_target_wgs" || n == "gs_xf" || n == "gs_wpack" || n == "w8_temporal" || n == "gs_fuse_ln" || n == "gs_rot" || n == "gs_dbg") {  // change the captured graphs: drop them
     if (n == "no_gemv1") e->opt_no_gemv1 = value != 0;
     else if (n == "gs_fuse_ln") e->opt_gs_fuse_ln = value != 0;
@@ -2052,6 +2096,16 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
   }
   if (n == "attn_v2" || n == "attn_xcd" || n == "attn_q128" || n == "attn_mode" || n == "attn_defer" || n == "attn_ring") {
     (n == "attn_v2" ? g_attn_v2 : n == "attn_xcd" ? g_attn_xcd : n == "attn_q128" ? g_attn_q128 : n == "attn_mode" ? g_attn_mode : n == "attn_defer" ? g_attn_defer : g_attn_ring) = (int)value;
+    return VLE_OK;
+  }
+  if (n == "gs_formal" || n == "g1_shared") {  // process-global kernel selection / argument: drop the captured graphs
+    (n == "gs_formal" ? g_gs_formal : g_g1_shared) = value != 0;
+    (void)hipStreamSynchronize(e->st);
+    for (auto& kv : e->graphs) {
+      if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
+      if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+    }
+    e->graphs.clear();
     return VLE_OK;
   }
   if (n == "glds_swz" || n == "glds_8ph" || n == "g8_stagger" || n == "g8_colgroup") {

@@ -292,9 +292,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const gs_f32x4*>(&red[w][i][lane][0]);
   }
   if (KS > 1) {  // uniform per launch
-    // Cross-workgroup hand-off WITHOUT fences: an agent-scope release fence writes the whole L2 back
-    // (measured: 30-70 us per kernel).  Partials go out as write-through (sc1) stores, the wave waits for
-    // their acknowledgement (vmcnt), then one lane takes the ticket; the last arriver reads with sc1 loads.
+    // Cross-workgroup hand-off, two forms (option / tune knob "gs_formal"):
+    //  0 (default) -- the write-through form, /opt/skills/guides/cdna_hip_programming.md Guideline 16 recipe R1: partials go out
+    //     as write-through (sc1) stores, EVERY storing wave drains them (asm vmcnt(0): an acknowledged sc1 store is at the memory
+    //     side, visible to every XCD), block barrier, one lane takes a relaxed agent-scope ticket; the last arriver reads the
+    //     partials with sc1 loads (they bypass its CU's L1 and were never in its L2: the producers' sc1 stores drop the line).
+    //     No cache-wide operation anywhere.
+    //  1 -- the same data path with the C++ memory model spelled out: release fence (buffer_wbl2 sc1 -- writes the XCD's whole
+    //     L2 back) before the ticket, acquire fence (buffer_inv sc1) after it.  Measured on MI355X: the fences
+    //     add whole-cache work to a ~10 us kernel; results are bit-identical, which is why form 0 is the default.
     __shared__ int s_last;
     float* part = a.ws_part + ((int64_t)blockIdx.x * KS * MF) * 256;  // tile (ks, i): [r][lane], 4 x 256-B rows
     if (wave < MF) {
@@ -305,7 +311,12 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
+      if (a.formal) {
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the compiler may drop its own wait after buffer_wbl2 (guide, compiler hazard)
+      }
       const int t = __hip_atomic_fetch_add(a.ws_cnt + blockIdx.x, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (a.formal) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
       s_last = t == KS - 1;
       if (t == KS - 1) __hip_atomic_store(a.ws_cnt + blockIdx.x, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // self-reset
     }
@@ -395,6 +406,8 @@ bool gemm_skinny_supports(int M, int N, int K, int epi, int dh) {
   return true;
 }
 
+int g_gs_formal = 0;  // "gs_formal": split-K hand-off with explicit agent-scope release / acquire fences (see the kernel)
+
 // returns 0 = launched, 1 = shape not covered
 int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a) {
   if (!gemm_skinny_supports(a.M, a.N, a.K, a.epi, a.dh)) return 1;
@@ -407,6 +420,7 @@ int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a) {
     while (KS > 1 && (a.K % (256 * KS) != 0 || nblk * KS > GS_WS_MAX_TILES || nblk > GS_WS_CNT_BYTES / 4)) KS >>= 1;
   }
   GemmSkinnyArgs b = a;
+  b.formal = g_gs_formal;
   b.ws_cnt = reinterpret_cast<int*>(a.workspace);
   b.ws_part = a.workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.workspace) + GS_WS_CNT_BYTES) : nullptr;
   if (a.M <= 16) return gs_launch<1>(st, b, KS);

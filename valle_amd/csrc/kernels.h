@@ -86,6 +86,7 @@ struct GemmSkinnyArgs {
   LnConsumer lnc;
   KTrace kt;  // diagnostic timeline (option "ktrace")
   int dbg = 0;  // timing diagnostics (option "gs_dbg"): 1 = no X loads, 2 = no W loads (results meaningless)
+  int formal = 0;  // split-K hand-off with explicit release / acquire fences (filled by the launcher from g_gs_formal)
   int rot = 0;  // rotate the order in which a workgroup walks X by its index (option "gs_rot")
   const void* x = nullptr;     // bf16 [M][K]
   const void* w = nullptr;     // bf16 [N][K]
@@ -112,13 +113,14 @@ struct GemmSkinnyArgs {
 };
 constexpr int GS_WS_CNT_BYTES = 4096;  // 1024 row-fragment tickets
 constexpr int GS_WS_MAX_TILES = 2048;  // partial 16 x 64 fp32 tiles (4 KB each)
+extern int g_gs_formal;
 size_t gemm_skinny_workspace_bytes();
 int gemm_skinny_ksplit(int N, int K, int target_wgs);
 bool gemm_skinny_supports(int M, int N, int K, int epi, int dh);
 int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a);  // 1 = shape not covered
 
 // ---- skinny.hip (AR-step weight-streaming GEMV, M = batch <= 8) --------------------------------
-enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2 };
+enum { PRO_PLAIN = 0, PRO_LN = 1, PRO_ATTN = 2, PRO_ATTN_SELF = 3 };  // ATTN_SELF: the partials exclude the new token (qkv_attn1), merged here
 enum { SEPI_STORE = 0, SEPI_RELU = 1, SEPI_RESID = 2, SEPI_QKV = 3 };
 struct SkinnyArgs {
   const void* w = nullptr;     // T [N][K]
@@ -134,6 +136,9 @@ struct SkinnyArgs {
   const float* part_o = nullptr; // f32 [B][nsplit][d] (PRO_ATTN): un-normalised partial outputs
   const float* part_ml = nullptr;// f32 [B][H][nsplit][2]  (running max, running sum)
   int nsplit = 1, nhead = 1, dh = 1;
+  const float* q_self = nullptr; // f32 [d] (PRO_ATTN_SELF, batch 1): the new token's query, key and value rows (cache-rounded) --
+  const float* k_self = nullptr; //   its own term of the softmax is one more "partial" (m = q.k / sqrt(dh), l = 1, o = v)
+  const float* v_self = nullptr;
   float* out = nullptr;          // f32 [B][N]           (SEPI_STORE / SEPI_RELU)
   float* resid = nullptr;        // f32 [B][N] += (.)    (SEPI_RESID)
   float* q_out = nullptr;        // f32 [B][d]           (SEPI_QKV)
@@ -147,6 +152,35 @@ struct SkinnyArgs {
 int launch_skinny(hipStream_t st, int dtype, const SkinnyArgs& a);
 // gemv1.hip: batch-1 wave-autonomous variant; returns 1 when the shape is not instantiated (use launch_skinny)
 int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a);
+extern int g_g1_shared;  // 1 = block-shared activations (default), 0 = wave-autonomous (A/B)
+
+// gemv1.hip: LN1 + QKV projection + KV-cache write + decode attention over the OLD keys of ONE utterance in ONE launch
+// (batch-1 AR step: 5 -> 4 launches per layer).  Workgroups [0, H * nsplit) each recompute their head's dh query rows (the
+// splits of a head sit on one XCD and share the rows through its L2) and stream their key chunks of the cache; the other
+// workgroups are the K / V rows of the GEMV (cache write + k_new / v_new).  Nothing is exchanged inside the launch: the new
+// token's own softmax term is merged by the out-proj GEMV's prologue (PRO_ATTN_SELF).  Returns 1 = shape not covered.
+struct QkvAttnArgs {
+  const void* w = nullptr;        // T [3d][d] in_proj_weight (valle/modules/activation.py:128-130)
+  const float* bias = nullptr;    // f32 [3d]
+  const float* wscale = nullptr;  // FP8W row scales
+  const float* x = nullptr;       // f32 [d] residual stream of the new token
+  const float* gamma = nullptr;   // norm1
+  const float* beta = nullptr;
+  float* q_out = nullptr;         // f32 [d]
+  float* k_new = nullptr;         // f32 [d], rounded to the cache type
+  float* v_new = nullptr;
+  void* k_cache = nullptr;        // cache_t [H][ctx_max][dh] of this layer
+  void* v_cache = nullptr;
+  const int32_t* kv_len = nullptr;
+  float* part_o = nullptr;        // [nsplit][d]
+  float* part_ml = nullptr;       // [H][nsplit][2]
+  int d = 0, nhead = 0, dh = 0, ctx_max = 0, nsplit = 8;
+  int n_attn = 0;                 // (filled by the launcher) workgroups with the attention role
+  int temporal = 0;               // FP8W: default-policy weight loads
+  KTrace kt;
+};
+bool qkv_attn1_supports(int dtype, int d, int nhead, int dh);
+int launch_qkv_attn1(hipStream_t st, int dtype, const QkvAttnArgs& a);
 
 // ---- attention.hip --------------------------------------------------------------------------
 // prefill (causal=1: prefix-LM mask) / NAR (causal=0) attention over packed sequences

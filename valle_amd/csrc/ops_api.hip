@@ -46,6 +46,8 @@ extern "C" int vle_op_tune(const char* name, int64_t value) {
   else if (n == "g8_dbg" && value >= 0 && value <= 7) vle::g_g8_dbg = (int)value;
   else if (n == "attn_mode" && value >= 0 && value <= 3) vle::g_attn_mode = (int)value;
   else if (n == "attn_ring" && (value == 0 || value == 2 || value == 4)) vle::g_attn_ring = (int)value;
+  else if (n == "g1_shared" && value >= 0 && value <= 1) vle::g_g1_shared = (int)value;
+  else if (n == "gs_formal" && value >= 0 && value <= 1) vle::g_gs_formal = (int)value;
   else if (n == "attn_defer" && value >= 0 && value <= 16) vle::g_attn_defer = (int)value;
   else return op_fail("vle_op_tune: unknown knob or value out of range");
   return VLE_OK;
@@ -168,6 +170,30 @@ extern "C" int vle_op_attn_out_proj(void* stream, int dtype, const float* worksp
     if (r <= 0) return op_done(r, "vle_op_attn_out_proj");
   }
   return op_done(launch_skinny((hipStream_t)stream, dtype, a), "vle_op_attn_out_proj");
+}
+
+extern "C" int vle_op_attn_step1(void* stream, int dtype, float* x, const float* gamma, const float* beta, const void* w_in, const float* b_in,
+                                 const void* w_out, const float* b_out, void* k_cache, void* v_cache, const int32_t* kv_len_dev,
+                                 float* workspace, int32_t nhead, int32_t dh, int32_t ctx_max, int32_t nsplit) {
+  if (!x || !gamma || !beta || !w_in || !w_out || !k_cache || !v_cache || !kv_len_dev || !workspace || nhead < 1 || dh < 1 || ctx_max < 1)
+    return op_fail("vle_op_attn_step1: bad argument");
+  if (!(dtype == DT_F32 || dtype == DT_BF16)) return op_fail("vle_op_attn_step1: dtype must be f32 or bf16");
+  if (!(nsplit == 4 || nsplit == 8 || nsplit == 16)) return op_fail("vle_op_attn_step1: nsplit must be 4, 8 or 16");
+  const int d = nhead * dh;
+  if (!qkv_attn1_supports(dtype, d, nhead, dh) || (nsplit == 16 && d / 64 > 16)) return op_fail("vle_op_attn_step1: shape not covered by the fused launch");
+  QkvAttnArgs q;
+  q.w = w_in; q.bias = b_in; q.x = x; q.gamma = gamma; q.beta = beta;
+  q.q_out = workspace; q.k_new = workspace + d; q.v_new = workspace + 2 * d;
+  q.part_o = workspace + 3 * d; q.part_ml = workspace + 3 * d + (int64_t)nsplit * d;
+  q.k_cache = k_cache; q.v_cache = v_cache; q.kv_len = kv_len_dev; q.d = d; q.nhead = nhead; q.dh = dh; q.ctx_max = ctx_max; q.nsplit = nsplit;
+  int r = launch_qkv_attn1((hipStream_t)stream, dtype, q);
+  if (r != 0) return op_done(r < 0 ? r : -1, "vle_op_attn_step1");
+  SkinnyArgs a;
+  a.w = w_out; a.bias = b_out; a.N = d; a.K = d; a.B = 1; a.pro = PRO_ATTN_SELF; a.epi = SEPI_RESID;
+  a.part_o = q.part_o; a.part_ml = q.part_ml; a.nsplit = nsplit; a.nhead = nhead; a.dh = dh; a.resid = x;
+  a.q_self = q.q_out; a.k_self = q.k_new; a.v_self = q.v_new;
+  r = launch_gemv1((hipStream_t)stream, dtype, a);
+  return op_done(r == 0 ? 0 : (r < 0 ? r : -1), "vle_op_attn_step1");
 }
 
 extern "C" int vle_op_token_embedding(void* stream, const int64_t* ids, const float* table, float* out, int64_t n, int32_t d) {

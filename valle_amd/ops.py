@@ -148,6 +148,26 @@ def decode_attention(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tens
     return out, ws
 
 
+def attn_step1(x: torch.Tensor, gamma: torch.Tensor, beta: torch.Tensor, w_in: torch.Tensor, b_in: torch.Tensor, w_out: torch.Tensor,
+               b_out: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, kv_len: int, nhead: int, nsplit: int = 8) -> torch.Tensor:
+    """The attention half of one utterance's decode step as the batch-1 AR step runs it (vle_op_attn_step1): returns
+    x + out_proj(MHA(LayerNorm(x))) for the new token (x fp32 (d,)), appends its K / V to slot ``kv_len`` of the caches
+    (nhead, ctx_max, dh) IN PLACE and attends slots 0 .. kv_len.  w_in (3d, d), w_out (d, d) fp32|bf16, caches of the same dtype."""
+    lib = _lib.load()
+    assert x.dtype == torch.float32 and x.dim() == 1 and w_in.dtype == w_out.dtype == k_cache.dtype == v_cache.dtype
+    assert k_cache.is_contiguous() and v_cache.is_contiguous() and k_cache.shape == v_cache.shape and k_cache.shape[0] == nhead
+    d = x.shape[0]
+    _, ctx_max, dh = k_cache.shape
+    assert nhead * dh == d and 0 <= kv_len < ctx_max
+    x = x.clone().contiguous()
+    w_in, w_out = w_in.contiguous(), w_out.contiguous()
+    ws = torch.empty(3 * d + nsplit * (d + 2 * nhead), dtype=torch.float32, device=x.device)
+    kl = torch.tensor([kv_len], dtype=torch.int32, device=x.device)
+    _lib.check(lib.vle_op_attn_step1(_st(x), _dt(w_in), _p(x), _p(gamma.contiguous()), _p(beta.contiguous()), _p(w_in), _p(b_in.contiguous()),
+                                     _p(w_out), _p(b_out.contiguous()), _p(k_cache), _p(v_cache), _p(kl), _p(ws), nhead, dh, ctx_max, nsplit))
+    return x
+
+
 def attn_out_proj(ws: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], resid: torch.Tensor, nhead: int,
                   nsplit: int) -> torch.Tensor:
     """resid (B, d) fp32 += merge(split partials in ws) @ w.T + bias  -- out_proj of the AR step."""

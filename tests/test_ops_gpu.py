@@ -237,7 +237,8 @@ STEP1_SHAPES = [(256, 4, torch.float32), (1024, 16, torch.float32), (512, 8, tor
 @pytest.mark.parametrize("d,H,dt", STEP1_SHAPES)
 @pytest.mark.parametrize("nsplit", [4, 8, 16])
 @pytest.mark.parametrize("kv_len,ctx_max", [(0, 40), (1, 40), (271, 1026), (127, 1026), (128, 1026), (129, 1026), (1025, 1026), (2050, 2100)])
-def test_fused_qkv_attention_step_vs_fp64(d, H, dt, nsplit, kv_len, ctx_max):
+@pytest.mark.parametrize("waves", [8, 4])
+def test_fused_qkv_attention_step_vs_fp64(d, H, dt, nsplit, kv_len, ctx_max, waves):
     """vle_op_attn_step1 = the batch-1 AR step's two attention launches (qkv_attn1_kernel: LN1 + QKV GEMV + cache append + decode
     attention over the OLD keys; out-proj GEMV with the new token's own softmax term merged in its prologue) against the fp64
     definition  x + out_proj(softmax(q K^T / sqrt(dh)) V)  with K / V = the cache rows 0 .. kv_len-1 plus the new token's
@@ -257,8 +258,12 @@ def test_fused_qkv_attention_step_vs_fp64(d, H, dt, nsplit, kv_len, ctx_max):
     kc[:, kv_len:] = 50.0   # stale slots: finite, adversarially large
     vc[:, kv_len:] = -1000.0
     kc_d, vc_d = kc.clone().to(DEV), vc.clone().to(DEV)
-    got = ops.attn_step1(x.to(DEV), gamma.to(DEV), beta.to(DEV), w_in.to(DEV), b_in.to(DEV), w_out.to(DEV), b_out.to(DEV), kc_d, vc_d,
-                         kv_len, H, nsplit).cpu()
+    ops.tune("qa_waves", waves)  # 4 = default; 8 falls back to 4 where a 512-thread workgroup would leave threads without a row element
+    try:
+        got = ops.attn_step1(x.to(DEV), gamma.to(DEV), beta.to(DEV), w_in.to(DEV), b_in.to(DEV), w_out.to(DEV), b_out.to(DEV), kc_d, vc_d,
+                             kv_len, H, nsplit).cpu()
+    finally:
+        ops.tune("qa_waves", 4)
     xd = x.double()
     xn = (xd - xd.mean()) / torch.sqrt(xd.var(unbiased=False) + 1e-5) * gamma.double() + beta.double()
     qkv = w_in.double() @ xn + b_in.double()

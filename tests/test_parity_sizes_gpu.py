@@ -324,10 +324,11 @@ def test_c5_architecture_whole_model_teacher_forced(c5_fixture, dtype, pre):
     assert gl == [G0]
     lg = eng.fetch_ar_logits()[:, 0]
     sigma = float(z[pre + "ar_sigma"][0])
+    tau1 = FP8_C5_TAU if dtype == "fp8" else TAU
     for j, stp in enumerate(int(v) for v in z["ar_steps"]):
         if stp <= G0:
             d = (lg[stp] - torch.from_numpy(z[pre + "ar_logits_f16"][0, j].astype(np.float32))).abs().max().item()
-            assert d <= TAU * sigma + 2.5e-3, (stp, d, sigma)
+            assert d <= tau1 * sigma + 2.5e-3, (stp, d, sigma)
 
 
 # ------------------------------------------------------------------------------------------------------------------------

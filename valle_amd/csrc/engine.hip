@@ -161,7 +161,8 @@ struct vle_engine {
   int opt_nk = 0;             // option "attn_nk": keys per lane per round of the decode attention (0 auto, 4, 8)
   int opt_spg = 0;            // option "steps_per_graph": overrides cfg.steps_per_graph when > 0
   int opt_qkv_attn = 1;       // option "qkv_attn": batch 1, QKV GEMV + decode attention in one launch (gemv1.hip qkv_attn1_kernel)
-  int opt_qa_nsplit = 8;      // option "qa_nsplit": KV splits per head of that launch (4, 8, 16)
+  int opt_qa_nsplit = 4;      // option "qa_nsplit": KV splits per head of that launch (4, 8, 16); measured at C2: 215.9 / 218.8 / 263 us per step
+  int opt_qa_qtemporal = 1;   // option "qa_qtemporal": its query-row loads with the default cache policy (shared by a head's splits through L2)
   int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
   int opt_rpw_qkv = 0;        // option "gemv1_rpw_qkv": the same for the QKV GEMV only
   int opt_rpw_ffn1 = 0;       // option "gemv1_rpw_ffn1": ... for the FFN1 GEMV only
@@ -1100,6 +1101,7 @@ int enqueue_ar_step(vle_engine* e) {
           const int64_t w8_bytes = (int64_t)e->L * 12 * e->d * e->d + (int64_t)V_AR * e->d;
           q.temporal = e->opt_w8_temporal >= 0 ? e->opt_w8_temporal : (w8_bytes <= (int64_t)192 << 20 ? 1 : 0);
         }
+        q.q_temporal = e->opt_qa_qtemporal;
         q.kt = e->next_kt();
         const int fr = launch_qkv_attn1(st, qdt, q);
         if (fr < 0) return e->fail(VLE_EHIP, "launch_qkv_attn1 failed");
@@ -2055,9 +2057,9 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
-  if (n == "qkv_attn" || n == "qa_nsplit") {  // changes the captured graphs: drop them
+  if (n == "qkv_attn" || n == "qa_nsplit" || n == "qa_qtemporal") {  // changes the captured graphs: drop them
     if (n == "qa_nsplit" && !(value == 4 || value == 8 || value == 16)) return e->fail(VLE_EINVAL, "qa_nsplit must be 4, 8 or 16");
-    (n == "qkv_attn" ? e->opt_qkv_attn : e->opt_qa_nsplit) = (int)value;
+    (n == "qkv_attn" ? e->opt_qkv_attn : n == "qa_nsplit" ? e->opt_qa_nsplit : e->opt_qa_qtemporal) = (int)value;
     (void)hipStreamSynchronize(e->st);
     for (auto& kv : e->graphs) {
       if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
@@ -2098,8 +2100,13 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     (n == "attn_v2" ? g_attn_v2 : n == "attn_xcd" ? g_attn_xcd : n == "attn_q128" ? g_attn_q128 : n == "attn_mode" ? g_attn_mode : n == "attn_defer" ? g_attn_defer : g_attn_ring) = (int)value;
     return VLE_OK;
   }
-  if (n == "gs_formal" || n == "g1_shared") {  // process-global kernel selection / argument: drop the captured graphs
-    (n == "gs_formal" ? g_gs_formal : g_g1_shared) = value != 0;
+  if (n == "gs_formal" || n == "g1_shared" || n == "qa_waves") {  // process-global kernel selection / argument: drop the captured graphs
+    if (n == "qa_waves") {
+      if (!(value == 4 || value == 8)) return e->fail(VLE_EINVAL, "qa_waves must be 4 or 8");
+      g_qa_waves = (int)value;
+    } else {
+      (n == "gs_formal" ? g_gs_formal : g_g1_shared) = value != 0;
+    }
     (void)hipStreamSynchronize(e->st);
     for (auto& kv : e->graphs) {
       if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);

@@ -65,6 +65,9 @@ struct G1W {
   typedef T cache_t;
   static constexpr bool kScaled = false;
   __device__ static inline u32x4_t load(const T* p) { return __builtin_nontemporal_load(reinterpret_cast<const u32x4_t*>(p)); }
+  // rows several workgroups of one XCD read in the same launch (the query rows of the fused QKV + attention launch): default
+  // cache policy, so that the first miss leaves the line in that XCD's L2 for the others
+  __device__ static inline u32x4_t load_shared(const T* p) { return *reinterpret_cast<const u32x4_t*>(p); }
 };
 template <>
 struct G1W<bf16w8_t> {
@@ -73,6 +76,11 @@ struct G1W<bf16w8_t> {
   __device__ static inline u32x4_t load(const bf16w8_t* p) {
     typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
     const u32x2_t t = __builtin_nontemporal_load(reinterpret_cast<const u32x2_t*>(p));
+    return u32x4_t{t.x, t.y, 0u, 0u};
+  }
+  __device__ static inline u32x4_t load_shared(const bf16w8_t* p) {
+    typedef unsigned int u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t t = *reinterpret_cast<const u32x2_t*>(p);
     return u32x4_t{t.x, t.y, 0u, 0u};
   }
 };
@@ -86,6 +94,7 @@ struct G1W<bf16w8t_t> {
     const u32x2_t t = *reinterpret_cast<const u32x2_t*>(p);  // default cache policy
     return u32x4_t{t.x, t.y, 0u, 0u};
   }
+  __device__ static inline u32x4_t load_shared(const bf16w8t_t* p) { return load(p); }
 };
 
 // VEC consecutive fp32 values at p (16-byte aligned)
@@ -321,20 +330,60 @@ __device__ inline void g1_layernorm(float (&x)[NCH][Elem<T>::VEC], const float (
 template <typename T, int NCH>
 __device__ inline float g1_dot(const u32x4_t (&wv)[NCH], const float (&x)[NCH][Elem<T>::VEC]) {
   constexpr int VEC = Elem<T>::VEC;
-  float t0 = 0.f, t1 = 0.f;
+  typedef float f32x2p_t __attribute__((ext_vector_type(2)));
+  f32x2p_t t = f32x2p_t{0.f, 0.f};  // .x: even elements, .y: odd elements -- two chains per row, one v_pk_fma_f32 per pair
 #pragma unroll
   for (int c = 0; c < NCH; ++c) {
     float wf[VEC];
     widen16<T>(wv[c], wf);
 #pragma unroll
-    for (int j = 0; j < VEC; j += 2) {
-      t0 = fmaf(wf[j], x[c][j], t0);
-      t1 = fmaf(wf[j + 1], x[c][j + 1], t1);
-    }
+    for (int j = 0; j < VEC; j += 2) t = __builtin_elementwise_fma(f32x2p_t{wf[j], wf[j + 1]}, f32x2p_t{x[c][j], x[c][j + 1]}, t);
   }
-  return t0 + t1;
+  return t.x + t.y;
 }
 
+// Totals of R = 8 / 16 per-lane partial sums over the 64 lanes of the wave, all at once: a butterfly that halves the number of
+// values at every step (lanes l and l ^ 2^b split the rows between them), R - 1 exchanges instead of R full wave reductions --
+// on the critical path of the fused launch's query rows (16 per wave).  Returns, in EVERY lane, the total of row
+// g1_rows_owner(lane) = the bit-reversed low log2(R) bits of the lane.
+template <int BIT>
+__device__ inline float g1_xchg(float v, int lane) {  // value of lane ^ (1 << BIT), BIT < 4
+  if constexpr (BIT == 0) return dpp_f32<0xB1>(v);
+  else if constexpr (BIT == 1) return dpp_f32<0x4E>(v);
+  else if constexpr (BIT == 2) {
+    const float up = dpp_f32<0x104>(v), dn = dpp_f32<0x114>(v);  // row_shl:4 (from lane + 4), row_shr:4 (from lane - 4)
+    return (lane & 4) ? dn : up;
+  } else return dpp_f32<0x128>(v);  // row_ror:8: the other half of the 16-lane row
+}
+template <int R, int BIT>
+__device__ inline void g1_rows_stage(float (&acc)[R], int lane) {
+  constexpr int H = R >> (BIT + 1);  // values kept after this stage
+  const bool hi = (lane >> BIT) & 1;
+#pragma unroll
+  for (int i = 0; i < H; ++i) {
+    const float keep = hi ? acc[i + H] : acc[i], send = hi ? acc[i] : acc[i + H];
+    acc[i] = keep + g1_xchg<BIT>(send, lane);
+  }
+}
+template <int R>
+__device__ inline float g1_rows_reduce(float (&acc)[R], int lane) {
+  static_assert(R == 8 || R == 16, "butterfly sizes");
+  g1_rows_stage<R, 0>(acc, lane);
+  g1_rows_stage<R, 1>(acc, lane);
+  g1_rows_stage<R, 2>(acc, lane);
+  if constexpr (R == 16) g1_rows_stage<R, 3>(acc, lane);
+  float v = acc[0];
+  if constexpr (R == 8) v += g1_xchg<3>(v, lane);
+  return rows4_sum(v);  // lanes l, l ^ 16, l ^ 32, l ^ 48
+}
+template <int R>
+__device__ inline int g1_rows_owner(int lane) {  // the row whose total g1_rows_reduce leaves in this lane
+  constexpr int LG = R == 16 ? 4 : 3;
+  int r = 0;
+#pragma unroll
+  for (int b = 0; b < LG; ++b) r |= ((lane >> b) & 1) << (LG - 1 - b);
+  return r;
+}
 
 // =====================================================================================================================
 // Block-shared activations (round 3; "g1_shared" = 1, the default).  The wave-autonomous kernel above has every wave fetch the
@@ -389,9 +438,9 @@ __device__ inline float head_group_sum64(float v, int lpk) {
 
 // LayerNorm of the K-element row whose elements [t * EPT, (t + 1) * EPT) this thread holds (valle/modules/transformer.py:57-74,
 // eps 1e-5, biased variance, two-pass fp32) -> sx[K]; red = 8 floats of LDS.  Ends with a barrier: sx is readable.
-template <int K>
-__device__ inline void g1_block_layernorm(const float (&xv)[K / G1_T], const float (&gv)[K / G1_T], const float (&bv)[K / G1_T], float* sx, float* red) {
-  constexpr int EPT = K / G1_T;
+template <int K, int NT = G1_T>
+__device__ inline void g1_block_layernorm(const float (&xv)[K / NT], const float (&gv)[K / NT], const float (&bv)[K / NT], float* sx, float* red) {
+  constexpr int EPT = K / NT, NWV = NT / 64;  // red: 2 * NWV floats
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   float s = 0.f;
 #pragma unroll
@@ -399,7 +448,9 @@ __device__ inline void g1_block_layernorm(const float (&xv)[K / G1_T], const flo
   s = wave_sum_dpp(s);
   if (lane == 0) red[w] = s;
   g1_lds_barrier();
-  const float mean = ((red[0] + red[1]) + (red[2] + red[3])) * (1.0f / (float)K);
+  float rs = (red[0] + red[1]) + (red[2] + red[3]);
+  if constexpr (NWV == 8) rs += (red[4] + red[5]) + (red[6] + red[7]);
+  const float mean = rs * (1.0f / (float)K);
   float q = 0.f;
 #pragma unroll
   for (int i = 0; i < EPT; ++i) {
@@ -407,9 +458,11 @@ __device__ inline void g1_block_layernorm(const float (&xv)[K / G1_T], const flo
     q = fmaf(t, t, q);
   }
   q = wave_sum_dpp(q);
-  if (lane == 0) red[4 + w] = q;
+  if (lane == 0) red[NWV + w] = q;
   g1_lds_barrier();
-  const float rstd = 1.0f / sqrtf(((red[4] + red[5]) + (red[6] + red[7])) * (1.0f / (float)K) + LN_EPS);
+  float rq = (red[NWV] + red[NWV + 1]) + (red[NWV + 2] + red[NWV + 3]);
+  if constexpr (NWV == 8) rq += (red[NWV + 4] + red[NWV + 5]) + (red[NWV + 6] + red[NWV + 7]);
+  const float rstd = 1.0f / sqrtf(rq * (1.0f / (float)K) + LN_EPS);
   float o[EPT];
 #pragma unroll
   for (int i = 0; i < EPT; ++i) o[i] = (xv[i] - mean) * rstd * gv[i] + bv[i];
@@ -711,8 +764,9 @@ int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a) {
 //     for free (gemv1_kernel PRO_ATTN_SELF: one more partial with l = 1).
 // No workgroup waits for another: a kernel boundary less per layer (62 -> 50 launches per step at L = 12) and one HBM round
 // trip instead of two on the critical path.
-template <typename T, int NCH, int DH, int RPW>
-__global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
+template <typename T, int NCH, int DH, int RPW, int NW>
+__global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
+  constexpr int NT = NW * 64;  // 4 or 8 waves per workgroup
   constexpr int VEC = Elem<T>::VEC;
   constexpr int CH = 64 * VEC;
   constexpr int K = NCH * CH;  // = d
@@ -724,9 +778,9 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
 
   // ---- common part of the burst: this thread's slice of the token's residual row and of the LayerNorm affine (the row is
   // normalised ONCE per workgroup and shared through LDS, g1_block_layernorm) -----------------------------------------------
-  constexpr int EPT = K / G1_T;
+  constexpr int EPT = K / NT;
   __shared__ __attribute__((aligned(16))) float sx[K];
-  __shared__ float red[8];
+  __shared__ float red[2 * NW];
   float xv[EPT], gv[EPT], bv[EPT];
   load_ept<EPT>(a.x + threadIdx.x * EPT, xv);
   load_ept<EPT>(a.gamma + threadIdx.x * EPT, gv);
@@ -735,7 +789,7 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
 
   if ((int)blockIdx.x >= a.n_attn) {
     // ================= K / V rows of the in-projection: rows [d, 3d), RPW per wave (gemv1_kernel's structure) =============
-    const int wave = ((int)blockIdx.x - a.n_attn) * (G1_T / 64) + w;
+    const int wave = ((int)blockIdx.x - a.n_attn) * NW + w;
     const int row0 = K + wave * RPW;
     const bool live = row0 < 3 * K;  // wave-uniform; dead waves still take part in the shared LayerNorm's barriers
     u32x4_t wv[RPW][NCH];
@@ -757,7 +811,7 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
       kvl = a.kv_len[0];
     }
     __builtin_amdgcn_sched_barrier(0);
-    g1_block_layernorm<K>(xv, gv, bv, sx, red);
+    g1_block_layernorm<K, NT>(xv, gv, bv, sx, red);
     if (!live) return;
     g1_read_shared<T, NCH>(sx, x);
     float mine = 0.f;
@@ -766,7 +820,7 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
       const float t = wave_sum_dpp(g1_dot<T, NCH>(wv[r], x));
       mine = lane == r ? t : mine;
     }
-    if (lane == 0) ktrace_end(a.kt, kt0, (int)blockIdx.x * (G1_T / 64) + w);
+    if (lane == 0) ktrace_end(a.kt, kt0, (int)blockIdx.x * NW + w);
     if (!writer) return;
     const float v = G1W<T>::kScaled ? fmaf(mine, scale_v, bias_v) : mine + bias_v;
     const int which = myrow / K, j = myrow - which * K;  // 1 = K, 2 = V  (valle/modules/activation.py:128-130)
@@ -793,7 +847,7 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
       s = ab - h * NS;
     }
   }
-  constexpr int QRT = DH / 4;                                  // query rows per wave
+  constexpr int QRT = DH / NW;                                 // query rows per wave
   constexpr int QR = (QRT * NCH <= 32) ? QRT : (32 / NCH);     // ... per pass (<= 32 weight vectors in flight per lane)
   constexpr int QP = QRT / QR;
   static_assert(QRT % QR == 0 && QR >= 1 && QR <= 64, "query-row passes");
@@ -801,11 +855,11 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
   constexpr int KPW = 64 / LPK;    // keys per wave-load
   constexpr int NK = 4;
   constexpr int WCH = NK * KPW;    // keys per wave per round
-  constexpr int CHUNK = 4 * WCH;   // keys per workgroup per round
+  constexpr int CHUNK = NW * WCH;   // keys per workgroup per round
   static_assert(DH % CVEC == 0 && (LPK & (LPK - 1)) == 0 && LPK <= 32, "head size");
   __shared__ float sq[DH];
-  __shared__ float sm_m[4], sm_l[4];
-  __shared__ float sm_o[4][DH];
+  __shared__ float sm_m[NW], sm_l[NW];
+  __shared__ float sm_o[NW][DH];
 
   const int qrow0 = h * DH + w * QRT;  // this wave's first query row (= row of W: the Q block is rows [0, d))
   u32x4_t wv[QR][NCH];
@@ -814,7 +868,7 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
     for (int r = 0; r < QR; ++r) {
       const T* wr = W + (int64_t)(qrow0 + p * QR + r) * K + lane * VEC;
 #pragma unroll
-      for (int c = 0; c < NCH; ++c) wv[r][c] = G1W<T>::load(wr + c * CH);
+      for (int c = 0; c < NCH; ++c) wv[r][c] = a.q_temporal ? G1W<T>::load_shared(wr + c * CH) : G1W<T>::load(wr + c * CH);
     }
   };
   const int slot = lane / LPK, part = lane % LPK;
@@ -857,7 +911,7 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
   }
   __builtin_amdgcn_sched_barrier(0);
 
-  g1_block_layernorm<K>(xv, gv, bv, sx, red);
+  g1_block_layernorm<K, NT>(xv, gv, bv, sx, red);
   g1_read_shared<T, NCH>(sx, x);
 #pragma unroll
   for (int p = 0; p < QP; ++p) {
@@ -865,18 +919,31 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
 #pragma unroll
     for (int r = 0; r < QR; ++r) acc[r] = g1_dot<T, NCH>(wv[r], x);
     if (p + 1 < QP) load_pass(p + 1);  // the registers are free again
-    float mine = 0.f;
+    if constexpr (QR == 8 || QR == 16) {
+      const float tot = g1_rows_reduce<QR>(acc, lane);  // every lane: the total of row g1_rows_owner(lane)
+      const int r = g1_rows_owner<QR>(lane);
+      // bias / scale were loaded per lane for row `lane`: fetch the owner row's through the LDS crossbar (one bpermute each)
+      const float qbr = __shfl(qb[p], r, 64), qscr = __shfl(qsc[p], r, 64);
+      if (lane < QR) {  // lanes 0 .. QR-1 own each row exactly once (the bit-reversal is a permutation of them)
+        const float qv1 = G1W<T>::kScaled ? fmaf(tot, qscr, qbr) : tot + qbr;
+        sq[w * QRT + p * QR + r] = qv1;
+        if (s == 0) a.q_out[qrow0 + p * QR + r] = qv1;
+      }
+    } else {
+      float mine = 0.f;
 #pragma unroll
-    for (int r = 0; r < QR; ++r) {
-      const float t = wave_sum_dpp(acc[r]);
-      mine = lane == r ? t : mine;
-    }
-    if (lane < QR) {
-      const float qv1 = G1W<T>::kScaled ? fmaf(mine, qsc[p], qb[p]) : mine + qb[p];
-      sq[w * QRT + p * QR + lane] = qv1;
-      if (s == 0) a.q_out[qrow0 + p * QR + lane] = qv1;
+      for (int r = 0; r < QR; ++r) {
+        const float t = wave_sum_dpp(acc[r]);
+        mine = lane == r ? t : mine;
+      }
+      if (lane < QR) {
+        const float qv1 = G1W<T>::kScaled ? fmaf(mine, qsc[p], qb[p]) : mine + qb[p];
+        sq[w * QRT + p * QR + lane] = qv1;
+        if (s == 0) a.q_out[qrow0 + p * QR + lane] = qv1;
+      }
     }
   }
+  const unsigned long long ktm1 = ktrace_mark(a.kt);  // this wave's query rows are done
   __syncthreads();
   float qv[CVEC];
 #pragma unroll
@@ -921,12 +988,29 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
     if (base >= ctx) break;  // block-uniform
     issue(base);
   }
+  const unsigned long long ktm2 = ktrace_mark(a.kt);  // key loop done
   // ---- merge the KPW key slots of the wave (one running max per wave: plain sums), then the 4 waves through LDS -------------
+  // lanes l ^ 8 by a DPP row rotation, l ^ 16 / l ^ 32 by the permlane swaps (common.h rows4_sum); ds_bpermute only where a
+  // head is narrower than 8 lanes
 #pragma unroll
-  for (int o = LPK; o < 64; o <<= 1) {
+  for (int o = LPK; o < 8; o <<= 1) {
     l += __shfl_xor(l, o, 64);
 #pragma unroll
     for (int j = 0; j < CVEC; ++j) oacc[j] += __shfl_xor(oacc[j], o, 64);
+  }
+  if constexpr (LPK <= 8) {
+    l += dpp_f32<0x128>(l);
+#pragma unroll
+    for (int j = 0; j < CVEC; ++j) oacc[j] += dpp_f32<0x128>(oacc[j]);
+  }
+  if constexpr (LPK <= 16) {
+    l = rows4_sum(l);
+#pragma unroll
+    for (int j = 0; j < CVEC; ++j) oacc[j] = rows4_sum(oacc[j]);
+  } else {  // LPK == 32
+    l += __shfl_xor(l, 32, 64);
+#pragma unroll
+    for (int j = 0; j < CVEC; ++j) oacc[j] += __shfl_xor(oacc[j], 32, 64);
   }
   if (slot == 0) {
     if (part == 0) {
@@ -938,21 +1022,22 @@ __global__ __launch_bounds__(G1_T) void qkv_attn1_kernel(QkvAttnArgs a) {
   }
   __syncthreads();
   const int tid = threadIdx.x;
-  if (tid == 0) ktrace_end(a.kt, kt0, (int)blockIdx.x * (G1_T / 64));
-  if (tid < DH || tid == 255) {
-    const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
-    float f[4];
+  if (lane == 0) ktrace_end(a.kt, kt0, (int)blockIdx.x * NW + w, ktm1, ktm2);
+  if (tid < DH || tid == NT - 1) {  // DH <= 128 < NT - 1
+    float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+    if constexpr (NW == 8) M = fmaxf(M, fmaxf(fmaxf(sm_m[4], sm_m[5]), fmaxf(sm_m[6], sm_m[7])));
+    float f[NW];
 #pragma unroll
-    for (int ww = 0; ww < 4; ++ww) f[ww] = __expf(sm_m[ww] - M);
+    for (int ww = 0; ww < NW; ++ww) f[ww] = __expf(sm_m[ww] - M);
     if (tid < DH) {
       float o = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < 4; ++ww) o = fmaf(sm_o[ww][tid], f[ww], o);
+      for (int ww = 0; ww < NW; ++ww) o = fmaf(sm_o[ww][tid], f[ww], o);
       a.part_o[(int64_t)s * K + h * DH + tid] = o;
     } else {
       float L = 0.f;
 #pragma unroll
-      for (int ww = 0; ww < 4; ++ww) L = fmaf(sm_l[ww], f[ww], L);
+      for (int ww = 0; ww < NW; ++ww) L = fmaf(sm_l[ww], f[ww], L);
       float* ml = a.part_ml + ((int64_t)h * NS + s) * 2;
       ml[0] = M;
       ml[1] = L;
@@ -968,15 +1053,26 @@ bool qkv_attn1_supports(int dtype, int d, int nhead, int dh) {
   return dh == 64 || dh == 128;
 }
 
-template <typename T, int NCH, int DH>
+template <typename T, int NCH, int DH, int NW>
 static int qa_launch(hipStream_t st, const QkvAttnArgs& a) {
   constexpr int RPW = NCH <= 2 ? 4 : 2;
   QkvAttnArgs b = a;
   b.n_attn = a.nhead * a.nsplit;
   const int kv_waves = (2 * a.d + RPW - 1) / RPW;
-  const dim3 grid(b.n_attn + (kv_waves + G1_T / 64 - 1) / (G1_T / 64)), block(G1_T);
-  hipLaunchKernelGGL((qkv_attn1_kernel<T, NCH, DH, RPW>), grid, block, 0, st, b);
+  const dim3 grid(b.n_attn + (kv_waves + NW - 1) / NW), block(NW * 64);
+  hipLaunchKernelGGL((qkv_attn1_kernel<T, NCH, DH, RPW, NW>), grid, block, 0, st, b);
   return 0;
+}
+
+int g_qa_waves = 4;  // "qa_waves": waves per workgroup of the fused launch (4 or 8).  Measured (MI355X, C2): 4 waves 215.9 us/step, 8 waves
+                     // (two per SIMD, half the query rows each) 224.5 -- the 512-thread workgroups start later and their barriers cost more than the overlap buys
+
+template <typename T, int NCH, int DH>
+static int qa_pick(hipStream_t st, const QkvAttnArgs& a) {
+  if constexpr ((NCH * 64 * Elem<T>::VEC) % 512 == 0) {  // 8 waves: every thread still owns >= 1 element of the shared row
+    if (g_qa_waves == 8) return qa_launch<T, NCH, DH, 8>(st, a);
+  }
+  return qa_launch<T, NCH, DH, 4>(st, a);
 }
 
 template <typename T>
@@ -984,12 +1080,12 @@ static int qa_dispatch(hipStream_t st, const QkvAttnArgs& a) {
   constexpr int CH = 64 * Elem<T>::VEC;
   const int key = (a.d / CH) * 1000 + a.dh;
   switch (key) {
-    case 1064: return qa_launch<T, 1, 64>(st, a);
-    case 2064: return qa_launch<T, 2, 64>(st, a);
-    case 4064: return qa_launch<T, 4, 64>(st, a);
-    case 1128: return qa_launch<T, 1, 128>(st, a);
-    case 2128: return qa_launch<T, 2, 128>(st, a);
-    case 4128: return qa_launch<T, 4, 128>(st, a);
+    case 1064: return qa_pick<T, 1, 64>(st, a);
+    case 2064: return qa_pick<T, 2, 64>(st, a);
+    case 4064: return qa_pick<T, 4, 64>(st, a);
+    case 1128: return qa_pick<T, 1, 128>(st, a);
+    case 2128: return qa_pick<T, 2, 128>(st, a);
+    case 4128: return qa_pick<T, 4, 128>(st, a);
     default: return 1;
   }
 }

@@ -152,6 +152,7 @@ struct SkinnyArgs {
 int launch_skinny(hipStream_t st, int dtype, const SkinnyArgs& a);
 // gemv1.hip: batch-1 wave-autonomous variant; returns 1 when the shape is not instantiated (use launch_skinny)
 int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a);
+extern int g_qa_waves;   // 4 / 8 waves per workgroup of the fused QKV + attention launch
 extern int g_g1_shared;  // 1 = block-shared activations (default), 0 = wave-autonomous (A/B)
 
 // gemv1.hip: LN1 + QKV projection + KV-cache write + decode attention over the OLD keys of ONE utterance in ONE launch
@@ -177,6 +178,7 @@ struct QkvAttnArgs {
   int d = 0, nhead = 0, dh = 0, ctx_max = 0, nsplit = 8;
   int n_attn = 0;                 // (filled by the launcher) workgroups with the attention role
   int temporal = 0;               // FP8W: default-policy weight loads
+  int q_temporal = 1;             // the query rows (read by the nsplit workgroups of a head) with the default cache policy
   KTrace kt;
 };
 bool qkv_attn1_supports(int dtype, int d, int nhead, int dh);

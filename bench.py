@@ -12,9 +12,15 @@ utterances per GPU); no collective on the decode path, one all_gather of the res
 Prints ONE JSON line on rank 0 (contract in the task statement) carrying `roofline` (AR step =
 the HBM-bound dominant phase; algorithmic bytes of SURVEY.md 8d / measured hipEvent time) and
 `cpu_baseline` (the CPU oracle -- a restatement of the reference's no-KV-cache algorithm -- timed
-on the host cores on a bounded sample) and `eager_gpu_baseline` (the same restatement as PyTorch-ROCm eager ops on the
-same GPU).  The default single-GPU run also carries `c3_batch64`: BASELINE.json
-configs[2] (64 utterances on one GPU) with its own AR (HBM) and NAR (MFMA) roofline fractions.
+on the host cores on a bounded sample; N > 1 lines carry the committed N = 1 measurement with its provenance) and
+`eager_gpu_baseline` (the same restatement as PyTorch-ROCm eager ops on the same GPU).
+
+Scaling.  Per-GPU work is the SAME at every N ("scaling": "weak"): `value` is BASELINE configs[1] -- one utterance per GPU --
+at N = 1, 2, 4, 8, and every line also carries `c3_batch64`: 64 utterances per GPU (configs[2] at N = 1, configs[3] at
+N = 8), run by all ranks under the same barrier-bracketed timing, with its own AR (HBM) and NAR (MFMA) roofline fractions.
+Scaling efficiency of either workload = its value at N / (N x its value at N = 1), from the lines alone (`scale_ref`).
+`fp32_exact` (N = 1) is the same decode in engine mode fp32 -- the mode whose greedy token ids are bit-identical to the
+reference (tests/test_parity_sizes_gpu.py) -- timed in the same process.
 """
 from __future__ import annotations
 
@@ -32,7 +38,37 @@ if ROOT not in sys.path:
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICROARCH.md)
 S_TEXT, P_PROMPT = 47, 225  # 47 phonemes, 3 s x 75 Hz prompt
-PMC_STEP_BYTES = 352_200_000  # (2 x FETCH_SIZE + WRITE_SIZE) KiB summed over the 62 kernels of one AR step, mean context (round 2 PMC pass)
+TRAFFIC_FILE = os.path.join(ROOT, "profiles", "ar_step_traffic.json")    # tools/make_traffic.py from the PMC passes
+CPU_CACHE_FILE = os.path.join(ROOT, "profiles", "cpu_baseline_n1.json")  # the N = 1 line's cpu_baseline, committed
+AR_STEP_KERNEL_SOURCES = ("gemv1.hip", "decode_attn.hip", "sampling.hip", "skinny.hip", "common.h")  # the batch-1 AR step's kernels
+
+
+def kernel_set_hash() -> str:
+    """sha256[:16] over the sources of the kernels one batch-1 AR step launches: `roofline.traffic` (HBM bytes per step from the
+    PMC counters) is only reported while the kernels are the ones it was measured on."""
+    import hashlib
+
+    h = hashlib.sha256()
+    for name in AR_STEP_KERNEL_SOURCES:
+        with open(os.path.join(ROOT, "valle_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def measured_traffic(args, B):
+    """HBM bytes per AR step of the default workload (C2, batch 1, bf16) from profiles/ar_step_traffic.json -- rocprofv3 --pmc
+    FETCH_SIZE / WRITE_SIZE in separate passes, FETCH_SIZE doubled per the gfx950 correction of MI355X_MICROARCH.md -- or
+    (None, reason) when the file is missing, was measured on other kernels, or the workload is not the one it describes."""
+    if not (B == 1 and args.dtype == "bf16" and args.d_model == 1024 and args.layers == 12 and not args.opt):
+        return None, "measured for the default workload only (C2, batch 1, bf16)"
+    try:
+        with open(TRAFFIC_FILE) as f:
+            t = json.load(f)
+    except OSError:
+        return None, "profiles/ar_step_traffic.json missing"
+    if t.get("kernel_set") != kernel_set_hash():
+        return None, f"stale: measured on kernel set {t.get('kernel_set')}, the kernels have changed since (re-run tools/gpu_pmc.sh + tools/make_traffic.py)"
+    return int(t["bytes_per_step"]), t.get("source", "profiles/")
 
 
 def synth_inputs(index: int, S: int = S_TEXT, P: int = P_PROMPT):
@@ -109,52 +145,60 @@ def eager_gpu_baseline(sd_cpu, d_model, nhead, num_layers, frames, dev):
 MFMA_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def c3_leg(sd, args, dev, B=64, steps=2, warmup=1):
-    """BASELINE.json configs[2] (same architecture, 64 utterances on one GPU) measured beside the headline line:
-    an extra object in the JSON, not `value`.  Same timing rules (inputs resident, whole decode calls)."""
+def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label=""):
+    """A second workload measured beside the headline under the SAME rules (inputs resident, whole decode calls incl. the
+    gather, barrier + device sync on both sides, MAX over ranks, tokens summed over ranks): `c3_batch64` = BASELINE
+    configs[2] / [3] (64 utterances per GPU), `fp32_exact` = the headline workload in the token-exact engine mode.
+    An extra object of the JSON line, never `value`."""
     import valle_amd
 
-    model = valle_amd.VALLE(args.d_model, args.nhead, args.layers, prefix_mode=1, engine_dtype=args.dtype, max_batch=B)
+    model = valle_amd.VALLE(args.d_model, args.nhead, args.layers, prefix_mode=1, engine_dtype=dtype, max_batch=B)
     model.load_state_dict(sd)
     model = model.to(dev).eval()
     eng = model.engine_for(B, S_TEXT, P_PROMPT)
-    eng.set_option("ignore_eos", 1)  # every utterance runs to the reference's length cap, like the batch-1 line
-    X = torch.stack([synth_inputs(b)[0] for b in range(B)]).to(dev)
-    Y = torch.stack([synth_inputs(b)[1] for b in range(B)]).to(dev)
-    lens = ([S_TEXT] * B, [P_PROMPT] * B)
+    if B > 1:
+        eng.set_option("ignore_eos", 1)  # every utterance runs to the reference's length cap, like the batch-1 line
+    X = torch.stack([synth_inputs(rank * B + b)[0] for b in range(B)]).to(dev)
+    Y = torch.stack([synth_inputs(rank * B + b)[1] for b in range(B)]).to(dev)
+    s_lens, p_lens = [S_TEXT] * B, [P_PROMPT] * B
+    acc = dict(tokens=0, pre=0.0, ar=0.0, nar=0.0, ar_steps=0, ar_bytes=0, gl=None)
 
     def step():
-        eng.prefill(X, lens[0], Y, lens[1])
-        _, gl = eng.generate(top_k=args.top_k, temperature=1.0, seed=0, allow_empty=True)
-        eng.nar(None)
-        return gl
+        return decode_step(eng, X, s_lens, Y, p_lens, args.top_k, world, world * B, dev)
 
-    for _ in range(warmup):
-        step()
-    torch.cuda.synchronize(dev)
-    t0 = time.perf_counter()
-    tokens, pre, ar, nar, ar_steps, ar_bytes = 0, 0.0, 0.0, 0.0, 0, 0
-    for _ in range(steps):
-        gl = step()
-        tokens += sum(gl) * 8
+    def on_step(r):
+        gl, _ = r
+        acc["gl"] = gl
+        acc["tokens"] += sum(gl) * 8
         tm = eng.timings()
-        pre += tm["prefill_ms"]; ar += tm["ar_ms"]; nar += tm["nar_ms"]; ar_steps += int(tm["ar_steps"])
+        acc["pre"] += tm["prefill_ms"]; acc["ar"] += tm["ar_ms"]; acc["nar"] += tm["nar_ms"]; acc["ar_steps"] += int(tm["ar_steps"])
         for t in range(1, max(gl) + 1):
-            ar_bytes += eng.ar_step_bytes(B, B * (S_TEXT + P_PROMPT + t))
-    torch.cuda.synchronize(dev)
-    elapsed = time.perf_counter() - t0
+            live = sum(1 for b in range(B) if gl[b] >= t)
+            acc["ar_bytes"] += eng.ar_step_bytes(live, live * (S_TEXT + P_PROMPT + t))
+
+    elapsed = timed_loop(step, steps, warmup, world, dev, on_step)
+    tokens = acc["tokens"]
+    if world > 1:
+        tk = torch.tensor([tokens], dtype=torch.float64, device=dev)
+        torch.distributed.all_reduce(tk, op=torch.distributed.ReduceOp.SUM)
+        tokens = int(tk.item())
+    gl, pre, ar, nar, ar_steps, ar_bytes = acc["gl"], acc["pre"], acc["ar"], acc["nar"], acc["ar_steps"], acc["ar_bytes"]
     d, L, N, G = args.d_model, args.layers, S_TEXT + P_PROMPT + gl[0], gl[0]
-    nar_flops = B * (7 * (2 * N * 12 * L * d * d + 4 * L * N * N * d) + 14 * G * d * 1024)  # SURVEY.md 8(d)
+    nar_flops = B * (7 * (2 * N * 12 * L * d * d + 4 * L * N * N * d) + 14 * G * d * 1024)  # SURVEY.md 8(d), this rank
     hbm = (ar_bytes / 1e9) / (ar / 1e3)
     tfs = nar_flops * steps / 1e12 / (nar / 1e3)
     model._invalidate()
+    del model
+    mfma_peak = MFMA_PEAK_TFS if dtype != "fp32" else 157.0  # fp32 mode: v_mfma_f32_16x16x4_f32 runs at the vector rate
     return {
-        "workload": f"dim{d}-L{L}-h{args.nhead} {args.dtype}, batch={B}, S={S_TEXT}, P={P_PROMPT} -> G={G}, greedy, ignore_eos",
-        "value": round(tokens / elapsed, 1), "unit": "audio-tokens/s", "steps": steps, "warmup": warmup,
+        "workload": f"dim{d}-L{L}-h{args.nhead} {dtype}, batch={B} per GPU x {world} GPU(s), S={S_TEXT}, P={P_PROMPT} -> G={G}, "
+                    f"greedy{', ignore_eos' if B > 1 else ''}{label}",
+        "value": round(tokens / elapsed, 1), "unit": "audio-tokens/s", "n_gpus": world, "per_gpu_value": round(tokens / elapsed / world, 1),
+        "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
         "phase_ms": {"prefill": round(pre / steps, 3), "ar": round(ar / steps, 3), "nar": round(nar / steps, 3)},
         "roofline_ar": {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
-                        "launch_us": round(ar / ar_steps * 1e3, 2), "bytes_per_launch": int(ar_bytes / ar_steps)},
-        "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": MFMA_PEAK_TFS, "unit": "TFLOP/s", "frac": round(tfs / MFMA_PEAK_TFS, 4)},
+                        "launch_us": round(ar / ar_steps * 1e3, 2), "bytes_per_launch": int(ar_bytes / ar_steps), "rank": 0},
+        "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tfs / mfma_peak, 4), "rank": 0},
     }
 
 
@@ -283,8 +327,9 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=2)
-    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU; default 1 at --gpus 1 (configs[1], the headline) and "
-                                                         "64 at --gpus N > 1 (configs[3]: 512 prompts over 8 GPUs)")
+    ap.add_argument("--batch", type=int, default=0, help="utterances per GPU of the headline `value`; default 1 at every --gpus N "
+                                                         "(configs[1] per GPU: weak scaling); 64 per GPU (configs[2] / [3]) is the "
+                                                         "`c3_batch64` object of every line")
     ap.add_argument("--dtype", default="bf16", choices=["bf16", "fp32", "fp8w", "fp8"],
                     help="fp8w: bf16 arithmetic on fp8 e4m3 weights; fp8: fp8w + fp8 activations on the CDNA4 fp8 MFMA (configs[4])")
     ap.add_argument("--d-model", type=int, default=1024)
@@ -293,7 +338,8 @@ def main():
     ap.add_argument("--top-k", type=int, default=1, help="1 = the reference's greedy; -100 = pure multinomial")
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
-    ap.add_argument("--no-c3", action="store_true", help="skip the extra batch-64 (BASELINE configs[2]) object of the default run")
+    ap.add_argument("--no-c3", action="store_true", help="skip the extra batch-64-per-GPU (BASELINE configs[2] / [3]) object")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32_exact object (token-exact engine mode) of the N = 1 line")
     ap.add_argument("--c5", action="store_true", help="add the per-GPU share of BASELINE configs[4] (d1536-L24-h16, fp8 weights + fp8 MFMA, "
                                                       "32 utterances) as an extra object (~2 min: 1.6 B parameters are initialised and quantised)")
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine tuning option (vle_set_option), repeatable")
@@ -316,13 +362,14 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     world_seen = torch.distributed.get_world_size() if world > 1 else 1
-    B = args.batch if args.batch > 0 else (1 if world == 1 else 64)
+    B = args.batch if args.batch > 0 else 1
 
     # random-init weights of the named architecture (no network for checkpoints), reference init distributions
     torch.manual_seed(0)
     model = valle_amd.VALLE(args.d_model, args.nhead, args.layers, prefix_mode=1, engine_dtype=args.dtype,
                             max_batch=B, use_graph=not args.no_graph)
-    sd_cpu = {k: v.clone() for k, v in model.state_dict().items()} if (rank == 0 and args.gpus == 1 and args.cpu_frames > 0) else None
+    sd_all = {k: v.clone() for k, v in model.state_dict().items()}  # fp32 master weights: the side legs load the same ones
+    sd_cpu = sd_all if (rank == 0 and args.gpus == 1 and args.cpu_frames > 0) else None
     model = model.to(dev).eval()
     eng = model.engine_for(B, S_TEXT, P_PROMPT)
     for kv in args.opt:
@@ -373,9 +420,12 @@ def main():
         kernel_prof = eng.kernel_times()
         eng.set_option("profile_kernels", 0)
 
+    out = None
     if rank == 0:
         step_ms = ar_ms / max(ar_steps, 1)
         achieved = (ar_bytes / 1e9) / (ar_ms / 1e3) if ar_ms > 0 else 0.0
+        traffic, traffic_src = measured_traffic(args, B)
+        fused = args.d_model // args.nhead in (64, 128) and B == 1 and "qkv_attn=0" not in args.opt
         out = {
             "metric": "audio-tokens/sec (AR+NAR decode, 3 s prompt -> 10 s target)",
             "value": round(tokens / elapsed, 1),
@@ -400,55 +450,76 @@ def main():
                 "hip_graph": not args.no_graph,
             },
             "per_gpu_value": round(tokens / elapsed / args.gpus, 1),
+            "scale_ref": {
+                "per_gpu_work": f"{B} utterance(s) per GPU at every N (`value`); 64 utterances per GPU at every N (`c3_batch64.value`)",
+                "efficiency": "value(N) / (N * value(1)), and c3_batch64.value(N) / (N * c3_batch64.value(1)): both from the N = 1, 2, 4, 8 lines alone",
+            },
             "phase_ms": {"prefill": round(pre_ms / args.steps, 3), "ar": round(ar_ms / args.steps, 3), "nar": round(nar_ms / args.steps, 3)},
             "roofline": {
-                "kernel": "AR decode step (hipGraph replay: 5 kernels/layer x L + logits + sample; weights + KV streamed once)",
+                "kernel": ("AR decode step (hipGraph replay: 4 launches/layer x L -- fused LN1+QKV+attention, out-proj, FFN1, FFN2 -- + logits + sample; "
+                           "weights + KV streamed once)") if fused else
+                          "AR decode step (hipGraph replay: launches/layer x L + logits + sample; weights + KV streamed once)",
                 "bound": "hbm",
                 "achieved": round(achieved, 1),
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": round(achieved / HBM_PEAK_GBS, 4),
-                # HBM bytes per AR step from the PMC pass (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs,
-                # FETCH_SIZE doubled per the gfx950 correction): profiles/r02_pmc_*_by_kernel.csv, profiles/README.md.
-                # Measured for the default workload only (C2, batch 1, bf16).
-                "traffic": PMC_STEP_BYTES if (B == 1 and args.dtype == "bf16" and args.d_model == 1024 and args.layers == 12) else None,
+                # HBM bytes per AR step from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, FETCH_SIZE
+                # doubled per the gfx950 correction), read from profiles/ar_step_traffic.json and only reported while the step's
+                # kernels are the ones it was measured on (kernel-set hash); null + the reason otherwise
+                "traffic": traffic,
+                "traffic_source": traffic_src,
                 "launch_us": round(step_ms * 1e3, 2),
                 "bytes_per_launch": int(ar_bytes / max(ar_steps, 1)),
                 "launches": ar_steps,
             },
         }
-        if world > 1:
-            out["config"]["scaling_reference"] = ("weak scaling at 64 utterances per GPU: the 1-GPU value of the SAME per-GPU work is the "
-                                                  "`c3_batch64.value` object of the default `--gpus 1` line, not its batch-1 `value`")
         if kernel_prof is not None:
             out["roofline"]["kernel_us"] = kernel_prof
-        # the two side legs must never cost the headline line: report their failure instead of raising
+        # the side legs must never cost the headline line: report their failure instead of raising
         if sd_cpu is not None:
             try:
                 out["cpu_baseline"] = cpu_baseline(sd_cpu, args.d_model, args.nhead, args.layers, args.cpu_frames)
             except Exception as err:  # noqa: BLE001
                 out["cpu_baseline"] = {"error": repr(err)[:200]}
-        else:
-            out["cpu_baseline"] = None
+        else:  # N > 1 (or --cpu-frames 0): the committed N = 1 measurement, with its provenance
+            try:
+                with open(CPU_CACHE_FILE) as f:
+                    out["cpu_baseline"] = dict(json.load(f), cached=True, source="profiles/cpu_baseline_n1.json (the `cpu_baseline` object of a "
+                                               "default N = 1 run of this bench.py on an MI355X box; timed on rank 0 at N = 1 only)")
+            except OSError:
+                out["cpu_baseline"] = None
         if sd_cpu is not None:
             try:
                 model._invalidate()
                 out["eager_gpu_baseline"] = eager_gpu_baseline(sd_cpu, args.d_model, args.nhead, args.layers, args.cpu_frames, dev)
             except Exception as err:  # noqa: BLE001
                 out["eager_gpu_baseline"] = {"error": repr(err)[:200]}
-        if args.gpus == 1 and B == 1 and not args.no_c3 and not args.opt and args.profile_kernels == 0:
-            try:
-                model._invalidate()
-                out["c3_batch64"] = c3_leg(model.state_dict(), args, dev)
-            except Exception as err:  # noqa: BLE001
-                out["c3_batch64"] = {"error": repr(err)[:200]}
-        if args.c5 and args.gpus == 1:
-            try:
-                model._invalidate()
-                del model
-                out["c5_share_fp8"] = c5_leg(args, dev)
-            except Exception as err:  # noqa: BLE001
-                out["c5_share_fp8"] = {"error": repr(err)[:200]}
+    # ---- side legs: every rank takes part (same timing contract as the headline) ---------------------------------------
+    plain = B == 1 and not args.opt and args.profile_kernels == 0 and args.dtype == "bf16"
+    model._invalidate()
+    if plain and not args.no_c3:
+        try:
+            leg = side_leg(sd_all, args, dev, rank, world, 64, args.dtype)
+        except Exception as err:  # noqa: BLE001
+            leg = {"error": repr(err)[:200]}
+        if out is not None:
+            out["c3_batch64"] = leg
+    if plain and not args.no_fp32 and world == 1:
+        try:
+            leg = side_leg(sd_all, args, dev, rank, world, 1, "fp32", steps=3, warmup=1,
+                           label="; engine mode fp32 = greedy token ids bit-identical to the reference (tests/test_parity_sizes_gpu.py)")
+        except Exception as err:  # noqa: BLE001
+            leg = {"error": repr(err)[:200]}
+        if out is not None:
+            out["fp32_exact"] = leg
+    if args.c5 and args.gpus == 1:
+        try:
+            del model
+            out["c5_share_fp8"] = c5_leg(args, dev)
+        except Exception as err:  # noqa: BLE001
+            out["c5_share_fp8"] = {"error": repr(err)[:200]}
+    if out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -343,6 +343,49 @@ def test_linear_split_k_tickets(M, N, K, ksplit, epi):
         assert int(ops.linear_workspace(a.device)[:4096].view(torch.int32).abs().sum()) == 0, "tickets not reset"
 
 
+@pytest.mark.parametrize("M,N,K", [(64, 1024, 4096), (64, 1024, 1024), (33, 1025, 1024), (24, 1536, 6144), (48, 1024, 1536), (17, 512, 2048), (64, 1536, 1536)])
+@pytest.mark.parametrize("epi", [ops.EPI_RESID, ops.EPI_F32, ops.EPI_RELU])
+@pytest.mark.parametrize("fp8w", [False, True])
+def test_skinny_gemm_m_split_kernel(M, N, K, epi, fp8w):
+    """gemm_skinny.hip's M-split kernel (one workgroup per (16 rows of W, 16 utterances), all of K, 4 / 8 / 16 waves; taken by
+    the engine's `ksplit = 0` policy where N / 16 row fragments alone would leave CUs idle) against the fp64 product and
+    against the split-K kernel it replaces (knob gs_msplit = 0): same values up to fp32 summation order, deterministic."""
+    a = _rand(M, K, seed=140).to(torch.bfloat16)
+    w32 = _rand(N, K, seed=141) / math.sqrt(K)
+    bias = _rand(N, seed=142) * 0.1
+    r0 = _rand(M, N, seed=143)
+    if fp8w:
+        from oracle import valle_oracle as vo
+        q8, sc, deq = vo.fp8w_quantize(w32.cpu())
+        q8, sc, wref = q8.to(DEV), sc.to(DEV), deq.to(DEV)
+    else:
+        wbf = w32.to(torch.bfloat16)
+        wref = wbf.float()
+
+    def run():
+        kw = dict(resid=r0.clone()) if epi == ops.EPI_RESID else {}
+        if fp8w:
+            return ops.linear_fp8w(a, q8, sc, bias, epi, ksplit=0, **kw).clone()
+        return ops.linear(a, wbf, bias, epi, ksplit=0, **kw).clone()
+
+    ref = a.double() @ wref.double().t() + bias.double()
+    want = ref + r0.double() if epi == ops.EPI_RESID else ref.clamp_min(0) if epi == ops.EPI_RELU else ref
+    tol = 2e-5 * math.sqrt(K / 64) * max(1.0, want.abs().max().item()) if epi != ops.EPI_RELU else 0.02 * max(1.0, want.abs().max().item())
+    ops.tune("gs_msplit", 2)  # every K (the default, 1, keeps K > 2048 on the split-K kernel)
+    try:
+        outs = [run(), run()]
+        assert torch.equal(outs[0], outs[1])
+        assert (outs[0].double() - want).abs().max().item() < tol
+        ops.tune("gs_msplit", 3)  # non-temporal W loads
+        assert torch.equal(run(), outs[0])
+        ops.tune("gs_msplit", 0)
+        old = run()
+    finally:
+        ops.tune("gs_msplit", 1)
+    assert (old.double() - want).abs().max().item() < tol
+    assert (outs[0].double() - old.double()).abs().max().item() < tol
+
+
 @pytest.mark.parametrize("M,N,K", [(17408, 1024, 1024), (1041, 4096, 1024), (300, 1025, 1024), (130, 256, 256), (4100, 3072, 1536), (2049, 1024, 4096)])
 @pytest.mark.parametrize("knob", ["glds_swz", "glds_prio", "glds_epi", "glds_swz+glds_epi", "glds_8ph", "glds_8ph+g8_stagger", "glds_8ph+glds_swz", "glds_8ph+g8_stagger+glds_swz", "glds_8ph+g8_stagger+g8_colgroup", "glds_8ph+g8_stagger+g8_dbg"])  # listed = 1 (g8_colgroup: 4; g8_dbg: 4 = stores straight from the fragments instead of the LDS-staged epilogue), others 0
 def test_linear_gemm_tile_policy_knobs(M, N, K, knob):

@@ -171,56 +171,59 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   const bool xfrag = a.x_xf != 0;  // X stored fragment-major (common.h xf_index): one contiguous 1 KB per fragment load
   const bf16_t* xfb = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)(kbeg / 64) * 2 * MF * 512 + lane * 8;
 
-  // epilogue operands requested up front
+  // epilogue operands: requested right AFTER the first round's W / X loads (vmcnt retires in issue order, and the MFMAs need
+  // only W and X: issued first, the 32-40 KB of group statistics / bias / residual per workgroup used to sit in the texture
+  // path ahead of the weight requests -- round 3, same finding as gemv1.hip's block-shared activations)
   const int ncol = n0 + fg * 4;  // first of this lane's 4 output columns
   gs_f32x4 bias4 = gs_f32x4{0.f, 0.f, 0.f, 0.f};
-  if (a.bias != nullptr) {
-    if (ncol + 3 < N) bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
-    else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) bias4[r] = ncol + r < N ? a.bias[ncol + r] : 0.f;
-    }
-  }
   gs_f32x4 scale4 = gs_f32x4{1.f, 1.f, 1.f, 1.f};
-  if constexpr (W8) {
-    if (ncol + 3 < N) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
-    else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) scale4[r] = ncol + r < N ? a.wscale[ncol + r] : 1.f;
-    }
-  }
-
-  // fused LayerNorm (kernels.h): consumer operands (wg of this lane's 4 columns; the group statistics of the row this lane
-  // finishes, 16 rows per wave, the lane's quarter of the row's slots) and the producer's gamma, all requested up front
   gs_f32x4 wg4 = gs_f32x4{0.f, 0.f, 0.f, 0.f}, gamma4 = gs_f32x4{1.f, 1.f, 1.f, 1.f};
   constexpr int LN_MAXQ = 16;  // float4 (= 2 slots) per lane: rows up to 4 * 32 * 16 = 2048 wide
   gs_f32x4 lst[LN_MAXQ];
   const bool ln_in = a.lnc.stats != nullptr;
   const int ln_nq = ln_in ? a.lnc.nslots >> 3 : 0;  // float4 per lane = (nslots / 4 lanes) / 2
-  if (ln_in) {
-    if (ncol + 3 < N) wg4 = *reinterpret_cast<const gs_f32x4*>(a.lnc.wg + ncol);
-    else {
-#pragma unroll
-      for (int r = 0; r < 4; ++r) wg4[r] = ncol + r < N ? a.lnc.wg[ncol + r] : 0.f;
-    }
-    if (wave < MF) {
-      const float* sp = a.lnc.stats + ((int64_t)min(wave * 16 + fr, M - 1) * a.lnc.nslots + fg * (a.lnc.nslots >> 2)) * 2;
-#pragma unroll
-      for (int j = 0; j < LN_MAXQ; ++j)
-        if (j < ln_nq) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 4);
-    }
-  }
   gs_f32x4 old4 = gs_f32x4{0.f, 0.f, 0.f, 0.f};
   int kvl = 0;
-  if constexpr (EPI == GS_EPI_RESID) {
-    if (a.lnp.gamma != nullptr && ncol + 3 < N) gamma4 = *reinterpret_cast<const gs_f32x4*>(a.lnp.gamma + ncol);
-    // the residual row this lane finishes (wave i: fragment i): nobody else writes it during this launch
-    if (wave < MF && wave * 16 + fr < M && ncol + 3 < N && (N & 3) == 0)
-      old4 = *reinterpret_cast<const gs_f32x4*>(a.resid + (int64_t)(wave * 16 + fr) * N + ncol);
-  }
-  if constexpr (EPI == GS_EPI_QKV) {
-    if (wave < MF) kvl = a.kv_len[min(wave * 16 + fr, M - 1)];
-  }
+  auto request_epilogue_operands = [&]() {
+    if (a.bias != nullptr) {
+      if (ncol + 3 < N) bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[r] = ncol + r < N ? a.bias[ncol + r] : 0.f;
+      }
+    }
+    if constexpr (W8) {
+      if (ncol + 3 < N) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scale4[r] = ncol + r < N ? a.wscale[ncol + r] : 1.f;
+      }
+    }
+    // fused LayerNorm (kernels.h): consumer operands (wg of this lane's 4 columns; the group statistics of the row this lane
+    // finishes, 16 rows per wave, the lane's quarter of the row's slots) and the producer's gamma
+    if (ln_in) {
+      if (ncol + 3 < N) wg4 = *reinterpret_cast<const gs_f32x4*>(a.lnc.wg + ncol);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wg4[r] = ncol + r < N ? a.lnc.wg[ncol + r] : 0.f;
+      }
+      if (wave < MF) {
+        const float* sp = a.lnc.stats + ((int64_t)min(wave * 16 + fr, M - 1) * a.lnc.nslots + fg * (a.lnc.nslots >> 2)) * 2;
+#pragma unroll
+        for (int j = 0; j < LN_MAXQ; ++j)
+          if (j < ln_nq) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 4);
+      }
+    }
+    if constexpr (EPI == GS_EPI_RESID) {
+      if (a.lnp.gamma != nullptr && ncol + 3 < N) gamma4 = *reinterpret_cast<const gs_f32x4*>(a.lnp.gamma + ncol);
+      // the residual row this lane finishes (wave i: fragment i): nobody else writes it during this launch
+      if (wave < MF && wave * 16 + fr < M && ncol + 3 < N && (N & 3) == 0)
+        old4 = *reinterpret_cast<const gs_f32x4*>(a.resid + (int64_t)(wave * 16 + fr) * N + ncol);
+    }
+    if constexpr (EPI == GS_EPI_QKV) {
+      if (wave < MF) kvl = a.kv_len[min(wave * 16 + fr, M - 1)];
+    }
+  };
 
   gs_f32x4 acc[MF];
 #pragma unroll
@@ -261,6 +264,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
         xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 1) * MF + fi(i)) * 512 : xp[i] + c * 64 + SSTEP);
       }
     }
+    if (c0 == 0) request_epilogue_operands();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
@@ -406,6 +410,196 @@ bool gemm_skinny_supports(int M, int N, int K, int epi, int dh) {
   return true;
 }
 
+
+// =====================================================================================================================
+// M-split variant (round 3): N / 16 < #CUs (out-proj, FFN2, logits: N = d -> 64 row fragments at d = 1024).
+// The kernel above fills the chip there by cutting K across workgroups, and pays for it: the partial tiles go through a
+// write-through hand-off + ticket and the last arriver's combine -- 3.1 us of FFN2's 8.3 us, and out-proj (K too short to
+// split) runs on 64 workgroups only (profiles/r03_ktrace_b64_timeline.csv).  Here a workgroup owns ONE 16-row fragment of W
+// and ONE 16-utterance fragment of the batch, for ALL of K: grid = (N / 16, M / 16).  Its NW = 4 / 8 / 16 waves split K
+// (one round of <= 4 chunks each) and combine through LDS -- no cross-workgroup exchange at all.  The M / 16 workgroups of a
+// W fragment run on the same XCD when N / 16 is a multiple of 8 (block -> XCD = linear index % 8) and share the rows through
+// its L2 (default cache policy instead of non-temporal loads); each reads only ITS 16 rows of X.  Texture-path bytes per CU:
+// W 2 K / NW x NW + X 2 K x 16 = 64 K bytes (vs 160 KB at d = 1024 above), on 256 CUs instead of 64.
+template <int NW, int EPI, bool W8>
+__global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs a) {
+  constexpr int G = 4;
+  __shared__ __attribute__((aligned(16))) float red[NW][64][4];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned long long kt0 = ktrace_begin(a.kt);
+  const int fr = lane & 15, fg = lane >> 4;
+  const int n0 = blockIdx.x * 16, mi = blockIdx.y, m0 = mi * 16;
+  const int K = a.K, N = a.N, M = a.M, MFt = gridDim.y;
+  const int Kw = K / NW;  // multiple of 64 (launcher)
+  const int kbeg = wave * Kw;
+  const int nrow = min(n0 + fr, N - 1);
+  constexpr int KOFS = W8 ? 16 : 8;
+  constexpr int SSTEP = W8 ? 8 : 32;
+  const bf16_t* wp = reinterpret_cast<const bf16_t*>(a.w) + (int64_t)nrow * K + kbeg + fg * 8;
+  const unsigned char* wp8 = reinterpret_cast<const unsigned char*>(a.w) + (int64_t)nrow * K + kbeg + fg * 16;
+  const bf16_t* xp = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)min(m0 + fr, M - 1) * K + kbeg + fg * KOFS;
+  const bool xfrag = a.x_xf != 0;
+  const bf16_t* xfb = reinterpret_cast<const bf16_t*>(a.x) + (int64_t)(kbeg / 64) * 2 * MFt * 512 + lane * 8;
+
+  const int ncol = n0 + fg * 4;
+  gs_f32x4 bias4 = gs_f32x4{0.f, 0.f, 0.f, 0.f}, scale4 = gs_f32x4{1.f, 1.f, 1.f, 1.f};
+  gs_f32x4 wg4 = gs_f32x4{0.f, 0.f, 0.f, 0.f}, gamma4 = gs_f32x4{1.f, 1.f, 1.f, 1.f}, old4 = gs_f32x4{0.f, 0.f, 0.f, 0.f};
+  constexpr int LN_MAXQ = 16;
+  gs_f32x4 lst[LN_MAXQ];
+  const bool ln_in = a.lnc.stats != nullptr;
+  const int ln_nq = ln_in ? a.lnc.nslots >> 3 : 0;
+  int kvl = 0;
+  auto request_epilogue_operands = [&]() {  // wave 0 finishes the tile
+    if (wave != 0) return;
+    if (a.bias != nullptr) {
+      if (ncol + 3 < N) bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) bias4[r] = ncol + r < N ? a.bias[ncol + r] : 0.f;
+      }
+    }
+    if constexpr (W8) {
+      if (ncol + 3 < N) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) scale4[r] = ncol + r < N ? a.wscale[ncol + r] : 1.f;
+      }
+    }
+    if (ln_in) {
+      if (ncol + 3 < N) wg4 = *reinterpret_cast<const gs_f32x4*>(a.lnc.wg + ncol);
+      else {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) wg4[r] = ncol + r < N ? a.lnc.wg[ncol + r] : 0.f;
+      }
+      const float* sp = a.lnc.stats + ((int64_t)min(m0 + fr, M - 1) * a.lnc.nslots + fg * (a.lnc.nslots >> 2)) * 2;
+#pragma unroll
+      for (int j = 0; j < LN_MAXQ; ++j)
+        if (j < ln_nq) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 4);
+    }
+    if constexpr (EPI == GS_EPI_RESID) {
+      if (a.lnp.gamma != nullptr && ncol + 3 < N) gamma4 = *reinterpret_cast<const gs_f32x4*>(a.lnp.gamma + ncol);
+      if (m0 + fr < M && ncol + 3 < N && (N & 3) == 0) old4 = *reinterpret_cast<const gs_f32x4*>(a.resid + (int64_t)(m0 + fr) * N + ncol);
+    }
+    if constexpr (EPI == GS_EPI_QKV) kvl = a.kv_len[min(m0 + fr, M - 1)];
+  };
+
+  gs_f32x4 acc = gs_f32x4{0.f, 0.f, 0.f, 0.f};
+  const int chunks = Kw >> 6;
+  for (int c0 = 0; c0 < chunks; c0 += G) {
+    gs_u32x4 wv[G][2], xv[G][2];
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int c = min(c0 + g, chunks - 1);
+      if (a.w_packed) {
+        const int64_t cc = (int64_t)blockIdx.x * (K >> 6) + (kbeg >> 6) + c;
+        if constexpr (W8) {
+          wv[g][0] = *reinterpret_cast<const gs_u32x4*>(reinterpret_cast<const unsigned char*>(a.w) + cc * 1024 + lane * 16);
+        } else {
+          const bf16_t* wf = reinterpret_cast<const bf16_t*>(a.w) + cc * 1024 + lane * 8;
+          if (a.ms_nt) {
+            wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wf));
+            wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wf + 512));
+          } else {
+            wv[g][0] = *reinterpret_cast<const gs_u32x4*>(wf);
+            wv[g][1] = *reinterpret_cast<const gs_u32x4*>(wf + 512);
+          }
+        }
+      } else if constexpr (W8) {
+        wv[g][0] = *reinterpret_cast<const gs_u32x4*>(wp8 + c * 64);
+      } else {
+        wv[g][0] = *reinterpret_cast<const gs_u32x4*>(wp + c * 64);
+        wv[g][1] = *reinterpret_cast<const gs_u32x4*>(wp + c * 64 + 32);
+      }
+    }
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      const int c = min(c0 + g, chunks - 1);
+      xv[g][0] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 0) * MFt + mi) * 512 : xp + c * 64);
+      xv[g][1] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 1) * MFt + mi) * 512 : xp + c * 64 + SSTEP);
+    }
+    if (c0 == 0) request_epilogue_operands();
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int g = 0; g < G; ++g) {
+      if (c0 + g < chunks) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          gs_bf16x8 wa;
+          if constexpr (W8) wa = gs_fp8x8_to_bf16(wv[g][0][2 * s], wv[g][0][2 * s + 1]);
+          else wa = __builtin_bit_cast(gs_bf16x8, wv[g][s]);
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(gs_bf16x8, xv[g][s]), acc, 0, 0, 0);
+        }
+      }
+    }
+  }
+  const unsigned long long ktm1 = ktrace_mark(a.kt);
+  *reinterpret_cast<gs_f32x4*>(&red[wave][lane][0]) = acc;
+  __syncthreads();
+  const unsigned long long ktm2 = ktrace_mark(a.kt);
+  if (wave != 0) return;
+  gs_f32x4 v = *reinterpret_cast<const gs_f32x4*>(&red[0][lane][0]);
+#pragma unroll
+  for (int w = 1; w < NW; ++w) v += *reinterpret_cast<const gs_f32x4*>(&red[w][lane][0]);  // fixed order
+  if (ln_in) {  // merge of the row's group statistics: see gemm_skinny_kernel
+    float msum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j)
+      if (j < ln_nq) msum += lst[j][0] + lst[j][2];
+    msum = rows4_sum(msum);
+    const float cnt = 16.f * (float)a.lnc.nslots;
+    const float mean = msum / (float)a.lnc.nslots;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j)
+      if (j < ln_nq) {
+        const float d0 = lst[j][0] - mean, d1 = lst[j][2] - mean;
+        m2 += (lst[j][1] + lst[j][3]) + 16.f * (d0 * d0 + d1 * d1);
+      }
+    m2 = rows4_sum(m2);
+    const float rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
+    if constexpr (W8) v = v * scale4;
+    v = (v - mean * wg4) * rstd + bias4;
+  } else {
+    if constexpr (W8) v = v * scale4 + bias4;
+    else v += bias4;
+  }
+  gs_epilogue<EPI>(a, v, m0 + fr, ncol, gamma4, old4, kvl);
+  if (lane == 0) ktrace_end(a.kt, kt0, (int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x, ktm1, ktm2);
+}
+
+// "gs_msplit": 0 = never (split-K across workgroups, A/B); 1 (default) = where N / 16 leaves CUs idle AND K <= 2048 (out-proj,
+// logits); 2 = also for long K (FFN2); 3 = 2 with non-temporal W loads.  Measured at 64 utterances, d = 1024 (MI355X, ktrace):
+// out-proj 5.08 -> 2.57 us per launch; FFN2 (K = 4096: 128 KB of W + 128 KB of X per workgroup) 8.3 -> 12.6-13.0 us -- each
+// of the four workgroups of a W fragment ends up pulling its own copy of the rows (nt or not), 32 MB instead of 8 MB per launch,
+// so long K keeps the split-K kernel; AR loop of C3 600 -> 577 ms with 1, 642 with 2, 648 with 3.
+int g_gs_msplit = 1;
+
+template <int NW, bool W8>
+static int gs_ms_launch_w(hipStream_t st, const GemmSkinnyArgs& a) {
+  const dim3 grid((a.N + 15) / 16, (a.M + 15) / 16), block(NW * 64);
+  switch (a.epi) {
+    case GS_EPI_STORE: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_STORE, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_RELU: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_RELU, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_RESID: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_RESID, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_F32: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_F32, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_QKV: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_QKV, W8>), grid, block, 0, st, a); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+// M-split when it fills the chip better than N / 16 row fragments alone: returns the waves per workgroup (4 / 8 / 16) or 0
+static int gs_msplit_waves(const GemmSkinnyArgs& a) {
+  if (!g_gs_msplit || a.ksplit > 0 || a.M <= 16) return 0;
+  if (g_gs_msplit == 1 && a.K > 2048) return 0;  // long K stays on the split-K kernel (see g_gs_msplit)
+  const int nfrag = (a.N + 15) / 16, mf = (a.M + 15) / 16;
+  if (nfrag >= 160 || nfrag * mf > 384) return 0;  // QKV / FFN1 already have a workgroup per CU
+  for (int nw : {4, 8, 16})
+    if (a.K % (64 * nw) == 0 && a.K / (64 * nw) <= 4) return nw;
+  return a.K % (64 * 16) == 0 ? 16 : 0;
+}
+
 int g_gs_formal = 0;  // "gs_formal": split-K hand-off with explicit agent-scope release / acquire fences (see the kernel)
 
 // returns 0 = launched, 1 = shape not covered
@@ -418,6 +612,17 @@ int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a) {
     KS = a.ksplit > 0 ? a.ksplit : gemm_skinny_ksplit(a.N, a.K, a.target_wgs > 0 ? a.target_wgs : 256);
     const int nblk = (a.N + 15) / 16;
     while (KS > 1 && (a.K % (256 * KS) != 0 || nblk * KS > GS_WS_MAX_TILES || nblk > GS_WS_CNT_BYTES / 4)) KS >>= 1;
+  }
+  if (const int nw = gs_msplit_waves(a)) {
+    const bool w8 = a.wscale != nullptr;
+    GemmSkinnyArgs a2 = a;
+    a2.ms_nt = g_gs_msplit == 3;
+    const GemmSkinnyArgs& a = a2;
+    switch (nw) {
+      case 4: return w8 ? gs_ms_launch_w<4, true>(st, a) : gs_ms_launch_w<4, false>(st, a);
+      case 8: return w8 ? gs_ms_launch_w<8, true>(st, a) : gs_ms_launch_w<8, false>(st, a);
+      default: return w8 ? gs_ms_launch_w<16, true>(st, a) : gs_ms_launch_w<16, false>(st, a);
+    }
   }
   GemmSkinnyArgs b = a;
   b.formal = g_gs_formal;

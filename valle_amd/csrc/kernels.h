@@ -86,6 +86,7 @@ struct GemmSkinnyArgs {
   LnConsumer lnc;
   KTrace kt;  // diagnostic timeline (option "ktrace")
   int dbg = 0;  // timing diagnostics (option "gs_dbg"): 1 = no X loads, 2 = no W loads (results meaningless)
+  int ms_nt = 0;   // M-split kernel: non-temporal W loads (A/B; filled by the launcher)
   int formal = 0;  // split-K hand-off with explicit release / acquire fences (filled by the launcher from g_gs_formal)
   int rot = 0;  // rotate the order in which a workgroup walks X by its index (option "gs_rot")
   const void* x = nullptr;     // bf16 [M][K]
@@ -114,6 +115,7 @@ struct GemmSkinnyArgs {
 constexpr int GS_WS_CNT_BYTES = 4096;  // 1024 row-fragment tickets
 constexpr int GS_WS_MAX_TILES = 2048;  // partial 16 x 64 fp32 tiles (4 KB each)
 extern int g_gs_formal;
+extern int g_gs_msplit;  // gemm_skinny.hip: M-split kernel for N / 16 < #CUs (default 1)
 size_t gemm_skinny_workspace_bytes();
 int gemm_skinny_ksplit(int N, int K, int target_wgs);
 bool gemm_skinny_supports(int M, int N, int K, int epi, int dh);

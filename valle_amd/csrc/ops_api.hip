@@ -48,6 +48,7 @@ extern "C" int vle_op_tune(const char* name, int64_t value) {
   else if (n == "attn_ring" && (value == 0 || value == 2 || value == 4)) vle::g_attn_ring = (int)value;
   else if (n == "qa_waves" && (value == 4 || value == 8)) vle::g_qa_waves = (int)value;
   else if (n == "g1_shared" && value >= 0 && value <= 1) vle::g_g1_shared = (int)value;
+  else if (n == "gs_msplit" && value >= 0 && value <= 3) vle::g_gs_msplit = (int)value;
   else if (n == "gs_formal" && value >= 0 && value <= 1) vle::g_gs_formal = (int)value;
   else if (n == "attn_defer" && value >= 0 && value <= 16) vle::g_attn_defer = (int)value;
   else return op_fail("vle_op_tune: unknown knob or value out of range");

@@ -20,7 +20,8 @@ at N = 1, 2, 4, 8, and every line also carries `c3_batch64`: 64 utterances per G
 N = 8), run by all ranks under the same barrier-bracketed timing, with its own AR (HBM) and NAR (MFMA) roofline fractions.
 Scaling efficiency of either workload = its value at N / (N x its value at N = 1), from the lines alone (`scale_ref`).
 `fp32_exact` (N = 1) is the same decode in engine mode fp32 -- the mode whose greedy token ids are bit-identical to the
-reference (tests/test_parity_sizes_gpu.py) -- timed in the same process.
+reference (tests/test_parity_sizes_gpu.py) -- timed in the same process; `c5_share_fp8` (N = 1) is the per-GPU share of BASELINE
+configs[4] (d1536-L24-h16, fp8 weights, fp8 MFMA in prefill / NAR, 32 utterances).
 """
 from __future__ import annotations
 
@@ -339,12 +340,17 @@ def main():
     ap.add_argument("--cpu-frames", type=int, default=128, help="frames of the bounded CPU-baseline sample (0 = skip)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--no-c3", action="store_true", help="skip the extra batch-64-per-GPU (BASELINE configs[2] / [3]) object")
+    ap.add_argument("--no-side", action="store_true", help="headline only: no c3_batch64 / fp32_exact / c5_share_fp8 legs (profiling runs)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32_exact object (token-exact engine mode) of the N = 1 line")
-    ap.add_argument("--c5", action="store_true", help="add the per-GPU share of BASELINE configs[4] (d1536-L24-h16, fp8 weights + fp8 MFMA, "
-                                                      "32 utterances) as an extra object (~2 min: 1.6 B parameters are initialised and quantised)")
+    ap.add_argument("--no-c5", action="store_true", help="skip the extra `c5_share_fp8` object of the N = 1 line: the per-GPU share of BASELINE "
+                                                         "configs[4] (d1536-L24-h16, fp8 weights + fp8 MFMA, 32 utterances; ~20 s on an MI355X box "
+                                                         "now that the host-side weight preparation is multi-threaded)")
+    ap.add_argument("--c5", action="store_true", help=argparse.SUPPRESS)  # round-2 spelling: the leg is on by default now
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine tuning option (vle_set_option), repeatable")
     ap.add_argument("--profile-kernels", type=int, default=0, help="extra untimed pass: hipEvent time per AR-step kernel family over n steps")
     args = ap.parse_args()
+    if args.no_side:
+        args.no_c3 = args.no_fp32 = args.no_c5 = True
 
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         sys.exit(spawn_ranks(args.gpus))
@@ -513,7 +519,7 @@ def main():
             leg = {"error": repr(err)[:200]}
         if out is not None:
             out["fp32_exact"] = leg
-    if args.c5 and args.gpus == 1:
+    if plain and world == 1 and not args.no_c5 and (args.d_model, args.layers, args.nhead) == (1024, 12, 16):
         try:
             del model
             out["c5_share_fp8"] = c5_leg(args, dev)

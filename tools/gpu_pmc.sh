@@ -4,7 +4,7 @@
 cd $GRAFT_REPO_ROOT
 D=gpurun_out/$1; mkdir -p $D
 shift
-FLAGS="${@:---steps 1 --warmup 1 --cpu-frames 0 --no-graph --no-c3}"
+FLAGS="${@:---steps 1 --warmup 1 --cpu-frames 0 --no-graph --no-side}"
 export TMPDIR=/tmp
 for SET in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES"; do
   TAG=$(echo $SET | tr ' ' '+')

@@ -315,6 +315,11 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   }
 }
 
+// "attn_lds_pad": dynamic LDS bytes requested per workgroup of the batched decode attention (never touched): caps the workgroups
+// a CU can host (160 KB / pad), so that the B * H workgroups of a launch spread evenly over the CUs instead of wherever the
+// dispatcher finds room first (the launch is one wave of equal workgroups: its time is the fullest CU's)
+int g_da_lds_pad = 0;
+
 template <typename T>
 static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const void* vc, const int32_t* kv_len, float* part_o,
                            float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit, int nk_override, void* out_norm,
@@ -328,14 +333,15 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
   else while (lpk < dh) lpk *= 2;
   const int keys4 = nsplit * 16 * (64 / lpk);
   (void)keys4;
-  const bool nk8 = nk_override == 8;  // measured (tools/ar_tune.py, C2 batch 1): 4 keys x 2 rounds beats 8 keys x 1 round
+  const bool nk8 = nk_override == 8;
+  const unsigned lds_pad = (B > 1 && g_da_lds_pad > 0) ? (unsigned)g_da_lds_pad : 0u;  // measured (tools/ar_tune.py, C2 batch 1): 4 keys x 2 rounds beats 8 keys x 1 round
 #define VLE_DA(VEC, LPK)                                                                                                    \
   do {                                                                                                                      \
     if (nk8)                                                                                                                \
-      hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 8>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
+      hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 8>), grid, block, lds_pad, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
                          part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf, kt);                                                              \
     else                                                                                                                    \
-      hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 4>), grid, block, 0, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
+      hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 4>), grid, block, lds_pad, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
                          part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf, kt);                                                              \
   } while (0)
   if (dh % VFULL == 0) {

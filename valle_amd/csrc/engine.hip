@@ -14,6 +14,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "common.h"
@@ -229,10 +230,35 @@ int upload_f32(vle_engine* e, float** dst, const float* src, size_t n) {
   return 0;
 }
 
+// Host-side weight preparation (quantisation, bf16 conversion, W gamma / W beta sums) is row-parallel: up to 16 threads over
+// contiguous row ranges -- loading the 1.6 B parameters of BASELINE configs[4] in engine mode FP8 is otherwise a minute of
+// single-threaded loops.  Results do not depend on the thread count (every row is computed by one thread, in the same order).
+template <typename F>
+void parallel_rows(int64_t n, int64_t work_per_row, F f) {
+  unsigned hw = std::thread::hardware_concurrency();
+  int nt = (int)std::min<int64_t>(std::min<unsigned>(hw ? hw : 1u, 16u), n);
+  if (nt <= 1 || n * work_per_row < (int64_t)1 << 18) {
+    f((int64_t)0, n);
+    return;
+  }
+  std::vector<std::thread> th;
+  const int64_t per = (n + nt - 1) / nt;
+  for (int t = 0; t < nt; ++t) {
+    const int64_t a = t * per, b = std::min<int64_t>(n, a + per);
+    if (a >= b) break;
+    th.emplace_back([=]() { f(a, b); });
+  }
+  for (auto& t : th) t.join();
+}
+
 // FP8W weight format (common.h): per row, scale = the smallest power of two with max|w| / scale <= 448,
 // q = RNE_e4m3fn(w / scale); W' = q * scale is what every kernel of the mode computes with.
+void quantize_rows_fp8w_range(const float* w, int64_t n0, int64_t n1, int64_t K, uint8_t* q, float* scale, float* deq);
 void quantize_rows_fp8w(const float* w, int64_t N, int64_t K, uint8_t* q, float* scale, float* deq) {
-  for (int64_t n = 0; n < N; ++n) {
+  parallel_rows(N, K, [=](int64_t a, int64_t b) { quantize_rows_fp8w_range(w, a, b, K, q, scale, deq); });
+}
+void quantize_rows_fp8w_range(const float* w, int64_t n0, int64_t n1, int64_t K, uint8_t* q, float* scale, float* deq) {
+  for (int64_t n = n0; n < n1; ++n) {
     const float* row = w + n * K;
     float amax = 0.f;
     for (int64_t k = 0; k < K; ++k) amax = std::max(amax, std::fabs(row[k]));
@@ -259,7 +285,13 @@ int upload_fp8w(vle_engine* e, void** dst, void** q8, float** sc, const float* s
   std::vector<float> scale((size_t)N), deq((size_t)(N * K));
   quantize_rows_fp8w(src, N, K, q.data(), scale.data(), deq.data());
   std::vector<uint16_t> tmp((size_t)(N * K));
-  for (size_t i = 0; i < tmp.size(); ++i) tmp[i] = f32_to_bf16(deq[i]);  // exact: 4 significant bits * 2^e
+  {
+    uint16_t* tp = tmp.data();
+    const float* dp = deq.data();
+    parallel_rows(N, K, [=](int64_t a, int64_t b) {
+      for (int64_t i = a * K; i < b * K; ++i) tp[i] = f32_to_bf16(dp[i]);  // exact: 4 significant bits * 2^e
+    });
+  }
   uint16_t* p = nullptr;
   int r = dev_alloc(e, &p, tmp.size());
   if (r) return r;
@@ -287,16 +319,22 @@ int upload_wg_wb(vle_engine* e, const float* w, int64_t N, int64_t K, const floa
     w = deq.data();
   }
   std::vector<float> wg((size_t)N), wb((size_t)N);
-  for (int64_t n = 0; n < N; ++n) {
-    const float* row = w + n * K;
-    double ag = 0.0, ab = 0.0;
-    for (int64_t k = 0; k < K; ++k) {
-      const double wv = e->w8 ? (double)row[k] : (double)bf16_to_f32(f32_to_bf16(row[k]));
-      ag += wv * (double)gamma[k];
-      ab += wv * (double)beta[k];
-    }
-    wg[n] = (float)ag;
-    wb[n] = (float)(ab + (bias ? (double)bias[n] : 0.0));
+  {
+    float *wgp = wg.data(), *wbp = wb.data();
+    const bool w8 = e->w8;
+    parallel_rows(N, K, [=](int64_t a, int64_t b) {
+      for (int64_t n = a; n < b; ++n) {
+        const float* row = w + n * K;
+        double ag = 0.0, ab = 0.0;
+        for (int64_t k = 0; k < K; ++k) {
+          const double wv = w8 ? (double)row[k] : (double)bf16_to_f32(f32_to_bf16(row[k]));
+          ag += wv * (double)gamma[k];
+          ab += wv * (double)beta[k];
+        }
+        wgp[n] = (float)ag;
+        wbp[n] = (float)(ab + (bias ? (double)bias[n] : 0.0));
+      }
+    });
   }
   int r = upload_f32(e, wg_dev, wg.data(), wg.size());
   if (r) return r;
@@ -307,7 +345,13 @@ int upload_wg_wb(vle_engine* e, const float* w, int64_t N, int64_t K, const floa
 int upload_T(vle_engine* e, void** dst, const float* src, size_t n) {
   if (e->dtype == DT_F32) return upload_f32(e, (float**)dst, src, n);
   std::vector<uint16_t> tmp(n);
-  for (size_t i = 0; i < n; ++i) tmp[i] = f32_to_bf16(src[i]);
+  {
+    uint16_t* tp = tmp.data();
+    const int64_t blk = 4096, nb = ((int64_t)n + blk - 1) / blk;
+    parallel_rows(nb, blk, [=](int64_t a, int64_t b) {
+      for (int64_t i = a * blk; i < std::min<int64_t>((int64_t)n, b * blk); ++i) tp[i] = f32_to_bf16(src[i]);
+    });
+  }
   uint16_t* p = nullptr;
   int r = dev_alloc(e, &p, n);
   if (r) return r;
@@ -2100,12 +2144,13 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     (n == "attn_v2" ? g_attn_v2 : n == "attn_xcd" ? g_attn_xcd : n == "attn_q128" ? g_attn_q128 : n == "attn_mode" ? g_attn_mode : n == "attn_defer" ? g_attn_defer : g_attn_ring) = (int)value;
     return VLE_OK;
   }
-  if (n == "gs_formal" || n == "g1_shared" || n == "qa_waves" || n == "gs_msplit") {  // process-global kernel selection / argument: drop the captured graphs
+  if (n == "gs_formal" || n == "g1_shared" || n == "qa_waves" || n == "gs_msplit" || n == "attn_lds_pad") {  // process-global kernel selection / argument: drop the captured graphs
     if (n == "qa_waves") {
       if (!(value == 4 || value == 8)) return e->fail(VLE_EINVAL, "qa_waves must be 4 or 8");
       g_qa_waves = (int)value;
     } else {
-      if (n == "gs_msplit") g_gs_msplit = (int)value;
+      if (n == "attn_lds_pad") g_da_lds_pad = (int)std::max<int64_t>(0, std::min<int64_t>(value, 60 * 1024));
+      else if (n == "gs_msplit") g_gs_msplit = (int)value;
       else (n == "gs_formal" ? g_gs_formal : g_g1_shared) = value != 0;
     }
     (void)hipStreamSynchronize(e->st);

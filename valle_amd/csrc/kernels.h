@@ -114,6 +114,7 @@ struct GemmSkinnyArgs {
 };
 constexpr int GS_WS_CNT_BYTES = 4096;  // 1024 row-fragment tickets
 constexpr int GS_WS_MAX_TILES = 2048;  // partial 16 x 64 fp32 tiles (4 KB each)
+extern int g_da_lds_pad;  // decode_attn.hip: dynamic LDS bytes per workgroup of the batched decode attention (occupancy cap)
 extern int g_gs_formal;
 extern int g_gs_msplit;  // gemm_skinny.hip: M-split kernel for N / 16 < #CUs (default 1)
 size_t gemm_skinny_workspace_bytes();

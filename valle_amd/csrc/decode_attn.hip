@@ -136,7 +136,7 @@ __device__ inline void attn_oproj_tail(const AttnOproj& fo, const float* sm_on, 
   }
 }
 
-template <typename T, int VEC, int LPK, int NK, bool FO = false>
+template <typename T, int VEC, int LPK, int NK, bool FO = false, bool NT = false>
 __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restrict__ q, const T* __restrict__ kc,
                                                           const T* __restrict__ vc, const int32_t* __restrict__ kv_len,
                                                           float* __restrict__ part_o, float* __restrict__ part_ml, int nhead,
@@ -167,8 +167,16 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
       int key = base + w * WCH + i * KPW + slot;
       key = key < ctx_max ? key : ctx_max - 1;
       if constexpr (kVec) {
-        kraw[i] = *reinterpret_cast<const uint4*>(Kb + (int64_t)key * dh);
-        vraw[i] = *reinterpret_cast<const uint4*>(Vb + (int64_t)key * dh);
+        if constexpr (NT) {  // a KV stream far larger than the 256 MB memory-side cache: read once per step, do not allocate
+          typedef unsigned int da_u32x4 __attribute__((ext_vector_type(4)));
+          const da_u32x4 kk = __builtin_nontemporal_load(reinterpret_cast<const da_u32x4*>(Kb + (int64_t)key * dh));
+          const da_u32x4 vv = __builtin_nontemporal_load(reinterpret_cast<const da_u32x4*>(Vb + (int64_t)key * dh));
+          kraw[i] = uint4{kk.x, kk.y, kk.z, kk.w};
+          vraw[i] = uint4{vv.x, vv.y, vv.z, vv.w};
+        } else {
+          kraw[i] = *reinterpret_cast<const uint4*>(Kb + (int64_t)key * dh);
+          vraw[i] = *reinterpret_cast<const uint4*>(Vb + (int64_t)key * dh);
+        }
       } else {
 #pragma unroll
         for (int j = 0; j < VEC; ++j) {
@@ -319,11 +327,12 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
 // a CU can host (160 KB / pad), so that the B * H workgroups of a launch spread evenly over the CUs instead of wherever the
 // dispatcher finds room first (the launch is one wave of equal workgroups: its time is the fullest CU's)
 int g_da_lds_pad = 0;
+int g_da_nt = -1;  // "attn_nt" (see decode_dispatch)
 
 template <typename T>
 static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const void* vc, const int32_t* kv_len, float* part_o,
                            float* part_ml, int B, int nhead, int dh, int ctx_max, int nsplit, int nk_override, void* out_norm,
-                           const int32_t* done, int out_xf, KTrace kt) {
+                           const int32_t* done, int out_xf, KTrace kt, int kv_nt) {
   constexpr int VFULL = Elem<T>::VEC;
   if (dh > 254) return -1;
   const dim3 grid(nhead, nsplit, B), block(256);
@@ -334,10 +343,20 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
   const int keys4 = nsplit * 16 * (64 / lpk);
   (void)keys4;
   const bool nk8 = nk_override == 8;
-  const unsigned lds_pad = (B > 1 && g_da_lds_pad > 0) ? (unsigned)g_da_lds_pad : 0u;  // measured (tools/ar_tune.py, C2 batch 1): 4 keys x 2 rounds beats 8 keys x 1 round
+  const unsigned lds_pad = (B > 1 && g_da_lds_pad > 0) ? (unsigned)g_da_lds_pad : 0u;
+  // Non-temporal K / V loads when the step's whole KV stream (all layers) exceeds the 256 MB memory-side cache: every byte is read
+  // once per step and nothing survives to the next one, so allocating it only evicts what could stay.  Measured (MI355X, C2
+  // architecture): 64 utterances AR loop 573 -> 536 ms (decode attention ~5.2 -> ~6 TB/s), 8 utterances 291 -> 283 ms; one
+  // utterance (50 MB of KV per step) keeps the default policy -- its cache stays resident.  The caller knows the layer count and
+  // passes kv_nt (1 / 0); -1 = decide from this layer's size alone; knob "attn_nt" (g_da_nt >= 0) overrides both.
+  const int64_t layer_kv = (int64_t)2 * B * nhead * ctx_max * dh * (int64_t)sizeof(T);
+  const bool nt_stream = g_da_nt >= 0 ? g_da_nt != 0 : kv_nt >= 0 ? kv_nt != 0 : layer_kv > ((int64_t)64 << 20);  // measured (tools/ar_tune.py, C2 batch 1): 4 keys x 2 rounds beats 8 keys x 1 round
 #define VLE_DA(VEC, LPK)                                                                                                    \
   do {                                                                                                                      \
-    if (nk8)                                                                                                                \
+    if (nt_stream && !nk8)                                                                                                  \
+      hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 4, false, true>), grid, block, lds_pad, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
+                         part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf, kt, AttnOproj());                     \
+    else if (nk8)                                                                                                           \
       hipLaunchKernelGGL((decode_attn_kernel<T, VEC, LPK, 8>), grid, block, lds_pad, st, q, (const T*)kc, (const T*)vc, kv_len, part_o, \
                          part_ml, nhead, dh, ctx_max, nsplit, (T*)out_norm, done, out_xf, kt);                                                              \
     else                                                                                                                    \
@@ -368,13 +387,13 @@ static int decode_dispatch(hipStream_t st, const float* q, const void* kc, const
 
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
-                            int nsplit, int nk_override, void* out_norm, const int32_t* done, int out_xf, KTrace kt) {
+                            int nsplit, int nk_override, void* out_norm, const int32_t* done, int out_xf, KTrace kt, int kv_nt) {
   if (B <= 0) return 0;
   if (out_xf != 0 && (out_norm == nullptr || dtype != DT_BF16 || B > 64)) return -1;
   if (out_norm != nullptr && nsplit != 1) return -1;
   if (dtype == DT_F32)
-    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf, kt);
-  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf, kt);
+    return decode_dispatch<float>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf, kt, kv_nt);
+  return decode_dispatch<bf16_t>(st, q, k_cache, v_cache, kv_len, part_o, part_ml, B, nhead, dh, ctx_max, nsplit, nk_override, out_norm, done, out_xf, kt, kv_nt);
 }
 
 // decode attention + out-proj + residual (+ LayerNorm producer) of the batched step in ONE launch: bf16 cache, one block per

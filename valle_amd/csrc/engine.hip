@@ -1038,6 +1038,13 @@ int enqueue_ar_sample(vle_engine* e, int first, const int32_t* slot_map = nullpt
   return 0;
 }
 
+// the step's KV stream (all layers, this batch, full capacity) against the 256 MB memory-side cache: decode_attn.hip reads it
+// non-temporally when nothing of it can survive until the next step
+int kv_stream_nt(const vle_engine* e) {
+  const int64_t bytes = (int64_t)2 * e->L * e->B * e->H * e->ctx_max * e->dh * (int64_t)dtype_size(e->dtype);
+  return bytes > ((int64_t)192 << 20) ? 1 : 0;
+}
+
 // One AR step = one new token per utterance through the L layers + logits + sampling.
 int enqueue_ar_step(vle_engine* e) {
   hipStream_t st = e->st;
@@ -1089,7 +1096,7 @@ int enqueue_ar_step(vle_engine* e) {
         ProfScope ps(e, 1);
         E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
                                             e->ctx_max, e->nsplit, e->opt_nk, direct ? e->att_step : nullptr, e->S.done,
-                                            direct ? xfw : 0, e->next_kt()));
+                                            direct ? xfw : 0, e->next_kt(), kv_stream_nt(e)));
       }
       if (!oproj_done) {
         ProfScope ps(e, 2);
@@ -1170,7 +1177,7 @@ int enqueue_ar_step(vle_engine* e) {
     if (!fused_qa) {
       ProfScope ps(e, 1);
       E_LAUNCH(e, launch_decode_attention(st, e->dtype, e->q_step, kc, vc, e->S.kv_len, e->part_o, e->part_ml, e->B, e->H, e->dh,
-                                          e->ctx_max, e->nsplit, e->opt_nk, nullptr, e->B > 1 ? e->S.done : nullptr, 0, e->next_kt()));
+                                          e->ctx_max, e->nsplit, e->opt_nk, nullptr, e->B > 1 ? e->S.done : nullptr, 0, e->next_kt(), kv_stream_nt(e)));
     }
     if (sk) {
       {
@@ -2144,12 +2151,13 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     (n == "attn_v2" ? g_attn_v2 : n == "attn_xcd" ? g_attn_xcd : n == "attn_q128" ? g_attn_q128 : n == "attn_mode" ? g_attn_mode : n == "attn_defer" ? g_attn_defer : g_attn_ring) = (int)value;
     return VLE_OK;
   }
-  if (n == "gs_formal" || n == "g1_shared" || n == "qa_waves" || n == "gs_msplit" || n == "attn_lds_pad") {  // process-global kernel selection / argument: drop the captured graphs
+  if (n == "gs_formal" || n == "g1_shared" || n == "qa_waves" || n == "gs_msplit" || n == "attn_lds_pad" || n == "attn_nt") {  // process-global kernel selection / argument: drop the captured graphs
     if (n == "qa_waves") {
       if (!(value == 4 || value == 8)) return e->fail(VLE_EINVAL, "qa_waves must be 4 or 8");
       g_qa_waves = (int)value;
     } else {
-      if (n == "attn_lds_pad") g_da_lds_pad = (int)std::max<int64_t>(0, std::min<int64_t>(value, 60 * 1024));
+      if (n == "attn_nt") g_da_nt = (int)value;
+      else if (n == "attn_lds_pad") g_da_lds_pad = (int)std::max<int64_t>(0, std::min<int64_t>(value, 60 * 1024));
       else if (n == "gs_msplit") g_gs_msplit = (int)value;
       else (n == "gs_formal" ? g_gs_formal : g_g1_shared) = value != 0;
     }

@@ -124,6 +124,23 @@ __device__ inline void gs_epilogue(const GemmSkinnyArgs& a, gs_f32x4 v, int m, i
   }
 }
 
+// 16-byte write-through (sc1) store / L1-bypassing (sc1) loads of the split-K hand-off.  The guide's pitfall 7 ("bulk publish 3-20x
+// slow: data held 16 B per lane re-issued as narrow sc1 stores"): a dword sc1 store is one fabric write, ~6x the dwordx4 time per
+// byte.  hipcc has no 16-byte atomic: inline asm (the compiler does not count these operations -- the store is drained by the
+// explicit vmcnt(0) that follows it, the loads carry their own wait).
+__device__ inline void gs_store16_wt(float* p, gs_f32x4 v) {
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(p), "v"(v) : "memory");
+}
+__device__ inline void gs_load16x4_sc1(const float* p0, const float* p1, const float* p2, const float* p3, gs_f32x4& t0, gs_f32x4& t1,
+                                       gs_f32x4& t2, gs_f32x4& t3) {
+  asm volatile(
+      "global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\tglobal_load_dwordx4 %2, %6, off sc1\n\t"
+      "global_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+      : "=&v"(t0), "=&v"(t1), "=&v"(t2), "=&v"(t3)
+      : "v"(p0), "v"(p1), "v"(p2), "v"(p3)
+      : "memory");
+}
+
 // FP8W: 8 e4m3fn weights (two dwords) -> the bf16 MFMA operand; exact (every e4m3fn value is a bf16 value)
 __device__ inline gs_bf16x8 gs_fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
   typedef float f32x2v_t __attribute__((ext_vector_type(2)));
@@ -306,12 +323,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     //     L2 back) before the ticket, acquire fence (buffer_inv sc1) after it.  Measured on MI355X: the fences
     //     add whole-cache work to a ~10 us kernel; results are bit-identical, which is why form 0 is the default.
     __shared__ int s_last;
-    float* part = a.ws_part + ((int64_t)blockIdx.x * KS * MF) * 256;  // tile (ks, i): [r][lane], 4 x 256-B rows
-    if (wave < MF) {
-      float* p = part + (ks * MF + i) * 256 + lane;
-#pragma unroll
-      for (int r = 0; r < 4; ++r) __hip_atomic_store(p + r * 64, v[r], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    }
+    float* part = a.ws_part + ((int64_t)blockIdx.x * KS * MF) * 256;  // tile (ks, i): [lane][4] fp32, one 16-byte vector per lane
+    if (wave < MF) gs_store16_wt(part + (ks * MF + i) * 256 + lane * 4, v);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -328,12 +341,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     if (!s_last) return;
     if (wave < MF) {
       v = gs_f32x4{0.f, 0.f, 0.f, 0.f};
-      for (int q = 0; q < KS; ++q) {  // fixed slice order: the sum does not depend on who arrived last
-        const float* pq = part + (q * MF + i) * 256 + lane;
-        gs_f32x4 t;
-#pragma unroll
-        for (int r = 0; r < 4; ++r) t[r] = __hip_atomic_load(pq + r * 64, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v += t;
+      for (int q0 = 0; q0 < KS; q0 += 4) {  // fixed slice order: the sum does not depend on who arrived last; 4 loads in flight
+        const float* pb = part + i * 256 + lane * 4;
+        gs_f32x4 t0, t1, t2, t3;
+        gs_load16x4_sc1(pb + min(q0, KS - 1) * MF * 256, pb + min(q0 + 1, KS - 1) * MF * 256, pb + min(q0 + 2, KS - 1) * MF * 256,
+                        pb + min(q0 + 3, KS - 1) * MF * 256, t0, t1, t2, t3);
+        v += t0;
+        if (q0 + 1 < KS) v += t1;
+        if (q0 + 2 < KS) v += t2;
+        if (q0 + 3 < KS) v += t3;
       }
     }
   }

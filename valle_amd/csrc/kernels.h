@@ -114,6 +114,7 @@ struct GemmSkinnyArgs {
 };
 constexpr int GS_WS_CNT_BYTES = 4096;  // 1024 row-fragment tickets
 constexpr int GS_WS_MAX_TILES = 2048;  // partial 16 x 64 fp32 tiles (4 KB each)
+extern int g_da_nt;       // decode_attn.hip: non-temporal K / V loads (-1 auto, 0, 1)
 extern int g_da_lds_pad;  // decode_attn.hip: dynamic LDS bytes per workgroup of the batched decode attention (occupancy cap)
 extern int g_gs_formal;
 extern int g_gs_msplit;  // gemm_skinny.hip: M-split kernel for N / 16 < #CUs (default 1)
@@ -211,7 +212,7 @@ int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache,
 int launch_decode_attention(hipStream_t st, int dtype, const float* q, const void* k_cache, const void* v_cache,
                             const int32_t* kv_len, float* part_o, float* part_ml, int B, int nhead, int dh, int ctx_max,
                             int nsplit, int nk_override = 0, void* out_norm = nullptr, const int32_t* done = nullptr,
-                            int out_xf = 0, KTrace kt = KTrace());
+                            int out_xf = 0, KTrace kt = KTrace(), int kv_nt = -1);  // kv_nt: non-temporal K / V loads (1 / 0; -1 = by this layer's size)
 // the same + the layer's out-proj, residual and LayerNorm producer in one launch (decode_attn.hip AttnOproj); 1 = shape not covered
 int launch_decode_attention_oproj(hipStream_t st, const float* q, const void* k_cache, const void* v_cache, const int32_t* kv_len, int B,
                                   int nhead, int dh, int ctx_max, const int32_t* done, const void* wo_bf16, const float* bias, float* resid,

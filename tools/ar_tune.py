@@ -45,10 +45,11 @@ def main():
             for k in ("nsplit", "gemv1_rpw", "gemv1_rpw_qkv", "gemv1_rpw_ffn1", "no_gemv1", "attn_nk", "steps_per_graph"):
                 eng.set_option(k, 0)
             eng.set_option("qkv_attn", 1)
-            eng.set_option("qa_nsplit", 4)
+            eng.set_option("qa_nsplit", 8)
             eng.set_option("g1_shared", 1)
             eng.set_option("qa_waves", 4)
             eng.set_option("qa_qtemporal", 1)
+            eng.set_option("qa_handoff", 1)
             for k, v in opts.items():
                 eng.set_option(k, v)
             for rep in range(2):  # first pass (re)captures the graph

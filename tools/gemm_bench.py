@@ -34,14 +34,16 @@ def tflops(M, N, K, epi, reps=20):
 def main():
     shapes = [("qkv", 3072, 1024, ops.EPI_STORE), ("oproj", 1024, 1024, ops.EPI_RESID), ("ffn1", 4096, 1024, ops.EPI_RELU),
               ("ffn2", 1024, 4096, ops.EPI_RESID)]
-    for M in (65600, 8200, 1025):
-        for knobs in ({}, {"g8_dbg": 4}, {"g8_dbg": 1}, {"g8_colgroup": 4}, {"glds_8ph": 0}, {"glds_8ph": 0, "glds_epi": 0}, {}):
+    quick = "--quick" in sys.argv
+    for M in ((65600,) if quick else (65600, 8200, 1025)):
+        for knobs in (({}, {"g8_nt": 1}, {"g8_nt": 2}, {"g8_nt": 3}, {"g8_dbg": 1}, {}) if quick else
+                      ({}, {"g8_nt": 1}, {"g8_nt": 2}, {"g8_nt": 3}, {"g8_dbg": 4}, {"g8_dbg": 1}, {"g8_colgroup": 4}, {"glds_8ph": 0}, {"glds_8ph": 0, "glds_epi": 0}, {})):
             for k, v in knobs.items():
                 ops.tune(k, v)
             row = [f"{name} {tflops(M, N, K, epi):7.1f}" for name, N, K, epi in shapes]
             print(f"M={M:6d} {str(knobs):22s} TF/s: " + "  ".join(row), flush=True)
             for k in knobs:
-                ops.tune(k, {"glds_swz": 0, "glds_prio": 0, "glds_w8": 1, "glds_big": -1, "glds_8ph": -1, "g8_stagger": 1, "g8_colgroup": 0, "g8_dbg": 0, "glds_epi": 1}[k])
+                ops.tune(k, {"glds_swz": 0, "glds_prio": 0, "glds_w8": 1, "glds_big": -1, "glds_8ph": -1, "g8_stagger": 1, "g8_colgroup": 0, "g8_dbg": 0, "glds_epi": 1, "g8_nt": 0}[k])
 
 
 if __name__ == "__main__":

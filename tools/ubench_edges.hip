@@ -40,6 +40,9 @@ struct Params {
   int gmax;         // granules per buffer
   int per_wg;       // granules each workgroup publishes per edge (gmax = per_wg * gridDim.x)
   int edges;        // edges per launch
+  int producers;    // workgroups that publish (the others only gather): x of a decode layer is produced by ~32 CUs
+  int lean;         // round 3: the retry path touches no global word (the round-2 loop polled p.err after EVERY failed pass -- a second
+                    // dependent fabric round trip per retry -- and slept); the timeout is a local spin count only
   const u32x4* stream;  // weight stand-in
   size_t stream_vecs;   // 16-byte vectors available
   int stream_vecs_per_edge;  // per workgroup per edge (0 = idle chip)
@@ -64,11 +67,12 @@ __global__ __launch_bounds__(T) void edges_kernel(Params p) {
     u64* buf = p.gran + (size_t)(e & 1) * p.gmax;
     if (wave == 0) {
       // ---- publish this workgroup's granules (write-through 8-byte stores: the data is the flag) ----
-      for (int g = lane; g < p.per_wg; g += 64) {
-        const float v = carry + (float)g;
-        __hip_atomic_store(buf + (size_t)wg * p.per_wg + g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
-                           __HIP_MEMORY_SCOPE_AGENT);
-      }
+      if (wg < p.producers)
+        for (int g = lane; g < p.per_wg; g += 64) {
+          const float v = carry + (float)g;
+          __hip_atomic_store(buf + (size_t)wg * p.per_wg + g, ((u64)epoch << 32) | (u64)__float_as_uint(v), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+        }
       // ---- sweep ALL granules until every tag carries this epoch ----
       float s = 0.f;
       bool fail = false;
@@ -77,6 +81,23 @@ __global__ __launch_bounds__(T) void edges_kernel(Params p) {
         while (true) {
           bool ok = true;
           float part = 0.f;
+          if (p.lean) {
+            // round 3: ALL 16 loads of the pass issued back to back, ONE wait (the guide's pass).  The round-2 loop below guards
+            // every load with `idx < gmax`: hipcc turns that into 16 exec-masked branches with `s_waitcnt vmcnt(0)` after each
+            // load -- 16 SERIAL fabric round trips per pass, which is what round 2 measured as "7.1 us per edge".
+            u64 x[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              const int idx = min(base + k * 64 + lane, p.gmax - 1);
+              x[k] = __hip_atomic_load(buf + idx, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+              const bool valid = base + k * 64 + lane < p.gmax;
+              ok &= !valid || (unsigned)(x[k] >> 32) == epoch;
+              part += valid ? __uint_as_float((unsigned)x[k]) : 0.f;
+            }
+          } else {
 #pragma unroll
           for (int k = 0; k < 16; ++k) {
             const int idx = base + k * 64 + lane;
@@ -86,15 +107,23 @@ __global__ __launch_bounds__(T) void edges_kernel(Params p) {
               part += __uint_as_float((unsigned)x);
             }
           }
+          }
           if (__all(ok)) {
             s += part;
             break;
           }
-          if (++spins > SPIN_LIMIT || __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
-            fail = true;
-            break;
+          if (p.lean) {
+            if (++spins > SPIN_LIMIT) {
+              fail = true;
+              break;
+            }
+          } else {
+            if (++spins > SPIN_LIMIT || __hip_atomic_load(p.err, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) {
+              fail = true;
+              break;
+            }
+            __builtin_amdgcn_s_sleep(1);
           }
-          __builtin_amdgcn_s_sleep(1);
         }
         if (fail) break;
       }
@@ -130,10 +159,13 @@ __global__ __launch_bounds__(T) void edges_kernel(Params p) {
   if (junk == 12345.f) p.sink[wg] = junk + carry;
 }
 
-static double run(int nwg, int per_wg, int edges, int stream_kb, const u32x4* stream, size_t stream_vecs, int reps) {
+static double run(int nwg, int per_wg, int edges, int stream_kb, const u32x4* stream, size_t stream_vecs, int reps, int producers = 0,
+                  int lean = 0) {
   Params p{};
   p.per_wg = per_wg;
-  p.gmax = per_wg * nwg;
+  p.producers = producers > 0 ? producers : nwg;
+  p.lean = lean;
+  p.gmax = per_wg * p.producers;
   p.edges = edges;
   p.stream = stream;
   p.stream_vecs = stream_vecs;
@@ -201,7 +233,15 @@ int main(int argc, char** argv) {
     fflush(stdout);
   }
   // fewer gatherers: 64 workgroups (one per 4 CUs) -- the attention merge edge, or a two-level scheme
-  printf(" ],\n \"x_1024f32_idle_64wg\": %.3f\n}\n", run(64, 16, edges, 0, stream, sv, reps));
+  printf(" ],\n \"x_1024f32_idle_64wg\": %.3f,\n", run(64, 16, edges, 0, stream, sv, reps));
+  // round 3: the same edges with a retry path that touches no global word, and with the vector published by
+  // the CUs that actually produce it (32 for the 1024-float x of a decode layer: 32 granules each)
+  printf(" \"round3_lean\": {\"x_1024f32_256producers\": %.3f, ", run(ncu, 4, edges, 0, stream, sv, reps, 0, 1));
+  printf("\"x_1024f32_32producers\": %.3f, ", run(ncu, 32, edges, 0, stream, sv, reps, 32, 1));
+  printf("\"x_1024f32_32producers_stream24KB\": %.3f, ", run(ncu, 32, edges, 24, stream, sv, reps, 32, 1));
+  printf("\"h_4096f32_256producers\": %.3f, ", run(ncu, 16, edges, 0, stream, sv, reps, 0, 1));
+  printf("\"partials_4224f32_64producers\": %.3f, ", run(ncu, 66, edges, 0, stream, sv, reps, 64, 1));
+  printf("\"x_1024f32_32producers_64gatherers\": %.3f}\n}\n", run(64, 32, edges, 0, stream, sv, reps, 32, 1));
   CK(hipFree(stream));
   return 0;
 }

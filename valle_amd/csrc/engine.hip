@@ -103,6 +103,8 @@ struct vle_engine {
   // ---- buffers ------------------------------------------------------------------------------------
   void *kcache = nullptr, *vcache = nullptr;  // T [L][B][H][ctx_max][dh]
   float *x_step = nullptr, *q_step = nullptr, *h_step = nullptr, *part_o = nullptr, *part_ml = nullptr, *logits = nullptr;
+  unsigned long long* qgran = nullptr;       // [L][d] {epoch, q} granules of the fused launch's in-launch hand-off (zeroed at every prefill)
+  unsigned* qa_spin_fail = nullptr;          // workgroups that gave up waiting and recomputed their query rows (diagnostic)
   float *k_new = nullptr, *v_new = nullptr;  // [B][d] the new token's K / V rows (cache-rounded) of the fused batch-1 QKV + attention launch
   void *xn_step = nullptr, *qkv_step = nullptr, *att_step = nullptr, *hT_step = nullptr;  // batch > 8 path
   int32_t* state_dev = nullptr;  // kv_len, audio_pos, n_gen, done, cap, iter [max_B] each, then done_count
@@ -162,7 +164,10 @@ struct vle_engine {
   int opt_nk = 0;             // option "attn_nk": keys per lane per round of the decode attention (0 auto, 4, 8)
   int opt_spg = 0;            // option "steps_per_graph": overrides cfg.steps_per_graph when > 0
   int opt_qkv_attn = 1;       // option "qkv_attn": batch 1, QKV GEMV + decode attention in one launch (gemv1.hip qkv_attn1_kernel)
-  int opt_qa_nsplit = 4;      // option "qa_nsplit": KV splits per head of that launch (4, 8, 16); measured at C2: 215.9 / 218.8 / 263 us per step
+  int opt_qa_nsplit = 8;      // option "qa_nsplit": KV splits per head of that launch (4, 8, 16).  With the q hand-off (no redundant query rows) 8
+                              // splits cover 1024 keys in one round: 212.4 us per step over the whole 753-step run against 215.3 with 4 (which wins
+                              // below context 512: 208.1 vs 212.3); without the hand-off: 215.9 / 218.8 / 263 us for 4 / 8 / 16
+  int opt_qa_handoff = 1;     // option "qa_handoff": q reaches the attention workgroups through granules instead of being recomputed per split
   int opt_qa_qtemporal = 1;   // option "qa_qtemporal": its query-row loads with the default cache policy (shared by a head's splits through L2)
   int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
   int opt_rpw_qkv = 0;        // option "gemv1_rpw_qkv": the same for the QKV GEMV only
@@ -502,7 +507,7 @@ static void release_buffers(vle_engine* e) {
   e->prog_dev = nullptr;
   e->kcache = e->vcache = nullptr;
   e->x_step = e->q_step = e->h_step = e->part_o = e->part_ml = e->logits = nullptr;
-  e->k_new = e->v_new = nullptr;
+  e->k_new = e->v_new = nullptr; e->qgran = nullptr; e->qa_spin_fail = nullptr;
   e->xn_step = e->qkv_step = e->att_step = e->hT_step = nullptr;
   e->gs_ws = nullptr; e->ln_stats = nullptr; e->ao_part = nullptr; e->ao_cnt = nullptr;
   e->state_dev = nullptr; e->S = ArState{}; e->dyn_dev = nullptr;
@@ -789,6 +794,10 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->h_step, B * 4 * d))) return r;
   if ((r = dev_alloc(e, &e->k_new, B * d))) return r;
   if ((r = dev_alloc(e, &e->v_new, B * d))) return r;
+  if ((r = dev_alloc(e, &e->qgran, (size_t)e->L * d))) return r;
+  E_HIP(e, hipMemset(e->qgran, 0, (size_t)e->L * d * sizeof(unsigned long long)));
+  if ((r = dev_alloc(e, &e->qa_spin_fail, 4))) return r;
+  E_HIP(e, hipMemset(e->qa_spin_fail, 0, 4 * sizeof(unsigned)));
   if ((r = dev_alloc(e, &e->part_o, (size_t)B * e->H * 16 * e->dh))) return r;
   if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
   if ((r = dev_alloc(e, &e->logits, B * V_AR))) return r;
@@ -1153,6 +1162,9 @@ int enqueue_ar_step(vle_engine* e) {
           q.temporal = e->opt_w8_temporal >= 0 ? e->opt_w8_temporal : (w8_bytes <= (int64_t)192 << 20 ? 1 : 0);
         }
         q.q_temporal = e->opt_qa_qtemporal;
+        if (e->opt_qa_handoff && e->qgran != nullptr) {
+          q.q_gran = e->qgran + (size_t)l * d; q.epoch_ptr = e->S.iter; q.spin_fail = e->qa_spin_fail;
+        }
         q.kt = e->next_kt();
         const int fr = launch_qkv_attn1(st, qdt, q);
         if (fr < 0) return e->fail(VLE_EHIP, "launch_qkv_attn1 failed");
@@ -1313,6 +1325,8 @@ extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, 
   h_seq_off[B] = (int32_t)off;
   E_HIP(e, hipMemcpyAsync(e->tables_dev, e->tables_host, tb.used * sizeof(int32_t), hipMemcpyHostToDevice, st));
   E_HIP(e, hipMemcpyAsync(e->state_dev, d_state, (6 * e->max_B + 8) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
+  // the AR iteration counters restart at 0: so do the epochs of the fused launch's q granules -- forget the old tags
+  if (e->qgran) E_HIP(e, hipMemsetAsync(e->qgran, 0, (size_t)e->L * e->d * sizeof(unsigned long long), st));
   // id range check on the engine-owned copies (sanitises them); the flag is read at the end of this call, by which
   // time these three tiny operations have long completed -- no stall of the stream
   E_HIP(e, hipMemsetAsync(e->id_err_dev, 0, sizeof(int32_t), st));
@@ -1895,6 +1909,7 @@ extern "C" int vle_slots_prefill(vle_engine* e, void* stream, int32_t n, const i
     return e->fail(VLE_EINDEX, kIdErrMsg);
   }
   E_LAUNCH(e, launch_slot_state_init(st, e->state_dev, e->max_B, d_slots, d_kv, d_ap, d_cap, n, e->slot_seed_dev, seed, e->admitted));
+  if (e->qgran && e->max_B == 1) E_HIP(e, hipMemsetAsync(e->qgran, 0, (size_t)e->L * e->d * sizeof(unsigned long long), st));  // see vle_ar_prefill
   e->admitted += (unsigned long long)n;
 
   PrefillEmbedArgs pa{};
@@ -2108,9 +2123,9 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
-  if (n == "qkv_attn" || n == "qa_nsplit" || n == "qa_qtemporal") {  // changes the captured graphs: drop them
+  if (n == "qkv_attn" || n == "qa_nsplit" || n == "qa_qtemporal" || n == "qa_handoff") {  // changes the captured graphs: drop them
     if (n == "qa_nsplit" && !(value == 4 || value == 8 || value == 16)) return e->fail(VLE_EINVAL, "qa_nsplit must be 4, 8 or 16");
-    (n == "qkv_attn" ? e->opt_qkv_attn : n == "qa_nsplit" ? e->opt_qa_nsplit : e->opt_qa_qtemporal) = (int)value;
+    (n == "qkv_attn" ? e->opt_qkv_attn : n == "qa_nsplit" ? e->opt_qa_nsplit : n == "qa_handoff" ? e->opt_qa_handoff : e->opt_qa_qtemporal) = (int)value;
     (void)hipStreamSynchronize(e->st);
     for (auto& kv : e->graphs) {
       if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
@@ -2167,6 +2182,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
       if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
     }
     e->graphs.clear();
+    return VLE_OK;
+  }
+  if (n == "g8_nt") {
+    g_g8_nt = (int)value & 3;
     return VLE_OK;
   }
   if (n == "glds_swz" || n == "glds_8ph" || n == "g8_stagger" || n == "g8_colgroup") {

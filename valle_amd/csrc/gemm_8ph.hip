@@ -262,7 +262,10 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
         g8_u32x4 v = *reinterpret_cast<const g8_u32x4*>(E + r * 512 + ((l ^ (r & 7)) << 4));
         if ((r >> 3) & 1) v = g8_u32x4{v[2], v[3], v[0], v[1]};
         const int64_t m = m0 + r;
-        if (m < M && !(dbg & 1)) *reinterpret_cast<g8_u32x4*>(outp + m * N + n0 + l * 8) = v;
+        if (m < M && !(dbg & 1)) {
+          if (dbg & 8) __builtin_nontemporal_store(v, reinterpret_cast<g8_u32x4*>(outp + m * N + n0 + l * 8));
+          else *reinterpret_cast<g8_u32x4*>(outp + m * N + n0 + l * 8) = v;
+        }
       }
     } else {
 #pragma unroll
@@ -285,7 +288,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
 #pragma unroll
           for (int it = 0; it < 16; ++it) {
             const int64_t m = m0 + a * 128 + wave * 16 + it;
-            old[it] = *reinterpret_cast<const g8_f32x4*>(base + (m < M ? m : M - 1) * N);
+            old[it] = (dbg & 16) ? __builtin_nontemporal_load(reinterpret_cast<const g8_f32x4*>(base + (m < M ? m : M - 1) * N))
+                                 : *reinterpret_cast<const g8_f32x4*>(base + (m < M ? m : M - 1) * N);
           }
         }
         __syncthreads();
@@ -295,7 +299,10 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
           g8_f32x4 v = *reinterpret_cast<const g8_f32x4*>(E + r * 1024 + ((lane ^ (r & 7)) << 4));
           if constexpr (EPI == EPI_RESID) v = old[it] + v;
           const int64_t m = m0 + a * 128 + r;
-          if (m < M && !(dbg & 1)) *reinterpret_cast<g8_f32x4*>(base + m * N) = v;
+          if (m < M && !(dbg & 1)) {
+            if (dbg & 16) __builtin_nontemporal_store(v, reinterpret_cast<g8_f32x4*>(base + m * N));
+            else *reinterpret_cast<g8_f32x4*>(base + m * N) = v;
+          }
         }
       }
     }
@@ -334,6 +341,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
     }
 }
 
+int g_g8_nt = 0;        // "g8_nt": non-temporal epilogue traffic -- 1 the bf16 output tiles, 2 the fp32 residual read-modify-write, 3 both
 int g_g8_dbg = 0;       // "g8_dbg": diagnostics -- 1 no epilogue stores, 2 two K-tiles only (what do prologue / epilogue cost?), 4 legacy epilogue
 int g_g8_colgroup = 0;  // "g8_colgroup": column tiles per group of the tile order (0 / 1 = row-major)
 int g_g8_stagger = 1;  // "g8_stagger": waves 4-7 half a phase behind waves 0-3 (measured +7-10 %: 905 -> 970 TF/s); 0 = lock step
@@ -345,7 +353,7 @@ int launch_gemm_8ph(hipStream_t st, const void* A, const void* W, const float* b
   const dim3 grid(N / 256, (unsigned)((M + 255) / 256)), block(512);
   const bf16_t* a = (const bf16_t*)A;
   const bf16_t* w = (const bf16_t*)W;
-#define VLE_G8(E, ST, SW) hipLaunchKernelGGL((gemm_8ph_kernel<E, ST, SW>), grid, block, 0, st, a, w, bias, out, resid, M, N, K, g_g8_colgroup, g_g8_dbg)
+#define VLE_G8(E, ST, SW) hipLaunchKernelGGL((gemm_8ph_kernel<E, ST, SW>), grid, block, 0, st, a, w, bias, out, resid, M, N, K, g_g8_colgroup, g_g8_dbg | (g_g8_nt << 3))
 #define VLE_G8E(ST, SW)                           \
   switch (epi) {                                  \
     case EPI_STORE: VLE_G8(EPI_STORE, ST, SW); break; \

@@ -764,7 +764,7 @@ int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a) {
 //     for free (gemv1_kernel PRO_ATTN_SELF: one more partial with l = 1).
 // No workgroup waits for another: a kernel boundary less per layer (62 -> 50 launches per step at L = 12) and one HBM round
 // trip instead of two on the critical path.
-template <typename T, int NCH, int DH, int RPW, int NW>
+template <typename T, int NCH, int DH, int RPW, int NW, bool HO>
 __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
   constexpr int NT = NW * 64;  // 4 or 8 waves per workgroup
   constexpr int VEC = Elem<T>::VEC;
@@ -790,7 +790,7 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
   if ((int)blockIdx.x >= a.n_attn) {
     // ================= K / V rows of the in-projection: rows [d, 3d), RPW per wave (gemv1_kernel's structure) =============
     const int wave = ((int)blockIdx.x - a.n_attn) * NW + w;
-    const int row0 = K + wave * RPW;
+    const int row0 = (HO ? 0 : K) + wave * RPW;  // hand-off mode: the query rows are GEMV rows too
     const bool live = row0 < 3 * K;  // wave-uniform; dead waves still take part in the shared LayerNorm's barriers
     u32x4_t wv[RPW][NCH];
 #pragma unroll
@@ -804,11 +804,12 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
     const int myrow = row0 + lane;
     const bool writer = live && lane < RPW && myrow < 3 * K;
     float bias_v = 0.f, scale_v = 1.f;
-    int kvl = 0;
+    int kvl = 0, kvl_epoch = 0;
     if (writer) {
       if (a.bias) bias_v = a.bias[myrow];
       if constexpr (G1W<T>::kScaled) scale_v = a.wscale[myrow];
       kvl = a.kv_len[0];
+      if constexpr (HO) kvl_epoch = a.epoch_ptr[0] + 1;
     }
     __builtin_amdgcn_sched_barrier(0);
     g1_block_layernorm<K, NT>(xv, gv, bv, sx, red);
@@ -823,7 +824,16 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
     if (lane == 0) ktrace_end(a.kt, kt0, (int)blockIdx.x * NW + w);
     if (!writer) return;
     const float v = G1W<T>::kScaled ? fmaf(mine, scale_v, bias_v) : mine + bias_v;
-    const int which = myrow / K, j = myrow - which * K;  // 1 = K, 2 = V  (valle/modules/activation.py:128-130)
+    const int which = myrow / K, j = myrow - which * K;  // 0 = Q (hand-off mode), 1 = K, 2 = V  (valle/modules/activation.py:128-130)
+    if constexpr (HO) {
+      if (which == 0) {  // publish: ONE aligned 8-byte write-through store per value, tag = this step's epoch
+        a.q_out[j] = v;
+        const unsigned epoch = (unsigned)kvl_epoch;
+        __hip_atomic_store(a.q_gran + j, ((unsigned long long)epoch << 32) | (unsigned long long)__float_as_uint(v), __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+        return;
+      }
+    }
     const int h = j / DH, e = j - h * DH;
     CT* dst = reinterpret_cast<CT*>(which == 1 ? a.k_cache : a.v_cache) + ((int64_t)h * a.ctx_max + kvl) * DH + e;
     store_elem<CT>(dst, v);
@@ -896,11 +906,13 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
     }
   };
 
-  // ---- the rest of the burst: the first pass of W_q rows, the first chunk of K / V, kv_len, the rows' bias / scale ---------
-  load_pass(0);
+  // ---- the rest of the burst: (no hand-off: the first pass of W_q rows,) the first chunk of K / V, kv_len, the rows' bias / scale
+  if constexpr (!HO) load_pass(0);
   int base = s * CHUNK;
   issue(base);
   const int ctx = a.kv_len[0];  // OLD keys only: slots [0, kv_len); slot kv_len is being written by the K / V workgroups
+  unsigned epoch = 0;
+  if constexpr (HO) epoch = (unsigned)(a.epoch_ptr[0] + 1);
   float qb[QP], qsc[QP];
 #pragma unroll
   for (int p = 0; p < QP; ++p) {
@@ -912,6 +924,43 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
   __builtin_amdgcn_sched_barrier(0);
 
   g1_block_layernorm<K, NT>(xv, gv, bv, sx, red);
+  bool have_q = false;
+  if constexpr (HO) {
+    // poll this head's dh granules (one or two per lane of wave 0; relaxed agent-scope loads bypass L1): ready when every tag
+    // carries this step's epoch.  ~1 us after the producing GEMV workgroups stored them; bounded -- a workgroup that gives up
+    // computes the rows itself below.
+    __shared__ int s_have_q;
+    if (w == 0) {
+      constexpr int GPL = (DH + 63) / 64;
+      const unsigned long long* gq = a.q_gran + h * DH;
+      bool ok = false;
+      unsigned long long gx[GPL];
+      for (unsigned spins = 0; spins < 40000u; ++spins) {
+#pragma unroll
+        for (int k = 0; k < GPL; ++k) gx[k] = __hip_atomic_load(gq + min(k * 64 + lane, DH - 1), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool mine_ok = true;
+#pragma unroll
+        for (int k = 0; k < GPL; ++k) mine_ok &= (unsigned)(gx[k] >> 32) == epoch;
+        if (__all(mine_ok)) {
+          ok = true;
+          break;
+        }
+      }
+      if (ok) {
+#pragma unroll
+        for (int k = 0; k < GPL; ++k)
+          if (k * 64 + lane < DH) sq[k * 64 + lane] = __uint_as_float((unsigned)gx[k]);
+      }
+      if (lane == 0) {
+        s_have_q = ok ? 1 : 0;
+        if (!ok && a.spin_fail) atomicAdd(a.spin_fail, 1u);
+      }
+    }
+    __syncthreads();
+    have_q = s_have_q != 0;
+    if (!have_q) load_pass(0);  // fall back: block-uniform
+  }
+  if (!have_q) {
   g1_read_shared<T, NCH>(sx, x);
 #pragma unroll
   for (int p = 0; p < QP; ++p) {
@@ -919,7 +968,9 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
 #pragma unroll
     for (int r = 0; r < QR; ++r) acc[r] = g1_dot<T, NCH>(wv[r], x);
     if (p + 1 < QP) load_pass(p + 1);  // the registers are free again
-    if constexpr (QR == 8 || QR == 16) {
+    // (hand-off mode: this is the give-up path; it reduces row by row like the GEMV workgroups whose result it replaces, so that
+    // a fallback cannot change a bit of q)
+    if constexpr (!HO && (QR == 8 || QR == 16)) {
       const float tot = g1_rows_reduce<QR>(acc, lane);  // every lane: the total of row g1_rows_owner(lane)
       const int r = g1_rows_owner<QR>(lane);
       // bias / scale were loaded per lane for row `lane`: fetch the owner row's through the LDS crossbar (one bpermute each)
@@ -942,6 +993,7 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
         if (s == 0) a.q_out[qrow0 + p * QR + lane] = qv1;
       }
     }
+  }
   }
   const unsigned long long ktm1 = ktrace_mark(a.kt);  // this wave's query rows are done
   __syncthreads();
@@ -1058,9 +1110,11 @@ static int qa_launch(hipStream_t st, const QkvAttnArgs& a) {
   constexpr int RPW = NCH <= 2 ? 4 : 2;
   QkvAttnArgs b = a;
   b.n_attn = a.nhead * a.nsplit;
-  const int kv_waves = (2 * a.d + RPW - 1) / RPW;
-  const dim3 grid(b.n_attn + (kv_waves + NW - 1) / NW), block(NW * 64);
-  hipLaunchKernelGGL((qkv_attn1_kernel<T, NCH, DH, RPW, NW>), grid, block, 0, st, b);
+  const bool ho = a.q_gran != nullptr && a.epoch_ptr != nullptr;
+  const int gemv_waves = ((ho ? 3 : 2) * a.d + RPW - 1) / RPW;  // hand-off: the query rows are GEMV rows of the launch too
+  const dim3 grid(b.n_attn + (gemv_waves + NW - 1) / NW), block(NW * 64);
+  if (ho) hipLaunchKernelGGL((qkv_attn1_kernel<T, NCH, DH, RPW, NW, true>), grid, block, 0, st, b);
+  else hipLaunchKernelGGL((qkv_attn1_kernel<T, NCH, DH, RPW, NW, false>), grid, block, 0, st, b);
   return 0;
 }
 

@@ -183,6 +183,13 @@ struct QkvAttnArgs {
   int n_attn = 0;                 // (filled by the launcher) workgroups with the attention role
   int temporal = 0;               // FP8W: default-policy weight loads
   int q_temporal = 1;             // the query rows (read by the nsplit workgroups of a head) with the default cache policy
+  // In-launch hand-off of q (round 3, option "qa_handoff"): the query rows are ordinary GEMV rows spread over all CUs (each written
+  // once, as an 8-byte {tag = epoch, value} granule: the guide's recipe R2, "the data is the flag"); the attention workgroups only
+  // stream their K / V chunks and poll their head's dh granules.  Bounded spin: on a timeout a workgroup recomputes its head's
+  // query rows itself (the hand-off-free path), so a result never depends on the hand-off succeeding.
+  unsigned long long* q_gran = nullptr;  // [d] granules of this layer (zeroed whenever *epoch_ptr restarts); null = no hand-off
+  const int32_t* epoch_ptr = nullptr;    // device word that grows by one per AR step (ArState::iter): epoch = *epoch_ptr + 1
+  unsigned* spin_fail = nullptr;         // optional: counts workgroups that fell back
   KTrace kt;
 };
 bool qkv_attn1_supports(int dtype, int d, int nhead, int dh);
@@ -201,6 +208,7 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
                            int max_len, int64_t rows, int d, int nhead, int causal);
 int attn2_reserve(int64_t rows, int B, int d, void** scratch_out = nullptr);  // pre-pass modes only (attn_mode <= 2)
 extern int g_g8_dbg;
+extern int g_g8_nt;
 extern int g_glds_epi;
 extern int g_attn_v2, g_attn_xcd, g_attn_q128, g_attn_mode, g_attn_defer, g_attn_ring;
 // copy K,V of packed prefill rows into the cache: cache[b][h][pos][e]

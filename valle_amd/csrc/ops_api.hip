@@ -44,6 +44,7 @@ extern "C" int vle_op_tune(const char* name, int64_t value) {
   else if (n == "attn_q128" && value >= -1 && value <= 1) vle::g_attn_q128 = (int)value;
   else if (n == "glds_epi" && value >= 0 && value <= 1) vle::g_glds_epi = (int)value;
   else if (n == "g8_dbg" && value >= 0 && value <= 7) vle::g_g8_dbg = (int)value;
+  else if (n == "g8_nt" && value >= 0 && value <= 3) vle::g_g8_nt = (int)value;
   else if (n == "attn_mode" && value >= 0 && value <= 3) vle::g_attn_mode = (int)value;
   else if (n == "attn_ring" && (value == 0 || value == 2 || value == 4)) vle::g_attn_ring = (int)value;
   else if (n == "qa_waves" && (value == 4 || value == 8)) vle::g_qa_waves = (int)value;

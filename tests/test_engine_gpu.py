@@ -497,3 +497,39 @@ def test_nar_force_is_one_shot_on_every_exit_path():
     del short
     codes = eng.nar()  # the rejected pointer was forgotten: an ordinary arg-max decode
     assert torch.equal(codes[0][:G].cpu(), want[0])
+
+
+def test_fused_qkv_attention_launch_and_its_q_handoff_agree_with_the_separate_launches():
+    """Batch-1 AR step, C2 architecture (d1024-L12-h16), bf16 and fp32: the fused LN1 + QKV + attention launch with the in-launch
+    hand-off of q (default), the same launch recomputing q per KV split (qa_handoff = 0), 4 / 8 / 16 splits, and the two separate
+    launches (qkv_attn = 0) produce the same teacher-forced logits up to fp32 summation order; no workgroup of the hand-off ever
+    had to give up (qa_spin_fail == 0); a second utterance after the first (epochs restart at the prefill) is still right."""
+    import ctypes as C
+
+    case = load_case("c2_d1024_L12_short")
+    z = case["z"]
+    S, P = int(z["S"]), int(z["P"])
+    forced = case["codes"][:, :, 0].contiguous()
+    G = forced.shape[1]
+    for dtype, tol in (("bf16", 2e-3), ("fp32", 2e-4)):
+        m = build_model(case["cfg"], case["sd"], dtype)
+        eng = m.engine_for(1, S, P)
+        eng.set_option("trace_ar_logits", 1)
+
+        def run(**opts):
+            for k, v in dict(qkv_attn=1, qa_handoff=1, qa_nsplit=8).items():
+                eng.set_option(k, v)
+            for k, v in opts.items():
+                eng.set_option(k, v)
+            eng.prefill(case["x"].to(DEV), [S], case["y"].to(DEV), [P])
+            eng.generate(top_k=1, forced=forced.to(DEV), forced_lens=[G])
+            return eng.fetch_ar_logits()[:, 0].clone()
+
+        base = run()
+        sigma = base.std().item()
+        assert torch.equal(run(), base)  # a second utterance on the same engine: the granules' epochs restart
+        for opts in (dict(qa_handoff=0), dict(qa_nsplit=4), dict(qa_nsplit=16), dict(qa_handoff=0, qa_nsplit=4), dict(qkv_attn=0)):
+            other = run(**opts)
+            assert (other - base).abs().max().item() <= tol * sigma, (dtype, opts, (other - base).abs().max().item(), sigma)
+        fails = C.c_uint(0)
+        assert eng.lib.vle_debug_fetch(eng.h, b"qa_spin_fail", C.byref(fails), 4) == 4 and fails.value == 0

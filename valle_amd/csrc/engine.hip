@@ -2265,6 +2265,10 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
     if (!e->ktrace_buf) return e->fail(VLE_ESTATE, "ktrace was not enabled");
     src = e->ktrace_buf;
     n = (size_t)KT_STEPS * KT_KERNELS * KT_WAVES * 4 * sizeof(unsigned long long);
+  } else if (w == "qa_spin_fail") {  // workgroups of the fused launch that gave up waiting for q and recomputed it (expected: 0)
+    if (!e->qa_spin_fail) return e->fail(VLE_ESTATE, "no hand-off counter");
+    src = e->qa_spin_fail;
+    n = sizeof(unsigned);
   } else if (w == "last_logits") {
     src = e->logits;
     n = (size_t)e->B * V_AR * sizeof(float);

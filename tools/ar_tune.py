@@ -50,6 +50,7 @@ def main():
             eng.set_option("qa_waves", 4)
             eng.set_option("qa_qtemporal", 1)
             eng.set_option("qa_handoff", 1)
+            eng.set_option("qa_nk", 4)
             for k, v in opts.items():
                 eng.set_option(k, v)
             for rep in range(2):  # first pass (re)captures the graph

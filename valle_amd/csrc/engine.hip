@@ -167,6 +167,7 @@ struct vle_engine {
   int opt_qa_nsplit = 8;      // option "qa_nsplit": KV splits per head of that launch (4, 8, 16).  With the q hand-off (no redundant query rows) 8
                               // splits cover 1024 keys in one round: 212.4 us per step over the whole 753-step run against 215.3 with 4 (which wins
                               // below context 512: 208.1 vs 212.3); without the hand-off: 215.9 / 218.8 / 263 us for 4 / 8 / 16
+  int opt_qa_nk = 4;          // option "qa_nk": keys per lane per round of the fused launch's attention workgroups (4 / 8)
   int opt_qa_handoff = 1;     // option "qa_handoff": q reaches the attention workgroups through granules instead of being recomputed per split
   int opt_qa_qtemporal = 1;   // option "qa_qtemporal": its query-row loads with the default cache policy (shared by a head's splits through L2)
   int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
@@ -1164,6 +1165,7 @@ int enqueue_ar_step(vle_engine* e) {
         q.q_temporal = e->opt_qa_qtemporal;
         if (e->opt_qa_handoff && e->qgran != nullptr) {
           q.q_gran = e->qgran + (size_t)l * d; q.epoch_ptr = e->S.iter; q.spin_fail = e->qa_spin_fail;
+          q.nk = e->opt_qa_nk == 8 ? 8 : 4;
         }
         q.kt = e->next_kt();
         const int fr = launch_qkv_attn1(st, qdt, q);
@@ -2123,9 +2125,9 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
-  if (n == "qkv_attn" || n == "qa_nsplit" || n == "qa_qtemporal" || n == "qa_handoff") {  // changes the captured graphs: drop them
+  if (n == "qkv_attn" || n == "qa_nsplit" || n == "qa_qtemporal" || n == "qa_handoff" || n == "qa_nk") {  // changes the captured graphs: drop them
     if (n == "qa_nsplit" && !(value == 4 || value == 8 || value == 16)) return e->fail(VLE_EINVAL, "qa_nsplit must be 4, 8 or 16");
-    (n == "qkv_attn" ? e->opt_qkv_attn : n == "qa_nsplit" ? e->opt_qa_nsplit : n == "qa_handoff" ? e->opt_qa_handoff : e->opt_qa_qtemporal) = (int)value;
+    (n == "qkv_attn" ? e->opt_qkv_attn : n == "qa_nsplit" ? e->opt_qa_nsplit : n == "qa_handoff" ? e->opt_qa_handoff : n == "qa_nk" ? e->opt_qa_nk : e->opt_qa_qtemporal) = (int)value;
     (void)hipStreamSynchronize(e->st);
     for (auto& kv : e->graphs) {
       if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);

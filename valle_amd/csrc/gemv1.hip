@@ -764,7 +764,7 @@ int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a) {
 //     for free (gemv1_kernel PRO_ATTN_SELF: one more partial with l = 1).
 // No workgroup waits for another: a kernel boundary less per layer (62 -> 50 launches per step at L = 12) and one HBM round
 // trip instead of two on the critical path.
-template <typename T, int NCH, int DH, int RPW, int NW, bool HO>
+template <typename T, int NCH, int DH, int RPW, int NW, bool HO, int NK = 4>
 __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
   constexpr int NT = NW * 64;  // 4 or 8 waves per workgroup
   constexpr int VEC = Elem<T>::VEC;
@@ -863,8 +863,7 @@ __global__ __launch_bounds__(NW * 64) void qkv_attn1_kernel(QkvAttnArgs a) {
   static_assert(QRT % QR == 0 && QR >= 1 && QR <= 64, "query-row passes");
   constexpr int LPK = DH / CVEC;   // lanes per key
   constexpr int KPW = 64 / LPK;    // keys per wave-load
-  constexpr int NK = 4;
-  constexpr int WCH = NK * KPW;    // keys per wave per round
+  constexpr int WCH = NK * KPW;    // keys per wave per round (NK = 4, or 8 with the q hand-off: no weight registers to share the file with)
   constexpr int CHUNK = NW * WCH;   // keys per workgroup per round
   static_assert(DH % CVEC == 0 && (LPK & (LPK - 1)) == 0 && LPK <= 32, "head size");
   __shared__ float sq[DH];
@@ -1113,7 +1112,8 @@ static int qa_launch(hipStream_t st, const QkvAttnArgs& a) {
   const bool ho = a.q_gran != nullptr && a.epoch_ptr != nullptr;
   const int gemv_waves = ((ho ? 3 : 2) * a.d + RPW - 1) / RPW;  // hand-off: the query rows are GEMV rows of the launch too
   const dim3 grid(b.n_attn + (gemv_waves + NW - 1) / NW), block(NW * 64);
-  if (ho) hipLaunchKernelGGL((qkv_attn1_kernel<T, NCH, DH, RPW, NW, true>), grid, block, 0, st, b);
+  if (ho && a.nk == 8) hipLaunchKernelGGL((qkv_attn1_kernel<T, NCH, DH, RPW, NW, true, 8>), grid, block, 0, st, b);
+  else if (ho) hipLaunchKernelGGL((qkv_attn1_kernel<T, NCH, DH, RPW, NW, true>), grid, block, 0, st, b);
   else hipLaunchKernelGGL((qkv_attn1_kernel<T, NCH, DH, RPW, NW, false>), grid, block, 0, st, b);
   return 0;
 }

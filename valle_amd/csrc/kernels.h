@@ -182,6 +182,7 @@ struct QkvAttnArgs {
   int d = 0, nhead = 0, dh = 0, ctx_max = 0, nsplit = 8;
   int n_attn = 0;                 // (filled by the launcher) workgroups with the attention role
   int temporal = 0;               // FP8W: default-policy weight loads
+  int nk = 4;                     // keys per lane per round of the attention workgroups (8: hand-off mode only)
   int q_temporal = 1;             // the query rows (read by the nsplit workgroups of a head) with the default cache policy
   // In-launch hand-off of q (round 3, option "qa_handoff"): the query rows are ordinary GEMV rows spread over all CUs (each written
   // once, as an 8-byte {tag = epoch, value} granule: the guide's recipe R2, "the data is the flag"); the attention workgroups only

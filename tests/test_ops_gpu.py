@@ -155,8 +155,11 @@ def test_attention_mfma_long(nhead, dh, lens, text_lens, causal, v2, qw, mode, q
     try:
         for ring in ((2, 4) if (v2 == 2 and mode == 2) else (0,)):  # (mode 3 = mode 2 with V read through ds_read_b64_tr_b16)  # LDS ring depth of the LDS-DMA staging (0 = by launch size)
             ops.tune("attn_ring", ring)
-            _attention_mfma_long(nhead, dh, lens, text_lens, causal)
+            for lsum in ((1, 0) if mode == 3 else (1,)):  # mode 3: softmax row sums on the MFMA pipe (default) / VALU adds
+                ops.tune("attn_lsum", lsum)
+                _attention_mfma_long(nhead, dh, lens, text_lens, causal)
     finally:
+        ops.tune("attn_lsum", 1)
         ops.tune("attn_ring", 0)
         ops.tune("attn_qw", 0)
         ops.tune("attn_v2", 1)

@@ -38,6 +38,17 @@ def main():
         ms, tf = bench(64, 1025, 16, 64, False, reps=3)
         print(f"C3 NAR default policy: {ms:7.3f} ms {tf:6.1f} TF")
         return
+    if "--lsum" in sys.argv:  # round 3: softmax row sums on the MFMA pipe (attn_lsum = 1, default) vs VALU adds
+        for name, B, N, H, dh, causal in [("C2 NAR", 1, 1025, 16, 64, False), ("C3 NAR", 64, 1025, 16, 64, False), ("C3 prefill", 64, 272, 16, 64, True),
+                                          ("C5 share NAR", 32, 1025, 16, 96, False)]:
+            row = []
+            for v in (1, 0, 1, 0):
+                ops.tune("attn_lsum", v)
+                ms, tf = bench(B, N, H, dh, causal)
+                row.append(f"lsum={v}: {ms:7.3f} ms {tf:6.1f} TF")
+            ops.tune("attn_lsum", 1)
+            print(f"{name:14s} " + " | ".join(row), flush=True)
+        return
     for name, B, N, H, dh, causal in [("C2 NAR", 1, 1025, 16, 64, False), ("C3 NAR", 64, 1025, 16, 64, False), ("C3 prefill", 64, 272, 16, 64, True),
                                       ("C5 share NAR", 32, 1025, 16, 96, False)]:
         row = []

@@ -97,7 +97,7 @@ __device__ inline void a2_wait_vm() {
 //         NS = ring depth: 2 (one tile in flight under the current one's math).  4 (three tiles ahead, counted vmcnt) is a
 //         measured dead end kept as knob "attn_ring": one 1025-row sequence (272 blocks, nobody else to hide the DMA latency)
 //         runs 17.1 us per launch either way, the batched passes lose occupancy (C3 NAR shape 451 -> 338 TF/s).
-template <int DH, int QW, int MODE, int NS = 2>
+template <int DH, int QW, int MODE, int NS = 2, bool LSUM = false>
 __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ qkv, const bf16_t* __restrict__ vt, bf16_t* __restrict__ out,
                                                     const int32_t* __restrict__ seq_off, const int32_t* __restrict__ text_len, int d,
                                                     int nhead, int causal, int64_t rp, int xcd_remap, float defer_exp2) {
@@ -223,11 +223,17 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
   const float sl2 = 1.4426950408889634f / sqrtf((float)DH);  // log2(e) / sqrt(dh)
   const float defer = defer_exp2 / sl2;                       // threshold on raw scores
   float m[QW], l[QW];  // m: running max of the RAW scores of the row (shared by its 4 lanes); l: this lane's part of the row sum
+  // LSUM (round 3): the row sums ride on the MFMA pipe -- O^T += V^T P^T with one more "row block" of V^T that is all ones gives
+  // sum_k P[k][q] in every row of ol[f]: 2 MFMAs per fragment and tile instead of 16 VALU adds (the kernel is bound by the VALU
+  // issue port, 5.9 VALU instructions per MFMA, with the MFMA pipe 37 % busy).  The sum is then over the bf16-rounded P the
+  // numerator uses too (numerator and denominator carry the same rounding).
+  a2_f32x4 ol[QW];
   a2_f32x4 o[QW][EB];
 #pragma unroll
   for (int f = 0; f < QW; ++f) {
     m[f] = A2_NEG;
     l[f] = 0.f;
+    ol[f] = a2_f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
     for (int eb = 0; eb < EB; ++eb) o[f][eb] = a2_f32x4{0.f, 0.f, 0.f, 0.f};
   }
@@ -305,7 +311,8 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
         const float mn = fmaxf(m[f], mt);
         const float alpha = __builtin_amdgcn_exp2f((m[f] - mn) * sl2);  // 1 exactly for the rows whose maximum did not grow
         m[f] = mn;
-        l[f] *= alpha;
+        if constexpr (LSUM) ol[f] *= alpha;
+        else l[f] *= alpha;
 #pragma unroll
         for (int eb = 0; eb < EB; ++eb) o[f][eb] *= alpha;
       }
@@ -319,16 +326,26 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
         s[f][kb][1] = __builtin_amdgcn_exp2f(t0[1]);
         s[f][kb][2] = __builtin_amdgcn_exp2f(t1[0]);
         s[f][kb][3] = __builtin_amdgcn_exp2f(t1[1]);
-        ps[kb] = (s[f][kb][0] + s[f][kb][1]) + (s[f][kb][2] + s[f][kb][3]);
+        if constexpr (!LSUM) ps[kb] = (s[f][kb][0] + s[f][kb][1]) + (s[f][kb][2] + s[f][kb][3]);
       }
-      const float rowsum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
-      l[f] += rowsum;
+      if constexpr (!LSUM) {
+        const float rowsum = (ps[0] + ps[1]) + (ps[2] + ps[3]);
+        l[f] += rowsum;
+      }
 #pragma unroll
       for (int j = 0; j < 2; ++j)
 #pragma unroll
         for (int tt = 0; tt < 8; ++tt) pf[f][j][tt] = (__bf16)s[f][2 * j + (tt >> 2)][tt & 3];
     }
     // ---- O^T += V^T P^T -----------------------------------------------------------------------------------
+    if constexpr (LSUM) {
+      typedef short a2_s16x8l __attribute__((ext_vector_type(8)));
+      const a2_bf16x8 ones = __builtin_bit_cast(a2_bf16x8, a2_s16x8l{0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80, 0x3F80});
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+#pragma unroll
+        for (int f = 0; f < QW; ++f) ol[f] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(ones, pf[f][j], ol[f], 0, 0, 0);
+    }
 #pragma unroll
     for (int eb = 0; eb < EB; ++eb)
 #pragma unroll
@@ -367,7 +384,8 @@ __global__ __launch_bounds__(256) void attn2_kernel(const bf16_t* __restrict__ q
 #pragma unroll
   for (int f = 0; f < QW; ++f) {
     float lf = l[f];
-    lf = rows4_sum(lf);
+    if constexpr (LSUM) lf = ol[f][0];  // every row of ol holds the whole row sum of query c already
+    else lf = rows4_sum(lf);
     if (qvalid[f]) {
       const float inv = 1.0f / lf;
       bf16_t* op = out + (int64_t)(off + qrow[f]) * d + h * DH + g * 4;
@@ -423,6 +441,7 @@ int g_attn_xcd = 1;   // "attn_xcd": XCD-aware block order (A/B)
 int g_attn_mode = 3;  // "attn_mode": tile staging of attn2_kernel -- 0 registers + 16-byte row padding (round 2's first layout), 1 registers +
                       // 32-byte padding (conflict-free), 2 LDS-DMA + XOR swizzle where the head size allows (64 / 128), else 1;
                       // 3 = 2 with V staged row-major and read by ds_read_b64_tr_b16 (no V^T pre-pass)
+int g_attn_lsum = 1;  // "attn_lsum": row sums of the softmax on the MFMA pipe (an all-ones row block of V^T) instead of VALU adds (mode 3)
 int g_attn_ring = 0;  // "attn_ring": LDS ring depth of the LDS-DMA staging: 0 / 2 = two buffers, 4 = four (A/B knob, see attn2_kernel)
 int g_attn_defer = 8; // "attn_defer": deferred-maximum threshold of attn2_kernel in exp2-domain units (0 = exact running maximum)
 int g_attn_q128 = -1; // "attn_q128": 128-query blocks (each K / V^T fragment read from LDS feeds two MFMAs): 0 never, 1 always, -1 (default) =
@@ -459,7 +478,10 @@ int launch_attention_mfma2(hipStream_t st, const void* qkv, void* out, const int
                      text_len, d, nhead, causal, rp8, g_attn_xcd, (float)g_attn_defer)
 #define VLE_A2K(DH, QW)                                  \
   do {                                                   \
-    if (mode == 3) {                                     \
+    if (mode == 3 && g_attn_lsum) {                      \
+      hipLaunchKernelGGL((attn2_kernel<DH, QW, 3, 2, true>), grid, block, 0, st, (const bf16_t*)qkv, (const bf16_t*)vt, (bf16_t*)out, seq_off, \
+                         text_len, d, nhead, causal, rp8, g_attn_xcd, (float)g_attn_defer);                                                   \
+    } else if (mode == 3) {                              \
       VLE_A2M(DH, QW, 3, 2);                             \
     } else if (mode == 2) {                              \
       if constexpr (DH == 64 || (DH == 128 && QW == 1)) { \

@@ -591,18 +591,40 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs 
 // so long K keeps the split-K kernel; AR loop of C3 600 -> 577 ms with 1, 642 with 2, 648 with 3.
 int g_gs_msplit = 1;
 
+// "gs_ms_pad": dynamic LDS bytes requested (never touched) by the 1024-thread M-split workgroups: > 80 KB leaves room for ONE such
+// workgroup per CU, so that the 256 of them cannot be packed two to a CU while other CUs stay empty
+int g_gs_ms_pad = 0;
+
+template <int NW, int EPI, bool W8>
+static int gs_ms_launch_one(hipStream_t st, const GemmSkinnyArgs& a, dim3 grid, dim3 block) {
+  unsigned pad = (NW == 16 && g_gs_ms_pad > 0) ? (unsigned)g_gs_ms_pad : 0u;
+  if (pad > 0) {
+    static bool attr_set = false;
+    if (!attr_set) {
+      if (hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_skinny_ms_kernel<NW, EPI, W8>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              140 * 1024) != hipSuccess) {
+        (void)hipGetLastError();
+        pad = 0;
+      } else {
+        attr_set = true;
+      }
+    }
+  }
+  hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, EPI, W8>), grid, block, pad, st, a);
+  return 0;
+}
+
 template <int NW, bool W8>
 static int gs_ms_launch_w(hipStream_t st, const GemmSkinnyArgs& a) {
   const dim3 grid((a.N + 15) / 16, (a.M + 15) / 16), block(NW * 64);
   switch (a.epi) {
-    case GS_EPI_STORE: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_STORE, W8>), grid, block, 0, st, a); break;
-    case GS_EPI_RELU: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_RELU, W8>), grid, block, 0, st, a); break;
-    case GS_EPI_RESID: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_RESID, W8>), grid, block, 0, st, a); break;
-    case GS_EPI_F32: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_F32, W8>), grid, block, 0, st, a); break;
-    case GS_EPI_QKV: hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, GS_EPI_QKV, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_STORE: return gs_ms_launch_one<NW, GS_EPI_STORE, W8>(st, a, grid, block);
+    case GS_EPI_RELU: return gs_ms_launch_one<NW, GS_EPI_RELU, W8>(st, a, grid, block);
+    case GS_EPI_RESID: return gs_ms_launch_one<NW, GS_EPI_RESID, W8>(st, a, grid, block);
+    case GS_EPI_F32: return gs_ms_launch_one<NW, GS_EPI_F32, W8>(st, a, grid, block);
+    case GS_EPI_QKV: return gs_ms_launch_one<NW, GS_EPI_QKV, W8>(st, a, grid, block);
     default: return -1;
   }
-  return 0;
 }
 
 // M-split when it fills the chip better than N / 16 row fragments alone: returns the waves per workgroup (4 / 8 / 16) or 0

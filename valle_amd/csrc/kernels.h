@@ -117,6 +117,7 @@ constexpr int GS_WS_MAX_TILES = 2048;  // partial 16 x 64 fp32 tiles (4 KB each)
 extern int g_da_nt;       // decode_attn.hip: non-temporal K / V loads (-1 auto, 0, 1)
 extern int g_da_lds_pad;  // decode_attn.hip: dynamic LDS bytes per workgroup of the batched decode attention (occupancy cap)
 extern int g_gs_formal;
+extern int g_gs_ms_pad;
 extern int g_gs_msplit;  // gemm_skinny.hip: M-split kernel for N / 16 < #CUs (default 1)
 size_t gemm_skinny_workspace_bytes();
 int gemm_skinny_ksplit(int N, int K, int target_wgs);
@@ -211,7 +212,7 @@ int attn2_reserve(int64_t rows, int B, int d, void** scratch_out = nullptr);  //
 extern int g_g8_dbg;
 extern int g_g8_nt;
 extern int g_glds_epi;
-extern int g_attn_v2, g_attn_xcd, g_attn_q128, g_attn_mode, g_attn_defer, g_attn_ring;
+extern int g_attn_v2, g_attn_xcd, g_attn_q128, g_attn_mode, g_attn_defer, g_attn_ring, g_attn_lsum;
 // copy K,V of packed prefill rows into the cache: cache[b][h][pos][e]
 int launch_kv_scatter(hipStream_t st, int dtype, const void* qkv, void* k_cache, void* v_cache, const int32_t* row_seq,
                       const int32_t* row_pos, int64_t rows, int d, int nhead, int ctx_max);

@@ -106,3 +106,21 @@ def test_sampled_decode_is_per_request_reproducible_across_batch_sizes():
     got = ContinuousBatcher(mm, 2, max_text=8, max_prompt=18).decode(same, top_k=50, temperature=1.5, seed=7)
     firsts = [g[:, 0].cpu() for g in got]
     assert any(f.shape != firsts[0].shape or not torch.equal(f, firsts[0]) for f in firsts[1:])
+
+
+def test_single_slot_serving_on_the_fused_batch1_step():
+    """One slot (max_batch = 1) at a width the fused batch-1 launches cover (d256-h4: head size 64): requests run one after the other
+    through the slot API on the SAME engine -- the AR iteration counter, and with it the epochs of the fused launch's q granules,
+    restarts at every admission (vle_slots_prefill clears the granules) -- and every request equals its oracle decode."""
+    cfg = vo.OracleConfig(d_model=256, nhead=4, num_layers=2, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 9)
+    ins = _requests(5, 3)
+    want = [vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True)[0] for x, xl, y in ins]
+    m = build_model(cfg, sd, "fp32", max_batch=1)
+    cb = ContinuousBatcher(m, 1, max_text=8, max_prompt=18, steps_per_round=8)
+    got = cb.decode([Request(x[0], y[0]) for x, _, y in ins], top_k=1)
+    for i, (g, w) in enumerate(zip(got, want)):
+        assert torch.equal(g.cpu(), w), f"request {i} differs"
+    # and the dense API afterwards (vle_ar_prefill clears them too)
+    for (x, xl, y), w in zip(ins[:2], want[:2]):
+        assert torch.equal(m.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1).cpu()[0], w)

@@ -31,7 +31,18 @@ CASES = {
     "fwd_vallf_postnorm_prenet_pm0": dict(cfg=dict(d_model=64, nhead=2, num_layers=1, prefix_mode=0, norm_first=False, add_prenet=True, model="vallf"),
                                           N=1, S=5, T=15, train_stage=0, seed=19),
     "fwd_pm0_bos": dict(cfg=dict(d_model=64, nhead=4, num_layers=1, prefix_mode=0, prepend_bos=True), N=1, S=5, T=13, train_stage=0, seed=13),
+    # prefix_mode 2 (a random stretch of the utterance itself is the prompt, blanked in the target codebook) and 4 (PromptedFeatures)
+    "fwd_pm2_n2": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=2), N=2, S=6, T=28, train_stage=0, seed=23),
+    "fwd_pm2_nar_only_n3": dict(cfg=dict(d_model=128, nhead=2, num_layers=1, prefix_mode=2), N=3, S=5, T=41, train_stage=2, seed=29),
+    "fwd_pm4_n2": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=4), N=2, S=7, T=22, train_stage=0, seed=31, P4=9),
+    "fwd_vallf_pm2_n1": dict(cfg=dict(d_model=64, nhead=4, num_layers=1, prefix_mode=2, model="vallf"), N=1, S=6, T=24, train_stage=0, seed=37),
 }
+
+
+def make_prompts(N, P, seed):
+    """prefix_mode 4: the prompts half of the PromptedFeatures, (N, P, 8) codes, seeded like the batch."""
+    g = torch.Generator().manual_seed(seed * 1000 + 7)
+    return torch.randint(0, 1024, (N, P, 8), generator=g, dtype=torch.int64)
 
 
 def make_batch(N, S, T, seed):
@@ -58,23 +69,36 @@ def main():
         orig = model._prepare_prompts
 
         def spy(y_, y_lens_, codes_, nar_stage, y_prompts_codes):
+            state = model.rng.getstate()  # prefix_mode 2 draws one segment start per utterance from self.rng (:368-369): replay them
             emb, plen = orig(y_, y_lens_, codes_, nar_stage, y_prompts_codes)
             drawn.update(nar_stage=int(nar_stage), prefix_len=int(plen))
+            if cfg.prefix_mode == 2:
+                r = random.Random()
+                r.setstate(state)
+                drawn["starts"] = [r.randint(0, int(y_lens_[b]) - int(plen)) for b in range(codes_.shape[0])]
             return emb, plen
 
         model._prepare_prompts = spy
         orig_fwd = torch.nn.TransformerDecoder.forward
         if cfg.model == "vallf":
             torch.nn.TransformerDecoder.forward = dec_forward_113
+        y_in, yl_in = y, yl
+        if cfg.prefix_mode == 4:  # y / y_lens arrive as PromptedFeatures (valle/data/input_strategies.py:16-35; valle.py:792-798)
+            from valle.data.input_strategies import PromptedFeatures
+
+            pr = make_prompts(spec["N"], spec["P4"], spec["seed"])
+            y_in = PromptedFeatures(pr, y)
+            yl_in = PromptedFeatures(torch.full((spec["N"],), spec["P4"], dtype=torch.int32), yl)
         try:
             with torch.no_grad():
-                _, loss, metrics = model(x, xl, y, yl, reduction="sum", train_stage=spec["train_stage"])
+                _, loss, metrics = model(x, xl, y_in, yl_in, reduction="sum", train_stage=spec["train_stage"])
         finally:
             torch.nn.TransformerDecoder.forward = orig_fwd
         out = dict(loss=np.float64(float(loss)), N=np.int32(spec["N"]), S=np.int32(spec["S"]), T=np.int32(spec["T"]),
                    seed=np.int32(spec["seed"]), train_stage=np.int32(spec["train_stage"]),
                    nar_stage=np.int32(drawn.get("nar_stage", -1)), prefix_len=np.int32(drawn.get("prefix_len", -1)),
                    ar_top10=np.float64(metrics.get("ArTop10Accuracy", -1.0)), nar_top10=np.float64(metrics.get("NarTop10Accuracy", -1.0)),
+                   starts=np.asarray(drawn.get("starts", []), dtype=np.int32), P4=np.int32(spec.get("P4", 0)),
                    torch_version=np.bytes_(torch.__version__))
         for k, v in spec["cfg"].items():
             out[f"cfg_{k}"] = np.asarray(v)

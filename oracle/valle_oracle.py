@@ -707,15 +707,16 @@ def _topk_counts(logits: torch.Tensor, targets: torch.Tensor, k: int = 10, ignor
 
 @torch.no_grad()
 def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum", train_stage: int = 0,
-            nar_stage: Optional[int] = None, prefix_len: Optional[int] = None, trace=None):
-    """VALLE.forward (valle.py:762-959) for UNPADDED batches (every x_lens == x.shape[1], every y_lens == y.shape[1]) and
-    prefix_mode 0 / 1, dropout off (eval).  The two random draws of the reference -- ``nar_stage`` (self.rng.choices,
-    :891-895) and, for prefix_mode 1, ``prefix_len`` (torch.randint, :348-350) -- are explicit arguments.
-    Returns (total_loss, metrics) like the last two elements of the reference's tuple."""
+            nar_stage: Optional[int] = None, prefix_len: Optional[int] = None, trace=None, prompt_starts=None, y_prompts=None):
+    """VALLE.forward (valle.py:762-959) for UNPADDED batches (every x_lens == x.shape[1], every y_lens == y.shape[1]), every
+    prefix_mode, dropout off (eval).  The random draws of the reference are explicit arguments: ``nar_stage`` (self.rng.choices,
+    :891-895); prefix_mode 1's ``prefix_len`` (torch.randint, :348-350); prefix_mode 2's per-utterance segment starts
+    ``prompt_starts`` (self.rng.randint, :368-369).  prefix_mode 4's prompts (the PromptedFeatures' first half, :792-798) are
+    ``y_prompts`` (N, P, Q).  Returns (total_loss, metrics) like the last two elements of the reference's tuple."""
     cfg.check_supported()
     assert x.ndim == 2 and x_lens.ndim == 1 and y.ndim == 3 and y_lens.ndim == 1  # :789-790, 801-802
     assert reduction == "sum"
-    assert cfg.prefix_mode in (0, 1)
+    assert cfg.prefix_mode in (0, 1, 2, 4)
     N, S = x.shape
     T = y.shape[1]
     assert all(int(v) == S for v in x_lens) and all(int(v) == T for v in y_lens), "unpadded batches only"
@@ -757,9 +758,51 @@ def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum",
         if cfg.prefix_mode == 1:
             assert prefix_len is not None
             P = int(prefix_len)
+        elif cfg.prefix_mode == 2:
+            P = min(225, int(0.25 * T))  # :364
+            assert prompt_starts is not None and len(prompt_starts) == N
+        elif cfg.prefix_mode == 4:
+            assert y_prompts is not None and y_prompts.shape[0] == N
+            P = int(y_prompts.shape[1])  # :377
         nar_loss = torch.zeros(())
         hits, kept = torch.zeros(()), torch.zeros(())
         for b in range(N):
+            if cfg.prefix_mode in (2, 4):
+                # _prepare_prompts :362-389: the prompt is a separate segment IN FRONT of the whole utterance; prefix_mode 2 cuts
+                # it out of the utterance itself and blanks that stretch of the TARGET codebook (ignore_index), :370-373
+                cb = codes[b].clone()
+                if cfg.prefix_mode == 2:
+                    st = int(prompt_starts[b])
+                    assert 0 <= st <= T - P
+                    pr = cb[st: st + P].clone()
+                    cb[st: st + P, nar_stage] = NUM_AUDIO_TOKENS
+                else:
+                    pr = y_prompts[b].to(torch.int64)
+                xe = token_embedding(sd, "nar_text_embedding", x[b])
+                if cfg.add_prenet:
+                    xe = text_prenet(sd, "nar_text_prenet", xe)
+                xe = sine_position(xe, sd["nar_text_position.alpha"])
+                y_pr = token_embedding(sd, "nar_audio_embeddings.0", pr[:, 0]).clone()
+                y_emb = token_embedding(sd, "nar_audio_embeddings.0", cb[:, 0]).clone()
+                for j in range(1, cfg.num_quantizers):
+                    y_pr += token_embedding(sd, f"nar_audio_embeddings.{j}", pr[:, j])
+                    if j < nar_stage:
+                        y_emb += token_embedding(sd, f"nar_audio_embeddings.{j}", cb[:, j])
+                y_emb = torch.cat([y_pr, y_emb], 0)  # :389
+                targets = cb[:, nar_stage]           # :906 (the whole utterance; the blanked stretch is ignored by the loss)
+                ye = sine_position(audio_prenet(sd, "nar_audio_prenet", y_emb) if cfg.add_prenet else y_emb, sd["nar_audio_position.alpha"])
+                stage = sd[f"nar_stage_embeddings.{nar_stage - 1}.word_embeddings.weight"]
+                if cfg.model == "vallf":
+                    dec = decoder(sd, "nar_decoder", cfg, ye, xe, tgt_mask=None, stage_emb=stage)[P:]  # :531-533
+                else:
+                    dec = encoder(sd, "nar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=None, stage_emb=stage)[S + P:]  # :927
+                logits = F.linear(dec, sd[f"nar_predict_layers.{nar_stage - 1}.weight"])
+                if trace is not None:
+                    trace.setdefault("nar_logits", []).append(logits.clone())
+                nar_loss = nar_loss + F.cross_entropy(logits, targets, ignore_index=NUM_AUDIO_TOKENS, reduction="sum")
+                h, kp = _topk_counts(logits, targets)
+                hits, kept = hits + h, kept + kp
+                continue
             y0 = codes[b, :, 0]
             xe = token_embedding(sd, "nar_text_embedding", x[b])
             if cfg.add_prenet:
@@ -788,6 +831,8 @@ def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum",
             h, kp = _topk_counts(logits, targets)  # the reference pads a 1025th class with the global minimum: never in the top 10
             hits, kept = hits + h, kept + kp
         total_length = float(N * T)
+        if cfg.prefix_mode == 4:
+            P = 0  # :929-930 "reset for Top10Accuracy metric" -- which also resets the loss's length correction
         total = total + nar_loss * (total_length / (total_length - P * N))  # :943
         metrics["NarTop10Accuracy"] = float(hits / kept.clamp_min(1)) * total_length  # :945-956
     if train_stage == 0:

@@ -7,7 +7,7 @@ import pytest
 import torch
 
 from oracle import valle_oracle as vo
-from oracle.make_golden_forward import CASES, make_batch
+from oracle.make_golden_forward import CASES, make_batch, make_prompts
 from tests.golden_util import GOLDEN_DIR
 
 
@@ -18,6 +18,10 @@ def load_forward_case(name):
     kw = dict(train_stage=int(z["train_stage"]))
     if int(z["nar_stage"]) >= 1:
         kw.update(nar_stage=int(z["nar_stage"]), prefix_len=int(z["prefix_len"]))
+        if cfg.prefix_mode == 2:
+            kw.update(prompt_starts=[int(v) for v in z["starts"]])
+        if cfg.prefix_mode == 4:
+            kw.update(y_prompts=make_prompts(int(z["N"]), int(z["P4"]), int(z["seed"])))
     return z, cfg, vo.make_state_dict(cfg, 0), x, xl, y, yl, kw
 
 

@@ -22,10 +22,23 @@ def test_forward_loss_matches_reference(name, dtype, rtol):
             prepend_bos=cfg.prepend_bos, engine_dtype=dtype)
     m.load_state_dict(sd, strict=True)
     m = m.to(DEV).eval()
-    (_, codes), loss, metrics = m(x.to(DEV), xl.to(DEV), y.to(DEV), yl.to(DEV), reduction="sum", **kw)
+    mkw = {k: v for k, v in kw.items() if k != "y_prompts"}  # the oracle's argument names, except prefix_mode 4's prompts:
+    y_in, yl_in = y.to(DEV), yl.to(DEV)
+    if cfg.prefix_mode == 4:                                  # they arrive as PromptedFeatures, like in the reference (valle.py:792-798)
+        pr = kw["y_prompts"]
+        y_in = valle_amd.PromptedFeatures(pr.to(DEV), y.to(DEV))
+        yl_in = valle_amd.PromptedFeatures(torch.full((x.shape[0],), pr.shape[1], dtype=torch.int32), yl.to(DEV))
+    (_, codes), loss, metrics = m(x.to(DEV), xl.to(DEV), y_in, yl_in, reduction="sum", **mkw)
     want = float(z["loss"])
     assert abs(float(loss) - want) <= rtol * abs(want), (float(loss), want)
-    assert torch.equal(codes.cpu(), y)
+    if cfg.prefix_mode == 2 and "prompt_starts" in kw:        # the returned codes carry the blanked stretch of the target codebook (:370-373)
+        blank = y.clone()
+        P = min(225, int(0.25 * y.shape[1]))
+        for n, st in enumerate(kw["prompt_starts"]):
+            blank[n, st: st + P, kw["nar_stage"]] = 1024
+        assert torch.equal(codes.cpu(), blank)
+    else:
+        assert torch.equal(codes.cpu(), y)
     _, ometrics = vo.forward(sd, cfg, x, xl, y, yl, **kw)
     for k, v in ometrics.items():
         tol = 1e-4 if dtype == "fp32" else 0.05 * float(x.shape[0] * y.shape[1])
@@ -52,3 +65,28 @@ def test_forward_default_draws_follow_the_reference_rng():
     assert abs(float(loss) - float(want)) <= 2e-5 * abs(float(want))
     with pytest.raises(NotImplementedError):
         m(x.to(DEV), torch.tensor([4], dtype=torch.int32), y.to(DEV), yl)  # padded text: not an unpadded batch
+
+
+def test_forward_prefix_mode_2_draws_its_segment_starts_like_the_reference():
+    """prompt_starts left None: one self.rng.randint(0, T - P) per utterance AFTER the nar_stage draw (valle.py:891-895, :368-369)."""
+    import random
+
+    cfg = vo.OracleConfig(d_model=64, nhead=4, num_layers=1, prefix_mode=2)
+    sd = vo.make_state_dict(cfg, 0)
+    m = valle_amd.VALLE(64, 4, 1, prefix_mode=2, engine_dtype="fp32")
+    m.load_state_dict(sd, strict=True)
+    m = m.to(DEV).eval()
+    N, S, T = 2, 5, 24
+    xs, ys = zip(*[(vo.make_inputs(S, T, 70 + b)[0][0], vo.make_inputs(S, T, 70 + b)[2][0]) for b in range(N)])
+    x, y = torch.stack(xs), torch.stack(ys)
+    xl, yl = torch.full((N,), S, dtype=torch.int32), torch.full((N,), T, dtype=torch.int32)
+    (_, _), loss, _ = m(x.to(DEV), xl, y.to(DEV), yl)
+    r = random.Random(0)
+    stage = r.choices(list(range(1, 8)), weights=[1.0 / 7] * 7, k=1)[0]
+    P = min(225, int(0.25 * T))
+    starts = [r.randint(0, T - P) for _ in range(N)]
+    want, _ = vo.forward(sd, cfg, x, xl, y, yl, train_stage=0, nar_stage=stage, prompt_starts=starts)
+    assert abs(float(loss) - float(want)) <= 2e-5 * abs(float(want))
+    with pytest.raises(ValueError):  # prefix_mode 4 without PromptedFeatures
+        m4 = valle_amd.VALLE(64, 4, 1, prefix_mode=4, engine_dtype="fp32").to(DEV).eval()
+        m4(x.to(DEV), xl, y.to(DEV), yl)

@@ -59,6 +59,29 @@ def _request_seed_base(seed: int, b: int) -> int:
     return (seed + 0x9E3779B97F4A7C15 * b) & (2**64 - 1)
 
 
+class PromptedFeatures:
+    """``valle.data.input_strategies.PromptedFeatures`` (valle/data/input_strategies.py:16-35): the (prompts, features) pair the
+    prefix_mode 4 collation hands to ``forward`` as ``y`` -- and, holding the two length vectors, as ``y_lens`` (valle.py:792-798)."""
+
+    def __init__(self, prompts, features):
+        self.prompts = prompts
+        self.features = features
+
+    def to(self, device):
+        return PromptedFeatures(self.prompts.to(device), self.features.to(device))
+
+    def sum(self):
+        return self.features.sum()
+
+    @property
+    def ndim(self):
+        return self.features.ndim
+
+    @property
+    def data(self):
+        return (self.prompts, self.features)
+
+
 class VALLE(nn.Module):
     """HIP-backed VALL-E (valle/models/valle.py:722-1238)."""
 
@@ -396,30 +419,39 @@ class VALLE(nn.Module):
 
     # ---- VALLE.forward (valle/models/valle.py:762-959), teacher-forced, eval mode ----------------------------
     @torch.no_grad()
-    def forward(self, x: torch.Tensor, x_lens: torch.Tensor, y: torch.Tensor, y_lens: torch.Tensor, reduction: str = "sum",
-                train_stage: int = 0, *, nar_stage: Optional[int] = None, prefix_len: Optional[int] = None, **kwargs):
+    def forward(self, x: torch.Tensor, x_lens: torch.Tensor, y, y_lens, reduction: str = "sum",
+                train_stage: int = 0, *, nar_stage: Optional[int] = None, prefix_len: Optional[int] = None,
+                prompt_starts: Optional[Sequence[int]] = None, **kwargs):
         """The reference's teacher-forced pass as a SCORING function (validation loss / Top10Accuracy of given codes):
         returns ``((x_emb, codes), total_loss, metrics)`` like valle.py:959, computed by the HIP block modules (AR: one
         prefix-LM pass over [text; y]; NAR: one unmasked pass at stage ``nar_stage``) and ``vle_op_cross_entropy``.
 
-        Scope: eval mode (no dropout, no gradients), prefix_mode 0 / 1, ``reduction="sum"``, unpadded batches (every
-        ``x_lens == x.shape[1]`` and ``y_lens == y.shape[1]``; the reference's AR loss also sums over PADDED positions
-        (:875 has no ignore_index), which only a padded evaluation reproduces).  The reference's two random draws are
-        keyword arguments; left None they are drawn the way the reference draws them: ``nar_stage`` from ``self.rng``
-        (random.Random(0) at construction, :165, :891-895), prefix_mode 1's ``prefix_len`` from torch's global generator
-        (:348-350)."""
+        Scope: eval mode (no dropout, no gradients), every prefix_mode (0 / 1 / 2; 4 with ``y`` / ``y_lens`` as
+        ``PromptedFeatures``, :792-798), ``reduction="sum"``, unpadded batches (every ``x_lens == x.shape[1]`` and
+        ``y_lens == y.shape[1]``; the reference's AR loss also sums over PADDED positions (:875 has no ignore_index), which only
+        a padded evaluation reproduces).  The reference's random draws are keyword arguments; left None they are drawn the way
+        the reference draws them: ``nar_stage`` from ``self.rng`` (random.Random(0) at construction, :165, :891-895),
+        prefix_mode 1's ``prefix_len`` from torch's global generator (:348-350), prefix_mode 2's per-utterance segment starts
+        ``prompt_starts`` from ``self.rng.randint`` (:368-369, after the ``nar_stage`` draw, like the reference)."""
         from . import ops
 
         assert x.ndim == 2, x.shape
         assert x_lens.ndim == 1, x_lens.shape
+        y_prompts_codes = None
+        if isinstance(y, PromptedFeatures):                                          # :792-798
+            y_prompts_codes, y = y.data
+            prompts_len, y_lens = y_lens.data
+            assert prompts_len.min() == prompts_len.max()
+            assert self.prefix_mode == 4
+            y_prompts_codes = y_prompts_codes.type(torch.int64)
         assert y.ndim == 3, y.shape
         assert y_lens.ndim == 1, y_lens.shape
         if self.training:
             raise NotImplementedError("forward() is a scoring pass: call .eval() first (training is outside the decode path)")
         if reduction != "sum":
             raise NotImplementedError("only reduction='sum' (the trainer's, valle/bin/trainer.py) is implemented")
-        if self.prefix_mode not in (0, 1):
-            raise NotImplementedError("forward(): prefix_mode 2 / 4 (random prompt segments, PromptedFeatures) is not implemented")
+        if self.prefix_mode == 4 and y_prompts_codes is None and train_stage in (0, 2) and self.num_quantizers > 1:
+            raise ValueError("prefix_mode 4 takes y / y_lens as PromptedFeatures (prompts, features), like the reference (valle.py:792-798)")
         N, S = x.shape
         T = y.shape[1]
         if any(int(v) != S for v in x_lens) or any(int(v) != T for v in y_lens):
@@ -470,6 +502,43 @@ class VALLE(nn.Module):
                 P = int(prefix_len)
             xe = self.nar_text_position(self.nar_text_prenet(self.nar_text_embedding(x)))         # :897-899
             x_emb = xe
+            if self.prefix_mode in (2, 4):
+                # _prepare_prompts :362-389: the prompt is a separate segment in front of the WHOLE utterance.  prefix_mode 2 cuts it
+                # out of the utterance itself (one self.rng.randint per utterance) and blanks that stretch of the target codebook
+                # IN PLACE (the returned codes carry the blanks, like the reference's); prefix_mode 4 gets it from the caller.
+                if self.prefix_mode == 2:
+                    P = min(225, int(0.25 * T))                                      # :364
+                    if prompt_starts is None:
+                        prompt_starts = [self.rng.randint(0, T - P) for _ in range(N)]  # :368-369
+                    assert len(prompt_starts) == N and all(0 <= int(v) <= T - P for v in prompt_starts)
+                    codes = codes.clone()  # the reference blanks its own copy (:811), never the caller's tensor
+                    prompts = torch.stack([codes[n, int(st): int(st) + P].clone() for n, st in enumerate(prompt_starts)])
+                    for n, st in enumerate(prompt_starts):
+                        codes[n, int(st): int(st) + P, nar_stage] = NUM_AUDIO_TOKENS  # :370-373
+                else:
+                    prompts = y_prompts_codes.to(dev)
+                    assert prompts.shape[0] == N and prompts.shape[2] == self.num_quantizers
+                    P = int(prompts.shape[1])                                        # :377
+                y_pr = self.nar_audio_embeddings[0](prompts[..., 0])
+                y_full = self.nar_audio_embeddings[0](codes[..., 0])
+                for j in range(1, self.num_quantizers):
+                    self.nar_audio_embeddings[j].add_to(y_pr, prompts[..., j])
+                    if j < nar_stage:
+                        self.nar_audio_embeddings[j].add_to(y_full, codes[..., j])
+                y_emb = torch.cat([y_pr, y_full], dim=1)                            # :389
+                targets = codes[..., nar_stage].reshape(-1)                          # :906 (the blanked stretch = ignore_index)
+                ye = self.nar_audio_position(self.nar_audio_prenet(y_emb))
+                h = self._fwd_nar_hidden(xe, ye, self.nar_stage_embeddings[nar_stage - 1].weight)
+                logits = predict(h[:, P:].reshape(N * T, -1), self.nar_predict_layers[nar_stage - 1].weight)  # :927, VALLF :531-533
+                loss_rows, hit = ops.cross_entropy_rows(logits, targets, ignore_index=NUM_AUDIO_TOKENS, topk=10)
+                if self.prefix_mode == 4:
+                    P = 0                                                            # :929-930: also resets the length correction
+                total_loss = total_loss + loss_rows.sum() * (total_length / (total_length - P * N))  # :936-943
+                kept = hit >= 0
+                metrics["NarTop10Accuracy"] = (hit == 1).sum().float() / kept.sum().clamp_min(1).float() * total_length
+                if train_stage == 0:
+                    total_loss = total_loss / 2.0
+                return ((x_emb, codes), total_loss, metrics)
             y_emb = self.nar_audio_embeddings[0](codes[..., 0])                      # _prepare_prompts :335-393
             if self.prefix_mode == 0:
                 for j in range(1, nar_stage):

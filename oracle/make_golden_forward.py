@@ -36,6 +36,19 @@ CASES = {
     "fwd_pm2_nar_only_n3": dict(cfg=dict(d_model=128, nhead=2, num_layers=1, prefix_mode=2), N=3, S=5, T=41, train_stage=2, seed=29),
     "fwd_pm4_n2": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=4), N=2, S=7, T=22, train_stage=0, seed=31, P4=9),
     "fwd_vallf_pm2_n1": dict(cfg=dict(d_model=64, nhead=4, num_layers=1, prefix_mode=2, model="vallf"), N=1, S=6, T=24, train_stage=0, seed=37),
+    # PADDED batches (the collater's shapes: every utterance padded to the longest): the AR loss sums the padded rows too (:875)
+    "fwd_pad_pm1_n3": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=1), N=3, S=7, T=24, train_stage=0, seed=41,
+                           x_lens=[7, 5, 6], y_lens=[24, 17, 21]),
+    "fwd_pad_pm0_bos_n2": dict(cfg=dict(d_model=64, nhead=4, num_layers=1, prefix_mode=0, prepend_bos=True), N=2, S=5, T=13, train_stage=0, seed=43,
+                               x_lens=[5, 4], y_lens=[9, 13]),
+    "fwd_pad_pm2_n2": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=2), N=2, S=6, T=28, train_stage=0, seed=47,
+                           x_lens=[6, 6], y_lens=[28, 20]),
+    "fwd_pad_pm4_n2": dict(cfg=dict(d_model=64, nhead=4, num_layers=2, prefix_mode=4), N=2, S=7, T=22, train_stage=0, seed=53, P4=8,
+                           x_lens=[4, 7], y_lens=[22, 15]),
+    "fwd_pad_postnorm_prenet_pm1_n2": dict(cfg=dict(d_model=64, nhead=2, num_layers=1, prefix_mode=1, norm_first=False, add_prenet=True), N=2, S=6, T=20,
+                                           train_stage=0, seed=59, x_lens=[6, 5], y_lens=[14, 20]),
+    "fwd_pad_nar_only_pm1_n2": dict(cfg=dict(d_model=128, nhead=2, num_layers=1, prefix_mode=1), N=2, S=5, T=30, train_stage=2, seed=61,
+                                    x_lens=[3, 5], y_lens=[30, 22]),
 }
 
 
@@ -45,13 +58,19 @@ def make_prompts(N, P, seed):
     return torch.randint(0, 1024, (N, P, 8), generator=g, dtype=torch.int64)
 
 
-def make_batch(N, S, T, seed):
+def make_batch(N, S, T, seed, x_lens=None, y_lens=None):
+    """Unpadded: N utterances of S text tokens / T frames.  Padded (x_lens / y_lens given, max == S / T): utterance b is
+    make_inputs(x_lens[b], y_lens[b]) padded with text id 0 (the collater's <pad>) and with JUNK codes 777 (the forward must
+    blank padded frames itself, valle.py:811)."""
     xs, ys = [], []
     for b in range(N):
-        x, _, y = vo.make_inputs(S, T, seed * 100 + b)
-        xs.append(x[0])
-        ys.append(y[0])
-    return torch.stack(xs), torch.full((N,), S, dtype=torch.int32), torch.stack(ys), torch.full((N,), T, dtype=torch.int32)
+        Sb, Tb = (S, T) if x_lens is None else (int(x_lens[b]), int(y_lens[b]))
+        x, _, y = vo.make_inputs(Sb, Tb, seed * 100 + b)
+        xs.append(torch.nn.functional.pad(x[0], (0, S - Sb), value=0))
+        ys.append(torch.nn.functional.pad(y[0], (0, 0, 0, T - Tb), value=777))
+    xl = torch.full((N,), S, dtype=torch.int32) if x_lens is None else torch.tensor(x_lens, dtype=torch.int32)
+    yl = torch.full((N,), T, dtype=torch.int32) if y_lens is None else torch.tensor(y_lens, dtype=torch.int32)
+    return torch.stack(xs), xl, torch.stack(ys), yl
 
 
 def main():
@@ -62,7 +81,7 @@ def main():
         cfg = vo.OracleConfig(**spec["cfg"])
         sd = vo.make_state_dict(cfg, 0)
         model = build_reference(vm, cfg, sd)
-        x, xl, y, yl = make_batch(spec["N"], spec["S"], spec["T"], spec["seed"])
+        x, xl, y, yl = make_batch(spec["N"], spec["S"], spec["T"], spec["seed"], spec.get("x_lens"), spec.get("y_lens"))
         model.rng = random.Random(spec["seed"])
         torch.manual_seed(spec["seed"])
         drawn = {}
@@ -99,6 +118,7 @@ def main():
                    nar_stage=np.int32(drawn.get("nar_stage", -1)), prefix_len=np.int32(drawn.get("prefix_len", -1)),
                    ar_top10=np.float64(metrics.get("ArTop10Accuracy", -1.0)), nar_top10=np.float64(metrics.get("NarTop10Accuracy", -1.0)),
                    starts=np.asarray(drawn.get("starts", []), dtype=np.int32), P4=np.int32(spec.get("P4", 0)),
+                   x_lens=np.asarray(spec.get("x_lens", []), dtype=np.int32), y_lens=np.asarray(spec.get("y_lens", []), dtype=np.int32),
                    torch_version=np.bytes_(torch.__version__))
         for k, v in spec["cfg"].items():
             out[f"cfg_{k}"] = np.asarray(v)

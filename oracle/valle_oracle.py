@@ -719,7 +719,8 @@ def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum",
     assert cfg.prefix_mode in (0, 1, 2, 4)
     N, S = x.shape
     T = y.shape[1]
-    assert all(int(v) == S for v in x_lens) and all(int(v) == T for v in y_lens), "unpadded batches only"
+    if not (all(int(v) == S for v in x_lens) and all(int(v) == T for v in y_lens)):
+        return forward_padded(sd, cfg, x, x_lens, y, y_lens, train_stage, nar_stage, prefix_len, prompt_starts, y_prompts)
     codes = y.to(torch.int64)
     bos = int(cfg.prepend_bos)
     total = torch.zeros(())
@@ -837,4 +838,118 @@ def forward(sd, cfg: OracleConfig, x, x_lens, y, y_lens, reduction: str = "sum",
         metrics["NarTop10Accuracy"] = float(hits / kept.clamp_min(1)) * total_length  # :945-956
     if train_stage == 0:
         total = total / 2.0  # :958-959
+    return total, metrics
+
+
+@torch.no_grad()
+def forward_padded(sd, cfg: OracleConfig, x, x_lens, y, y_lens, train_stage: int = 0, nar_stage: Optional[int] = None,
+                   prefix_len: Optional[int] = None, prompt_starts=None, y_prompts=None):
+    """VALLE.forward (valle.py:762-959) on a PADDED batch (x_lens.max() == x.shape[1], y_lens.max() == y.shape[1], the collater's
+    shapes), literally: padded frames' codes are zeroed (:811), padded first-codebook inputs / targets are EOS (pad_y_eos,
+    :322-333), padded KEYS are masked in every attention (:846-856, :908-926) -- and padded QUERY rows are computed like any
+    other, because the AR loss (:875, no ignore_index) sums over them with target EOS.  VALL-E only (model "valle")."""
+    assert cfg.model != "vallf", "padded forward: VALL-E only"
+    N, S = x.shape
+    T = y.shape[1]
+    x_lens, y_lens = x_lens.to(torch.int64), y_lens.to(torch.int64)
+    assert int(x_lens.max()) == S and int(y_lens.max()) == T, "the collater pads to the longest utterance (make_pad_mask sizes to it)"
+    x_mask = torch.arange(S)[None] >= x_lens[:, None]  # make_pad_mask, :805-806
+    y_mask = torch.arange(T)[None] >= y_lens[:, None]
+    codes = y.to(torch.int64) * (~y_mask)[..., None].to(torch.int64)  # :811
+    bos = int(cfg.prepend_bos)
+    t_all = F.pad(codes[..., 0], (0, 1), value=0) + NUM_AUDIO_TOKENS * F.pad(y_mask.to(torch.int64), (0, 1), value=1)  # pad_y_eos
+    if bos:
+        inputs, targets = F.pad(t_all[:, :-1], (1, 0), value=NUM_AUDIO_TOKENS + 1), t_all
+    else:
+        inputs, targets = t_all[:, :-1], t_all[:, 1:]
+    total = torch.zeros(())
+    metrics = {}
+    total_length = float(y_lens.sum())
+    if train_stage in (0, 1):
+        ar_y_mask = F.pad(y_mask, (1, 0), value=False) if bos else y_mask  # :821-826
+        Ta = inputs.shape[1]
+        ar_loss, hits, kept = torch.zeros(()), torch.zeros(()), torch.zeros(())
+        for b in range(N):
+            xe, ye = token_embedding(sd, "ar_text_embedding", x[b]), token_embedding(sd, "ar_audio_embedding", inputs[b])
+            if cfg.add_prenet:
+                xe, ye = text_prenet(sd, "ar_text_prenet", xe), audio_prenet(sd, "ar_audio_prenet", ye)
+            xe = sine_position(xe, sd["ar_text_position.alpha"])
+            ye = sine_position(ye, sd["ar_audio_position.alpha"])
+            mask = prefix_lm_mask(S, Ta) | torch.cat([x_mask[b], ar_y_mask[b]])[None, :]  # :846-852
+            dec = encoder(sd, "ar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=mask)[S:]
+            logits = F.linear(dec, sd["ar_predict_layer.weight"])
+            ar_loss = ar_loss + F.cross_entropy(logits, targets[b], reduction="sum")  # :875: padded rows included
+            h, kp = _topk_counts(logits, targets[b])
+            hits, kept = hits + h, kept + kp
+        total = total + ar_loss
+        metrics["ArTop10Accuracy"] = float(hits / kept.clamp_min(1)) * total_length
+    if cfg.num_quantizers == 1:
+        return total, metrics
+    y_in = inputs[:, 1:] if bos else inputs  # :886-887
+    if train_stage in (0, 2):
+        assert nar_stage is not None and 1 <= nar_stage < cfg.num_quantizers
+        ymin = int(y_lens.min())
+        P = 0
+        if cfg.prefix_mode == 1:
+            assert prefix_len is not None
+            P = int(prefix_len)
+        elif cfg.prefix_mode == 2:
+            P = min(225, int(0.25 * ymin))
+            assert prompt_starts is not None and len(prompt_starts) == N
+        elif cfg.prefix_mode == 4:
+            assert y_prompts is not None
+            P = int(y_prompts.shape[1])
+        nar_loss, hits, kept = torch.zeros(()), torch.zeros(()), torch.zeros(())
+        for b in range(N):
+            cb = codes[b].clone()
+            xe = token_embedding(sd, "nar_text_embedding", x[b])
+            if cfg.add_prenet:
+                xe = text_prenet(sd, "nar_text_prenet", xe)
+            xe = sine_position(xe, sd["nar_text_position.alpha"])
+            if cfg.prefix_mode in (2, 4):
+                if cfg.prefix_mode == 2:
+                    st = int(prompt_starts[b])
+                    assert 0 <= st <= int(y_lens[b]) - P
+                    pr = cb[st: st + P].clone()
+                    cb[st: st + P, nar_stage] = NUM_AUDIO_TOKENS
+                else:
+                    pr = y_prompts[b].to(torch.int64)
+                y_pr = token_embedding(sd, "nar_audio_embeddings.0", pr[:, 0]).clone()
+                y_emb = token_embedding(sd, "nar_audio_embeddings.0", y_in[b]).clone()
+                for j in range(1, cfg.num_quantizers):
+                    y_pr += token_embedding(sd, f"nar_audio_embeddings.{j}", pr[:, j])
+                    if j < nar_stage:
+                        y_emb += token_embedding(sd, f"nar_audio_embeddings.{j}", cb[:, j])
+                y_emb = torch.cat([y_pr, y_emb], 0)
+                kpm = torch.cat([x_mask[b], F.pad(y_mask[b], (P, 0), value=False)])  # :908-915
+                tgt = cb[:, nar_stage] + NUM_AUDIO_TOKENS * y_mask[b].to(torch.int64)  # :906
+                lo = S + P
+            else:
+                y_emb = token_embedding(sd, "nar_audio_embeddings.0", y_in[b]).clone()
+                if cfg.prefix_mode == 0:
+                    for j in range(1, nar_stage):
+                        y_emb += token_embedding(sd, f"nar_audio_embeddings.{j}", cb[:, j])
+                else:
+                    for j in range(1, cfg.num_quantizers):
+                        y_emb[:P] += token_embedding(sd, f"nar_audio_embeddings.{j}", cb[:P, j])
+                        if j < nar_stage:
+                            y_emb[P:] += token_embedding(sd, f"nar_audio_embeddings.{j}", cb[P:, j])
+                kpm = torch.cat([x_mask[b], y_mask[b]])
+                tgt = (cb[:, nar_stage] + NUM_AUDIO_TOKENS * y_mask[b].to(torch.int64))[P:]  # :906, :916-917
+                lo = S + P
+            ye = sine_position(audio_prenet(sd, "nar_audio_prenet", y_emb) if cfg.add_prenet else y_emb, sd["nar_audio_position.alpha"])
+            stage = sd[f"nar_stage_embeddings.{nar_stage - 1}.word_embeddings.weight"]
+            Ltot = S + ye.shape[0]
+            mask = kpm[None, :].expand(Ltot, Ltot)  # src_key_padding_mask only (:922-926)
+            dec = encoder(sd, "nar_decoder", cfg, torch.cat([xe, ye], 0), attn_mask=mask, stage_emb=stage)[lo:]
+            logits = F.linear(dec, sd[f"nar_predict_layers.{nar_stage - 1}.weight"])
+            nar_loss = nar_loss + F.cross_entropy(logits, tgt, ignore_index=NUM_AUDIO_TOKENS, reduction="sum")
+            h, kp = _topk_counts(logits, tgt)
+            hits, kept = hits + h, kept + kp
+        if cfg.prefix_mode == 4:
+            P = 0
+        total = total + nar_loss * (total_length / (total_length - P * N))  # :943
+        metrics["NarTop10Accuracy"] = float(hits / kept.clamp_min(1)) * total_length
+    if train_stage == 0:
+        total = total / 2.0
     return total, metrics

@@ -14,7 +14,9 @@ from tests.golden_util import GOLDEN_DIR
 def load_forward_case(name):
     z = np.load(os.path.join(GOLDEN_DIR, "forward", f"{name}.npz"))
     cfg = vo.OracleConfig(**{k[4:]: z[k].item() for k in z.files if k.startswith("cfg_")})
-    x, xl, y, yl = make_batch(int(z["N"]), int(z["S"]), int(z["T"]), int(z["seed"]))
+    padded = "x_lens" in z.files and len(z["x_lens"]) > 0
+    x, xl, y, yl = make_batch(int(z["N"]), int(z["S"]), int(z["T"]), int(z["seed"]),
+                              [int(v) for v in z["x_lens"]] if padded else None, [int(v) for v in z["y_lens"]] if padded else None)
     kw = dict(train_stage=int(z["train_stage"]))
     if int(z["nar_stage"]) >= 1:
         kw.update(nar_stage=int(z["nar_stage"]), prefix_len=int(z["prefix_len"]))

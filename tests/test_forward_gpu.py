@@ -31,14 +31,13 @@ def test_forward_loss_matches_reference(name, dtype, rtol):
     (_, codes), loss, metrics = m(x.to(DEV), xl.to(DEV), y_in, yl_in, reduction="sum", **mkw)
     want = float(z["loss"])
     assert abs(float(loss) - want) <= rtol * abs(want), (float(loss), want)
+    expect = y.clone()
+    expect[torch.arange(y.shape[1])[None, :] >= yl.to(torch.int64)[:, None]] = 0  # padded frames are blanked (valle.py:811)
     if cfg.prefix_mode == 2 and "prompt_starts" in kw:        # the returned codes carry the blanked stretch of the target codebook (:370-373)
-        blank = y.clone()
-        P = min(225, int(0.25 * y.shape[1]))
+        P = min(225, int(0.25 * int(yl.min())))
         for n, st in enumerate(kw["prompt_starts"]):
-            blank[n, st: st + P, kw["nar_stage"]] = 1024
-        assert torch.equal(codes.cpu(), blank)
-    else:
-        assert torch.equal(codes.cpu(), y)
+            expect[n, st: st + P, kw["nar_stage"]] = 1024
+    assert torch.equal(codes.cpu(), expect)
     _, ometrics = vo.forward(sd, cfg, x, xl, y, yl, **kw)
     for k, v in ometrics.items():
         tol = 1e-4 if dtype == "fp32" else 0.05 * float(x.shape[0] * y.shape[1])
@@ -63,8 +62,12 @@ def test_forward_default_draws_follow_the_reference_rng():
     plen = min(int(torch.randint(5, 10, size=()).item()), 225)
     want, _ = vo.forward(sd, cfg, x, xl, y, yl, train_stage=0, nar_stage=stage, prefix_len=plen)
     assert abs(float(loss) - float(want)) <= 2e-5 * abs(float(want))
-    with pytest.raises(NotImplementedError):
-        m(x.to(DEV), torch.tensor([4], dtype=torch.int32), y.to(DEV), yl)  # padded text: not an unpadded batch
+    with pytest.raises(ValueError):
+        m(x.to(DEV), torch.tensor([4], dtype=torch.int32), y.to(DEV), yl)  # lengths shorter than the tensors: not the collater's shapes
+    mf = valle_amd.VALLF(64, 4, 1, prefix_mode=1, engine_dtype="fp32").to(DEV).eval()
+    x2, y2 = torch.cat([x, x]), torch.cat([y, y])
+    with pytest.raises(NotImplementedError):  # VALL-F scores unpadded batches only
+        mf(x2.to(DEV), torch.tensor([5, 4], dtype=torch.int32), y2.to(DEV), torch.tensor([20, 20], dtype=torch.int32))
 
 
 def test_forward_prefix_mode_2_draws_its_segment_starts_like_the_reference():

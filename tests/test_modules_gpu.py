@@ -170,3 +170,44 @@ def test_block_modules_reproduce_the_engine_tokens():
     assert torch.equal(got.cpu(), want.cpu()), "block-module decode and engine decode disagree (fp32, greedy)"
     ref = vo.inference(sd, cfg, x, x_lens, y, None, top_k=1, kv_cache=True, max_new=max_new)
     assert torch.equal(got.cpu(), ref), "block-module decode differs from the oracle"
+
+
+@pytest.mark.parametrize("mask_kind", ["none", "prefix_lm"])
+def test_multihead_attention_key_padding_mask(mask_kind):
+    """``key_padding_mask`` of the block MultiheadAttention (the teacher-forced forward's src_key_padding_mask, valle.py:846-856,
+    :908-926): padded keys are invisible; VALID query rows equal the fp64 definition softmax((QK^T)/sqrt(dh) + masks) V with the
+    reference's merged mask, for padding in the MIDDLE of a sequence (text pad | audio pad) too; padded AUDIO rows (the AR loss
+    reads them) see exactly the valid keys of their sequence."""
+    import math
+
+    DEV = "cuda:0"
+    torch.manual_seed(3)
+    B, S, T, d, H = 3, 5, 9, 64, 4
+    L = S + T
+    mha = M.MultiheadAttention(d, H, batch_first=True).to(DEV).eval()
+    M.set_compute_dtype(mha, "fp32")
+    x = torch.randn(B, L, d, device=DEV)
+    x_lens, y_lens = [5, 3, 4], [9, 6, 9]
+    pad = torch.zeros(B, L, dtype=torch.bool)
+    for b in range(B):
+        pad[b, x_lens[b]:S] = True
+        pad[b, S + y_lens[b]:] = True
+    attn_mask = vo.prefix_lm_mask(S, T).to(DEV) if mask_kind == "prefix_lm" else None
+    out, _ = mha(x, x, x, key_padding_mask=pad.to(DEV), need_weights=False, attn_mask=attn_mask)
+    w, bias = mha.in_proj_weight.detach().double().cpu(), mha.in_proj_bias.detach().double().cpu()
+    wo, bo = mha.out_proj.weight.detach().double().cpu(), mha.out_proj.bias.detach().double().cpu()
+    dh = d // H
+    for b in range(B):
+        qkv = x[b].double().cpu() @ w.t() + bias
+        q, k, v = (t.view(L, H, dh).transpose(0, 1) for t in (qkv[:, :d], qkv[:, d:2 * d], qkv[:, 2 * d:]))
+        sc = q @ k.transpose(1, 2) / math.sqrt(dh)
+        blocked = pad[b][None, :].expand(L, L).clone()
+        if attn_mask is not None:
+            blocked |= attn_mask.cpu()
+        sc = sc.masked_fill(blocked[None], float("-inf"))
+        ref = (torch.softmax(sc, -1) @ v).transpose(0, 1).reshape(L, d) @ wo.t() + bo
+        rows = (~pad[b]).clone()
+        rows[S + y_lens[b]:] = True  # ... and the padded audio rows
+        err = (out[b].double().cpu()[rows] - ref[rows]).abs().max().item()
+        assert err < 2e-4, (b, err)
+    assert torch.isfinite(out).all()

@@ -375,17 +375,19 @@ class VALLE(nn.Module):
         h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), stage_weight))
         return h[0, xe.shape[1] + P:]
 
-    def _fwd_ar_hidden(self, xe: torch.Tensor, ye: torch.Tensor) -> torch.Tensor:
-        """Teacher-forced AR pass over a batch: decoder outputs of the audio positions, (N, Ta, d) (valle.py:833-872)."""
+    def _fwd_ar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """Teacher-forced AR pass over a batch: decoder outputs of the audio positions, (N, Ta, d) (valle.py:833-872); a padded
+        batch passes its (N, S + Ta) padding mask (the reference merges it into the attention mask, :846-856)."""
         S, T = xe.shape[1], ye.shape[1]
         i = torch.arange(S + T, device=xe.device)
         allowed = i[None, :] < torch.maximum(i[:, None] + 1, torch.tensor(S, device=xe.device))       # prefix-LM mask
-        h, _ = self.ar_decoder((torch.cat([xe, ye], dim=1), None), mask=~allowed)
+        h, _ = self.ar_decoder((torch.cat([xe, ye], dim=1), None), mask=~allowed, src_key_padding_mask=key_padding_mask)
         return h[:, S:]
 
-    def _fwd_nar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, stage_weight: torch.Tensor) -> torch.Tensor:
+    def _fwd_nar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, stage_weight: torch.Tensor,
+                        key_padding_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Teacher-forced NAR pass: decoder outputs of the audio positions, (N, T, d) (valle.py:922-926)."""
-        h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), stage_weight))
+        h, _ = self.nar_decoder((torch.cat([xe, ye], dim=1), stage_weight), src_key_padding_mask=key_padding_mask)
         return h[:, xe.shape[1]:]
 
     def _nar_blocks(self, text, y0, prompts, P: int, prefix_mode: int, enrolled_len) -> torch.Tensor:
@@ -427,9 +429,9 @@ class VALLE(nn.Module):
         prefix-LM pass over [text; y]; NAR: one unmasked pass at stage ``nar_stage``) and ``vle_op_cross_entropy``.
 
         Scope: eval mode (no dropout, no gradients), every prefix_mode (0 / 1 / 2; 4 with ``y`` / ``y_lens`` as
-        ``PromptedFeatures``, :792-798), ``reduction="sum"``, unpadded batches (every ``x_lens == x.shape[1]`` and
-        ``y_lens == y.shape[1]``; the reference's AR loss also sums over PADDED positions (:875 has no ignore_index), which only
-        a padded evaluation reproduces).  The reference's random draws are keyword arguments; left None they are drawn the way
+        ``PromptedFeatures``, :792-798), ``reduction="sum"``; padded batches (the collater's shapes) for VALL-E since round 3: padded frames blanked,
+        padded keys masked, and -- like the reference, whose AR loss has no ignore_index (:875) -- the padded rows' EOS targets
+        summed into the AR loss (VALL-F: unpadded batches).  The reference's random draws are keyword arguments; left None they are drawn the way
         the reference draws them: ``nar_stage`` from ``self.rng`` (random.Random(0) at construction, :165, :891-895),
         prefix_mode 1's ``prefix_len`` from torch's global generator (:348-350), prefix_mode 2's per-utterance segment starts
         ``prompt_starts`` from ``self.rng.randint`` (:368-369, after the ``nar_stage`` draw, like the reference)."""
@@ -454,12 +456,26 @@ class VALLE(nn.Module):
             raise ValueError("prefix_mode 4 takes y / y_lens as PromptedFeatures (prompts, features), like the reference (valle.py:792-798)")
         N, S = x.shape
         T = y.shape[1]
-        if any(int(v) != S for v in x_lens) or any(int(v) != T for v in y_lens):
-            raise NotImplementedError("forward(): unpadded batches only (the reference's AR loss sums padded positions too)")
         dev = next(self.parameters()).device
         if dev.type != "cuda":
             raise RuntimeError("the HIP operators need the model on a ROCm device: call .to('cuda') first (no CPU path)")
+        xl, yl = [int(v) for v in x_lens], [int(v) for v in y_lens]
+        padded = any(v != S for v in xl) or any(v != T for v in yl)
+        x_mask = y_mask = None
+        if padded:
+            # the collater's shapes (valle/data/collation.py): every utterance padded to the longest.  Padded frames are blanked
+            # (:811), padded first-codebook inputs / targets are EOS (pad_y_eos :322-333), padded keys are masked (:846-856,
+            # :908-926), and the AR loss still sums over the padded rows (:875 has no ignore_index), like the reference's.
+            if type(self)._decoder_factory is not _decoder:
+                raise NotImplementedError("forward(): VALL-F scores unpadded batches only")
+            if max(xl) != S or max(yl) != T or min(xl) < 1 or min(yl) < 1:
+                raise ValueError("padded batch: x / y must be padded to their longest utterance (make_pad_mask sizes the masks to it)")
+            x_mask = torch.arange(S, device=dev)[None, :] >= torch.tensor(xl, device=dev)[:, None]      # make_pad_mask, :805-806
+            y_mask = torch.arange(T, device=dev)[None, :] >= torch.tensor(yl, device=dev)[:, None]
         x, codes = x.to(dev, torch.int64), y.to(dev, torch.int64)
+        if padded:
+            codes = codes * (~y_mask)[..., None].to(torch.int64)                     # :811
+        ymin = min(yl)
         bos = int(self.ar_audio_prepend_bos)
         tdt = self.ar_decoder._tdtype()
 
@@ -468,19 +484,22 @@ class VALLE(nn.Module):
 
         total_loss = torch.zeros((), device=dev)
         metrics = {}
-        total_length = float(N * T)
+        total_length = float(sum(yl))                                                 # y_lens.sum(), :878, :935
+        F_pad = torch.nn.functional.pad
+        ym_int = y_mask.to(torch.int64) if padded else torch.zeros(N, T, dtype=torch.int64, device=dev)
+        t_all = F_pad(codes[..., 0], (0, 1), value=0) + NUM_AUDIO_TOKENS * F_pad(ym_int, (0, 1), value=1)  # pad_y_eos, valle.py:322-333
+        if bos:
+            inputs, targets = F_pad(t_all[:, :-1], (1, 0), value=NUM_AUDIO_TOKENS + 1), t_all
+        else:
+            inputs, targets = t_all[:, :-1], t_all[:, 1:]
         if train_stage in (0, 1):
-            y0 = codes[..., 0]
-            eos = torch.full((N, 1), NUM_AUDIO_TOKENS, dtype=torch.int64, device=dev)
-            if bos:  # pad_y_eos, valle.py:322-333
-                inputs = torch.cat([torch.full((N, 1), NUM_AUDIO_TOKENS + 1, dtype=torch.int64, device=dev), y0], dim=1)
-                targets = torch.cat([y0, eos], dim=1)
-            else:
-                inputs, targets = y0, torch.cat([y0[:, 1:], eos], dim=1)
             Ta = inputs.shape[1]
             xe = self.ar_text_position(self.ar_text_prenet(self.ar_text_embedding(x)))            # :827-829
             ye = self.ar_audio_position(self.ar_audio_prenet(self.ar_audio_embedding(inputs)))     # :861-863
-            logits = predict(self._fwd_ar_hidden(xe, ye).reshape(N * Ta, -1), self.ar_predict_layer.weight)  # :833-873
+            ar_kpm = None
+            if padded:
+                ar_kpm = torch.cat([x_mask, F_pad(y_mask, (1, 0), value=False) if bos else y_mask], dim=1)  # :820-826
+            logits = predict(self._fwd_ar_hidden(xe, ye, ar_kpm).reshape(N * Ta, -1), self.ar_predict_layer.weight)  # :833-873
             loss_rows, hit = ops.cross_entropy_rows(logits, targets.reshape(-1), ignore_index=-100, topk=10)
             total_loss = total_loss + loss_rows.sum()                                 # :875 (no ignore_index)
             kept = targets.reshape(-1) != NUM_AUDIO_TOKENS                           # the metric ignores EOS targets (:157-163)
@@ -497,20 +516,22 @@ class VALLE(nn.Module):
             P = 0
             if self.prefix_mode == 1:
                 if prefix_len is None:
-                    int_low = int(0.25 * T)
+                    int_low = int(0.25 * ymin)
                     prefix_len = min(int(torch.randint(int_low, int_low * 2, size=()).item()), 225)  # :348-350
                 P = int(prefix_len)
             xe = self.nar_text_position(self.nar_text_prenet(self.nar_text_embedding(x)))         # :897-899
             x_emb = xe
+            y_in = inputs[:, 1:] if bos else inputs                                  # :886-887: first-codebook stream, EOS where padded
+            nar_tgt = codes[..., nar_stage] + NUM_AUDIO_TOKENS * ym_int              # :906 (padded rows = ignore_index)
             if self.prefix_mode in (2, 4):
                 # _prepare_prompts :362-389: the prompt is a separate segment in front of the WHOLE utterance.  prefix_mode 2 cuts it
                 # out of the utterance itself (one self.rng.randint per utterance) and blanks that stretch of the target codebook
                 # IN PLACE (the returned codes carry the blanks, like the reference's); prefix_mode 4 gets it from the caller.
                 if self.prefix_mode == 2:
-                    P = min(225, int(0.25 * T))                                      # :364
+                    P = min(225, int(0.25 * ymin))                                   # :364
                     if prompt_starts is None:
-                        prompt_starts = [self.rng.randint(0, T - P) for _ in range(N)]  # :368-369
-                    assert len(prompt_starts) == N and all(0 <= int(v) <= T - P for v in prompt_starts)
+                        prompt_starts = [self.rng.randint(0, yl[n] - P) for n in range(N)]  # :368-369
+                    assert len(prompt_starts) == N and all(0 <= int(v) <= yl[n] - P for n, v in enumerate(prompt_starts))
                     codes = codes.clone()  # the reference blanks its own copy (:811), never the caller's tensor
                     prompts = torch.stack([codes[n, int(st): int(st) + P].clone() for n, st in enumerate(prompt_starts)])
                     for n, st in enumerate(prompt_starts):
@@ -519,16 +540,19 @@ class VALLE(nn.Module):
                     prompts = y_prompts_codes.to(dev)
                     assert prompts.shape[0] == N and prompts.shape[2] == self.num_quantizers
                     P = int(prompts.shape[1])                                        # :377
+                if self.prefix_mode == 2:
+                    nar_tgt = codes[..., nar_stage] + NUM_AUDIO_TOKENS * ym_int      # after the blanking
                 y_pr = self.nar_audio_embeddings[0](prompts[..., 0])
-                y_full = self.nar_audio_embeddings[0](codes[..., 0])
+                y_full = self.nar_audio_embeddings[0](y_in)
                 for j in range(1, self.num_quantizers):
                     self.nar_audio_embeddings[j].add_to(y_pr, prompts[..., j])
                     if j < nar_stage:
                         self.nar_audio_embeddings[j].add_to(y_full, codes[..., j])
                 y_emb = torch.cat([y_pr, y_full], dim=1)                            # :389
-                targets = codes[..., nar_stage].reshape(-1)                          # :906 (the blanked stretch = ignore_index)
+                targets = nar_tgt.reshape(-1)                                        # :906 (the blanked stretch / padding = ignore_index)
                 ye = self.nar_audio_position(self.nar_audio_prenet(y_emb))
-                h = self._fwd_nar_hidden(xe, ye, self.nar_stage_embeddings[nar_stage - 1].weight)
+                kpm = torch.cat([x_mask, F_pad(y_mask, (P, 0), value=False)], dim=1) if padded else None  # :908-915
+                h = self._fwd_nar_hidden(xe, ye, self.nar_stage_embeddings[nar_stage - 1].weight, kpm)
                 logits = predict(h[:, P:].reshape(N * T, -1), self.nar_predict_layers[nar_stage - 1].weight)  # :927, VALLF :531-533
                 loss_rows, hit = ops.cross_entropy_rows(logits, targets, ignore_index=NUM_AUDIO_TOKENS, topk=10)
                 if self.prefix_mode == 4:
@@ -539,7 +563,7 @@ class VALLE(nn.Module):
                 if train_stage == 0:
                     total_loss = total_loss / 2.0
                 return ((x_emb, codes), total_loss, metrics)
-            y_emb = self.nar_audio_embeddings[0](codes[..., 0])                      # _prepare_prompts :335-393
+            y_emb = self.nar_audio_embeddings[0](y_in)                               # _prepare_prompts :335-393
             if self.prefix_mode == 0:
                 for j in range(1, nar_stage):
                     self.nar_audio_embeddings[j].add_to(y_emb, codes[..., j])
@@ -549,9 +573,10 @@ class VALLE(nn.Module):
                         self.nar_audio_embeddings[j].add_to(y_emb[n, :P], codes[n, :P, j])
                         if j < nar_stage:
                             self.nar_audio_embeddings[j].add_to(y_emb[n, P:], codes[n, P:, j])
-            targets = codes[:, P:, nar_stage].reshape(-1)                            # :906, :916-917
+            targets = nar_tgt[:, P:].reshape(-1)                                     # :906, :916-917
             ye = self.nar_audio_position(self.nar_audio_prenet(y_emb))                             # :919-920
-            h = self._fwd_nar_hidden(xe, ye, self.nar_stage_embeddings[nar_stage - 1].weight)                 # :922-926
+            kpm = torch.cat([x_mask, y_mask], dim=1) if padded else None             # :816
+            h = self._fwd_nar_hidden(xe, ye, self.nar_stage_embeddings[nar_stage - 1].weight, kpm)            # :922-926
             logits = predict(h[:, P:].reshape(N * (T - P), -1), self.nar_predict_layers[nar_stage - 1].weight)   # :927-932
             loss_rows, hit = ops.cross_entropy_rows(logits, targets, ignore_index=NUM_AUDIO_TOKENS, topk=10)
             total_loss = total_loss + loss_rows.sum() * (total_length / (total_length - P * N))  # :936-943
@@ -583,13 +608,15 @@ class VALLF(VALLE):
         h, _ = self.nar_decoder((ye, stage_weight), xe, tgt_mask=None, memory_mask=None)               # :691-697
         return h[0, P:]                                                                               # :698
 
-    def _fwd_ar_hidden(self, xe: torch.Tensor, ye: torch.Tensor) -> torch.Tensor:
+    def _fwd_ar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, key_padding_mask=None) -> torch.Tensor:
+        assert key_padding_mask is None  # forward() rejects padded batches for VALL-F before it gets here
         T = ye.shape[1]
         tgt_mask = torch.triu(torch.ones(T, T, device=ye.device, dtype=torch.bool), diagonal=1)        # valle.py:474-480
         h, _ = self.ar_decoder((ye, None), xe, tgt_mask=tgt_mask, memory_mask=None)                    # :481-488
         return h
 
-    def _fwd_nar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, stage_weight: torch.Tensor) -> torch.Tensor:
+    def _fwd_nar_hidden(self, xe: torch.Tensor, ye: torch.Tensor, stage_weight: torch.Tensor, key_padding_mask=None) -> torch.Tensor:
+        assert key_padding_mask is None
         h, _ = self.nar_decoder((ye, stage_weight), xe, tgt_mask=None, memory_mask=None)               # :537-544
         return h
 

@@ -347,13 +347,44 @@ class MultiheadAttention(_HipModule):
         nn.init.constant_(self.in_proj_bias, 0.0)
         nn.init.constant_(self.out_proj.bias, 0.0)
 
-    def _attend(self, xn: Tensor, B: int, T: int, attn_mask: Optional[Tensor]) -> Tensor:
-        """xn (B*T, d) in the compute dtype -> attention output (B*T, d), before out_proj."""
+    def _attend(self, xn: Tensor, B: int, T: int, attn_mask: Optional[Tensor], key_padding_mask: Optional[Tensor] = None) -> Tensor:
+        """xn (B*T, d) in the compute dtype -> attention output (B*T, d), before out_proj.
+
+        ``key_padding_mask`` (B, T) bool, True = padded position (``src_key_padding_mask`` of the teacher-forced forward,
+        valle.py:846-856, :908-926; any pattern -- VALL-E's is [text | text pad | audio | audio pad]): padded KEYS are invisible to
+        everyone.  Valid rows are packed per sequence and attend under ``attn_mask`` restricted to the valid keys (the ragged
+        packed-row kernel: positions keep their order, the prefix-LM text length counts valid text rows).  Padded QUERY rows are
+        real rows of the reference's batch (its AR loss sums over them): each sees exactly the valid keys of its sequence -- every
+        valid key precedes a padded audio row, so that is what the prefix-LM / causal mask leaves it, and for padded text rows
+        (never read by anyone: masked as keys, not part of the logits) it is merely finite -- computed by the un-masked
+        cross-attention kernel against the sequence's valid K / V."""
         text_len, causal = classify_attn_mask(attn_mask, T)
         qkv = ops.linear(xn, self._w(self.in_proj_weight), self.in_proj_bias.detach())
-        seq_off = torch.arange(0, (B + 1) * T, T, dtype=torch.int32, device=xn.device)
-        tl = torch.full((B,), text_len, dtype=torch.int32, device=xn.device)
-        return ops.attention(qkv, seq_off, tl, self.num_heads, causal)
+        if key_padding_mask is None or not bool(key_padding_mask.to(torch.bool).any()):
+            seq_off = torch.arange(0, (B + 1) * T, T, dtype=torch.int32, device=xn.device)
+            tl = torch.full((B,), text_len, dtype=torch.int32, device=xn.device)
+            return ops.attention(qkv, seq_off, tl, self.num_heads, causal)
+        pad = key_padding_mask.to(torch.bool).to(xn.device)
+        assert tuple(pad.shape) == (B, T), (tuple(pad.shape), B, T)
+        if bool(pad.all(dim=1).any()):
+            raise ValueError("key_padding_mask leaves a sequence without any key")
+        d = qkv.shape[1] // 3
+        valid = ~pad
+        flat_valid = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)
+        n_valid = valid.sum(dim=1)
+        seq_off = torch.zeros(B + 1, dtype=torch.int32, device=xn.device)
+        seq_off[1:] = n_valid.cumsum(0).to(torch.int32)
+        tl = valid[:, :text_len].sum(dim=1).to(torch.int32) if text_len > 0 else torch.zeros(B, dtype=torch.int32, device=xn.device)
+        att = torch.empty(B * T, d, dtype=qkv.dtype, device=xn.device)
+        att[flat_valid] = ops.attention(qkv[flat_valid].contiguous(), seq_off, tl, self.num_heads, causal)
+        offs = seq_off.tolist()
+        for b in range(B):  # padded query rows: all valid keys of their own sequence (scoring batches: a few rows each)
+            prow = pad[b].nonzero(as_tuple=False).squeeze(1) + b * T
+            if prow.numel() == 0:
+                continue
+            vrow = flat_valid[offs[b]: offs[b + 1]]
+            att[prow] = ops.cross_attention(qkv[prow, :d].contiguous(), qkv[vrow, d:].contiguous(), self.num_heads)
+        return att
 
     def _cross_forward(self, query: Tensor, key: Tensor, value: Tensor, key_padding_mask, need_weights, attn_mask):
         """MultiheadAttention.forward(x, mem, mem): VALL-F's ``multihead_attn`` (valle/modules/transformer.py:582-597): queries
@@ -396,8 +427,6 @@ class MultiheadAttention(_HipModule):
             return self._cross_forward(query, key, value, key_padding_mask, need_weights, attn_mask)
         if value is not query:
             raise NotImplementedError("self-attention with a separate value tensor is not on the decode path")
-        if key_padding_mask is not None and bool(key_padding_mask.any()):
-            raise NotImplementedError("key_padding_mask: the decode path runs unpadded sequences")
         if need_weights:
             raise NotImplementedError("need_weights=True (attention maps) is not produced by the flash kernels; "
                                       "the decode path calls with need_weights=False (transformer.py:327)")
@@ -411,7 +440,7 @@ class MultiheadAttention(_HipModule):
             x = x.transpose(0, 1)
         B, T, d = x.shape
         xt = x.reshape(B * T, d).to(self._tdtype()).contiguous()
-        att = self._attend(xt, B, T, attn_mask)
+        att = self._attend(xt, B, T, attn_mask, key_padding_mask)
         out = ops.linear(att, self._w(self.out_proj.weight), self.out_proj.bias.detach(), epilogue=ops.EPI_F32).view(B, T, d)
         if not self.batch_first:
             out = out.transpose(0, 1)
@@ -472,17 +501,17 @@ class TransformerEncoderLayer(_HipModule):
         if src_key_padding_mask is not None:
             if src_key_padding_mask.dtype != torch.bool and not torch.is_floating_point(src_key_padding_mask):
                 raise AssertionError("only bool and floating types of key_padding_mask are supported")
-            if bool(src_key_padding_mask.to(torch.bool).any()):
-                raise NotImplementedError("key_padding_mask: the decode path runs unpadded sequences")
+            if src_key_padding_mask.dtype != torch.bool:
+                raise NotImplementedError("floating key_padding_mask: the teacher-forced forward passes bool masks (make_pad_mask)")
         if self.training and self.dropout.p > 0:
             raise NotImplementedError("dropout (training) is outside the decode path")
         xb = x if self.batch_first else x.transpose(0, 1)
         B, T, d = xb.shape
         res = xb.to(torch.float32).reshape(B * T, d).clone()  # fp32 residual stream; the GEMM epilogues add into it
         if not self.norm_first:
-            return self._post_norm(res, B, T, d, src_mask, stage_embedding, is_src_tuple)
+            return self._post_norm(res, B, T, d, src_mask, stage_embedding, is_src_tuple, src_key_padding_mask)
         xn = self._n(self.norm1, res, stage_embedding)
-        att = self.self_attn._attend(xn, B, T, src_mask)
+        att = self.self_attn._attend(xn, B, T, src_mask, src_key_padding_mask)
         sa = self.self_attn
         ops.linear(att, sa._w(sa.out_proj.weight), sa.out_proj.bias.detach(), epilogue=ops.EPI_RESID, resid=res)
         xn = self._n(self.norm2, res, stage_embedding)
@@ -500,11 +529,11 @@ class TransformerEncoderLayer(_HipModule):
         assert stage_embedding is None
         return norm._norm(x2, torch.float32)
 
-    def _post_norm(self, res: Tensor, B: int, T: int, d: int, src_mask, stage_embedding, is_src_tuple: bool):
+    def _post_norm(self, res: Tensor, B: int, T: int, d: int, src_mask, stage_embedding, is_src_tuple: bool, key_padding_mask=None):
         """transformer.py:303-308: x = norm1(x + SA(x)); x = norm2(x + W2 relu(W1 x + b1) + b2)."""
         sa = self.self_attn
         tdt = self._tdtype()
-        att = sa._attend(res if tdt == torch.float32 else res.to(tdt), B, T, src_mask)
+        att = sa._attend(res if tdt == torch.float32 else res.to(tdt), B, T, src_mask, key_padding_mask)
         ops.linear(att, sa._w(sa.out_proj.weight), sa.out_proj.bias.detach(), epilogue=ops.EPI_RESID, resid=res)  # res = x + SA(x)
         x1 = self._n32(self.norm1, res, stage_embedding)                                                       # the new residual stream
         x1c = x1 if tdt == torch.float32 else self._n(self.norm1, res, stage_embedding)                         # ... in the GEMM's element type

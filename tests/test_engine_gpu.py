@@ -368,6 +368,43 @@ def test_fused_layernorm_batch_step_matches_layernorm_kernels(B, d, h, L, dtype)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8w"])
+@pytest.mark.parametrize("B", [64, 40, 9])
+def test_skinny_gemm_compile_time_layout_body_is_bit_identical(B, dtype):
+    """gemm_skinny.hip's FAST body (fragment-major W and X, whole rounds, every layout decision at compile time; option gs_fast,
+    default 1) against the general body of the same kernel on the batched AR step at d = 1024 (QKV / FFN1 / FFN2 / logits all
+    qualify): same loads, same MFMA order, same epilogue -- the logits of every step must be bit-identical."""
+    d, h, L = 1024, 16, 2
+    cfg = vo.OracleConfig(d_model=d, nhead=h, num_layers=L, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 22)
+    g = torch.Generator().manual_seed(10)
+    S = torch.randint(3, 9, (B,), generator=g).tolist()
+    P = torch.randint(4, 30, (B,), generator=g).tolist()
+    X = torch.zeros(B, max(S), dtype=torch.int64)
+    Y = torch.zeros(B, max(P), 8, dtype=torch.int64)
+    for b in range(B):
+        x, _, y = vo.make_inputs(S[b], P[b], seed=950 + b)
+        X[b, : S[b]] = x[0]; Y[b, : P[b]] = y[0]
+    X, Y = X.to(DEV), Y.to(DEV)
+    m = build_model(cfg, sd, dtype, max_batch=B)
+    eng = m.engine_for(B, max(S), max(P))
+    eng.set_option("trace_ar_logits", 1)
+    eng.set_option("ignore_eos", 1)
+    n = 10
+    out = {}
+    try:
+        for fast in (0, 1):
+            eng.set_option("gs_fast", fast)
+            eng.prefill(X, S, Y, P)
+            c, _ = eng.generate(top_k=1, max_new=n)
+            out[fast] = (c[:, :n].clone(), eng.fetch_ar_logits()[:n + 1].clone())
+    finally:
+        eng.set_option("gs_fast", 1)
+    assert torch.equal(out[0][0], out[1][0])
+    assert torch.equal(out[0][1], out[1][1]), (out[0][1] - out[1][1]).abs().max().item()
+    assert torch.isfinite(out[1][1]).all()
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8w"])
 @pytest.mark.parametrize("fuse_ln", [1, 0])
 @pytest.mark.parametrize("B,d,h,L", [(5, 256, 4, 3), (64, 1024, 16, 2), (33, 1024, 8, 2)])
 def test_attention_with_fused_out_proj_matches_separate_launches(B, d, h, L, dtype, fuse_ln):

@@ -76,7 +76,7 @@ def main():
     rows = []
     fam = {}
     for k in range(nk):
-        gap = ramp = body = spread = ph1 = ph2 = 0.0
+        gap = ramp = body = spread = ph1 = ph2 = ph1f = 0.0
         for s in steps:
             cur = kt[s, k]
             prev_end = kt[s, k - 1, 7] if k > 0 else kt[s - 1, nk - 1, 7]
@@ -85,10 +85,11 @@ def main():
             body += float(cur[7] - cur[0])
             spread += float(cur[7] - cur[6])
             ph1 += float(cur[3] - cur[0])
+            ph1f += float(cur[2] - cur[0])
             ph2 += float(cur[5] - cur[3])
         n = len(steps)
         name = NAMES[k % KPL] if k < KPL * L else ("final_LN+predict" if k == KPL * L else "sample+stop+embed")
-        rows.append((k, name, gap / n, ramp / n, body / n, spread / n, ph1 / n, ph2 / n))
+        rows.append((k, name, gap / n, ramp / n, body / n, spread / n, ph1 / n, ph2 / n, ph1f / n))
         f = fam.setdefault(name, [0, 0.0, 0.0, 0.0])
         f[0] += 1; f[1] += gap / n; f[2] += body / n; f[3] += ramp / n
     wall = sum(float(kt[s + 1, 0, 0] - kt[s, 0, 0]) for s in steps) / len(steps)
@@ -106,9 +107,9 @@ def main():
     )
     os.makedirs(os.path.dirname(os.path.abspath(args.out)), exist_ok=True)
     with open(args.out + "_timeline.csv", "w") as f:
-        f.write("idx,kernel,gap_before_us,start_ramp_us,body_us,end_spread_us,start_to_last_mark1_us,mark1_to_last_mark2_us\n")
+        f.write("idx,kernel,gap_before_us,start_ramp_us,body_us,end_spread_us,start_to_last_mark1_us,mark1_to_last_mark2_us,start_to_first_mark1_us\n")
         for r in rows:
-            f.write(f"{r[0]},{r[1]},{r[2]:.3f},{r[3]:.3f},{r[4]:.3f},{r[5]:.3f},{r[6]:.3f},{r[7]:.3f}\n")
+            f.write(f"{r[0]},{r[1]},{r[2]:.3f},{r[3]:.3f},{r[4]:.3f},{r[5]:.3f},{r[6]:.3f},{r[7]:.3f},{r[8]:.3f}\n")
     json.dump(out, open(args.out + "_summary.json", "w"), indent=1)
     print(json.dumps(out)[:3000])
 

@@ -156,7 +156,12 @@ __device__ inline gs_bf16x8 gs_fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
 // A lane then takes ONE 16-byte vector per 64-deep chunk = the 16 consecutive k of its quarter of the chunk; the two
 // MFMA k-halves use bytes 0-7 and 8-15, and X is read with the same k assignment (any k permutation is a valid dot
 // product as long as both operands agree), so W is still fetched as full 64-byte sectors per row.
-template <int MF, int EPI, bool W8>
+// FAST (round 3): the production configuration -- fragment-major W and X, whole rounds of 4 chunks per wave, N % 16 == 0, no
+// diagnostics -- with every layout decision taken at compile time.  The general body below re-decides them per load (uniform
+// branches on kernel arguments, 64-bit selects between the row-major and fragment-major addresses, clamps): ~6 instructions
+// and a branch per 16-byte load, ~1200 instructions ahead of the first MFMA, executed by the ONE wave a SIMD holds -- the
+// "burst" left the CU over ~1.5 us (tools/ubench_xload.hip: the same 160 KB requested back to back lands in ~1.2 us).
+template <int MF, int EPI, bool W8, bool FAST = false>
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   // k-chunks (64 deep) requested per round
   constexpr int G = 4;  // (8 / 16 at M <= 32 / 16 measured slower: 256 VGPRs + AGPR spills leave one workgroup per CU)
@@ -164,18 +169,24 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if constexpr (FAST) {
+    // one kernarg round trip: every argument the load burst needs is requested with the first s_load batch (left alone the
+    // compiler fetched the segment in three dependent steps, ~0.1-0.2 us each, ahead of the first global load)
+    asm volatile("" ::"s"(a.x), "s"(a.w), "s"(a.bias), "s"(a.wscale), "s"(a.K), "s"(a.N), "s"(a.M), "s"(a.lnc.stats), "s"(a.lnc.wg),
+                 "s"(a.resid), "s"(a.lnp.gamma), "s"(a.kv_len), "s"(a.kt.buf), "s"(a.ks_grid));
+  }
   const unsigned long long kt0 = ktrace_begin(a.kt);
   const int fr = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.x * 16;
   const int K = a.K, N = a.N, M = a.M;
-  const int KS = gridDim.y, ks = blockIdx.y;
+  const int KS = FAST ? a.ks_grid : (int)gridDim.y, ks = blockIdx.y;
   const int Kw = K / (4 * KS);  // this wave's share of K (multiple of 64)
   // Every workgroup reads ALL of X (<= 128 KB, L2-resident) while streaming its own 16 rows of W.  If all workgroups walked X
   // in the same order they would hit the same L2 channels at the same moment; so the K quarter a wave takes and the order of
   // the row fragments inside a chunk are rotated by the workgroup index (sums stay in K order: the combine indexes by quarter).
-  const int wq = a.rot ? (wave + (int)blockIdx.x) & 3 : wave;
-  const int frot = a.rot ? ((int)blockIdx.x >> 2) & 3 : 0;
-  auto fi = [&](int i) -> int { return MF == 4 ? (i ^ frot) : MF == 2 ? (i ^ (frot & 1)) : MF == 3 ? (i + frot) % 3 : 0; };
+  const int wq = (!FAST && a.rot) ? (wave + (int)blockIdx.x) & 3 : wave;
+  const int frot = (!FAST && a.rot) ? ((int)blockIdx.x >> 2) & 3 : 0;
+  auto fi = [&](int i) -> int { return FAST ? i : MF == 4 ? (i ^ frot) : MF == 2 ? (i ^ (frot & 1)) : MF == 3 ? (i + frot) % 3 : 0; };
   const int kbeg = (ks * 4 + wq) * Kw;
   const int nrow = min(n0 + fr, N - 1);
   constexpr int KOFS = W8 ? 16 : 8;   // first k of this lane inside a chunk = fg * KOFS
@@ -197,20 +208,45 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   gs_f32x4 wg4 = gs_f32x4{0.f, 0.f, 0.f, 0.f}, gamma4 = gs_f32x4{1.f, 1.f, 1.f, 1.f};
   constexpr int LN_MAXQ = 16;  // float4 (= 2 slots) per lane: rows up to 4 * 32 * 16 = 2048 wide
   gs_f32x4 lst[LN_MAXQ];
-  const bool ln_in = a.lnc.stats != nullptr;
-  const int ln_nq = ln_in ? a.lnc.nslots >> 3 : 0;  // float4 per lane = (nslots / 4 lanes) / 2
+  constexpr bool kFastLn = EPI == GS_EPI_QKV || EPI == GS_EPI_RELU || EPI == GS_EPI_F32;
+  const bool ln_in = FAST ? kFastLn : a.lnc.stats != nullptr;
+  // float4 per lane = (nslots / 4 lanes) / 2.  Kept a run-time value in the FAST body too (there it is 8): the merge loops of
+  // the epilogue then compile to the same instruction sequence in both bodies -- with a constant trip count hipcc contracted
+  // the mul / add chains into different fma's and the two bodies differed in the last bit of rstd (3e-3 on the logits)
+  const int ln_nq = ln_in ? a.lnc.nslots >> 3 : 0;
   gs_f32x4 old4 = gs_f32x4{0.f, 0.f, 0.f, 0.f};
   int kvl = 0;
   auto request_epilogue_operands = [&]() {
+    if constexpr (FAST) {
+      // no branches: the compiler then knows how many loads follow the W / X burst and lets the MFMAs wait for the burst only
+      // (vmcnt(n)); behind a uniform branch it waited for these operands too.  FAST launches have a bias, LayerNorm statistics
+      // exactly when the epilogue is one that consumes them (64 slots: 8 vectors per lane), and rows are clamped, not skipped.
+      constexpr bool LN = EPI == GS_EPI_QKV || EPI == GS_EPI_RELU || EPI == GS_EPI_F32;
+      const int mrow = min(wave * 16 + fr, M - 1);
+      bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
+      if constexpr (W8) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
+      if constexpr (LN) {
+        wg4 = *reinterpret_cast<const gs_f32x4*>(a.lnc.wg + ncol);
+        const float* sp = a.lnc.stats + (int64_t)mrow * 128 + fg * 4;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 16);
+      }
+      if constexpr (EPI == GS_EPI_RESID) {
+        gamma4 = *reinterpret_cast<const gs_f32x4*>((a.lnp.gamma != nullptr ? a.lnp.gamma : a.bias) + ncol);
+        old4 = *reinterpret_cast<const gs_f32x4*>(a.resid + (int64_t)mrow * N + ncol);
+      }
+      if constexpr (EPI == GS_EPI_QKV) kvl = a.kv_len[mrow];
+      return;
+    }
     if (a.bias != nullptr) {
-      if (ncol + 3 < N) bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
+      if (FAST || ncol + 3 < N) bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
       else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias4[r] = ncol + r < N ? a.bias[ncol + r] : 0.f;
       }
     }
     if constexpr (W8) {
-      if (ncol + 3 < N) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
+      if (FAST || ncol + 3 < N) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
       else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) scale4[r] = ncol + r < N ? a.wscale[ncol + r] : 1.f;
@@ -219,22 +255,28 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     // fused LayerNorm (kernels.h): consumer operands (wg of this lane's 4 columns; the group statistics of the row this lane
     // finishes, 16 rows per wave, the lane's quarter of the row's slots) and the producer's gamma
     if (ln_in) {
-      if (ncol + 3 < N) wg4 = *reinterpret_cast<const gs_f32x4*>(a.lnc.wg + ncol);
+      if (FAST || ncol + 3 < N) wg4 = *reinterpret_cast<const gs_f32x4*>(a.lnc.wg + ncol);
       else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) wg4[r] = ncol + r < N ? a.lnc.wg[ncol + r] : 0.f;
       }
       if (wave < MF) {
-        const float* sp = a.lnc.stats + ((int64_t)min(wave * 16 + fr, M - 1) * a.lnc.nslots + fg * (a.lnc.nslots >> 2)) * 2;
+        // lane (fr, fg) takes the slot pairs 4 j + fg, j = 0 .. nslots / 8: the four lanes of a row read one contiguous 64 bytes
+        // per instruction (16 segments per wave-load; a lane walking its own quarter of the row touched 64 lines per instruction)
+        const float* sp = a.lnc.stats + ((int64_t)min(wave * 16 + fr, M - 1) * a.lnc.nslots) * 2 + fg * 4;
 #pragma unroll
-        for (int j = 0; j < LN_MAXQ; ++j)
-          if (j < ln_nq) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 4);
+        for (int j0 = 0; j0 < LN_MAXQ; j0 += 4)
+          if (j0 < ln_nq) {
+#pragma unroll
+            for (int j = j0; j < j0 + 4; ++j)
+              if (FAST || j < ln_nq) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 16);
+          }
       }
     }
     if constexpr (EPI == GS_EPI_RESID) {
-      if (a.lnp.gamma != nullptr && ncol + 3 < N) gamma4 = *reinterpret_cast<const gs_f32x4*>(a.lnp.gamma + ncol);
+      if (a.lnp.gamma != nullptr && (FAST || ncol + 3 < N)) gamma4 = *reinterpret_cast<const gs_f32x4*>(a.lnp.gamma + ncol);
       // the residual row this lane finishes (wave i: fragment i): nobody else writes it during this launch
-      if (wave < MF && wave * 16 + fr < M && ncol + 3 < N && (N & 3) == 0)
+      if (wave < MF && wave * 16 + fr < M && (FAST || (ncol + 3 < N && (N & 3) == 0)))
         old4 = *reinterpret_cast<const gs_f32x4*>(a.resid + (int64_t)(wave * 16 + fr) * N + ncol);
     }
     if constexpr (EPI == GS_EPI_QKV) {
@@ -249,6 +291,21 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   const int chunks = Kw >> 6;
   for (int c0 = 0; c0 < chunks; c0 += G) {
     gs_u32x4 wv[G][2], xv[G][MF][2];
+    if constexpr (FAST) {
+      const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w) +
+                                ((int64_t)blockIdx.x * (K >> 6) + (kbeg >> 6) + c0) * (W8 ? 1024 : 2048) + lane * 16;
+      const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + (int64_t)((kbeg >> 6) + c0) * (2 * MF * 1024) + lane * 16;
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wb + g * (W8 ? 1024 : 2048)));
+        if constexpr (!W8) wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wb + g * 2048 + 1024));
+#pragma unroll
+        for (int i = 0; i < MF; ++i) {
+          xv[g][i][0] = *reinterpret_cast<const gs_u32x4*>(xb + ((g * 2 + 0) * MF + i) * 1024);
+          xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xb + ((g * 2 + 1) * MF + i) * 1024);
+        }
+      }
+    } else
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int c = min(c0 + g, chunks - 1);  // clamped: a short last round re-reads its final chunk, unused below
@@ -285,7 +342,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if (c0 + g < chunks) {
+      if (FAST || c0 + g < chunks) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           gs_bf16x8 wa;
@@ -372,12 +429,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     for (int j = 0; j < LN_MAXQ; ++j)
       if (j < ln_nq) {
         const float d0 = lst[j][0] - mean, d1 = lst[j][2] - mean;
-        m2 += (lst[j][1] + lst[j][3]) + 16.f * (d0 * d0 + d1 * d1);
+        m2 += fmaf(16.f, fmaf(d1, d1, d0 * d0), lst[j][1] + lst[j][3]);
       }
     m2 = rows4_sum(m2);
     const float rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
     if constexpr (W8) v = v * scale4;
-    v = (v - mean * wg4) * rstd + bias4;  // bias4 = wb = W beta + bias
+    // explicit fma's: left to -ffp-contract the compile-time-layout body fused the last step and the general body did not
+    v = __builtin_elementwise_fma(__builtin_elementwise_fma(gs_f32x4{-mean, -mean, -mean, -mean}, wg4, v), gs_f32x4{rstd, rstd, rstd, rstd}, bias4);  // bias4 = wb = W beta + bias
   } else {
     if constexpr (W8) v = v * scale4 + bias4;  // * 2^e is exact
     else v += bias4;
@@ -401,18 +459,33 @@ int gemm_skinny_ksplit(int N, int K, int target_wgs) {
 
 size_t gemm_skinny_workspace_bytes() { return GS_WS_CNT_BYTES + (size_t)GS_WS_MAX_TILES * 64 * 16 * sizeof(float); }
 
-template <int MF, bool W8>
-static int gs_launch_w(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
-  const dim3 grid((a.N + 15) / 16, KS), block(256);
+int g_gs_fast = 1;  // "gs_fast": 0 = always the general body (A/B)
+
+template <int MF, bool W8, bool FAST>
+static int gs_launch_f(hipStream_t st, const GemmSkinnyArgs& a0, int KS) {
+  const dim3 grid((a0.N + 15) / 16, KS), block(256);
+  GemmSkinnyArgs a = a0;
+  a.ks_grid = KS;
   switch (a.epi) {
-    case GS_EPI_STORE: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_STORE, W8>), grid, block, 0, st, a); break;
-    case GS_EPI_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RELU, W8>), grid, block, 0, st, a); break;
-    case GS_EPI_RESID: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RESID, W8>), grid, block, 0, st, a); break;
-    case GS_EPI_F32: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_F32, W8>), grid, block, 0, st, a); break;
-    case GS_EPI_QKV: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_QKV, W8>), grid, block, 0, st, a); break;
+    case GS_EPI_STORE: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_STORE, W8, FAST>), grid, block, 0, st, a); break;
+    case GS_EPI_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RELU, W8, FAST>), grid, block, 0, st, a); break;
+    case GS_EPI_RESID: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RESID, W8, FAST>), grid, block, 0, st, a); break;
+    case GS_EPI_F32: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_F32, W8, FAST>), grid, block, 0, st, a); break;
+    case GS_EPI_QKV: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_QKV, W8, FAST>), grid, block, 0, st, a); break;
     default: return -1;
   }
   return 0;
+}
+
+template <int MF, bool W8>
+static int gs_launch_w(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
+  // the compile-time layout (see the kernel): fragment-major W and X (X padded to MF * 16 rows), whole rounds of 4 chunks per
+  // wave, whole 16-column fragments, a bias, 64-slot LayerNorm statistics exactly on the consuming epilogues, no diagnostics
+  const bool ln_epi = a.epi == GS_EPI_QKV || a.epi == GS_EPI_RELU || a.epi == GS_EPI_F32;
+  const bool fast = g_gs_fast && a.w_packed && a.x_xf != 0 && a.dbg == 0 && a.rot == 0 && a.N % 16 == 0 && (a.K / (4 * KS)) % 256 == 0 &&
+                    a.bias != nullptr && (a.lnc.stats != nullptr) == ln_epi && (!ln_epi || a.lnc.nslots == 64) &&
+                    (a.epi != GS_EPI_RESID || a.resid != nullptr) && (a.epi != GS_EPI_QKV || a.kv_len != nullptr);
+  return fast ? gs_launch_f<MF, W8, true>(st, a, KS) : gs_launch_f<MF, W8, false>(st, a, KS);
 }
 
 template <int MF>
@@ -440,6 +513,7 @@ bool gemm_skinny_supports(int M, int N, int K, int epi, int dh) {
 template <int NW, int EPI, bool W8>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs a) {
   constexpr int G = 4;
+  constexpr bool FAST = false;  // (the compile-time layout of gemm_skinny_kernel is not instantiated for this kernel)
   __shared__ __attribute__((aligned(16))) float red[NW][64][4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -469,14 +543,14 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs 
   auto request_epilogue_operands = [&]() {  // wave 0 finishes the tile
     if (wave != 0) return;
     if (a.bias != nullptr) {
-      if (ncol + 3 < N) bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
+      if (FAST || ncol + 3 < N) bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
       else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) bias4[r] = ncol + r < N ? a.bias[ncol + r] : 0.f;
       }
     }
     if constexpr (W8) {
-      if (ncol + 3 < N) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
+      if (FAST || ncol + 3 < N) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
       else {
 #pragma unroll
         for (int r = 0; r < 4; ++r) scale4[r] = ncol + r < N ? a.wscale[ncol + r] : 1.f;
@@ -570,12 +644,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs 
     for (int j = 0; j < LN_MAXQ; ++j)
       if (j < ln_nq) {
         const float d0 = lst[j][0] - mean, d1 = lst[j][2] - mean;
-        m2 += (lst[j][1] + lst[j][3]) + 16.f * (d0 * d0 + d1 * d1);
+        m2 += fmaf(16.f, fmaf(d1, d1, d0 * d0), lst[j][1] + lst[j][3]);
       }
     m2 = rows4_sum(m2);
     const float rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
     if constexpr (W8) v = v * scale4;
-    v = (v - mean * wg4) * rstd + bias4;
+    // explicit fma's: left to -ffp-contract the compile-time-layout body fused the last step and the general body did not
+    v = __builtin_elementwise_fma(__builtin_elementwise_fma(gs_f32x4{-mean, -mean, -mean, -mean}, wg4, v), gs_f32x4{rstd, rstd, rstd, rstd}, bias4);
   } else {
     if constexpr (W8) v = v * scale4 + bias4;
     else v += bias4;

@@ -89,6 +89,7 @@ struct GemmSkinnyArgs {
   int ms_nt = 0;   // M-split kernel: non-temporal W loads (A/B; filled by the launcher)
   int formal = 0;  // split-K hand-off with explicit release / acquire fences (filled by the launcher from g_gs_formal)
   int rot = 0;  // rotate the order in which a workgroup walks X by its index (option "gs_rot")
+  int ks_grid = 1;  // = gridDim.y, filled by the launcher (the FAST body reads it with the other arguments instead of the implicit ones)
   const void* x = nullptr;     // bf16 [M][K]
   const void* w = nullptr;     // bf16 [N][K]
   const float* bias = nullptr; // f32 [N] or null
@@ -117,6 +118,7 @@ constexpr int GS_WS_MAX_TILES = 2048;  // partial 16 x 64 fp32 tiles (4 KB each)
 extern int g_da_nt;       // decode_attn.hip: non-temporal K / V loads (-1 auto, 0, 1)
 extern int g_da_lds_pad;  // decode_attn.hip: dynamic LDS bytes per workgroup of the batched decode attention (occupancy cap)
 extern int g_gs_formal;
+extern int g_gs_fast;  // gemm_skinny.hip: compile-time-layout body of the split-K skinny GEMM where the launch qualifies (default 1)
 extern int g_gs_ms_pad;
 extern int g_gs_msplit;  // gemm_skinny.hip: M-split kernel for N / 16 < #CUs (default 1)
 size_t gemm_skinny_workspace_bytes();

@@ -1,7 +1,7 @@
 #!/bin/bash
 # round 3: FAST body of gemm_skinny -- parity, then the B = 64 timeline and bench
 D=gpurun_out/r3v; mkdir -p $D
-timeout 900 python -m pytest tests/test_engine_gpu.py -q -k "compile_time_layout or fused_layernorm or fused_out_proj or batch_path or ragged_batch" 2>&1 | tail -8
+timeout 900 python -m pytest tests/test_engine_gpu.py tests/test_ops_gpu.py -q -k "compile_time_layout or fused_layernorm or fused_out_proj or batch_path or ragged_batch or m_split or split_k" 2>&1 | tail -8
 timeout 300 python tools/ktrace_dist.py --out $D/ktrace_dist.json > $D/ktrace_dist.log 2>&1
 python - <<'PY'
 import json

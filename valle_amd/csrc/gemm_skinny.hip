@@ -284,6 +284,38 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     }
   };
 
+  // merge of the row's 16-column groups (mean_g, M2_g = sum (x - mean_g)^2).  Every group has 16 elements, so the union is
+  //   mean = average of the group means,   M2 = sum_g M2_g + 16 sum_g (mean_g - mean)^2
+  // (Chan et al. for equal counts): two short passes over the lane's share of the slots, no dependent chain of running means
+  // (the general pairwise update cost ~15 instructions per group).  Fixed order, and the cross-lane sums over fg = 0..3 are
+  // commutative pairwise adds: all four lanes of a row agree bitwise.  ~150 dependent instructions for the one wave a SIMD
+  // holds (0.4 us): the FAST body requests the statistics AHEAD of the W / X burst and runs this while the burst is in flight.
+  float ln_mean = 0.f, ln_rstd = 1.f;
+  auto ln_merge = [&]() {
+    float msum = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j)
+      if (j < ln_nq) msum += lst[j][0] + lst[j][2];
+    msum = rows4_sum(msum);
+    const float cnt = 16.f * (float)a.lnc.nslots;  // = K of the producer's rows
+    const float mean = msum / (float)a.lnc.nslots;
+    float m2 = 0.f;
+#pragma unroll
+    for (int j = 0; j < LN_MAXQ; ++j)
+      if (j < ln_nq) {
+        const float d0 = lst[j][0] - mean, d1 = lst[j][2] - mean;
+        m2 += fmaf(16.f, fmaf(d1, d1, d0 * d0), lst[j][1] + lst[j][3]);
+      }
+    m2 = rows4_sum(m2);
+    ln_mean = mean;
+    ln_rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
+  };
+  // Measured (MI355X, 64 utterances, tools/ktrace_dist.py): with the statistics requested first and merged under the burst the
+  // epilogue after the MFMAs shrinks 1.2 -> 0.5 us, but the MFMAs start 0.7 us later (the statistics are the last thing the
+  // previous kernel wrote, and the slowest to arrive) and a 99th-percentile tail appears (4.6 -> 5.5-6.0 us): C3 553.2 vs 553.8 k
+  // tokens/s.  Kept off: the simpler order has no tail.
+  constexpr bool OPS_FIRST = false && FAST && kFastLn;
+
   gs_f32x4 acc[MF];
 #pragma unroll
   for (int i = 0; i < MF; ++i) acc[i] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
@@ -291,6 +323,9 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   const int chunks = Kw >> 6;
   for (int c0 = 0; c0 < chunks; c0 += G) {
     gs_u32x4 wv[G][2], xv[G][MF][2];
+    if constexpr (OPS_FIRST) {
+      if (c0 == 0) request_epilogue_operands();
+    }
     if constexpr (FAST) {
       const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w) +
                                 ((int64_t)blockIdx.x * (K >> 6) + (kbeg >> 6) + c0) * (W8 ? 1024 : 2048) + lane * 16;
@@ -338,8 +373,16 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
         xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 1) * MF + fi(i)) * 512 : xp[i] + c * 64 + SSTEP);
       }
     }
-    if (c0 == 0) request_epilogue_operands();
+    if constexpr (!OPS_FIRST) {
+      if (c0 == 0) request_epilogue_operands();
+    }
     __builtin_amdgcn_sched_barrier(0);
+    if constexpr (OPS_FIRST) {
+      if (c0 == 0) {
+        ln_merge();
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       if (FAST || c0 + g < chunks) {
@@ -412,27 +455,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   }
   if (wave >= MF) return;
   if (ln_in) {
-    // merge the row's 16-column groups (mean_g, M2_g = sum (x - mean_g)^2).  Every group has 16 elements, so the union is
-    //   mean = average of the group means,   M2 = sum_g M2_g + 16 sum_g (mean_g - mean)^2
-    // (Chan et al. for equal counts): two short passes over the lane's quarter of the slots, no divisions, no dependent chain of
-    // running means (the general pairwise update cost ~15 instructions per group on the epilogue's critical path).  Fixed order,
-    // and the cross-lane sums over fg = 0..3 are commutative pairwise adds: all four lanes of a row agree bitwise.
-    float msum = 0.f;
-#pragma unroll
-    for (int j = 0; j < LN_MAXQ; ++j)
-      if (j < ln_nq) msum += lst[j][0] + lst[j][2];
-    msum = rows4_sum(msum);
-    const float cnt = 16.f * (float)a.lnc.nslots;  // = K of the producer's rows
-    const float mean = msum / (float)a.lnc.nslots;
-    float m2 = 0.f;
-#pragma unroll
-    for (int j = 0; j < LN_MAXQ; ++j)
-      if (j < ln_nq) {
-        const float d0 = lst[j][0] - mean, d1 = lst[j][2] - mean;
-        m2 += fmaf(16.f, fmaf(d1, d1, d0 * d0), lst[j][1] + lst[j][3]);
-      }
-    m2 = rows4_sum(m2);
-    const float rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
+    if constexpr (!OPS_FIRST) ln_merge();
+    const float mean = ln_mean, rstd = ln_rstd;
     if constexpr (W8) v = v * scale4;
     // explicit fma's: left to -ffp-contract the compile-time-layout body fused the last step and the general body did not
     v = __builtin_elementwise_fma(__builtin_elementwise_fma(gs_f32x4{-mean, -mean, -mean, -mean}, wg4, v), gs_f32x4{rstd, rstd, rstd, rstd}, bias4);  // bias4 = wb = W beta + bias
@@ -510,17 +534,20 @@ bool gemm_skinny_supports(int M, int N, int K, int epi, int dh) {
 // W fragment run on the same XCD when N / 16 is a multiple of 8 (block -> XCD = linear index % 8) and share the rows through
 // its L2 (default cache policy instead of non-temporal loads); each reads only ITS 16 rows of X.  Texture-path bytes per CU:
 // W 2 K / NW x NW + X 2 K x 16 = 64 K bytes (vs 160 KB at d = 1024 above), on 256 CUs instead of 64.
-template <int NW, int EPI, bool W8>
+template <int NW, int EPI, bool W8, bool FAST = false>
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs a) {
-  constexpr int G = 4;
-  constexpr bool FAST = false;  // (the compile-time layout of gemm_skinny_kernel is not instantiated for this kernel)
+  constexpr int G = 4;  // FAST: the compile-time layout of gemm_skinny_kernel (fragment-major W and X, whole rounds, one kernarg batch)
   __shared__ __attribute__((aligned(16))) float red[NW][64][4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if constexpr (FAST) {
+    asm volatile("" ::"s"(a.x), "s"(a.w), "s"(a.bias), "s"(a.wscale), "s"(a.K), "s"(a.N), "s"(a.M), "s"(a.lnc.stats), "s"(a.lnc.wg),
+                 "s"(a.resid), "s"(a.lnp.gamma), "s"(a.kv_len), "s"(a.kt.buf), "s"(a.ks_grid));
+  }
   const unsigned long long kt0 = ktrace_begin(a.kt);
   const int fr = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.x * 16, mi = blockIdx.y, m0 = mi * 16;
-  const int K = a.K, N = a.N, M = a.M, MFt = gridDim.y;
+  const int K = a.K, N = a.N, M = a.M, MFt = FAST ? a.ks_grid : (int)gridDim.y;
   const int Kw = K / NW;  // multiple of 64 (launcher)
   const int kbeg = wave * Kw;
   const int nrow = min(n0 + fr, N - 1);
@@ -578,6 +605,22 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs 
   const int chunks = Kw >> 6;
   for (int c0 = 0; c0 < chunks; c0 += G) {
     gs_u32x4 wv[G][2], xv[G][2];
+    if constexpr (FAST) {
+      const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w) +
+                                ((int64_t)blockIdx.x * (K >> 6) + (kbeg >> 6) + c0) * (W8 ? 1024 : 2048) + lane * 16;
+      const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + ((int64_t)((kbeg >> 6) + c0) * 2 * MFt + mi) * 1024 + lane * 16;
+      const int64_t xs = (int64_t)MFt * 1024;  // bytes between the two k-halves of a chunk (and half a chunk)
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        wv[g][0] = *reinterpret_cast<const gs_u32x4*>(wb + g * (W8 ? 1024 : 2048));
+        if constexpr (!W8) wv[g][1] = *reinterpret_cast<const gs_u32x4*>(wb + g * 2048 + 1024);
+      }
+#pragma unroll
+      for (int g = 0; g < G; ++g) {
+        xv[g][0] = *reinterpret_cast<const gs_u32x4*>(xb + (g * 2 + 0) * xs);
+        xv[g][1] = *reinterpret_cast<const gs_u32x4*>(xb + (g * 2 + 1) * xs);
+      }
+    } else {
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int c = min(c0 + g, chunks - 1);
@@ -608,11 +651,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs 
       xv[g][0] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 0) * MFt + mi) * 512 : xp + c * 64);
       xv[g][1] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 1) * MFt + mi) * 512 : xp + c * 64 + SSTEP);
     }
+    }
     if (c0 == 0) request_epilogue_operands();
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if (c0 + g < chunks) {
+      if (FAST || c0 + g < chunks) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           gs_bf16x8 wa;
@@ -671,7 +715,7 @@ int g_gs_msplit = 1;
 int g_gs_ms_pad = 0;
 
 template <int NW, int EPI, bool W8>
-static int gs_ms_launch_one(hipStream_t st, const GemmSkinnyArgs& a, dim3 grid, dim3 block) {
+static int gs_ms_launch_one(hipStream_t st, const GemmSkinnyArgs& a0, dim3 grid, dim3 block) {
   unsigned pad = (NW == 16 && g_gs_ms_pad > 0) ? (unsigned)g_gs_ms_pad : 0u;
   if (pad > 0) {
     static bool attr_set = false;
@@ -685,7 +729,12 @@ static int gs_ms_launch_one(hipStream_t st, const GemmSkinnyArgs& a, dim3 grid, 
       }
     }
   }
-  hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, EPI, W8>), grid, block, pad, st, a);
+  GemmSkinnyArgs a = a0;
+  a.ks_grid = (int)grid.y;
+  // the compile-time layout (gemm_skinny_kernel's FAST body): fragment-major operands, whole rounds of 4 chunks per wave
+  const bool fast = g_gs_fast && pad == 0 && a.w_packed && a.x_xf != 0 && a.ms_nt == 0 && a.dbg == 0 && a.N % 16 == 0 && (a.K / NW) % 256 == 0;
+  if (fast) hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, EPI, W8, true>), grid, block, 0, st, a);
+  else hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, EPI, W8>), grid, block, pad, st, a);
   return 0;
 }
 

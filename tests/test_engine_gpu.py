@@ -368,12 +368,14 @@ def test_fused_layernorm_batch_step_matches_layernorm_kernels(B, d, h, L, dtype)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8w"])
-@pytest.mark.parametrize("B", [64, 40, 9])
-def test_skinny_gemm_compile_time_layout_body_is_bit_identical(B, dtype):
-    """gemm_skinny.hip's FAST body (fragment-major W and X, whole rounds, every layout decision at compile time; option gs_fast,
-    default 1) against the general body of the same kernel on the batched AR step at d = 1024 (QKV / FFN1 / FFN2 / logits all
-    qualify): same loads, same MFMA order, same epilogue -- the logits of every step must be bit-identical."""
-    d, h, L = 1024, 16, 2
+@pytest.mark.parametrize("B,d,h", [(64, 1024, 16), (40, 1024, 16), (9, 1024, 16), (33, 1536, 16), (17, 512, 8)])
+def test_skinny_gemm_compile_time_layout_body_is_bit_identical(B, d, h, dtype):
+    """gemm_skinny.hip's FAST bodies (fragment-major W and X, rounds of 4 chunks + a round of 2, every layout decision at compile
+    time; option gs_fast, default 1) against the general bodies of the same kernels on the batched AR step: d = 1024 (4 chunks
+    per wave: QKV / FFN1 / FFN2 and the M-split out-proj all qualify), d = 1536 (4 + 2 chunks, 96 statistics slots; M-split
+    with 3 chunks) and d = 512 (one round of 2; the LayerNorm consumers stay on the general body).  Same loads, same MFMA
+    order, same epilogue arithmetic (explicit fma's): the logits of every step must be bit-identical."""
+    L = 2
     cfg = vo.OracleConfig(d_model=d, nhead=h, num_layers=L, prefix_mode=1)
     sd = vo.make_state_dict(cfg, 22)
     g = torch.Generator().manual_seed(10)

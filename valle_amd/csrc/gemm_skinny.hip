@@ -31,6 +31,8 @@
 // the load -> LDS -> barrier -> ds_read prologue serialises what this kernel requests as one burst; LayerNorm fused
 // into that prologue 13.1 us vs 1.9 (LayerNorm launch) + 7.2.  All four shapes cost ~7.2 us regardless of W size
 // (2-8 MB): the launch is latency-bound on the X fragments (4x the bytes of W through each CU's texture path).
+#include <type_traits>
+
 #include "common.h"
 #include "kernels.h"
 
@@ -161,7 +163,7 @@ __device__ inline gs_bf16x8 gs_fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
 // branches on kernel arguments, 64-bit selects between the row-major and fragment-major addresses, clamps): ~6 instructions
 // and a branch per 16-byte load, ~1200 instructions ahead of the first MFMA, executed by the ONE wave a SIMD holds -- the
 // "burst" left the CU over ~1.5 us (tools/ubench_xload.hip: the same 160 KB requested back to back lands in ~1.2 us).
-template <int MF, int EPI, bool W8, bool FAST = false>
+template <int MF, int EPI, bool W8, int FAST = 0>  // FAST: 0 = general body, 1 = whole rounds of 4 chunks, 2 = + one round of 2
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   // k-chunks (64 deep) requested per round
   constexpr int G = 4;  // (8 / 16 at M <= 32 / 16 measured slower: 256 VGPRs + AGPR spills leave one workgroup per CU)
@@ -220,16 +222,17 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     if constexpr (FAST) {
       // no branches: the compiler then knows how many loads follow the W / X burst and lets the MFMAs wait for the burst only
       // (vmcnt(n)); behind a uniform branch it waited for these operands too.  FAST launches have a bias, LayerNorm statistics
-      // exactly when the epilogue is one that consumes them (64 slots: 8 vectors per lane), and rows are clamped, not skipped.
+      // exactly when the epilogue is one that consumes them (64 / 96 slots: 8 / 12 vectors per lane), and rows are clamped, not skipped.
       constexpr bool LN = EPI == GS_EPI_QKV || EPI == GS_EPI_RELU || EPI == GS_EPI_F32;
       const int mrow = min(wave * 16 + fr, M - 1);
       bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
       if constexpr (W8) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
       if constexpr (LN) {
         wg4 = *reinterpret_cast<const gs_f32x4*>(a.lnc.wg + ncol);
-        const float* sp = a.lnc.stats + (int64_t)mrow * 128 + fg * 4;
+        constexpr int NSLOTS = FAST == 2 ? 96 : 64;  // the launcher admits exactly these (d = 1024 / 1536)
+        const float* sp = a.lnc.stats + (int64_t)mrow * (2 * NSLOTS) + fg * 4;
 #pragma unroll
-        for (int j = 0; j < 8; ++j) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 16);
+        for (int j = 0; j < NSLOTS / 8; ++j) lst[j] = *reinterpret_cast<const gs_f32x4*>(sp + j * 16);
       }
       if constexpr (EPI == GS_EPI_RESID) {
         gamma4 = *reinterpret_cast<const gs_f32x4*>((a.lnp.gamma != nullptr ? a.lnp.gamma : a.bias) + ncol);
@@ -289,7 +292,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   // (Chan et al. for equal counts): two short passes over the lane's share of the slots, no dependent chain of running means
   // (the general pairwise update cost ~15 instructions per group).  Fixed order, and the cross-lane sums over fg = 0..3 are
   // commutative pairwise adds: all four lanes of a row agree bitwise.  ~150 dependent instructions for the one wave a SIMD
-  // holds (0.4 us): the FAST body requests the statistics AHEAD of the W / X burst and runs this while the burst is in flight.
+  // holds (0.4 us).
   float ln_mean = 0.f, ln_rstd = 1.f;
   auto ln_merge = [&]() {
     float msum = 0.f;
@@ -310,28 +313,26 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     ln_mean = mean;
     ln_rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
   };
-  // Measured (MI355X, 64 utterances, tools/ktrace_dist.py): with the statistics requested first and merged under the burst the
-  // epilogue after the MFMAs shrinks 1.2 -> 0.5 us, but the MFMAs start 0.7 us later (the statistics are the last thing the
-  // previous kernel wrote, and the slowest to arrive) and a 99th-percentile tail appears (4.6 -> 5.5-6.0 us): C3 553.2 vs 553.8 k
-  // tokens/s.  Kept off: the simpler order has no tail.
-  constexpr bool OPS_FIRST = false && FAST && kFastLn;
+  // Measured and rejected (MI355X, 64 utterances, tools/ktrace_dist.py): requesting the statistics AHEAD of the W / X burst and
+  // merging them while the burst is in flight shrinks the epilogue after the MFMAs 1.2 -> 0.5 us, but the MFMAs start 0.7 us
+  // later (the statistics are the last thing the previous kernel wrote, and the slowest to arrive): C3 553.2 vs 553.8 k tokens/s.
 
   gs_f32x4 acc[MF];
 #pragma unroll
   for (int i = 0; i < MF; ++i) acc[i] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int chunks = Kw >> 6;
-  for (int c0 = 0; c0 < chunks; c0 += G) {
-    gs_u32x4 wv[G][2], xv[G][MF][2];
-    if constexpr (OPS_FIRST) {
-      if (c0 == 0) request_epilogue_operands();
-    }
-    if constexpr (FAST) {
+  if constexpr (FAST != 0) {
+    // rounds of 4 chunks, then (FAST == 2) one round of 2: at d = 1536 a wave's share of K is 6 chunks.  One base per operand,
+    // every offset a compile-time constant; the epilogue's operands are requested behind the first round's burst.
+    auto round = [&](auto gn_c, const int c0) {
+      constexpr int GN = decltype(gn_c)::value;
+      gs_u32x4 wv[GN][2], xv[GN][MF][2];
       const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w) +
                                 ((int64_t)blockIdx.x * (K >> 6) + (kbeg >> 6) + c0) * (W8 ? 1024 : 2048) + lane * 16;
       const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + (int64_t)((kbeg >> 6) + c0) * (2 * MF * 1024) + lane * 16;
 #pragma unroll
-      for (int g = 0; g < G; ++g) {
+      for (int g = 0; g < GN; ++g) {
         wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wb + g * (W8 ? 1024 : 2048)));
         if constexpr (!W8) wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wb + g * 2048 + 1024));
 #pragma unroll
@@ -340,7 +341,27 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
           xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xb + ((g * 2 + 1) * MF + i) * 1024);
         }
       }
-    } else
+      if (c0 == 0) request_epilogue_operands();
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int g = 0; g < GN; ++g) {
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+          gs_bf16x8 wa;
+          if constexpr (W8) wa = gs_fp8x8_to_bf16(wv[g][0][2 * s], wv[g][0][2 * s + 1]);
+          else wa = __builtin_bit_cast(gs_bf16x8, wv[g][s]);
+#pragma unroll
+          for (int i = 0; i < MF; ++i)
+            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(gs_bf16x8, xv[g][i][s]), acc[i], 0, 0, 0);
+        }
+      }
+    };
+    int c0 = 0;
+    for (; c0 + 4 <= chunks; c0 += 4) round(std::integral_constant<int, 4>{}, c0);
+    if constexpr (FAST == 2) round(std::integral_constant<int, 2>{}, c0);
+  } else {
+  for (int c0 = 0; c0 < chunks; c0 += G) {
+    gs_u32x4 wv[G][2], xv[G][MF][2];
 #pragma unroll
     for (int g = 0; g < G; ++g) {
       const int c = min(c0 + g, chunks - 1);  // clamped: a short last round re-reads its final chunk, unused below
@@ -373,19 +394,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
         xv[g][i][1] = *reinterpret_cast<const gs_u32x4*>(xfrag ? xfb + ((c * 2 + 1) * MF + fi(i)) * 512 : xp[i] + c * 64 + SSTEP);
       }
     }
-    if constexpr (!OPS_FIRST) {
-      if (c0 == 0) request_epilogue_operands();
-    }
+    if (c0 == 0) request_epilogue_operands();
     __builtin_amdgcn_sched_barrier(0);
-    if constexpr (OPS_FIRST) {
-      if (c0 == 0) {
-        ln_merge();
-        __builtin_amdgcn_sched_barrier(0);
-      }
-    }
 #pragma unroll
     for (int g = 0; g < G; ++g) {
-      if (FAST || c0 + g < chunks) {
+      if (c0 + g < chunks) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
           gs_bf16x8 wa;
@@ -397,6 +410,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
         }
       }
     }
+  }
   }
 
   // ---- combine the four K quarters through LDS; wave i finishes m-fragment i ------------------------
@@ -455,7 +469,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   }
   if (wave >= MF) return;
   if (ln_in) {
-    if constexpr (!OPS_FIRST) ln_merge();
+    ln_merge();
     const float mean = ln_mean, rstd = ln_rstd;
     if constexpr (W8) v = v * scale4;
     // explicit fma's: left to -ffp-contract the compile-time-layout body fused the last step and the general body did not
@@ -485,7 +499,7 @@ size_t gemm_skinny_workspace_bytes() { return GS_WS_CNT_BYTES + (size_t)GS_WS_MA
 
 int g_gs_fast = 1;  // "gs_fast": 0 = always the general body (A/B)
 
-template <int MF, bool W8, bool FAST>
+template <int MF, bool W8, int FAST>
 static int gs_launch_f(hipStream_t st, const GemmSkinnyArgs& a0, int KS) {
   const dim3 grid((a0.N + 15) / 16, KS), block(256);
   GemmSkinnyArgs a = a0;
@@ -503,13 +517,15 @@ static int gs_launch_f(hipStream_t st, const GemmSkinnyArgs& a0, int KS) {
 
 template <int MF, bool W8>
 static int gs_launch_w(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
-  // the compile-time layout (see the kernel): fragment-major W and X (X padded to MF * 16 rows), whole rounds of 4 chunks per
-  // wave, whole 16-column fragments, a bias, 64-slot LayerNorm statistics exactly on the consuming epilogues, no diagnostics
+  // the compile-time layout (see the kernel): fragment-major W and X (X padded to MF * 16 rows), an even number of chunks per
+  // wave, whole 16-column fragments, a bias, 64-slot-multiple LayerNorm statistics exactly on the consuming epilogues, no diagnostics
   const bool ln_epi = a.epi == GS_EPI_QKV || a.epi == GS_EPI_RELU || a.epi == GS_EPI_F32;
-  const bool fast = g_gs_fast && a.w_packed && a.x_xf != 0 && a.dbg == 0 && a.rot == 0 && a.N % 16 == 0 && (a.K / (4 * KS)) % 256 == 0 &&
-                    a.bias != nullptr && (a.lnc.stats != nullptr) == ln_epi && (!ln_epi || a.lnc.nslots == 64) &&
+  const int chunks = a.K / (4 * KS) / 64;
+  const bool fast = g_gs_fast && a.w_packed && a.x_xf != 0 && a.dbg == 0 && a.rot == 0 && a.N % 16 == 0 && (a.K / (4 * KS)) % 128 == 0 &&
+                    a.bias != nullptr && (a.lnc.stats != nullptr) == ln_epi && (!ln_epi || a.lnc.nslots == (chunks % 4 == 0 ? 64 : 96)) &&
                     (a.epi != GS_EPI_RESID || a.resid != nullptr) && (a.epi != GS_EPI_QKV || a.kv_len != nullptr);
-  return fast ? gs_launch_f<MF, W8, true>(st, a, KS) : gs_launch_f<MF, W8, false>(st, a, KS);
+  if (!fast) return gs_launch_f<MF, W8, 0>(st, a, KS);
+  return chunks % 4 == 0 ? gs_launch_f<MF, W8, 1>(st, a, KS) : gs_launch_f<MF, W8, 2>(st, a, KS);
 }
 
 template <int MF>
@@ -534,9 +550,9 @@ bool gemm_skinny_supports(int M, int N, int K, int epi, int dh) {
 // W fragment run on the same XCD when N / 16 is a multiple of 8 (block -> XCD = linear index % 8) and share the rows through
 // its L2 (default cache policy instead of non-temporal loads); each reads only ITS 16 rows of X.  Texture-path bytes per CU:
 // W 2 K / NW x NW + X 2 K x 16 = 64 K bytes (vs 160 KB at d = 1024 above), on 256 CUs instead of 64.
-template <int NW, int EPI, bool W8, bool FAST = false>
+template <int NW, int EPI, bool W8, int FAST = 0>  // FAST = 1..4: the wave's chunks, ONE round, compile-time layout (gemm_skinny_kernel's FAST body)
 __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs a) {
-  constexpr int G = 4;  // FAST: the compile-time layout of gemm_skinny_kernel (fragment-major W and X, whole rounds, one kernarg batch)
+  constexpr int G = FAST != 0 ? FAST : 4;
   __shared__ __attribute__((aligned(16))) float red[NW][64][4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -732,8 +748,12 @@ static int gs_ms_launch_one(hipStream_t st, const GemmSkinnyArgs& a0, dim3 grid,
   GemmSkinnyArgs a = a0;
   a.ks_grid = (int)grid.y;
   // the compile-time layout (gemm_skinny_kernel's FAST body): fragment-major operands, whole rounds of 4 chunks per wave
-  const bool fast = g_gs_fast && pad == 0 && a.w_packed && a.x_xf != 0 && a.ms_nt == 0 && a.dbg == 0 && a.N % 16 == 0 && (a.K / NW) % 256 == 0;
-  if (fast) hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, EPI, W8, true>), grid, block, 0, st, a);
+  const int chunks = a.K / NW / 64;
+  const bool fast = g_gs_fast && pad == 0 && a.w_packed && a.x_xf != 0 && a.ms_nt == 0 && a.dbg == 0 && a.N % 16 == 0 && (a.K / NW) % 64 == 0 &&
+                    chunks >= 1 && chunks <= 4;
+  if (fast && chunks == 4) hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, EPI, W8, 4>), grid, block, 0, st, a);
+  else if (fast && chunks == 3) hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, EPI, W8, 3>), grid, block, 0, st, a);
+  else if (fast && chunks == 2) hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, EPI, W8, 2>), grid, block, 0, st, a);
   else hipLaunchKernelGGL((gemm_skinny_ms_kernel<NW, EPI, W8>), grid, block, pad, st, a);
   return 0;
 }

@@ -4,6 +4,8 @@ vectors of the reference (tests/golden) and against the CPU oracle on the same s
 Bars (BASELINE.json north_star): greedy token ids bit-identical in fp32 mode; logits within a
 stated tolerance (fp32: 2e-3 * max(1, sigma_logit) absolute; bf16: max 5% of sigma_logit,
 teacher-forced on the reference's own token history)."""
+import ctypes as C
+
 import numpy as np
 import pytest
 import torch
@@ -374,7 +376,8 @@ def test_skinny_gemm_compile_time_layout_body_is_bit_identical(B, d, h, dtype):
     time; option gs_fast, default 1) against the general bodies of the same kernels on the batched AR step: d = 1024 (4 chunks
     per wave: QKV / FFN1 / FFN2 and the M-split out-proj all qualify), d = 1536 (4 + 2 chunks, 96 statistics slots; M-split
     with 3 chunks) and d = 512 (one round of 2; the LayerNorm consumers stay on the general body).  Same loads, same MFMA
-    order, same epilogue arithmetic (explicit fma's): the logits of every step must be bit-identical."""
+    order, same epilogue arithmetic (explicit fma's): the logits of every step must be bit-identical -- also with the split-K
+    hand-off through granules (option gs_gran) instead of the ticket, whose finisher must never time out."""
     L = 2
     cfg = vo.OracleConfig(d_model=d, nhead=h, num_layers=L, prefix_mode=1)
     sd = vo.make_state_dict(cfg, 22)
@@ -394,16 +397,23 @@ def test_skinny_gemm_compile_time_layout_body_is_bit_identical(B, d, h, dtype):
     n = 10
     out = {}
     try:
-        for fast in (0, 1):
+        # gs_gran: the split-K hand-off (FFN2) through {tag, value} granules instead of the ticket -- same slice order, same sums
+        for fast, gran in ((0, 0), (1, 0), (1, 1), (0, 1)):
             eng.set_option("gs_fast", fast)
-            eng.prefill(X, S, Y, P)
-            c, _ = eng.generate(top_k=1, max_new=n)
-            out[fast] = (c[:, :n].clone(), eng.fetch_ar_logits()[:n + 1].clone())
+            eng.set_option("gs_gran", gran)
+            for _ in range(2):  # twice: the second decode starts on the granules the first one left behind
+                eng.prefill(X, S, Y, P)
+                c, _ = eng.generate(top_k=1, max_new=n)
+            out[fast, gran] = (c[:, :n].clone(), eng.fetch_ar_logits()[:n + 1].clone())
     finally:
         eng.set_option("gs_fast", 1)
-    assert torch.equal(out[0][0], out[1][0])
-    assert torch.equal(out[0][1], out[1][1]), (out[0][1] - out[1][1]).abs().max().item()
-    assert torch.isfinite(out[1][1]).all()
+        eng.set_option("gs_gran", 0)
+    for k in ((1, 0), (1, 1), (0, 1)):
+        assert torch.equal(out[0, 0][0], out[k][0]), k
+        assert torch.equal(out[0, 0][1], out[k][1]), (k, (out[0, 0][1] - out[k][1]).abs().max().item())
+    assert torch.isfinite(out[1, 1][1]).all()
+    fails = C.c_uint(123)
+    assert eng.lib.vle_debug_fetch(eng.h, b"gs_gran_fail", C.byref(fails), 4) == 4 and fails.value == 0
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8w"])

@@ -1070,6 +1070,9 @@ int enqueue_ar_step(vle_engine* e) {
       GemmSkinnyArgs g;
       g.M = e->B;
       g.workspace = e->gs_ws; g.target_wgs = e->opt_gs_target;
+      if (e->L >= 2 && e->L <= 63) {  // split-K hand-off through granules: (AR iteration, layer) tags (kernels.h gran_epoch)
+        g.gran_epoch = e->S.iter; g.gran_idx = l; g.gran_fail = e->qa_spin_fail ? e->qa_spin_fail + 1 : nullptr;
+      }
       const bool xf = use_xf(e);                 // step activations fragment-major (common.h xf_index)
       const int xfw = xf ? (e->w8 ? 2 : 1) : 0;  // producer-side code: which k split the consuming GEMM uses
       const bool fuse = use_fuse_ln(e);          // no LayerNorm launches: producers emit x * gamma + statistics (kernels.h)
@@ -2172,7 +2175,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     (n == "attn_v2" ? g_attn_v2 : n == "attn_xcd" ? g_attn_xcd : n == "attn_q128" ? g_attn_q128 : n == "attn_mode" ? g_attn_mode : n == "attn_defer" ? g_attn_defer : g_attn_ring) = (int)value;
     return VLE_OK;
   }
-  if (n == "gs_formal" || n == "g1_shared" || n == "qa_waves" || n == "gs_msplit" || n == "gs_fast" || n == "attn_lds_pad" || n == "attn_nt" || n == "gs_ms_pad") {  // process-global kernel selection / argument: drop the captured graphs
+  if (n == "gs_formal" || n == "g1_shared" || n == "qa_waves" || n == "gs_msplit" || n == "gs_fast" || n == "gs_gran" || n == "attn_lds_pad" || n == "attn_nt" || n == "gs_ms_pad") {  // process-global kernel selection / argument: drop the captured graphs
     if (n == "qa_waves") {
       if (!(value == 4 || value == 8)) return e->fail(VLE_EINVAL, "qa_waves must be 4 or 8");
       g_qa_waves = (int)value;
@@ -2182,6 +2185,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
       else if (n == "attn_lds_pad") g_da_lds_pad = (int)std::max<int64_t>(0, std::min<int64_t>(value, 60 * 1024));
       else if (n == "gs_msplit") g_gs_msplit = (int)value;
       else if (n == "gs_fast") g_gs_fast = value != 0;
+      else if (n == "gs_gran") g_gs_gran = value != 0;
       else (n == "gs_formal" ? g_gs_formal : g_g1_shared) = value != 0;
     }
     (void)hipStreamSynchronize(e->st);
@@ -2276,6 +2280,10 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
   } else if (w == "qa_spin_fail") {  // workgroups of the fused launch that gave up waiting for q and recomputed it (expected: 0)
     if (!e->qa_spin_fail) return e->fail(VLE_ESTATE, "no hand-off counter");
     src = e->qa_spin_fail;
+    n = sizeof(unsigned);
+  } else if (w == "gs_gran_fail") {  // split-K finishers that gave up waiting for a partial tile (expected: 0)
+    if (!e->qa_spin_fail) return e->fail(VLE_ESTATE, "no hand-off counter");
+    src = e->qa_spin_fail + 1;
     n = sizeof(unsigned);
   } else if (w == "last_logits") {
     src = e->logits;

@@ -143,6 +143,17 @@ __device__ inline void gs_load16x4_sc1(const float* p0, const float* p1, const f
       : "memory");
 }
 
+// granule form of a lane's 4 partial sums: {tag, v0, tag, v1} {tag, v2, tag, v3}, two write-through 16-byte stores (each 8-byte
+// half validates itself, so a torn 16-byte write is still never read as valid-with-old-data)
+__device__ inline void gs_store_gran(unsigned long long* p, gs_f32x4 v, unsigned tag) {
+  const gs_u32x4 a = gs_u32x4{tag, __float_as_uint(v[0]), tag, __float_as_uint(v[1])};
+  const gs_u32x4 b = gs_u32x4{tag, __float_as_uint(v[2]), tag, __float_as_uint(v[3])};
+  asm volatile("global_store_dwordx4 %0, %1, off sc1\n\tglobal_store_dwordx4 %0, %2, off offset:16 sc1" ::"v"(p), "v"(a), "v"(b) : "memory");
+}
+__device__ inline void gs_load_gran(const unsigned long long* p, gs_u32x4& a, gs_u32x4& b) {  // no wait: the caller drains vmcnt
+  asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %2, off offset:16 sc1" : "=&v"(a), "=&v"(b) : "v"(p) : "memory");
+}
+
 // FP8W: 8 e4m3fn weights (two dwords) -> the bf16 MFMA operand; exact (every e4m3fn value is a bf16 value)
 __device__ inline gs_bf16x8 gs_fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
   typedef float f32x2v_t __attribute__((ext_vector_type(2)));
@@ -175,13 +186,18 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     // one kernarg round trip: every argument the load burst needs is requested with the first s_load batch (left alone the
     // compiler fetched the segment in three dependent steps, ~0.1-0.2 us each, ahead of the first global load)
     asm volatile("" ::"s"(a.x), "s"(a.w), "s"(a.bias), "s"(a.wscale), "s"(a.K), "s"(a.N), "s"(a.M), "s"(a.lnc.stats), "s"(a.lnc.wg),
-                 "s"(a.resid), "s"(a.lnp.gamma), "s"(a.kv_len), "s"(a.kt.buf), "s"(a.ks_grid));
+                 "s"(a.resid), "s"(a.lnp.gamma), "s"(a.kv_len), "s"(a.kt.buf), "s"(a.ks_grid), "s"(a.gran_epoch), "s"(a.ws_gran),
+                 "s"(a.gran_idx), "s"(a.ws_part), "s"(a.ws_cnt));
   }
   const unsigned long long kt0 = ktrace_begin(a.kt);
   const int fr = lane & 15, fg = lane >> 4;
   const int n0 = blockIdx.x * 16;
   const int K = a.K, N = a.N, M = a.M;
   const int KS = FAST ? a.ks_grid : (int)gridDim.y, ks = blockIdx.y;
+  // granule hand-off: this launch's epoch word (written by the previous step's sampling kernel), requested with the other
+  // epilogue operands behind the burst -- as a per-lane vector load: forced into an SGPR up here it cost a full round trip
+  // ahead of the first weight request
+  int gran_ep = 0;
   const int Kw = K / (4 * KS);  // this wave's share of K (multiple of 64)
   // Every workgroup reads ALL of X (<= 128 KB, L2-resident) while streaming its own 16 rows of W.  If all workgroups walked X
   // in the same order they would hit the same L2 channels at the same moment; so the K quarter a wave takes and the order of
@@ -239,8 +255,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
         old4 = *reinterpret_cast<const gs_f32x4*>(a.resid + (int64_t)mrow * N + ncol);
       }
       if constexpr (EPI == GS_EPI_QKV) kvl = a.kv_len[mrow];
+      if constexpr (EPI == GS_EPI_RESID)  // (the only epilogue the engine splits across workgroups)
+        gran_ep = *(a.gran_epoch != nullptr ? a.gran_epoch : reinterpret_cast<const int32_t*>(a.bias));
       return;
     }
+    if (a.ws_gran != nullptr) gran_ep = a.gran_epoch[0];
     if (a.bias != nullptr) {
       if (FAST || ncol + 3 < N) bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
       else {
@@ -436,6 +455,41 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     //  1 -- the same data path with the C++ memory model spelled out: release fence (buffer_wbl2 sc1 -- writes the XCD's whole
     //     L2 back) before the ticket, acquire fence (buffer_inv sc1) after it.  Measured on MI355X: the fences
     //     add whole-cache work to a ~10 us kernel; results are bit-identical, which is why form 0 is the default.
+    //  granules ("gs_gran", engine launches that pass an epoch word; KS <= 4) -- the guide's recipe R2, "the data is the flag":
+    //     slices 0 .. KS-2 publish their tile as 8-byte {tag, value} granules (write-through) and are DONE -- no drain, no ticket;
+    //     slice KS-1 (dispatched last: blockIdx.y is the slow index, so its producers are already resident or finished) polls
+    //     the KS-1 tiles with L1-bypassing loads until every granule carries this launch's tag, adds them in slice order with
+    //     its own tile last -- the order of the ticket form, so the sums are bit-identical -- and runs the epilogue.  Removes
+    //     the store drain and the ticket's round trip from the critical path.  The tag = (AR iteration, layer) + 1 differs
+    //     from that of the launch that used this workspace before (>= 2 layers: the layer index alone alternates).
+    if (a.ws_gran != nullptr) {
+      const unsigned tag = (unsigned)gran_ep * 64u + (unsigned)a.gran_idx + 1u;
+      unsigned long long* gt = a.ws_gran + (((int64_t)blockIdx.x * KS) * MF + i) * 256 + lane * 4;  // tile (slice 0, i): 4 granules per lane
+      if (ks != KS - 1) {
+        if (wave < MF) gs_store_gran(gt + (int64_t)ks * MF * 256, v, tag);
+        return;
+      }
+      if (wave < MF) {
+        gs_u32x4 ga[3], gb[3];
+        bool ok = false;
+        for (unsigned spins = 0; spins < 400000u && !ok; ++spins) {
+#pragma unroll
+          for (int q = 0; q < 3; ++q) gs_load_gran(gt + (int64_t)min(q, KS - 2) * MF * 256, ga[q], gb[q]);
+          asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+          bool mine = true;
+#pragma unroll
+          for (int q = 0; q < 3; ++q) mine &= ga[q].x == tag && ga[q].z == tag && gb[q].x == tag && gb[q].z == tag;
+          ok = __all(mine);
+        }
+        if (!ok && lane == 0 && a.gran_fail != nullptr) atomicAdd(a.gran_fail, 1u);
+        const gs_f32x4 own = v;
+        v = gs_f32x4{__uint_as_float(ga[0].y), __uint_as_float(ga[0].w), __uint_as_float(gb[0].y), __uint_as_float(gb[0].w)};
+#pragma unroll
+        for (int q = 1; q < 3; ++q)
+          if (q < KS - 1) v += gs_f32x4{__uint_as_float(ga[q].y), __uint_as_float(ga[q].w), __uint_as_float(gb[q].y), __uint_as_float(gb[q].w)};
+        v += own;
+      }
+    } else {
     __shared__ int s_last;
     float* part = a.ws_part + ((int64_t)blockIdx.x * KS * MF) * 256;  // tile (ks, i): [lane][4] fp32, one 16-byte vector per lane
     if (wave < MF) gs_store16_wt(part + (ks * MF + i) * 256 + lane * 4, v);
@@ -466,6 +520,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
         if (q0 + 3 < KS) v += t3;
       }
     }
+    }
   }
   if (wave >= MF) return;
   if (ln_in) {
@@ -495,9 +550,16 @@ int gemm_skinny_ksplit(int N, int K, int target_wgs) {
   return ks;
 }
 
-size_t gemm_skinny_workspace_bytes() { return GS_WS_CNT_BYTES + (size_t)GS_WS_MAX_TILES * 64 * 16 * sizeof(float); }
+// [tickets][partial tiles, fp32][partial tiles as {tag, value} granules]
+size_t gemm_skinny_workspace_bytes() { return GS_WS_CNT_BYTES + (size_t)GS_WS_MAX_TILES * 64 * 16 * (sizeof(float) + 8); }
 
 int g_gs_fast = 1;  // "gs_fast": 0 = always the general body (A/B)
+// "gs_gran": 1 = split-K hand-off through {tag, value} granules where the caller provides an epoch (engine FFN2).  Measured
+// (MI355X, 64 utterances, d = 1024, FFN2 with 4 slices; tools/ktrace_dist.py): bit-identical sums, no time-outs, and SLOWER --
+// FFN2 6.25 -> 7.2 us per launch, AR step 670 -> 679 us: the finisher's first poll (6 x 16 B per lane from the memory side,
+// ~1 us) usually arrives before the other slices' write-through stores have landed and a second one follows, where the ticket's
+// last arriver reads exactly once, after the fact.  Default 0 (the ticket, recipe R1).
+int g_gs_gran = 0;
 
 template <int MF, bool W8, int FAST>
 static int gs_launch_f(hipStream_t st, const GemmSkinnyArgs& a0, int KS) {
@@ -810,6 +872,10 @@ int launch_gemm_skinny(hipStream_t st, const GemmSkinnyArgs& a) {
   b.formal = g_gs_formal;
   b.ws_cnt = reinterpret_cast<int*>(a.workspace);
   b.ws_part = a.workspace ? reinterpret_cast<float*>(reinterpret_cast<char*>(a.workspace) + GS_WS_CNT_BYTES) : nullptr;
+  b.ws_gran = (g_gs_gran && a.workspace && a.gran_epoch != nullptr && a.epi == GS_EPI_RESID && KS >= 2 && KS <= 4 && !g_gs_formal)
+                  ? reinterpret_cast<unsigned long long*>(reinterpret_cast<char*>(a.workspace) + GS_WS_CNT_BYTES +
+                                                          (size_t)GS_WS_MAX_TILES * 64 * 16 * sizeof(float))
+                  : nullptr;
   if (a.M <= 16) return gs_launch<1>(st, b, KS);
   if (a.M <= 32) return gs_launch<2>(st, b, KS);
   if (a.M <= 48) return gs_launch<3>(st, b, KS);

@@ -112,12 +112,20 @@ struct GemmSkinnyArgs {
   int out_xf = 0;          // STORE / RELU epilogues write `out` fragment-major for the next GEMM: 0 no, 1 bf16-W consumer, 2 fp8-W
   int* ws_cnt = nullptr;   // (filled by the launcher)
   float* ws_part = nullptr;
+  // split-K hand-off through self-validating granules instead of the ticket (engine only; gemm_skinny.hip "gs_gran"): a device
+  // word that differs between consecutive launches on this workspace when combined with gran_idx (the AR iteration counter +
+  // the layer index, >= 2 layers), and a counter of spin time-outs (stays 0)
+  const int32_t* gran_epoch = nullptr;
+  int gran_idx = 0;
+  unsigned* gran_fail = nullptr;
+  unsigned long long* ws_gran = nullptr;  // (filled by the launcher)
 };
 constexpr int GS_WS_CNT_BYTES = 4096;  // 1024 row-fragment tickets
 constexpr int GS_WS_MAX_TILES = 2048;  // partial 16 x 64 fp32 tiles (4 KB each)
 extern int g_da_nt;       // decode_attn.hip: non-temporal K / V loads (-1 auto, 0, 1)
 extern int g_da_lds_pad;  // decode_attn.hip: dynamic LDS bytes per workgroup of the batched decode attention (occupancy cap)
 extern int g_gs_formal;
+extern int g_gs_gran;  // gemm_skinny.hip: split-K hand-off through granules where the caller provides an epoch (default 0: measured slower)
 extern int g_gs_fast;  // gemm_skinny.hip: compile-time-layout body of the split-K skinny GEMM where the launch qualifies (default 1)
 extern int g_gs_ms_pad;
 extern int g_gs_msplit;  // gemm_skinny.hip: M-split kernel for N / 16 < #CUs (default 1)

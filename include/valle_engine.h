@@ -172,7 +172,11 @@ int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slo
  *          "steps_per_graph" (n > 0 overrides vle_config.steps_per_graph),
  *          "ignore_eos" (1: benchmark hook for random-init weights -- only the 16*S length cap stops an utterance),
  *          "profile_kernels" (n > 0: time each kernel of the next n AR steps with hipEvents on the
- *           engine stream, launches become eager; 0: off) */
+ *           engine stream, launches become eager; 0: off);
+ *          kernel A/B knobs, each described with its measurement where the kernel is defined:
+ *          "qkv_attn", "qa_handoff", "qa_nsplit", "g1_shared" (batch-1 step); "gs_fast" (compile-time-layout bodies of the
+ *          batched GEMMs, default 1), "gs_msplit", "gs_formal", "gs_gran" (split-K hand-off through granules, default 0),
+ *          "gs_fuse_ln", "attn_oproj", "attn_nt", "attn_lds_pad" (batched step); "ktrace" (in-kernel timeline) */
 int vle_set_option(vle_engine* e, const char* name, int64_t value);
 /* what: "ar_logits"  -> fp32 [n_steps, B, 1025] (row t = logits of AR loop iteration t)
  *       "nar_logits:<stage>" -> fp32 [sum_b G_b, 1024]

@@ -31,6 +31,10 @@
 // the load -> LDS -> barrier -> ds_read prologue serialises what this kernel requests as one burst; LayerNorm fused
 // into that prologue 13.1 us vs 1.9 (LayerNorm launch) + 7.2.  All four shapes cost ~7.2 us regardless of W size
 // (2-8 MB): the launch is latency-bound on the X fragments (4x the bytes of W through each CU's texture path).
+// Round 3 took that apart (tools/ubench_xload.hip, tools/ktrace_dist.py): the bare burst -- 32 KB of W from HBM + 128 KB of X from
+// L2 per workgroup -- lands in 2.7 us; the other ~1.4 us ahead of the MFMAs were this kernel's own instruction stream (per-load
+// layout decisions, three kernarg round trips, MFMAs waiting for the epilogue's operands).  The FAST bodies below fix the layout at
+// compile time: QKV 6.1 -> 5.1, FFN1 6.2 -> 4.8, FFN2 7.2 -> 6.3 us per launch at 64 utterances (DESIGN.md 4.2 vi).
 #include <type_traits>
 
 #include "common.h"

@@ -370,12 +370,13 @@ def test_fused_layernorm_batch_step_matches_layernorm_kernels(B, d, h, L, dtype)
 
 
 @pytest.mark.parametrize("dtype", ["bf16", "fp8w"])
-@pytest.mark.parametrize("B,d,h", [(64, 1024, 16), (40, 1024, 16), (9, 1024, 16), (33, 1536, 16), (17, 512, 8)])
+@pytest.mark.parametrize("B,d,h", [(64, 1024, 16), (40, 1024, 16), (9, 1024, 16), (33, 1536, 16), (24, 1536, 16), (12, 1536, 16), (17, 512, 8)])
 def test_skinny_gemm_compile_time_layout_body_is_bit_identical(B, d, h, dtype):
     """gemm_skinny.hip's FAST bodies (fragment-major W and X, rounds of 4 chunks + a round of 2, every layout decision at compile
     time; option gs_fast, default 1) against the general bodies of the same kernels on the batched AR step: d = 1024 (4 chunks
     per wave: QKV / FFN1 / FFN2 and the M-split out-proj all qualify), d = 1536 (4 + 2 chunks, 96 statistics slots; M-split
-    with 3 chunks) and d = 512 (one round of 2; the LayerNorm consumers stay on the general body).  Same loads, same MFMA
+    with 3 chunks; at <= 32 utterances TWO W fragments per workgroup, the one-fragment grids of 288 / 384 workgroups not fitting the
+    chip) and d = 512 (one round of 2; the LayerNorm consumers stay on the general body).  Same loads, same MFMA
     order, same epilogue arithmetic (explicit fma's): the logits of every step must be bit-identical -- also with the split-K
     hand-off through granules (option gs_gran) instead of the ticket, whose finisher must never time out."""
     L = 2

@@ -2175,7 +2175,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     (n == "attn_v2" ? g_attn_v2 : n == "attn_xcd" ? g_attn_xcd : n == "attn_q128" ? g_attn_q128 : n == "attn_mode" ? g_attn_mode : n == "attn_defer" ? g_attn_defer : g_attn_ring) = (int)value;
     return VLE_OK;
   }
-  if (n == "gs_formal" || n == "g1_shared" || n == "qa_waves" || n == "gs_msplit" || n == "gs_fast" || n == "gs_gran" || n == "attn_lds_pad" || n == "attn_nt" || n == "gs_ms_pad") {  // process-global kernel selection / argument: drop the captured graphs
+  if (n == "gs_formal" || n == "g1_shared" || n == "qa_waves" || n == "gs_msplit" || n == "gs_fast" || n == "gs_gran" || n == "gs_nf" || n == "attn_lds_pad" || n == "attn_nt" || n == "gs_ms_pad") {  // process-global kernel selection / argument: drop the captured graphs
     if (n == "qa_waves") {
       if (!(value == 4 || value == 8)) return e->fail(VLE_EINVAL, "qa_waves must be 4 or 8");
       g_qa_waves = (int)value;
@@ -2186,6 +2186,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
       else if (n == "gs_msplit") g_gs_msplit = (int)value;
       else if (n == "gs_fast") g_gs_fast = value != 0;
       else if (n == "gs_gran") g_gs_gran = value != 0;
+      else if (n == "gs_nf") g_gs_nf = value != 0;
       else (n == "gs_formal" ? g_gs_formal : g_g1_shared) = value != 0;
     }
     (void)hipStreamSynchronize(e->st);

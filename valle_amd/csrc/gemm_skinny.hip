@@ -178,11 +178,16 @@ __device__ inline gs_bf16x8 gs_fp8x8_to_bf16(unsigned int lo, unsigned int hi) {
 // branches on kernel arguments, 64-bit selects between the row-major and fragment-major addresses, clamps): ~6 instructions
 // and a branch per 16-byte load, ~1200 instructions ahead of the first MFMA, executed by the ONE wave a SIMD holds -- the
 // "burst" left the CU over ~1.5 us (tools/ubench_xload.hip: the same 160 KB requested back to back lands in ~1.2 us).
-template <int MF, int EPI, bool W8, int FAST = 0>  // FAST: 0 = general body, 1 = whole rounds of 4 chunks, 2 = + one round of 2
+// NF (FAST bodies, NF * MF <= 4): W row fragments per workgroup.  At d = 1536 the grids are 288 / 384 workgroups on 256 CUs, so
+// some CUs host two workgroups and each pulls the whole X again (2 x (24 + 96) KB at 32 utterances, fp8 W); with NF = 2 a
+// workgroup streams 2 x 16 rows of W against ONE pass over X (48 + 96 KB) and the grid (144 / 192) fits the chip.  Wave w then
+// finishes (W fragment w / MF, row fragment w % MF) -- the per-fragment arithmetic is unchanged (bit-identical).
+template <int MF, int EPI, bool W8, int FAST = 0, int NF = 1>  // FAST: 0 = general body, 1 = whole rounds of 4 chunks, 2 = + one round of 2
 __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
+  static_assert(NF == 1 || (FAST != 0 && NF * MF <= 4), "NF > 1: FAST bodies only, one finishing wave per (W fragment, row fragment)");
   // k-chunks (64 deep) requested per round
   constexpr int G = 4;  // (8 / 16 at M <= 32 / 16 measured slower: 256 VGPRs + AGPR spills leave one workgroup per CU)
-  __shared__ __attribute__((aligned(16))) float red[4][MF][64][4];
+  __shared__ __attribute__((aligned(16))) float red[4][NF * MF][64][4];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
@@ -195,7 +200,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   }
   const unsigned long long kt0 = ktrace_begin(a.kt);
   const int fr = lane & 15, fg = lane >> 4;
-  const int n0 = blockIdx.x * 16;
+  const int ff = NF > 1 ? min(wave / MF, NF - 1) : 0;  // the W fragment (of this workgroup's NF) whose tile this wave finishes
+  const int n0 = ((int)blockIdx.x * NF + ff) * 16;
   const int K = a.K, N = a.N, M = a.M;
   const int KS = FAST ? a.ks_grid : (int)gridDim.y, ks = blockIdx.y;
   // granule hand-off: this launch's epoch word (written by the previous step's sampling kernel), requested with the other
@@ -244,7 +250,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
       // (vmcnt(n)); behind a uniform branch it waited for these operands too.  FAST launches have a bias, LayerNorm statistics
       // exactly when the epilogue is one that consumes them (64 / 96 slots: 8 / 12 vectors per lane), and rows are clamped, not skipped.
       constexpr bool LN = EPI == GS_EPI_QKV || EPI == GS_EPI_RELU || EPI == GS_EPI_F32;
-      const int mrow = min(wave * 16 + fr, M - 1);
+      const int mrow = min((NF > 1 ? wave % MF : wave) * 16 + fr, M - 1);
       bias4 = *reinterpret_cast<const gs_f32x4*>(a.bias + ncol);
       if constexpr (W8) scale4 = *reinterpret_cast<const gs_f32x4*>(a.wscale + ncol);
       if constexpr (LN) {
@@ -340,9 +346,11 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
   // merging them while the burst is in flight shrinks the epilogue after the MFMAs 1.2 -> 0.5 us, but the MFMAs start 0.7 us
   // later (the statistics are the last thing the previous kernel wrote, and the slowest to arrive): C3 553.2 vs 553.8 k tokens/s.
 
-  gs_f32x4 acc[MF];
+  gs_f32x4 acc[NF][MF];
 #pragma unroll
-  for (int i = 0; i < MF; ++i) acc[i] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int i = 0; i < MF; ++i) acc[f][i] = gs_f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int chunks = Kw >> 6;
   if constexpr (FAST != 0) {
@@ -350,14 +358,19 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     // every offset a compile-time constant; the epilogue's operands are requested behind the first round's burst.
     auto round = [&](auto gn_c, const int c0) {
       constexpr int GN = decltype(gn_c)::value;
-      gs_u32x4 wv[GN][2], xv[GN][MF][2];
+      gs_u32x4 wv[GN][NF][2], xv[GN][MF][2];
+      constexpr int CB = W8 ? 1024 : 2048;  // bytes of one fragment-major chunk of W
       const unsigned char* wb = reinterpret_cast<const unsigned char*>(a.w) +
-                                ((int64_t)blockIdx.x * (K >> 6) + (kbeg >> 6) + c0) * (W8 ? 1024 : 2048) + lane * 16;
+                                ((int64_t)blockIdx.x * NF * (K >> 6) + (kbeg >> 6) + c0) * CB + lane * 16;
+      const int64_t wfs = (int64_t)(K >> 6) * CB;  // bytes between the workgroup's consecutive W fragments
       const unsigned char* xb = reinterpret_cast<const unsigned char*>(a.x) + (int64_t)((kbeg >> 6) + c0) * (2 * MF * 1024) + lane * 16;
 #pragma unroll
       for (int g = 0; g < GN; ++g) {
-        wv[g][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wb + g * (W8 ? 1024 : 2048)));
-        if constexpr (!W8) wv[g][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wb + g * 2048 + 1024));
+#pragma unroll
+        for (int f = 0; f < NF; ++f) {
+          wv[g][f][0] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wb + f * wfs + g * CB));
+          if constexpr (!W8) wv[g][f][1] = __builtin_nontemporal_load(reinterpret_cast<const gs_u32x4*>(wb + f * wfs + g * CB + 1024));
+        }
 #pragma unroll
         for (int i = 0; i < MF; ++i) {
           xv[g][i][0] = *reinterpret_cast<const gs_u32x4*>(xb + ((g * 2 + 0) * MF + i) * 1024);
@@ -370,12 +383,15 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
       for (int g = 0; g < GN; ++g) {
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
-          gs_bf16x8 wa;
-          if constexpr (W8) wa = gs_fp8x8_to_bf16(wv[g][0][2 * s], wv[g][0][2 * s + 1]);
-          else wa = __builtin_bit_cast(gs_bf16x8, wv[g][s]);
 #pragma unroll
-          for (int i = 0; i < MF; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(gs_bf16x8, xv[g][i][s]), acc[i], 0, 0, 0);
+          for (int f = 0; f < NF; ++f) {
+            gs_bf16x8 wa;
+            if constexpr (W8) wa = gs_fp8x8_to_bf16(wv[g][f][0][2 * s], wv[g][f][0][2 * s + 1]);
+            else wa = __builtin_bit_cast(gs_bf16x8, wv[g][f][s]);
+#pragma unroll
+            for (int i = 0; i < MF; ++i)
+              acc[f][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(gs_bf16x8, xv[g][i][s]), acc[f][i], 0, 0, 0);
+          }
         }
       }
     };
@@ -429,22 +445,26 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
           else wa = __builtin_bit_cast(gs_bf16x8, wv[g][s]);
 #pragma unroll
           for (int i = 0; i < MF; ++i)
-            acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(gs_bf16x8, xv[g][i][s]), acc[i], 0, 0, 0);
+            acc[0][i] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wa, __builtin_bit_cast(gs_bf16x8, xv[g][i][s]), acc[0][i], 0, 0, 0);
         }
       }
     }
   }
   }
 
-  // ---- combine the four K quarters through LDS; wave i finishes m-fragment i ------------------------
+  // ---- combine the four K quarters through LDS; wave i finishes tile i = (W fragment i / MF, row fragment i % MF) ------------
+  constexpr int NT = NF * MF;  // 16 x 16 output tiles of this workgroup
   const unsigned long long ktm1 = ktrace_mark(a.kt);  // MFMAs issued (the loads they wait for have landed)
 #pragma unroll
-  for (int i = 0; i < MF; ++i) *reinterpret_cast<gs_f32x4*>(&red[wq][fi(i)][lane][0]) = acc[i];  // [K quarter][row fragment]
+  for (int f = 0; f < NF; ++f)
+#pragma unroll
+    for (int i = 0; i < MF; ++i) *reinterpret_cast<gs_f32x4*>(&red[wq][f * MF + fi(i)][lane][0]) = acc[f][i];  // [K quarter][tile]
   __syncthreads();
   const unsigned long long ktm2 = ktrace_mark(a.kt);  // past the block barrier
-  const int i = wave;  // waves >= MF only take part in the barriers below
+  const int i = wave;  // waves >= NT only take part in the barriers below
+  const int ri = NF > 1 ? wave % MF : wave;  // the tile's row fragment
   gs_f32x4 v = gs_f32x4{0.f, 0.f, 0.f, 0.f};
-  if (wave < MF) {
+  if (wave < NT) {
     v = *reinterpret_cast<const gs_f32x4*>(&red[0][i][lane][0]);
 #pragma unroll
     for (int w = 1; w < 4; ++w) v += *reinterpret_cast<const gs_f32x4*>(&red[w][i][lane][0]);
@@ -468,17 +488,17 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     //     from that of the launch that used this workspace before (>= 2 layers: the layer index alone alternates).
     if (a.ws_gran != nullptr) {
       const unsigned tag = (unsigned)gran_ep * 64u + (unsigned)a.gran_idx + 1u;
-      unsigned long long* gt = a.ws_gran + (((int64_t)blockIdx.x * KS) * MF + i) * 256 + lane * 4;  // tile (slice 0, i): 4 granules per lane
+      unsigned long long* gt = a.ws_gran + (((int64_t)blockIdx.x * KS) * NT + i) * 256 + lane * 4;  // tile (slice 0, i): 4 granules per lane
       if (ks != KS - 1) {
-        if (wave < MF) gs_store_gran(gt + (int64_t)ks * MF * 256, v, tag);
+        if (wave < NT) gs_store_gran(gt + (int64_t)ks * NT * 256, v, tag);
         return;
       }
-      if (wave < MF) {
+      if (wave < NT) {
         gs_u32x4 ga[3], gb[3];
         bool ok = false;
         for (unsigned spins = 0; spins < 400000u && !ok; ++spins) {
 #pragma unroll
-          for (int q = 0; q < 3; ++q) gs_load_gran(gt + (int64_t)min(q, KS - 2) * MF * 256, ga[q], gb[q]);
+          for (int q = 0; q < 3; ++q) gs_load_gran(gt + (int64_t)min(q, KS - 2) * NT * 256, ga[q], gb[q]);
           asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
           bool mine = true;
 #pragma unroll
@@ -495,8 +515,8 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
       }
     } else {
     __shared__ int s_last;
-    float* part = a.ws_part + ((int64_t)blockIdx.x * KS * MF) * 256;  // tile (ks, i): [lane][4] fp32, one 16-byte vector per lane
-    if (wave < MF) gs_store16_wt(part + (ks * MF + i) * 256 + lane * 4, v);
+    float* part = a.ws_part + ((int64_t)blockIdx.x * KS * NT) * 256;  // tile (ks, i): [lane][4] fp32, one 16-byte vector per lane
+    if (wave < NT) gs_store16_wt(part + (ks * NT + i) * 256 + lane * 4, v);
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     if (tid == 0) {
@@ -511,13 +531,13 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     }
     __syncthreads();
     if (!s_last) return;
-    if (wave < MF) {
+    if (wave < NT) {
       v = gs_f32x4{0.f, 0.f, 0.f, 0.f};
       for (int q0 = 0; q0 < KS; q0 += 4) {  // fixed slice order: the sum does not depend on who arrived last; 4 loads in flight
         const float* pb = part + i * 256 + lane * 4;
         gs_f32x4 t0, t1, t2, t3;
-        gs_load16x4_sc1(pb + min(q0, KS - 1) * MF * 256, pb + min(q0 + 1, KS - 1) * MF * 256, pb + min(q0 + 2, KS - 1) * MF * 256,
-                        pb + min(q0 + 3, KS - 1) * MF * 256, t0, t1, t2, t3);
+        gs_load16x4_sc1(pb + min(q0, KS - 1) * NT * 256, pb + min(q0 + 1, KS - 1) * NT * 256, pb + min(q0 + 2, KS - 1) * NT * 256,
+                        pb + min(q0 + 3, KS - 1) * NT * 256, t0, t1, t2, t3);
         v += t0;
         if (q0 + 1 < KS) v += t1;
         if (q0 + 2 < KS) v += t2;
@@ -526,7 +546,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     }
     }
   }
-  if (wave >= MF) return;
+  if (wave >= NT) return;
   if (ln_in) {
     ln_merge();
     const float mean = ln_mean, rstd = ln_rstd;
@@ -538,7 +558,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
     else v += bias4;
   }
   // lane (fg, fr) holds C[m = 16 i + fr][n = n0 + 4 fg + r]
-  gs_epilogue<EPI>(a, v, i * 16 + fr, ncol, gamma4, old4, kvl);
+  gs_epilogue<EPI>(a, v, ri * 16 + fr, ncol, gamma4, old4, kvl);
   if (lane == 0) ktrace_end(a.kt, kt0, ((int)blockIdx.y * (int)gridDim.x + (int)blockIdx.x) * 4 + wave, ktm1, ktm2);
 }
 
@@ -565,21 +585,24 @@ int g_gs_fast = 1;  // "gs_fast": 0 = always the general body (A/B)
 // last arriver reads exactly once, after the fact.  Default 0 (the ticket, recipe R1).
 int g_gs_gran = 0;
 
-template <int MF, bool W8, int FAST>
+template <int MF, bool W8, int FAST, int NF = 1>
 static int gs_launch_f(hipStream_t st, const GemmSkinnyArgs& a0, int KS) {
-  const dim3 grid((a0.N + 15) / 16, KS), block(256);
+  const dim3 grid((a0.N + 15) / 16 / NF, KS), block(256);
   GemmSkinnyArgs a = a0;
   a.ks_grid = KS;
+  if (NF > 1) a.ws_gran = nullptr;  // (the granule hand-off indexes single-fragment workgroups)
   switch (a.epi) {
-    case GS_EPI_STORE: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_STORE, W8, FAST>), grid, block, 0, st, a); break;
-    case GS_EPI_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RELU, W8, FAST>), grid, block, 0, st, a); break;
-    case GS_EPI_RESID: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RESID, W8, FAST>), grid, block, 0, st, a); break;
-    case GS_EPI_F32: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_F32, W8, FAST>), grid, block, 0, st, a); break;
-    case GS_EPI_QKV: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_QKV, W8, FAST>), grid, block, 0, st, a); break;
+    case GS_EPI_STORE: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_STORE, W8, FAST, NF>), grid, block, 0, st, a); break;
+    case GS_EPI_RELU: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RELU, W8, FAST, NF>), grid, block, 0, st, a); break;
+    case GS_EPI_RESID: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_RESID, W8, FAST, NF>), grid, block, 0, st, a); break;
+    case GS_EPI_F32: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_F32, W8, FAST, NF>), grid, block, 0, st, a); break;
+    case GS_EPI_QKV: hipLaunchKernelGGL((gemm_skinny_kernel<MF, GS_EPI_QKV, W8, FAST, NF>), grid, block, 0, st, a); break;
     default: return -1;
   }
   return 0;
 }
+
+int g_gs_nf = 1;  // "gs_nf": 0 = one W fragment per workgroup always (A/B); 1 = two where the grid would not fit the chip
 
 template <int MF, bool W8>
 static int gs_launch_w(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
@@ -591,6 +614,12 @@ static int gs_launch_w(hipStream_t st, const GemmSkinnyArgs& a, int KS) {
                     a.bias != nullptr && (a.lnc.stats != nullptr) == ln_epi && (!ln_epi || a.lnc.nslots == (chunks % 4 == 0 ? 64 : 96)) &&
                     (a.epi != GS_EPI_RESID || a.resid != nullptr) && (a.epi != GS_EPI_QKV || a.kv_len != nullptr);
   if (!fast) return gs_launch_f<MF, W8, 0>(st, a, KS);
+  if constexpr (MF <= 2) {
+    // two W fragments per workgroup where one each would put more workgroups in flight than the chip has CUs (kernel header)
+    const int nfrag = a.N / 16;
+    if (g_gs_nf && nfrag % 2 == 0 && nfrag * KS > 256)
+      return chunks % 4 == 0 ? gs_launch_f<MF, W8, 1, 2>(st, a, KS) : gs_launch_f<MF, W8, 2, 2>(st, a, KS);
+  }
   return chunks % 4 == 0 ? gs_launch_f<MF, W8, 1>(st, a, KS) : gs_launch_f<MF, W8, 2>(st, a, KS);
 }
 

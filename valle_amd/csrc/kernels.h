@@ -126,6 +126,7 @@ extern int g_da_nt;       // decode_attn.hip: non-temporal K / V loads (-1 auto,
 extern int g_da_lds_pad;  // decode_attn.hip: dynamic LDS bytes per workgroup of the batched decode attention (occupancy cap)
 extern int g_gs_formal;
 extern int g_gs_gran;  // gemm_skinny.hip: split-K hand-off through granules where the caller provides an epoch (default 0: measured slower)
+extern int g_gs_nf;    // gemm_skinny.hip: two W fragments per workgroup where the one-fragment grid exceeds the chip (default 1)
 extern int g_gs_fast;  // gemm_skinny.hip: compile-time-layout body of the split-K skinny GEMM where the launch qualifies (default 1)
 extern int g_gs_ms_pad;
 extern int g_gs_msplit;  // gemm_skinny.hip: M-split kernel for N / 16 < #CUs (default 1)

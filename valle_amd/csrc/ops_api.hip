@@ -53,6 +53,7 @@ extern "C" int vle_op_tune(const char* name, int64_t value) {
   else if (n == "gs_formal" && value >= 0 && value <= 1) vle::g_gs_formal = (int)value;
   else if (n == "gs_fast" && value >= 0 && value <= 1) vle::g_gs_fast = (int)value;
   else if (n == "gs_gran" && value >= 0 && value <= 1) vle::g_gs_gran = (int)value;
+  else if (n == "gs_nf" && value >= 0 && value <= 1) vle::g_gs_nf = (int)value;
   else if (n == "attn_lsum" && value >= 0 && value <= 1) vle::g_attn_lsum = (int)value;
   else if (n == "attn_defer" && value >= 0 && value <= 16) vle::g_attn_defer = (int)value;
   else return op_fail("vle_op_tune: unknown knob or value out of range");

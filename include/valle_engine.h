@@ -175,7 +175,8 @@ int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slo
  *           engine stream, launches become eager; 0: off);
  *          kernel A/B knobs, each described with its measurement where the kernel is defined:
  *          "qkv_attn", "qa_handoff", "qa_nsplit", "g1_shared" (batch-1 step); "gs_fast" (compile-time-layout bodies of the
- *          batched GEMMs, default 1), "gs_msplit", "gs_formal", "gs_gran" (split-K hand-off through granules, default 0),
+ *          batched GEMMs, default 1), "gs_nf" (two W fragments per workgroup where the grid exceeds the chip, default 1), "gs_msplit",
+ *          "gs_formal", "gs_gran" (split-K hand-off through granules, default 0),
  *          "gs_fuse_ln", "attn_oproj", "attn_nt", "attn_lds_pad" (batched step); "ktrace" (in-kernel timeline) */
 int vle_set_option(vle_engine* e, const char* name, int64_t value);
 /* what: "ar_logits"  -> fp32 [n_steps, B, 1025] (row t = logits of AR loop iteration t)

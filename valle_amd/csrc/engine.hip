@@ -170,6 +170,15 @@ struct vle_engine {
   int opt_qa_nk = 4;          // option "qa_nk": keys per lane per round of the fused launch's attention workgroups (4 / 8)
   int opt_qa_handoff = 1;     // option "qa_handoff": q reaches the attention workgroups through granules instead of being recomputed per split
   int opt_qa_qtemporal = 1;   // option "qa_qtemporal": its query-row loads with the default cache policy (shared by a head's splits through L2)
+  // ---- the batch-1 step as one persistent launch (persist.hip; option "persist") ----
+  int opt_persist = 0;        // option "persist": 1 = batch-1 AR steps run pstep_kernel (+ the sampling launch) where the shape is covered
+  PLayer* ps_table = nullptr;               // device [L] operand table (rebuilt when the KV cache moves)
+  unsigned long long* ps_gran = nullptr;    // {epoch, value} granules of the step's edges (zeroed at every prefill)
+  size_t ps_gran_n = 0;
+  unsigned long long* ps_ptrace = nullptr;  // [8][256][PS_PT_SLOTS] in-kernel timeline (option "persist_trace")
+  bool opt_ps_trace = false;
+  int opt_ps_mode = 0;        // option "persist_mode": PStepArgs::mode
+  const void* ps_table_kc = nullptr; int ps_table_ctx = 0;  // what the table was built for
   int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
   int opt_rpw_qkv = 0;        // option "gemv1_rpw_qkv": the same for the QKV GEMV only
   int opt_rpw_ffn1 = 0;       // option "gemv1_rpw_ffn1": ... for the FFN1 GEMV only
@@ -509,6 +518,7 @@ static void release_buffers(vle_engine* e) {
   e->kcache = e->vcache = nullptr;
   e->x_step = e->q_step = e->h_step = e->part_o = e->part_ml = e->logits = nullptr;
   e->k_new = e->v_new = nullptr; e->qgran = nullptr; e->qa_spin_fail = nullptr;
+  e->ps_table = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0;
   e->xn_step = e->qkv_step = e->att_step = e->hT_step = nullptr;
   e->gs_ws = nullptr; e->ln_stats = nullptr; e->ao_part = nullptr; e->ao_cnt = nullptr;
   e->state_dev = nullptr; e->S = ArState{}; e->dyn_dev = nullptr;
@@ -799,6 +809,12 @@ static int alloc_buffers(vle_engine* e) {
   E_HIP(e, hipMemset(e->qgran, 0, (size_t)e->L * d * sizeof(unsigned long long)));
   if ((r = dev_alloc(e, &e->qa_spin_fail, 4))) return r;
   E_HIP(e, hipMemset(e->qa_spin_fail, 0, 4 * sizeof(unsigned)));
+  if (pstep_supports(e->w8 ? DT_FP8W : e->dtype, e->d, e->H, e->dh, V_AR)) {
+    e->ps_gran_n = pstep_gran_count(e->d, e->H, e->L);
+    if ((r = dev_alloc(e, &e->ps_gran, e->ps_gran_n))) return r;
+    E_HIP(e, hipMemset(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long)));
+    if ((r = dev_alloc(e, &e->ps_table, (size_t)e->L))) return r;
+  }
   if ((r = dev_alloc(e, &e->part_o, (size_t)B * e->H * 16 * e->dh))) return r;
   if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
   if ((r = dev_alloc(e, &e->logits, B * V_AR))) return r;
@@ -916,6 +932,7 @@ inline void* cache_layer(vle_engine* e, void* base, int l) {
 const char* kIdErrMsg = "token id out of range: text ids must be in [0, 512), first-codebook ids in [0, 1024], the other "
                         "codebooks in [0, 1024) (the reference's nn.Embedding raises IndexError)";
 constexpr int POLL_IDERR = 40;  // poll_host slot of the id-range flag
+constexpr int POLL_PSFAIL = 41; // ... of the persistent step's give-up counter
 
 // one transformer layer over packed rows (prefill: AR weights + prefix-LM mask; NAR: no mask, folded AdaLN)
 // one Linear over packed rows: engine mode FP8 quantises the bf16 activations per row and runs the fp8 MFMA GEMM on the
@@ -1055,11 +1072,57 @@ int kv_stream_nt(const vle_engine* e) {
   return bytes > ((int64_t)192 << 20) ? 1 : 0;
 }
 
+// The persistent step (persist.hip) covers this call: batch 1, the covered shape, bf16 weights, its table built for this cache
+bool persist_ready(const vle_engine* e) {
+  return e->opt_persist && e->B == 1 && !e->slot_mode && !e->w8 && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
+         e->ps_table_kc == e->kcache && e->ps_table_ctx == e->ctx_max && (int)e->ar.size() == e->L;
+}
+
+// (re)build the operand table for a batch-1 call and forget the granules' old tags (the iteration counter restarts at every
+// prefill).  Called from vle_ar_prefill: never inside a stream capture.
+int persist_prepare(vle_engine* e) {
+  if (!e->ps_table || !e->ps_gran || e->B != 1 || e->w8) return 0;
+  if (e->ps_table_kc != e->kcache || e->ps_table_ctx != e->ctx_max) {
+    std::vector<PLayer> tab(e->L);
+    for (int l = 0; l < e->L; ++l) {
+      const LayerW& w = e->ar[l];
+      PLayer& t = tab[l];
+      t.wqkv = w.wqkv; t.wo = w.wo; t.w1 = w.w1; t.w2 = w.w2;
+      t.bqkv = w.bqkv; t.bo = w.bo; t.b1 = w.b1; t.b2 = w.b2;
+      t.g1 = w.g1; t.be1 = w.be1; t.g2 = w.g2; t.be2 = w.be2;
+      t.kc = cache_layer(e, e->kcache, l); t.vc = cache_layer(e, e->vcache, l);
+    }
+    E_HIP(e, hipStreamSynchronize(e->st));
+    E_HIP(e, hipMemcpy(e->ps_table, tab.data(), tab.size() * sizeof(PLayer), hipMemcpyHostToDevice));
+    e->ps_table_kc = e->kcache; e->ps_table_ctx = e->ctx_max;
+  }
+  E_HIP(e, hipMemsetAsync(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long), e->st));
+  return 0;
+}
+
+int enqueue_persist_step(vle_engine* e) {
+  PStepArgs a;
+  a.layers = e->ps_table; a.L = e->L; a.d = e->d; a.nhead = e->H; a.dh = e->dh; a.V = V_AR; a.ctx_max = e->ctx_max;
+  a.x_in = e->x_step; a.norm_g = e->ar_norm_g; a.norm_b = e->ar_norm_b; a.w_pred = e->ar_predict; a.logits = e->logits;
+  a.kv_len = e->S.kv_len; a.iter = e->S.iter; a.done = e->S.done; a.gran = e->ps_gran;
+  a.fail = e->qa_spin_fail ? e->qa_spin_fail + 2 : nullptr;
+  a.ptrace = e->opt_ps_trace ? e->ps_ptrace : nullptr;
+  a.mode = e->opt_ps_mode;
+  const int r = launch_pstep(e->st, e->dtype, a);
+  if (r != 0) return e->fail(VLE_EINVAL, "launch_pstep rejected the step");
+  return 0;
+}
+
 // One AR step = one new token per utterance through the L layers + logits + sampling.
 int enqueue_ar_step(vle_engine* e) {
   hipStream_t st = e->st;
   const int d = e->d;
   e->kt_idx = 0;
+  if (persist_ready(e)) {
+    int pr = enqueue_persist_step(e);
+    if (pr) return pr;
+    return enqueue_ar_sample(e, 0, nullptr, 0);
+  }
   const bool sk = use_skinny(e);
   const bool gs = use_mfma_skinny(e);
   for (int l = 0; l < e->L; ++l) {
@@ -1168,7 +1231,7 @@ int enqueue_ar_step(vle_engine* e) {
         q.q_temporal = e->opt_qa_qtemporal;
         if (e->opt_qa_handoff && e->qgran != nullptr) {
           q.q_gran = e->qgran + (size_t)l * d; q.epoch_ptr = e->S.iter; q.spin_fail = e->qa_spin_fail;
-          q.nk = e->opt_qa_nk == 8 ? 8 : 4;
+          q.nk = e->opt_qa_nk == 8 ? 8 : e->opt_qa_nk == 2 ? 2 : 4;
         }
         q.kt = e->next_kt();
         const int fr = launch_qkv_attn1(st, qdt, q);
@@ -1332,6 +1395,7 @@ extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, 
   E_HIP(e, hipMemcpyAsync(e->state_dev, d_state, (6 * e->max_B + 8) * sizeof(int32_t), hipMemcpyDeviceToDevice, st));
   // the AR iteration counters restart at 0: so do the epochs of the fused launch's q granules -- forget the old tags
   if (e->qgran) E_HIP(e, hipMemsetAsync(e->qgran, 0, (size_t)e->L * e->d * sizeof(unsigned long long), st));
+  if ((r = persist_prepare(e))) return r;
   // id range check on the engine-owned copies (sanitises them); the flag is read at the end of this call, by which
   // time these three tiny operations have long completed -- no stall of the stream
   E_HIP(e, hipMemsetAsync(e->id_err_dev, 0, sizeof(int32_t), st));
@@ -1502,6 +1566,8 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   std::vector<int32_t> st_host(6 * e->max_B + 8);
   E_HIP(e, hipMemcpyAsync(e->tables_host, e->state_dev, st_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_IDERR, e->id_err_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  e->poll_host[POLL_PSFAIL] = 0;
+  if (e->qa_spin_fail) E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_PSFAIL, e->qa_spin_fail + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   if (codes0)
     E_HIP(e, hipMemcpy2DAsync(codes0, g_stride * sizeof(int64_t), e->tokens, e->max_G * sizeof(int64_t),
                               std::min<int64_t>(g_stride, e->max_G) * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
@@ -1533,6 +1599,8 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   e->have_gen = true;
   if ((r = leave(e, stream))) return r;
   if (e->poll_host[POLL_IDERR] != 0) return e->fail(VLE_EINDEX, "forced token id outside the audio vocabulary (the reference's nn.Embedding raises IndexError)");
+  if (e->poll_host[POLL_PSFAIL] != 0)
+    return e->fail(VLE_EHIP, "the persistent AR step gave up waiting for an in-launch hand-off (GPU shared with another workload?): results are invalid; set option persist = 0");
   if (not_done) return e->fail(VLE_ESTATE, "AR loop ended with unfinished utterances (capacity too small?)");
   if (no_token) return e->fail(VLE_ENOTOKEN, "well trained model shouldn't reach here.");
   return VLE_OK;
@@ -2209,6 +2277,33 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     (n == "glds_big" ? g_glds_big : n == "glds_w8" ? g_glds_w8 : g_glds_prio) = (int)value;
     return VLE_OK;
   }
+  if (n == "persist" || n == "persist_pf" || n == "persist_nk" || n == "persist_trace" || n == "persist_mode") {  // change the captured graphs: drop them
+    if (n == "persist") e->opt_persist = value != 0;
+    else if (n == "persist_mode") e->opt_ps_mode = (int)value;
+    else if (n == "persist_pf") {
+      if (value < 0 || value > 2) return e->fail(VLE_EINVAL, "persist_pf must be 0, 1 or 2");
+      g_ps_pf = (int)value;
+    } else if (n == "persist_nk") {
+      if (!(value == 2 || value == 4)) return e->fail(VLE_EINVAL, "persist_nk must be 2 or 4");
+      g_ps_nk = (int)value;
+    } else {
+      e->opt_ps_trace = value != 0;
+      if (e->opt_ps_trace && !e->ps_ptrace && e->finalized) {
+        unsigned long long* p = nullptr;
+        int r = dev_alloc(e, &p, (size_t)8 * 256 * PS_PT_SLOTS);
+        if (r) return r;
+        e->ps_ptrace = p;
+      }
+      if (e->ps_ptrace) (void)hipMemset(e->ps_ptrace, 0, (size_t)8 * 256 * PS_PT_SLOTS * sizeof(unsigned long long));
+    }
+    (void)hipStreamSynchronize(e->st);
+    for (auto& kv : e->graphs) {
+      if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
+      if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+    }
+    e->graphs.clear();
+    return VLE_OK;
+  }
   if (n == "ktrace") {  // changes the kernels' arguments: drop the captured graphs
     e->opt_ktrace = value != 0;
     if (e->opt_ktrace && !e->ktrace_buf && e->finalized) {
@@ -2286,6 +2381,19 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
     if (!e->qa_spin_fail) return e->fail(VLE_ESTATE, "no hand-off counter");
     src = e->qa_spin_fail + 1;
     n = sizeof(unsigned);
+  } else if (w == "persist_fail") {  // waves of the persistent step that gave up waiting (expected: 0)
+    if (!e->qa_spin_fail) return e->fail(VLE_ESTATE, "no hand-off counter");
+    src = e->qa_spin_fail + 2;
+    n = sizeof(unsigned);
+  } else if (w == "persist_active") {  // 1 when the next batch-1 step would run the persistent launch
+    const int32_t v = persist_ready(e) ? 1 : 0;
+    const size_t nb = std::min(bytes, sizeof(v));
+    memcpy(host_dst, &v, nb);
+    return (int64_t)nb;
+  } else if (w == "persist_trace") {
+    if (!e->ps_ptrace) return e->fail(VLE_ESTATE, "persist_trace was not enabled");
+    src = e->ps_ptrace;
+    n = (size_t)8 * 256 * PS_PT_SLOTS * sizeof(unsigned long long);
   } else if (w == "last_logits") {
     src = e->logits;
     n = (size_t)e->B * V_AR * sizeof(float);

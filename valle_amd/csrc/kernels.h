@@ -208,6 +208,37 @@ struct QkvAttnArgs {
 bool qkv_attn1_supports(int dtype, int d, int nhead, int dh);
 int launch_qkv_attn1(hipStream_t st, int dtype, const QkvAttnArgs& a);
 
+// ---- persist.hip: the batch-1 AR step as ONE persistent launch (256 workgroups, one per CU; option "persist") -------------------
+struct PLayer {  // one decoder layer's operands (device table, one entry per layer)
+  const void *wqkv = nullptr, *wo = nullptr, *w1 = nullptr, *w2 = nullptr;  // bf16 [N][K]
+  const float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
+  const float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
+  void *kc = nullptr, *vc = nullptr;  // this layer's KV cache [H][ctx_max][dh] (batch 1)
+};
+constexpr int PS_PT_SLOTS = 256;  // wall-clock stamps per workgroup and step of the in-kernel timeline (option "persist_trace")
+struct PStepArgs {
+  const PLayer* layers = nullptr;  // device [L]
+  int L = 0, d = 0, nhead = 0, dh = 0, V = 0, ctx_max = 0;
+  const float* x_in = nullptr;     // f32 [d]: the token's embedding + position (sampling kernel)
+  const float *norm_g = nullptr, *norm_b = nullptr;  // final LayerNorm
+  const void* w_pred = nullptr;    // bf16 [V][d]
+  float* logits = nullptr;         // f32 [V]
+  const int32_t* kv_len = nullptr; // [1] cache slot of the new token
+  const int32_t* iter = nullptr;   // [1] AR iteration counter: epoch = iter + 1
+  const int32_t* done = nullptr;   // [1] the utterance has stopped: the launch is a no-op
+  unsigned long long* gran = nullptr;  // [(L + 1) * pstep_gran_per_layer] {epoch, value} granules (zeroed whenever iter restarts)
+  unsigned* fail = nullptr;        // waves that gave up waiting (expected 0; the engine reports an error otherwise)
+  unsigned long long* ptrace = nullptr;  // [8][256][PS_PT_SLOTS] optional timeline
+  int never = 0;                   // always 0 (keeps the LDS carve allocated)
+  int mode = 0;                    // tuning bits ("persist_mode"): 1 barrier ahead of the attention edge's sweep, 2 16-byte sweeps,
+                                   // 4 hidden vector as bf16 pairs, bits 4..7 extra s_sleep units between polling passes
+};
+bool pstep_supports(int dtype, int d, int nhead, int dh, int V);
+size_t pstep_gran_count(int d, int nhead, int L);
+int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched, 1 shape not covered, < 0 error
+extern int g_ps_pf;  // how far ahead the operands are requested (0 at use, 1 one operator, 2 two)
+extern int g_ps_nk;  // keys per lane per round of the attention share (2 / 4)
+
 // ---- attention.hip --------------------------------------------------------------------------
 // prefill (causal=1: prefix-LM mask) / NAR (causal=0) attention over packed sequences
 int launch_attention(hipStream_t st, int dtype, const void* qkv, void* out, const int32_t* seq_off,

@@ -1,0 +1,673 @@
+// The batch-1 AR decode step as ONE persistent launch (option "persist"; kernels.h PStepArgs).
+//   reference: one iteration of the AR loop of VALLE.inference (valle/models/valle.py:1012-1057) through the L pre-norm decoder
+//   layers (valle/modules/transformer.py:296-302, 332-334; attention valle/modules/activation.py:408-427 on the last row of the
+//   prefix-LM mask valle.py:1019-1033), the final norm and ar_predict_layer (valle.py:1035-1039).
+//
+// Why.  As a launch chain the step is 4 dependent launches per layer (gemv1.hip): 50 boundaries of ~1.66 us plus 50 bodies that
+// each begin with one un-hidden HBM round trip -- 211 us per step for 336 MB (0.198 of the HBM roofline, traffic
+// ratio 1.10: latency, not bytes).  Here the whole step is one grid of 256 workgroups, ONE per CU, that never leaves the chip:
+//   * every workgroup owns the same slice of every operator (rows of W: 12 of the in-projection = 4 query + 4 key + 4 value rows
+//     of ITS head, 4 of out-proj, 16 of linear1, 4 of linear2, 4 of the predict layer; and one (head, 1/16 of the keys) share of
+//     the attention), so its weights never move: they are requested one or two operators AHEAD, straight into registers (a layer's
+//     share is 96 KB per workgroup = 96 VGPRs per lane of the 512 a one-wave-per-SIMD workgroup owns), and have landed when the
+//     operator's input arrives -- the HBM round trip that opens every kernel of the chain is gone from the critical path;
+//   * an operator's output vector travels producer -> consumers as 8-byte {epoch, value} granules (the guide's recipe R2: the data
+//     is the flag; one relaxed agent-scope store per value, consumers re-read their granules until every tag carries this step's
+//     epoch = the AR iteration counter + 1; nothing else orders anything).  Six edges per layer:
+//        x -> [LN1, in-proj] -> (q, k, v of head h: 16 workgroups of ONE XCD, 192 granules) -> [attention over the cached keys]
+//        -> (16 split partials of head h, same 16 workgroups, 96 granules each) -> [merge + the new token's own key]
+//        -> (attention output, 1024 granules, all) -> [out-proj + residual] -> (x', 1024, all) -> [LN2, linear1, ReLU]
+//        -> (hidden, 4096, all) -> [linear2 + residual] -> (x'', 1024, all) -> next layer;
+//   * every arithmetic step is the launch chain's own device function on the same lane <-> element mapping (gemv1_dev.h), and the
+//     attention share is qkv_attn1_kernel's code with 16 splits: the step is BIT-IDENTICAL to the chain run with
+//     qa_nsplit = 16, qa_nk = NK (tests/test_persist_gpu.py asserts equality of every logit of a whole decode).
+// Spins are bounded: a wave that gives up marks the launch failed (PStepArgs::fail, reported by the engine as an error), stops
+// waiting for the rest of the launch and lets every other workgroup run through, so a lost granule cannot hang the device.
+// Co-residency: 256 workgroups of 256 threads with > 80 KB of LDS each = one per CU on an otherwise idle MI355X (the engine
+// owns its stream; the step's neighbours in the graph are ordinary dependent launches).
+#include "common.h"
+#include "kernels.h"
+#include "gemv1_dev.h"
+
+namespace vle {
+
+namespace {
+
+constexpr int PS_T = 256;        // 4 waves, one per SIMD
+constexpr unsigned PS_SPINS = 1u << 18;  // polling passes before a wave gives up (>= 0.1 s)
+
+typedef unsigned long long gran_t;
+
+// Every pointer of the step comes out of the layer table in device memory: hipcc would treat it as a FLAT address (flat_load:
+// both counters, no scalar path).  The table is read through the constant address space (uniform index -> s_load) and the
+// operands through global-address-space pointers (global_load, vmcnt only).
+#define PS_GLOBAL __attribute__((address_space(1)))
+#define PS_CONST __attribute__((address_space(4)))
+template <typename X>
+__device__ inline const X PS_GLOBAL* as_g(unsigned long long v) { return (const X PS_GLOBAL*)v; }
+template <typename X>
+__device__ inline X PS_GLOBAL* as_gw(unsigned long long v) { return (X PS_GLOBAL*)v; }
+__device__ inline u32x4_t ps_load_nt(const u32x4_t PS_GLOBAL* p) { return __builtin_nontemporal_load(p); }  // weights: read once per step
+__device__ inline void ps_load4(const float PS_GLOBAL* p, float (&f)[4]) {
+  const f32x4v_t t = *reinterpret_cast<const f32x4v_t PS_GLOBAL*>(p);
+  f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
+}
+struct PsLayer {  // one entry of the table, as addresses
+  unsigned long long wqkv, wo, w1, w2, bqkv, bo, b1, b2, g1, be1, g2, be2, kc, vc;
+};
+__device__ inline PsLayer ps_layer(const PLayer* tab, int l) {
+  static_assert(sizeof(PLayer) == 14 * 8, "PLayer is 14 pointers");
+  const unsigned long long PS_CONST* t = (const unsigned long long PS_CONST*)tab + (size_t)l * 14;
+  PsLayer p;
+  p.wqkv = t[0]; p.wo = t[1]; p.w1 = t[2]; p.w2 = t[3]; p.bqkv = t[4]; p.bo = t[5]; p.b1 = t[6]; p.b2 = t[7];
+  p.g1 = t[8]; p.be1 = t[9]; p.g2 = t[10]; p.be2 = t[11]; p.kc = t[12]; p.vc = t[13];
+  return p;
+}
+
+__device__ inline gran_t gran_load(const gran_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ inline void gran_store(gran_t* p, unsigned epoch, float v) {
+  __hip_atomic_store(p, ((gran_t)epoch << 32) | (gran_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// Spin state of a wave: `budget` polling passes left in this launch (0 = gave up: never waits again).
+struct PsSpin {
+  unsigned budget;
+  unsigned* fail;
+  int sleep;        // s_sleep units between two polling passes
+  unsigned passes;  // passes of the last gather (timeline diagnostic)
+};
+__device__ inline bool ps_retry(PsSpin& sp) {  // wave-uniform; false = stop waiting
+  if (sp.budget == 0) return false;
+  if (--sp.budget == 0) {
+    if ((threadIdx.x & 63) == 0 && sp.fail) atomicAdd(sp.fail, 1u);
+    return false;
+  }
+  for (int i = 0; i < sp.sleep; ++i) __builtin_amdgcn_s_sleep(1);
+  return true;
+}
+
+// NV consecutive granules at g -> v[NV], re-read until all 64 lanes of the wave see this step's epoch on every tag
+template <int NV>
+__device__ inline void gather_vals(const gran_t* g, unsigned epoch, float (&v)[NV], PsSpin& sp) {
+  sp.passes = 0;
+  for (;;) {
+    gran_t raw[NV];
+#pragma unroll
+    for (int k = 0; k < NV; ++k) raw[k] = gran_load(g + k);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NV; ++k) {
+      ok &= (unsigned)(raw[k] >> 32) == epoch;
+      v[k] = __uint_as_float((unsigned)raw[k]);
+    }
+    ++sp.passes;
+    if (__all(ok)) return;
+    if (!ps_retry(sp)) return;
+  }
+}
+// the same with 16-byte loads (two granules each; the 8-byte halves are what the producers store: observed untorn on gfx950,
+// MI355X_MICROARCH.md "Valid forms"): half the load instructions of a sweep.  `off` = byte offset of g in the granule buffer.
+template <int NV>
+__device__ inline void gather_vals16(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned epoch, float (&v)[NV], PsSpin& sp) {
+  static_assert(NV % 2 == 0, "pairs of granules");
+  sp.passes = 0;
+  for (;;) {
+    u32x4_t raw[NV / 2];
+#pragma unroll
+    for (int k = 0; k < NV / 2; ++k) raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 16 * k), 0, 16 /* sc1 */);
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NV / 2; ++k) {
+      ok &= raw[k].y == epoch && raw[k].w == epoch;
+      v[2 * k] = __uint_as_float(raw[k].x);
+      v[2 * k + 1] = __uint_as_float(raw[k].z);
+    }
+    ++sp.passes;
+    if (__all(ok)) return;
+    if (!ps_retry(sp)) return;
+  }
+}
+
+template <int NV>
+__device__ inline void ps_gather(const gran_t* gbase, __amdgpu_buffer_rsrc_t rs, bool ld16, const gran_t* g, unsigned epoch, float (&v)[NV], PsSpin& sp) {
+  if constexpr (NV % 2 == 0) {
+    if (ld16) {
+      gather_vals16<NV>(rs, (unsigned)((const char*)g - (const char*)gbase), epoch, v, sp);
+      return;
+    }
+  }
+  gather_vals<NV>(g, epoch, v, sp);
+}
+
+// timeline (option "persist_trace"): per hand-off {wall clock when the wave began to wait, polling passes, wall clock when it had the data}
+struct PsTrace {
+  unsigned long long* p;  // this workgroup's slots, thread 0 only; null otherwise
+  int i;
+  unsigned long long t0;
+};
+__device__ inline void pt_begin(PsTrace& t) { if (t.p) t.t0 = wall_clock64(); }
+__device__ inline void pt_end(PsTrace& t, unsigned passes) {
+  if (t.p && t.i + 3 <= PS_PT_SLOTS) {
+    t.p[t.i] = t.t0; t.p[t.i + 1] = passes; t.p[t.i + 2] = wall_clock64();
+    t.i += 3;
+  }
+}
+
+}  // namespace
+
+// granules of one layer
+__host__ __device__ inline int ps_gran_per_layer(int d, int H, int NS) { return d + 3 * d + H * NS * (2 + d / H) + d + d + 4 * d; }
+
+template <typename T, int D, int H, int NK, int PF>
+__global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
+  constexpr int VEC = Elem<T>::VEC;
+  constexpr int CH = 64 * VEC;
+  constexpr int NCH = D / CH;        // K = d
+  constexpr int NCH2 = 4 * D / CH;   // K = 4d
+  constexpr int NWG = 256;
+  constexpr int DH = D / H;
+  constexpr int NS = NWG / H;        // key splits per head = workgroups per head
+  constexpr int QR = DH / NS;        // rows of each of Q, K, V this workgroup projects
+  constexpr int RQ = 3 * QR / 4;     // in-projection rows per wave
+  constexpr int R1 = 4 * D / NWG / 4;  // linear1 rows per wave
+  constexpr int EPT = D / PS_T;      // elements of a d-vector per thread
+  constexpr int EPT2 = 4 * D / PS_T; // ... of the hidden vector
+  static_assert(D % CH == 0 && D % PS_T == 0 && DH * H == D && NS * H == NWG && QR * NS == DH, "shape");
+  static_assert((3 * QR) % 4 == 0 && D / NWG == 4 && EPT == 4, "rows per wave");
+  static_assert(H % 8 == 0, "whole heads per XCD");
+  typedef typename G1W<T>::cache_t CT;
+  constexpr int CVEC = Elem<CT>::VEC;
+  constexpr int LPK = DH / CVEC, KPW = 64 / LPK, WCH = NK * KPW, CHUNK = 4 * WCH;
+  static_assert(DH % CVEC == 0 && (LPK & (LPK - 1)) == 0 && LPK <= 32, "head size");
+  static_assert(!G1W<T>::kScaled, "bf16 weights only");
+
+  // ---- LDS: one array (> 80 KB: one workgroup per CU) -------------------------------------------------------------------------
+  constexpr int SM_FLOATS = 21 * 1024;
+  __shared__ __attribute__((aligned(16))) float smem[SM_FLOATS];
+  float* const sx = smem;                       // [4 D] the operator's input vector
+  float* const red = smem + 4 * D;              // [8]
+  float* const sq = red + 8;                    // [DH] q of the head
+  float* const sk = sq + DH;                    // [DH] the new token's key (cache-rounded)
+  float* const sv = sk + DH;                    // [DH] ... value
+  float* const sm_m = sv + DH;                  // [4]
+  float* const sm_l = sm_m + 4;                 // [4]
+  float* const sm_o = sm_l + 4;                 // [4][DH]
+  float* const spm = sm_o + 4 * DH;             // [NS]
+  float* const spl = spm + NS;                  // [NS]
+  float* const spo = spl + NS;                  // [NS][QR]
+  float* const sres = spo + NS * QR;            // [4] residual values of the rows this workgroup owns
+  static_assert(4 * D + 8 + 3 * DH + 8 + 4 * DH + 2 * NS + NS * QR + 4 <= SM_FLOATS, "LDS carve");
+
+  const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
+  const int c = (int)blockIdx.x;
+  // the NS workgroups of a head on ONE XCD (block b runs on XCD b % 8: speed only)
+  const int jj = c >> 3;
+  const int h = (c & 7) * (H / 8) + jj / NS, s = jj % NS;
+  if (a.done[0]) return;  // the utterance has stopped: the remaining steps of the captured graph are no-ops
+  if (c == 0 && tid == 0 && a.never) smem[SM_FLOATS - 1] = 0.f;  // keeps the whole array allocated
+
+  const unsigned epoch = (unsigned)(a.iter[0] + 1);
+  const int kvl = a.kv_len[0];  // slot of the new token; the old keys are [0, kvl)
+  const int ctx_max = a.ctx_max;
+  const int mode = a.mode;
+  const bool ld16 = (mode & 2) != 0, hpack = (mode & 4) != 0;
+  PsSpin sp{PS_SPINS, a.fail, 1 + ((mode >> 4) & 15), 0u};
+  PsTrace pt{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)((a.iter[0]) & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
+  pt_begin(pt);
+  pt_end(pt, 0u);
+
+  const int GPL = ps_gran_per_layer(D, H, NS);
+  const gran_t* const GB = a.gran;
+  const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, (int)((size_t)(a.L + 1) * GPL * sizeof(gran_t)), 0x00020000);
+  // offsets inside a layer's granules
+  constexpr int G_X = 0, G_QKV = D, G_PART = 4 * D, G_ATT = G_PART + H * NS * (2 + DH), G_X2 = G_ATT + D, G_HID = G_X2 + D;
+
+  // ---- register-resident operands, requested ahead -----------------------------------------------------------------------------
+  u32x4_t wq[RQ][NCH], wo[NCH], w1[R1][NCH], w2[NCH2];
+  float bq = 0.f, bo_v = 0.f, b1_v = 0.f, b2_v = 0.f;
+  float g1v[EPT], be1v[EPT], g2v[EPT], be2v[EPT];
+  u32x4_t kraw[NK], vraw[NK];
+
+  const int slot = lane / LPK, part = lane % LPK;
+  // in-projection row r (0 .. 3 QR - 1) of this workgroup: which = r / QR (0 Q, 1 K, 2 V), e = r % QR -> row which * D + h * DH + s * QR + e
+  auto qkv_row = [&](int r) { return (r / QR) * D + h * DH + s * QR + (r % QR); };
+
+  // a row's 16-byte vectors of this lane: vector cc of row `row` of W[.][KK]
+  auto wvec = [&](unsigned long long W, int64_t row, int KK, int cc) {
+    return ps_load_nt(reinterpret_cast<const u32x4_t PS_GLOBAL*>(as_g<T>(W) + row * KK + lane * VEC + cc * CH));
+  };
+  auto issue_wqkv = [&](const PsLayer& p) {
+#pragma unroll
+    for (int r = 0; r < RQ; ++r) {
+      const int64_t row = qkv_row(w * RQ + r);
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) wq[r][cc] = wvec(p.wqkv, row, D, cc);
+    }
+    if (lane < RQ) bq = as_g<float>(p.bqkv)[qkv_row(w * RQ + lane)];
+    ps_load4(as_g<float>(p.g1) + tid * EPT, g1v);
+    ps_load4(as_g<float>(p.be1) + tid * EPT, be1v);
+  };
+  auto issue_kv = [&](const PsLayer& p, int base) {
+    const CT PS_GLOBAL* Kb = as_g<CT>(p.kc) + (int64_t)h * ctx_max * DH + part * CVEC;
+    const CT PS_GLOBAL* Vb = as_g<CT>(p.vc) + (int64_t)h * ctx_max * DH + part * CVEC;
+#pragma unroll
+    for (int i = 0; i < NK; ++i) {
+      int key = base + w * WCH + i * KPW + slot;
+      key = key < ctx_max ? key : ctx_max - 1;
+      kraw[i] = *reinterpret_cast<const u32x4_t PS_GLOBAL*>(Kb + (int64_t)key * DH);
+      vraw[i] = *reinterpret_cast<const u32x4_t PS_GLOBAL*>(Vb + (int64_t)key * DH);
+    }
+  };
+  auto issue_wo = [&](const PsLayer& p) {
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) wo[cc] = wvec(p.wo, 4 * c + w, D, cc);
+    if (lane == 0) bo_v = as_g<float>(p.bo)[4 * c + w];
+  };
+  auto issue_w1 = [&](const PsLayer& p) {
+#pragma unroll
+    for (int r = 0; r < R1; ++r) {
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) w1[r][cc] = wvec(p.w1, 4 * R1 * c + w * R1 + r, D, cc);
+    }
+    if (lane < R1) b1_v = as_g<float>(p.b1)[4 * R1 * c + w * R1 + lane];
+    ps_load4(as_g<float>(p.g2) + tid * EPT, g2v);
+    ps_load4(as_g<float>(p.be2) + tid * EPT, be2v);
+  };
+  auto issue_w2 = [&](const PsLayer& p) {
+#pragma unroll
+    for (int cc = 0; cc < NCH2; ++cc) w2[cc] = wvec(p.w2, 4 * c + w, 4 * D, cc);
+    if (lane == 0) b2_v = as_g<float>(p.b2)[4 * c + w];
+  };
+  // final norm + predict layer: its operands travel in the in-projection's registers (wq[0], wq[1]; g1v / be1v)
+  const bool extra_row = (c == 0 && w == 0 && 4 * NWG < a.V);  // wave-uniform: row 4 * 256 (the EOS row at V = 1025)
+  auto issue_pred = [&]() {
+    const unsigned long long Wp = (unsigned long long)a.w_pred;
+#pragma unroll
+    for (int cc = 0; cc < NCH; ++cc) wq[0][cc] = wvec(Wp, 4 * c + w, D, cc);
+    if (extra_row) {
+#pragma unroll
+      for (int cc = 0; cc < NCH; ++cc) wq[1][cc] = wvec(Wp, 4 * NWG, D, cc);
+    }
+    ps_load4(as_g<float>((unsigned long long)a.norm_g) + tid * EPT, g1v);
+    ps_load4(as_g<float>((unsigned long long)a.norm_b) + tid * EPT, be1v);
+  };
+
+  // ---- x of the first layer: the sampling kernel's output (previous launch) ----------------------------------------------------
+  float xv[EPT];
+  load_ept<EPT>(a.x_in + tid * EPT, xv);
+  {
+    const PsLayer p0 = ps_layer(a.layers, 0);
+    issue_wqkv(p0);
+    if constexpr (PF >= 1) issue_kv(p0, s * CHUNK);
+    if constexpr (PF >= 2) issue_wo(p0);
+  }
+  __builtin_amdgcn_sched_barrier(0);
+
+  for (int l = 0; l < a.L; ++l) {
+    const PsLayer p = ps_layer(a.layers, l);
+    const PsLayer pn = ps_layer(a.layers, l + 1 < a.L ? l + 1 : l);  // the next layer's entry, long before its operands are requested
+    gran_t* const G = a.gran + (size_t)l * GPL;
+    const bool last = l + 1 == a.L;
+
+    // ======== (1) LN1 + in-projection of this head's 3 QR rows =================================================================
+    if (l > 0) {
+      pt_begin(pt);
+      ps_gather<EPT>(GB, rs, ld16, G + G_X + tid * EPT, epoch, xv, sp);
+      pt_end(pt, sp.passes);
+      if constexpr (PF == 1) issue_kv(p, s * CHUNK);
+      if constexpr (PF >= 2) {
+        issue_kv(p, s * CHUNK);
+        issue_wo(p);
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (tid == c) store_ept_lds<EPT>(sres, xv);  // thread c holds x[4c .. 4c+3]: the residual of the rows this workgroup owns
+    g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
+    {
+      float x[NCH][VEC];
+      g1_read_shared<T, NCH>(sx, x);
+      float mine = 0.f;
+#pragma unroll
+      for (int r = 0; r < RQ; ++r) {
+        const float t = wave_sum_dpp(g1_dot<T, NCH>(wq[r], x));
+        mine = lane == r ? t : mine;
+      }
+      if (lane < RQ) {
+        const int r = w * RQ + lane, which = r / QR, e = s * QR + (r % QR);  // e: element of the head
+        const float v = mine + bq;
+        gran_t* gq = G + G_QKV + h * (3 * DH) + which * DH + e;
+        if (which == 0) {
+          gran_store(gq, epoch, v);
+        } else {
+          CT PS_GLOBAL* dst = as_gw<CT>(which == 1 ? p.kc : p.vc) + ((int64_t)h * ctx_max + kvl) * DH + e;
+          if constexpr (sizeof(CT) == 2) dst->v = f32_to_bf16(v);
+          else *reinterpret_cast<float PS_GLOBAL*>(dst) = v;
+          float vr = v;
+          if constexpr (sizeof(CT) == 2) vr = bf16_to_f32(f32_to_bf16(v));  // what later steps will read back from the cache
+          gran_store(gq, epoch, vr);
+        }
+      }
+    }
+    if constexpr (PF == 0) issue_kv(p, s * CHUNK);
+
+    // ======== (2) q, k_new, v_new of the head; attention over this workgroup's share of the cached keys ==========================
+    pt_begin(pt);
+    if (w < 3) {
+      float t[1];
+      gather_vals<1>(G + G_QKV + h * (3 * DH) + w * DH + (lane < DH ? lane : 0), epoch, t, sp);
+      if (lane < DH) (w == 0 ? sq : w == 1 ? sk : sv)[lane] = t[0];
+    }
+    g1_lds_barrier();
+    pt_end(pt, sp.passes);
+    if constexpr (PF == 1) issue_wo(p);
+    if constexpr (PF >= 2) issue_w1(p);
+    __builtin_amdgcn_sched_barrier(0);
+    {
+      auto widen = [&](const u32x4_t& r, float (&f)[CVEC]) {
+        if constexpr (sizeof(CT) == 4) {
+          f[0] = __uint_as_float(r.x); f[1 % CVEC] = __uint_as_float(r.y); f[2 % CVEC] = __uint_as_float(r.z); f[3 % CVEC] = __uint_as_float(r.w);
+        } else {
+          f[0] = __uint_as_float(r.x << 16); f[1 % CVEC] = __uint_as_float(r.x & 0xffff0000u);
+          f[2 % CVEC] = __uint_as_float(r.y << 16); f[3 % CVEC] = __uint_as_float(r.y & 0xffff0000u);
+          f[4 % CVEC] = __uint_as_float(r.z << 16); f[5 % CVEC] = __uint_as_float(r.z & 0xffff0000u);
+          f[6 % CVEC] = __uint_as_float(r.w << 16); f[7 % CVEC] = __uint_as_float(r.w & 0xffff0000u);
+        }
+      };
+      float qv[CVEC];
+#pragma unroll
+      for (int j = 0; j < CVEC; ++j) qv[j] = sq[part * CVEC + j];
+      const float scale = 1.0f / sqrtf((float)DH);
+      const int ctx = kvl;
+      int base = s * CHUNK;
+      float m = G1_NEG, lsum = 0.f, oacc[CVEC];
+#pragma unroll
+      for (int j = 0; j < CVEC; ++j) oacc[j] = 0.f;
+      while (true) {
+        float sc[NK];
+        float mx = G1_NEG;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+          float kf[CVEC];
+          widen(kraw[i], kf);
+          float t = 0.f;
+#pragma unroll
+          for (int j = 0; j < CVEC; ++j) t = fmaf(qv[j], kf[j], t);
+          t = head_group_sum(t, LPK) * scale;
+          const int key = base + w * WCH + i * KPW + slot;
+          sc[i] = key < ctx ? t : G1_NEG;
+          mx = fmaxf(mx, sc[i]);
+        }
+        const float mn = fmaxf(m, wave_max_dpp(mx));  // wave-uniform running max
+        const float f = __expf(m - mn);
+        lsum *= f;
+#pragma unroll
+        for (int j = 0; j < CVEC; ++j) oacc[j] *= f;
+#pragma unroll
+        for (int i = 0; i < NK; ++i) {
+          const int key = base + w * WCH + i * KPW + slot;
+          const float pr = key < ctx ? __expf(sc[i] - mn) : 0.f;
+          lsum += pr;
+          float vf[CVEC];
+          widen(vraw[i], vf);
+#pragma unroll
+          for (int j = 0; j < CVEC; ++j) oacc[j] = fmaf(pr, vf[j], oacc[j]);
+        }
+        m = mn;
+        base += NS * CHUNK;
+        if (base >= ctx) break;  // block-uniform
+        issue_kv(p, base);
+      }
+      // merge the KPW key slots of the wave, then the 4 waves through LDS (qkv_attn1_kernel's order)
+#pragma unroll
+      for (int o = LPK; o < 8; o <<= 1) {
+        lsum += __shfl_xor(lsum, o, 64);
+#pragma unroll
+        for (int j = 0; j < CVEC; ++j) oacc[j] += __shfl_xor(oacc[j], o, 64);
+      }
+      if constexpr (LPK <= 8) {
+        lsum += dpp_f32<0x128>(lsum);
+#pragma unroll
+        for (int j = 0; j < CVEC; ++j) oacc[j] += dpp_f32<0x128>(oacc[j]);
+      }
+      if constexpr (LPK <= 16) {
+        lsum = rows4_sum(lsum);
+#pragma unroll
+        for (int j = 0; j < CVEC; ++j) oacc[j] = rows4_sum(oacc[j]);
+      } else {
+        lsum += __shfl_xor(lsum, 32, 64);
+#pragma unroll
+        for (int j = 0; j < CVEC; ++j) oacc[j] += __shfl_xor(oacc[j], 32, 64);
+      }
+      if (slot == 0) {
+        if (part == 0) {
+          sm_m[w] = m;
+          sm_l[w] = lsum;
+        }
+#pragma unroll
+        for (int j = 0; j < CVEC; ++j) sm_o[w * DH + part * CVEC + j] = oacc[j];
+      }
+      g1_lds_barrier();
+      if (tid < DH || tid == PS_T - 1) {
+        const float M = fmaxf(fmaxf(sm_m[0], sm_m[1]), fmaxf(sm_m[2], sm_m[3]));
+        float f[4];
+#pragma unroll
+        for (int ww = 0; ww < 4; ++ww) f[ww] = __expf(sm_m[ww] - M);
+        gran_t* gp = G + G_PART + (h * NS + s) * (2 + DH);
+        if (tid < DH) {
+          float o = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < 4; ++ww) o = fmaf(sm_o[ww * DH + tid], f[ww], o);
+          gran_store(gp + 2 + tid, epoch, o);
+        } else {
+          float L = 0.f;
+#pragma unroll
+          for (int ww = 0; ww < 4; ++ww) L = fmaf(sm_l[ww], f[ww], L);
+          gran_store(gp + 0, epoch, M);
+          gran_store(gp + 1, epoch, L);
+        }
+      }
+    }
+    if constexpr (PF == 0) issue_wo(p);
+
+    // ======== (3) merge of the head's NS partials + the new token's own key, for this workgroup's QR output columns (wave 0) =====
+    if (w == 0) {
+      // lanes 0 .. NS-1: (m, l) of split j = lane; lanes NS .. NS + NS*QR/2 - 1: two of the QR columns of split j
+      const gran_t* gp = G + G_PART + (size_t)h * NS * (2 + DH);
+      constexpr int NL = NS + NS * QR / 2;
+      static_assert(NL <= 64 && QR % 2 == 0, "one wave gathers the partial pieces");
+      int j = lane, off = 0;
+      if (lane >= NS) {
+        const int t = lane - NS;
+        j = t / (QR / 2);
+        off = 2 + s * QR + 2 * (t % (QR / 2));
+      }
+      if (lane >= NL) { j = 0; off = 0; }
+      float t2[2];
+      pt_begin(pt);
+      ps_gather<2>(GB, rs, ld16, gp + (size_t)j * (2 + DH) + off, epoch, t2, sp);
+      if (lane < NS) {
+        spm[lane] = t2[0];
+        spl[lane] = t2[1];
+      } else if (lane < NL) {
+        const int t = lane - NS;
+        spo[j * QR + 2 * (t % (QR / 2))] = t2[0];
+        spo[j * QR + 2 * (t % (QR / 2)) + 1] = t2[1];
+      }
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pt_end(pt, sp.passes);
+      // the chain's PRO_ATTN_SELF prologue for thread (head-local index s): gemv1.hip gemv1s_kernel, EPT = QR, NS splits
+      float tq = 0.f;
+      {
+        const int i = lane & 15;  // DH / EPT = 16 threads per head in the chain: lane i holds elements [4 i, 4 i + 4)
+#pragma unroll
+        for (int e = 0; e < QR; ++e) tq = fmaf(sq[(i * QR + e) % DH], sk[(i * QR + e) % DH], tq);
+      }
+      const float sself = head_group_sum64(tq, DH / QR) * (1.0f / sqrtf((float)DH));
+      float M = spm[0];
+#pragma unroll
+      for (int q = 1; q < NS; ++q) M = fmaxf(M, spm[q]);
+      M = fmaxf(M, sself);
+      float L = 0.f, acc[QR];
+#pragma unroll
+      for (int e = 0; e < QR; ++e) acc[e] = 0.f;
+#pragma unroll
+      for (int q = 0; q < NS; ++q) {
+        const float f = __expf(spm[q] - M);
+        L = fmaf(spl[q], f, L);
+#pragma unroll
+        for (int e = 0; e < QR; ++e) acc[e] = fmaf(spo[q * QR + e], f, acc[e]);
+      }
+      {
+        const float f = __expf(sself - M);
+        L += f;
+#pragma unroll
+        for (int e = 0; e < QR; ++e) acc[e] = fmaf(sv[s * QR + e], f, acc[e]);
+      }
+      const float inv = 1.0f / L;
+      float outv = 0.f;
+#pragma unroll
+      for (int e = 0; e < QR; ++e) outv = lane == e ? acc[e] * inv : outv;
+      if (lane < QR) gran_store(G + G_ATT + h * DH + s * QR + lane, epoch, outv);
+    }
+
+    // ======== (4) out-proj + residual of rows 4c .. 4c+3 ==========================================================================
+    if (mode & 1) g1_lds_barrier();  // waves 1 .. 3 do not sweep the attention edge while wave 0 still merges: their polls would sit
+                                     // in front of its loads in the CU's memory queue
+    {
+      float av[EPT];
+      pt_begin(pt);
+      ps_gather<EPT>(GB, rs, ld16, G + G_ATT + tid * EPT, epoch, av, sp);
+      store_ept_lds<EPT>(sx + tid * EPT, av);
+      g1_lds_barrier();
+      pt_end(pt, sp.passes);
+      if constexpr (PF == 1) issue_w1(p);
+      if constexpr (PF >= 2) issue_w2(p);
+      __builtin_amdgcn_sched_barrier(0);
+      float x[NCH][VEC];
+      g1_read_shared<T, NCH>(sx, x);
+      const float mine = wave_sum_dpp(g1_dot<T, NCH>(wo, x));
+      if (lane == 0) {
+        const float v = mine + bo_v;
+        gran_store(G + G_X2 + 4 * c + w, epoch, sres[w] + v);
+      }
+    }
+    if constexpr (PF == 0) issue_w1(p);
+
+    // ======== (5) LN2 + linear1 + ReLU of rows 16c .. 16c+15 ======================================================================
+    {
+      pt_begin(pt);
+      ps_gather<EPT>(GB, rs, ld16, G + G_X2 + tid * EPT, epoch, xv, sp);
+      pt_end(pt, sp.passes);
+      if constexpr (PF == 1) issue_w2(p);
+      if constexpr (PF >= 2) {
+        if (!last) issue_wqkv(pn);
+        else issue_pred();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      if (tid == c) store_ept_lds<EPT>(sres, xv);
+      g1_block_layernorm<D, PS_T>(xv, g2v, be2v, sx, red);
+      float x[NCH][VEC];
+      g1_read_shared<T, NCH>(sx, x);
+      float mine = 0.f;
+#pragma unroll
+      for (int r = 0; r < R1; ++r) {
+        const float t = wave_sum_dpp(g1_dot<T, NCH>(w1[r], x));
+        mine = lane == r ? t : mine;
+      }
+      const float hval = fmaxf(mine + b1_v, 0.f);
+      if (!hpack) {
+        if (lane < R1) gran_store(G + G_HID + 4 * R1 * c + w * R1 + lane, epoch, hval);
+      } else {  // two bf16 values per granule: half the bytes of the widest edge (the batched path keeps the hidden rows in bf16 too)
+        const float nb = dpp_f32<0xB1>(hval);  // lane ^ 1
+        const unsigned pk = (unsigned)f32_to_bf16(hval) | ((unsigned)f32_to_bf16(nb) << 16);
+        if (lane < R1 && (lane & 1) == 0) gran_store(G + G_HID + (4 * R1 * c + w * R1 + lane) / 2, epoch, __uint_as_float(pk));
+      }
+    }
+    if constexpr (PF == 0) issue_w2(p);
+
+    // ======== (6) linear2 + residual of rows 4c .. 4c+3 ===========================================================================
+    {
+      float hv[EPT2];
+      pt_begin(pt);
+      if (!hpack) {
+        ps_gather<EPT2>(GB, rs, ld16, G + G_HID + tid * EPT2, epoch, hv, sp);
+      } else {
+        float pk[EPT2 / 2];
+        ps_gather<EPT2 / 2>(GB, rs, ld16, G + G_HID + tid * (EPT2 / 2), epoch, pk, sp);
+#pragma unroll
+        for (int k = 0; k < EPT2 / 2; ++k) {
+          const unsigned u = __float_as_uint(pk[k]);
+          hv[2 * k] = __uint_as_float(u << 16);
+          hv[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+        }
+      }
+      store_ept_lds<EPT2>(sx + tid * EPT2, hv);
+      g1_lds_barrier();
+      pt_end(pt, sp.passes);
+      if constexpr (PF == 1) {
+        if (!last) issue_wqkv(pn);
+        else issue_pred();
+      }
+      __builtin_amdgcn_sched_barrier(0);
+      float x[NCH2][VEC];
+      g1_read_shared<T, NCH2>(sx, x);
+      const float mine = wave_sum_dpp(g1_dot<T, NCH2>(w2, x));
+      if (lane == 0) {
+        const float v = mine + b2_v;
+        gran_store(G + GPL + G_X + 4 * c + w, epoch, sres[w] + v);  // the next layer's x edge (layer L: the final norm's)
+      }
+    }
+    if constexpr (PF == 0) {
+      if (!last) issue_wqkv(pn);
+      else issue_pred();
+    }
+  }
+
+  // ======== final norm + predict layer: rows 4c .. 4c+3 (+ row 1024) ================================================================
+  {
+    gran_t* const G = a.gran + (size_t)a.L * GPL;
+    pt_begin(pt);
+    ps_gather<EPT>(GB, rs, ld16, G + G_X + tid * EPT, epoch, xv, sp);
+    pt_end(pt, sp.passes);
+    g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
+    float x[NCH][VEC];
+    g1_read_shared<T, NCH>(sx, x);
+    const float t0 = wave_sum_dpp(g1_dot<T, NCH>(wq[0], x));
+    if (lane == 0) a.logits[4 * c + w] = t0 + 0.f;
+    if (extra_row) {
+      const float t1 = wave_sum_dpp(g1_dot<T, NCH>(wq[1], x));
+      if (lane == 0) a.logits[4 * NWG] = t1 + 0.f;
+    }
+    pt_begin(pt);
+    pt_end(pt, 0u);
+  }
+}
+
+bool pstep_supports(int dtype, int d, int nhead, int dh, int V) {
+  return dtype == DT_BF16 && d == 1024 && nhead == 16 && dh == 64 && V > 1024 && V <= 1025;
+}
+
+size_t pstep_gran_count(int d, int nhead, int L) { return (size_t)(L + 1) * ps_gran_per_layer(d, nhead, 256 / nhead); }
+
+int g_ps_pf = 2;  // "persist_pf": how far ahead the operands are requested (0 = at use, 1 = one operator, 2 = two)
+int g_ps_nk = 2;  // "persist_nk": keys per lane per round of the attention share (2: 1024 keys in one round; 4: the chain's qa_nk = 4)
+
+template <int NK>
+static int ps_launch_nk(hipStream_t st, const PStepArgs& a) {
+  const dim3 grid(256), block(PS_T);
+  switch (g_ps_pf) {
+    case 0: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, 0>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, 1>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, 2>), grid, block, 0, st, a); break;
+  }
+  return 0;
+}
+
+// returns 0 = launched, 1 = shape not covered, < 0 = error
+int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
+  if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
+  if (!a.layers || !a.x_in || !a.norm_g || !a.norm_b || !a.w_pred || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
+  return g_ps_nk == 4 ? ps_launch_nk<4>(st, a) : ps_launch_nk<2>(st, a);
+}
+
+}  // namespace vle

@@ -273,6 +273,23 @@ class Engine:
         self.ktrace_waves = valid.sum(-1)
         return out
 
+    def fetch_u32(self, what: str) -> int:
+        """One 32-bit diagnostic word: "qa_spin_fail", "gs_gran_fail", "persist_fail", "persist_active"."""
+        v = C.c_uint32(0)
+        n = self.lib.vle_debug_fetch(self.h, what.encode(), C.byref(v), 4)
+        if n < 0:
+            _lib.check(int(n), self.h)
+        return int(v.value)
+
+    def fetch_persist_trace(self) -> torch.Tensor:
+        """(8 step slots, 256 workgroups, 96) int64 wall-clock stamps (10 ns ticks) of the persistent step's edges (option
+        "persist_trace"): slot 0 = workgroup entry, then one stamp after every completed hand-off; 0 where nothing was stamped."""
+        raw = torch.zeros(8, 256, 256, dtype=torch.int64)
+        n = self.lib.vle_debug_fetch(self.h, b"persist_trace", C.c_void_p(raw.data_ptr()), raw.numel() * 8)
+        if n < 0:
+            _lib.check(int(n), self.h)
+        return raw
+
     def fetch_sampled(self) -> torch.Tensor:
         out = torch.empty(self._B, self.cfg.max_gen_eff(), dtype=torch.int64)
         n = self.lib.vle_debug_fetch(self.h, b"ar_sampled", C.c_void_p(out.data_ptr()), out.numel() * 8)

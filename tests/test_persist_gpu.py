@@ -1,0 +1,121 @@
+"""The persistent batch-1 AR step (valle_amd/csrc/persist.hip, option "persist") against the launch chain it replaces.
+
+The persistent launch runs the chain's own device functions on the same lane <-> element mapping and in the same reduction
+orders, so with the chain set to the same decomposition (16 key splits per head, the same keys per lane, the same bf16 rounding
+of the rows that travel packed) every logit of a decode must be BIT-IDENTICAL -- a far stronger check than a tolerance: one stale
+or torn hand-off anywhere in the 78 in-launch edges of a step shows up as a differing logit.  Parity of the numbers themselves
+with the reference is the business of tests/test_engine_gpu.py and tests/test_parity_sizes_gpu.py, which run with the engine's
+defaults -- i.e. through this launch -- at BASELINE configs[1]'s own size."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+import valle_amd  # noqa: E402
+
+DEV = "cuda:0"
+
+
+def _inputs(S, P, seed=0):
+    g = torch.Generator().manual_seed(4321 + seed)
+    x = torch.randint(3, 100, (1, S), generator=g, dtype=torch.int64)
+    x[0, 0], x[0, -1] = 1, 2
+    y = torch.randint(0, 1024, (1, P, 8), generator=g, dtype=torch.int64)
+    return x.to(DEV), y.to(DEV)
+
+
+@pytest.fixture(scope="module")
+def c2_model():
+    torch.manual_seed(11)
+    return valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()
+
+
+def _decode(eng, X, Y, S, P, steps, opts, top_k=1, seed=0):
+    base = {"persist": 0, "persist_pf": 0, "persist_nk": 2, "persist_mode": 0x33114, "act_bf16": 2, "qa_nsplit": 8, "qa_nk": 4,
+            "steps_per_graph": 0, "ignore_eos": 1}
+    base.update(opts)
+    for k, v in base.items():
+        eng.set_option(k, v)
+    eng.set_option("trace_ar_logits", 1)
+    eng.prefill(X, [S], Y, [P])
+    codes, gl = eng.generate(top_k=top_k, seed=seed, max_new=steps)
+    return codes[0, : gl[0]].cpu(), eng.fetch_ar_logits()[:, 0].clone()
+
+
+def _mode_to_act(mode):
+    return (2 if mode & 4 else 0) | (1 if mode & 8 else 0)
+
+
+@pytest.mark.parametrize("nk,pf,mode", [(2, 0, 0x33114), (2, 0, 0), (2, 0, 0x1c), (4, 0, 0x33114), (2, 1, 0x33114), (2, 1, 0x18)])
+def test_persistent_step_is_bit_identical_to_the_launch_chain(c2_model, nk, pf, mode):
+    S, P, steps = 20, 60, 40
+    eng = c2_model.engine_for(1, S, P)
+    X, Y = _inputs(S, P)
+    ref_codes, ref = _decode(eng, X, Y, S, P, steps, {"qa_nsplit": 16, "qa_nk": nk, "act_bf16": _mode_to_act(mode)})
+    assert eng.fetch_u32("persist_active") == 0
+    got_codes, got = _decode(eng, X, Y, S, P, steps, {"persist": 1, "persist_nk": nk, "persist_pf": pf, "persist_mode": mode,
+                                                      "act_bf16": _mode_to_act(mode)})
+    assert eng.fetch_u32("persist_active") == 1, "the persistent step did not run"
+    assert eng.fetch_u32("persist_fail") == 0, "a wave of the persistent step gave up waiting for a hand-off"
+    assert torch.equal(ref_codes, got_codes)
+    assert ref.shape == got.shape and torch.equal(ref, got), f"max |dlogit| {(ref - got).abs().max().item():.3e} (must be 0)"
+
+
+def test_persistent_step_past_1024_keys_and_at_full_length(c2_model):
+    """BASELINE configs[1]'s own lengths plus a longer text: the context passes 1024 keys, where a workgroup's attention share
+    takes a second round of key chunks (16 splits x 64 keys per round at 2 keys per lane)."""
+    S, P = 60, 225
+    eng = c2_model.engine_for(1, S, P)
+    X, Y = _inputs(S, P, seed=1)
+    steps = 16 * S + 1  # the reference's own cap (valle/models/valle.py:1047): 961 steps, context up to 1246
+    ref_codes, ref = _decode(eng, X, Y, S, P, steps, {"qa_nsplit": 16, "qa_nk": 2})
+    got_codes, got = _decode(eng, X, Y, S, P, steps, {"persist": 1})
+    assert eng.fetch_u32("persist_fail") == 0
+    assert ref_codes.numel() == steps
+    assert torch.equal(ref_codes, got_codes)
+    assert torch.equal(ref, got), f"first differing step {int((ref != got).any(-1).nonzero()[0])}"
+
+
+def test_persistent_step_graph_replay_equals_eager_and_sampled_decode_is_reproducible(c2_model):
+    S, P, steps = 24, 50, 33  # 33 steps: four 8-step graphs and one single-step replay
+    eng_g = c2_model.engine_for(1, S, P)
+    X, Y = _inputs(S, P, seed=2)
+    c1, l1 = _decode(eng_g, X, Y, S, P, steps, {"persist": 1}, top_k=-100, seed=7)
+    c2, l2 = _decode(eng_g, X, Y, S, P, steps, {"persist": 1}, top_k=-100, seed=7)
+    assert torch.equal(c1, c2) and torch.equal(l1, l2), "the same seed must reproduce the sampled decode"
+    m2 = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16", use_graph=False)
+    m2.load_state_dict(c2_model.state_dict(), strict=True)
+    m2 = m2.to(DEV).eval()
+    eng_e = m2.engine_for(1, S, P)
+    c3, l3 = _decode(eng_e, X, Y, S, P, steps, {"persist": 1}, top_k=-100, seed=7)
+    assert eng_e.fetch_u32("persist_fail") == 0
+    assert torch.equal(c1, c3) and torch.equal(l1, l3), "graph replay and eager launches must agree bit for bit"
+    c4, _ = _decode(eng_g, X, Y, S, P, steps, {"persist": 1}, top_k=-100, seed=8)
+    assert not torch.equal(c1, c4)
+
+
+def test_persistent_step_is_the_default_where_covered_and_only_there():
+    torch.manual_seed(3)
+    m = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()
+    eng = m.engine_for(1, 8, 10)
+    X, Y = _inputs(8, 10)
+    eng.prefill(X, [8], Y, [10])
+    assert eng.fetch_u32("persist_active") == 1
+    for dtype, d, h in (("fp32", 1024, 16), ("fp8w", 1024, 16), ("bf16", 512, 8)):
+        m2 = valle_amd.VALLE(d, h, 2, prefix_mode=1, engine_dtype=dtype).to(DEV).eval()
+        e2 = m2.engine_for(1, 8, 10)
+        e2.prefill(X, [8], Y, [10])
+        assert e2.fetch_u32("persist_active") == 0, (dtype, d)
+        codes, gl = e2.generate(top_k=1, max_new=4)
+        assert gl[0] >= 1
+    # two utterances: the batched path
+    m3 = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16", max_batch=2).to(DEV).eval()
+    e3 = m3.engine_for(2, 8, 10)
+    X2, Y2 = torch.cat([X, X]), torch.cat([Y, Y])
+    e3.prefill(X2, [8, 8], Y2, [10, 10])
+    assert e3.fetch_u32("persist_active") == 0
+    # ... and one utterance on the same engine: persistent again (the operand table is rebuilt for the one-utterance cache layout)
+    e3.prefill(X, [8], Y, [10])
+    assert e3.fetch_u32("persist_active") == 1
+    codes, gl = e3.generate(top_k=1, max_new=6)
+    assert e3.fetch_u32("persist_fail") == 0 and gl[0] >= 1

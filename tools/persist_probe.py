@@ -24,7 +24,7 @@ def reset(eng):
     for k in ("nsplit", "gemv1_rpw", "gemv1_rpw_qkv", "gemv1_rpw_ffn1", "no_gemv1", "attn_nk", "steps_per_graph"):
         eng.set_option(k, 0)
     for k, v in (("qkv_attn", 1), ("qa_nsplit", 8), ("g1_shared", 1), ("qa_waves", 4), ("qa_qtemporal", 1), ("qa_handoff", 1), ("qa_nk", 4),
-                 ("persist", 0), ("persist_pf", 2), ("persist_nk", 2), ("persist_mode", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
+                 ("persist", 0), ("persist_pf", 2), ("persist_nk", 2), ("persist_mode", 0), ("act_bf16", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
         eng.set_option(k, v)
 
 
@@ -49,9 +49,9 @@ def main():
     ap.add_argument("--check-steps", type=int, default=96)
     ap.add_argument("--out", default="gpurun_out/persist_probe")
     ap.add_argument("--skip-check", action="store_true")
-    ap.add_argument("--variants", nargs="*", default=["pf=0,mode=0", "pf=0,mode=1", "pf=0,mode=2", "pf=0,mode=3", "pf=0,mode=7", "pf=0,mode=0x33", "pf=0,mode=0x73", "pf=2,mode=3"],
+    ap.add_argument("--variants", nargs="*", default=["pf=0,mode=0", "pf=0,mode=4", "pf=0,mode=12", "pf=0,mode=16", "pf=0,mode=28", "pf=0,mode=28,nk=4", "pf=1,mode=28"],
                     help="persistent variants to time: comma-separated persist_* options, e.g. pf=0,mode=3,nk=2")
-    ap.add_argument("--trace", nargs="*", default=["pf=0,mode=0", "pf=0,mode=3"])
+    ap.add_argument("--trace", nargs="*", default=["pf=0,mode=28", "pf=0,mode=0x1001c"])
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     dev = torch.device("cuda", 0)
@@ -66,9 +66,10 @@ def main():
     # ---- 1. bit-identity with the chain --------------------------------------------------------------------------------------
     if not args.skip_check:
         checks = []
-        for nk in (2, 4):
-            ref = decode(eng, X, Y, args.check_steps, {"qa_nsplit": 16, "qa_nk": nk}, trace=True)
-            for pf, md in ((2, 0), (1, 3), (0, 3), (0, 0x33)):
+        for nk, pf, md in ((2, 1, 0), (2, 1, 4), (2, 1, 12), (2, 1, 16), (2, 1, 28), (4, 1, 28), (2, 0, 28), (2, 1, 0x201c)):
+            if True:
+                ab = (2 if md & 4 else 0) | (1 if md & 8 else 0)
+                ref = decode(eng, X, Y, args.check_steps, {"qa_nsplit": 16, "qa_nk": nk, "act_bf16": ab}, trace=True)
                 got = decode(eng, X, Y, args.check_steps, {"persist": 1, "persist_nk": nk, "persist_pf": pf, "persist_mode": md, "qa_nsplit": 16, "qa_nk": nk}, trace=True)
                 active = eng.fetch_u32("persist_active")
                 fail = eng.fetch_u32("persist_fail")
@@ -107,7 +108,8 @@ def main():
     report["us_per_step"] = res
     report["persist_fail_after_timing"] = eng.fetch_u32("persist_fail")
 
-    # ---- 3. timeline: per hand-off {time thread 0 of each workgroup spent computing before it, time it waited, polling passes} ----
+    # ---- 3. timeline (option "persist_trace"): thread 0 of every workgroup records, per hand-off, {wall clock when it began to wait,
+    #         polling passes, wall clock when it had the data} -------------------------------------------------------------------
     L = 12
     names = ["entry"] + ["L0." + n for n in STAGES[1:]] + [f"L{l}.{n}" for l in range(1, L) for n in STAGES] + ["final.x", "exit"]
     for name in args.trace:
@@ -144,6 +146,18 @@ def main():
                "entry_spread_us": round(float((t0[..., 0].amax(-1) - t0[..., 0].amin(-1)).mean()), 3),
                "final_x": {"compute_us": round(float(comp[..., -2].mean()), 3), "wait_us": round(float(wait[..., -2].mean()), 3)},
                "tail_us": round(float(comp[..., -1].mean()), 3)}
+        if opts.get("persist_mode", 0) & 0x10000:  # finer stamps: per layer 5 (out-proj stage) + 5 (linear2 stage)
+            half = raw.shape[-1] // 2
+            sb = raw[:, :, half: half + 10 * L].reshape(8, 256, L, 10)[ok].double() / 100.0
+            lab = ["lds_read", "dot_reduce", "publish", "next_weights_issue"]
+            o = sb[..., 1:5] - sb[..., 0:4]
+            f = sb[..., 6:10] - sb[..., 5:9]
+            rec["sub_outproj_us"] = {k: round(float(o[..., i].mean()), 3) for i, k in enumerate(lab)}
+            rec["sub_linear2_us"] = {k: round(float(f[..., i].mean()), 3) for i, k in enumerate(lab)}
+            ia = torch.tensor([names.index(f"L{l}.att") for l in range(L)])
+            ih = torch.tensor([names.index(f"L{l}.hid") for l in range(L)])
+            rec["sub_outproj_barrier_to_first"] = round(float((sb[..., 0] - t1[..., ia]).mean()), 3)
+            rec["sub_linear2_barrier_to_first"] = round(float((sb[..., 5] - t1[..., ih]).mean()), 3)
         print("[trace]", json.dumps(rec), flush=True)
         report.setdefault("trace", []).append(rec)
         import csv

@@ -171,13 +171,18 @@ struct vle_engine {
   int opt_qa_handoff = 1;     // option "qa_handoff": q reaches the attention workgroups through granules instead of being recomputed per split
   int opt_qa_qtemporal = 1;   // option "qa_qtemporal": its query-row loads with the default cache policy (shared by a head's splits through L2)
   // ---- the batch-1 step as one persistent launch (persist.hip; option "persist") ----
-  int opt_persist = 0;        // option "persist": 1 = batch-1 AR steps run pstep_kernel (+ the sampling launch) where the shape is covered
+  int opt_persist = 1;        // option "persist": 1 = batch-1 AR steps run pstep_kernel (+ the sampling launch) where the shape is covered
+  int opt_ps_nk = 2, opt_ps_pf = 0;  // options "persist_nk", "persist_pf" (PStepArgs)
+  bool ps_device_ok = false;  // the device has the 256 CUs the persistent grid needs
   PLayer* ps_table = nullptr;               // device [L] operand table (rebuilt when the KV cache moves)
   unsigned long long* ps_gran = nullptr;    // {epoch, value} granules of the step's edges (zeroed at every prefill)
   size_t ps_gran_n = 0;
   unsigned long long* ps_ptrace = nullptr;  // [8][256][PS_PT_SLOTS] in-kernel timeline (option "persist_trace")
   bool opt_ps_trace = false;
-  int opt_ps_mode = 0;        // option "persist_mode": PStepArgs::mode
+  int opt_ps_mode = PS_MODE_DEFAULT;  // option "persist_mode": PStepArgs::mode
+  int opt_act_bf16 = 2;       // option "act_bf16" (bf16 engines only): batch-1 chain, 1 = merged attention row, 2 = FFN hidden row rounded to
+                              // bf16 -- what the persistent step's packed edges carry (persist_mode bits 8 / 4), so that the chain (profiling,
+                              // slot mode, shapes the persistent step lacks) and the persistent step compute the same numbers
   const void* ps_table_kc = nullptr; int ps_table_ctx = 0;  // what the table was built for
   int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
   int opt_rpw_qkv = 0;        // option "gemv1_rpw_qkv": the same for the QKV GEMV only
@@ -484,6 +489,11 @@ extern "C" int vle_create(const vle_config* c, vle_engine** out) {
     delete e;
     set_global_error((std::string("hipSetDevice failed: ") + hipGetErrorString(sr)).c_str());
     return VLE_EHIP;
+  }
+  {  // the persistent batch-1 step is a grid of 256 co-resident workgroups, one per CU (persist.hip)
+    int cus = 0;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) (void)hipGetLastError();
+    e->ps_device_ok = cus >= 256;
   }
   auto chk = [&](hipError_t r, const char* what) {
     if (r != hipSuccess) {
@@ -1074,7 +1084,7 @@ int kv_stream_nt(const vle_engine* e) {
 
 // The persistent step (persist.hip) covers this call: batch 1, the covered shape, bf16 weights, its table built for this cache
 bool persist_ready(const vle_engine* e) {
-  return e->opt_persist && e->B == 1 && !e->slot_mode && !e->w8 && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
+  return e->opt_persist && e->ps_device_ok && e->B == 1 && !e->slot_mode && !e->w8 && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
          e->ps_table_kc == e->kcache && e->ps_table_ctx == e->ctx_max && (int)e->ar.size() == e->L;
 }
 
@@ -1107,7 +1117,7 @@ int enqueue_persist_step(vle_engine* e) {
   a.kv_len = e->S.kv_len; a.iter = e->S.iter; a.done = e->S.done; a.gran = e->ps_gran;
   a.fail = e->qa_spin_fail ? e->qa_spin_fail + 2 : nullptr;
   a.ptrace = e->opt_ps_trace ? e->ps_ptrace : nullptr;
-  a.mode = e->opt_ps_mode;
+  a.mode = e->opt_ps_mode; a.nk = e->opt_ps_nk; a.pf = e->opt_ps_pf;
   const int r = launch_pstep(e->st, e->dtype, a);
   if (r != 0) return e->fail(VLE_EINVAL, "launch_pstep rejected the step");
   return 0;
@@ -1268,13 +1278,14 @@ int enqueue_ar_step(vle_engine* e) {
         if (fused_qa) {  // the partials exclude the new token: merge its own term here
           a.pro = PRO_ATTN_SELF; a.nsplit = e->opt_qa_nsplit; a.q_self = e->q_step; a.k_self = e->k_new; a.v_self = e->v_new;
         }
+        a.act_bf16 = e->dtype == DT_BF16 ? (e->opt_act_bf16 & 1) : 0;
         E_LAUNCH(e, launch_ar_linear(e, a));
       }
       {
         ProfScope ps(e, 3);
         SkinnyArgs f1;
         f1.w = w.w1; f1.w8 = w.w18; f1.wscale = w.s1; f1.bias = w.b1; f1.N = 4 * d; f1.K = d; f1.B = e->B; f1.pro = PRO_LN; f1.epi = SEPI_RELU;
-        f1.x = e->x_step; f1.gamma = w.g2; f1.beta = w.be2; f1.out = e->h_step;
+        f1.x = e->x_step; f1.gamma = w.g2; f1.beta = w.be2; f1.out = e->h_step; f1.act_bf16 = e->dtype == DT_BF16 ? (e->opt_act_bf16 & 2) : 0;
         E_LAUNCH(e, launch_ar_linear(e, f1));
       }
       {
@@ -2277,15 +2288,16 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     (n == "glds_big" ? g_glds_big : n == "glds_w8" ? g_glds_w8 : g_glds_prio) = (int)value;
     return VLE_OK;
   }
-  if (n == "persist" || n == "persist_pf" || n == "persist_nk" || n == "persist_trace" || n == "persist_mode") {  // change the captured graphs: drop them
+  if (n == "persist" || n == "persist_pf" || n == "persist_nk" || n == "persist_trace" || n == "persist_mode" || n == "act_bf16") {  // change the captured graphs: drop them
     if (n == "persist") e->opt_persist = value != 0;
+    else if (n == "act_bf16") e->opt_act_bf16 = (int)value & 3;
     else if (n == "persist_mode") e->opt_ps_mode = (int)value;
     else if (n == "persist_pf") {
-      if (value < 0 || value > 2) return e->fail(VLE_EINVAL, "persist_pf must be 0, 1 or 2");
-      g_ps_pf = (int)value;
+      if (value < 0 || value > 1) return e->fail(VLE_EINVAL, "persist_pf must be 0 or 1");
+      e->opt_ps_pf = (int)value;
     } else if (n == "persist_nk") {
       if (!(value == 2 || value == 4)) return e->fail(VLE_EINVAL, "persist_nk must be 2 or 4");
-      g_ps_nk = (int)value;
+      e->opt_ps_nk = (int)value;
     } else {
       e->opt_ps_trace = value != 0;
       if (e->opt_ps_trace && !e->ps_ptrace && e->finalized) {

@@ -161,7 +161,7 @@ __global__ __launch_bounds__(G1_T) void gemv1_kernel(SkinnyArgs a) {
       }
       const float inv = 1.0f / L;
 #pragma unroll
-      for (int j = 0; j < VEC; ++j) x[c][j] = acc[j] * inv;
+      for (int j = 0; j < VEC; ++j) x[c][j] = (a.act_bf16 & 1) ? bf16_to_f32(f32_to_bf16(acc[j] * inv)) : acc[j] * inv;
     }
   }
 
@@ -196,7 +196,7 @@ __global__ __launch_bounds__(G1_T) void gemv1_kernel(SkinnyArgs a) {
   if constexpr (EPI == SEPI_STORE) {
     a.out[myrow] = v;
   } else if constexpr (EPI == SEPI_RELU) {
-    a.out[myrow] = fmaxf(v, 0.f);
+    a.out[myrow] = (a.act_bf16 & 2) ? bf16_to_f32(f32_to_bf16(fmaxf(v, 0.f))) : fmaxf(v, 0.f);  // bit 1: the hidden row in bf16 (hT_step of the batched path)
   } else if constexpr (EPI == SEPI_RESID) {
     a.resid[myrow] = resid_v + v;
   } else {  // SEPI_QKV: rows [0,d) = Q, [d,2d) = K, [2d,3d) = V  (valle/modules/activation.py:128-130)
@@ -397,6 +397,10 @@ __global__ __launch_bounds__(G1_T) void gemv1s_kernel(SkinnyArgs a) {
     const float inv = 1.0f / L;
 #pragma unroll
     for (int i = 0; i < EPT; ++i) acc[i] *= inv;
+    if (a.act_bf16 & 1) {  // the merged attention row in bf16, as the batched path (att_step) and the persistent step's packed edge carry it
+#pragma unroll
+      for (int i = 0; i < EPT; ++i) acc[i] = bf16_to_f32(f32_to_bf16(acc[i]));
+    }
     store_ept_lds<EPT>(sx + e0, acc);
     g1_lds_barrier();
   }
@@ -419,7 +423,7 @@ __global__ __launch_bounds__(G1_T) void gemv1s_kernel(SkinnyArgs a) {
   if constexpr (EPI == SEPI_STORE) {
     a.out[myrow] = v;
   } else if constexpr (EPI == SEPI_RELU) {
-    a.out[myrow] = fmaxf(v, 0.f);
+    a.out[myrow] = (a.act_bf16 & 2) ? bf16_to_f32(f32_to_bf16(fmaxf(v, 0.f))) : fmaxf(v, 0.f);  // bit 1: the hidden row in bf16 (hT_step of the batched path)
   } else if constexpr (EPI == SEPI_RESID) {
     a.resid[myrow] = resid_v + v;
   } else {

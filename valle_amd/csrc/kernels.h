@@ -163,6 +163,7 @@ struct SkinnyArgs {
   const int32_t* kv_len = nullptr; // [B] slot the new token's K/V go to
   int ctx_max = 0;
   int rpw_override = 0;          // tuning hook of the batch-1 path (rows per wave), 0 = heuristic
+  int act_bf16 = 0;              // gemv1 only: 1 = the merged attention row (PRO_ATTN*), 2 = the ReLU output (SEPI_RELU) rounded to bf16
   KTrace kt;                     // diagnostic timeline (gemv1 only)
 };
 int launch_skinny(hipStream_t st, int dtype, const SkinnyArgs& a);
@@ -215,7 +216,8 @@ struct PLayer {  // one decoder layer's operands (device table, one entry per la
   const float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
   void *kc = nullptr, *vc = nullptr;  // this layer's KV cache [H][ctx_max][dh] (batch 1)
 };
-constexpr int PS_PT_SLOTS = 256;  // wall-clock stamps per workgroup and step of the in-kernel timeline (option "persist_trace")
+constexpr int PS_PT_SLOTS = 512;
+constexpr int PS_MODE_DEFAULT = 0x33114;  // hidden as bf16 pairs, XCD-local group edges, 1 sleep unit, 3 x 8 units ahead of the attention / x sweeps (tools/persist_probe.py)  // wall-clock stamps per workgroup and step of the in-kernel timeline (option "persist_trace")
 struct PStepArgs {
   const PLayer* layers = nullptr;  // device [L]
   int L = 0, d = 0, nhead = 0, dh = 0, V = 0, ctx_max = 0;
@@ -230,14 +232,16 @@ struct PStepArgs {
   unsigned* fail = nullptr;        // waves that gave up waiting (expected 0; the engine reports an error otherwise)
   unsigned long long* ptrace = nullptr;  // [8][256][PS_PT_SLOTS] optional timeline
   int never = 0;                   // always 0 (keeps the LDS carve allocated)
-  int mode = 0;                    // tuning bits ("persist_mode"): 1 barrier ahead of the attention edge's sweep, 2 16-byte sweeps,
-                                   // 4 hidden vector as bf16 pairs, bits 4..7 extra s_sleep units between polling passes
+  // "persist_mode": bit 2 (4) the FFN hidden vector, bit 3 (8) the attention output travel as bf16 pairs; bit 4 (16) the two
+  // head-group edges also through XCD-local (default-policy) granules; bits 8..11 s_sleep units between two sweeps of an edge;
+  // bits 12..15 / 16..19 / 20..23 / 24..27 s_sleep(8) units ahead of the first sweep of the attention-output / x / x' / hidden edge
+  int mode = PS_MODE_DEFAULT;
+  int nk = 2;                      // "persist_nk": keys per lane per round of the attention share (2: 1024 keys in one round; 4)
+  int pf = 0;                      // "persist_pf": 0 = an operator's operands are requested ahead of the sweep that precedes it; 1 = behind it
 };
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V);
 size_t pstep_gran_count(int d, int nhead, int L);
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched, 1 shape not covered, < 0 error
-extern int g_ps_pf;  // how far ahead the operands are requested (0 at use, 1 one operator, 2 two)
-extern int g_ps_nk;  // keys per lane per round of the attention share (2 / 4)
 
 // ---- attention.hip --------------------------------------------------------------------------
 // prefill (causal=1: prefix-LM mask) / NAR (causal=0) attention over packed sequences

@@ -69,6 +69,17 @@ __device__ inline void gran_store(gran_t* p, unsigned epoch, float v) {
   __hip_atomic_store(p, ((gran_t)epoch << 32) | (gran_t)__float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
+__device__ inline void gran_store_bits(gran_t* p, unsigned epoch, unsigned bits) {
+  __hip_atomic_store(p, ((gran_t)epoch << 32) | (gran_t)bits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// the same granule with the DEFAULT cache policy: the line stays (dirty) in the storing CU's XCD L2, where the L1-bypassing polls of
+// the other CUs of that XCD hit it one L2 round trip later -- a fast path for the edges whose producers and consumers are placed on
+// one XCD.  Never the only copy: another XCD cannot see it, so the write-through granule above is always stored too.
+__device__ inline void gran_store_local(gran_t* p, unsigned epoch, unsigned bits) {
+  *reinterpret_cast<gran_t PS_GLOBAL*>((unsigned long long)p) = ((gran_t)epoch << 32) | (gran_t)bits;
+}
+__device__ inline unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+
 // Spin state of a wave: `budget` polling passes left in this launch (0 = gave up: never waits again).
 struct PsSpin {
   unsigned budget;
@@ -107,10 +118,31 @@ __device__ inline void gather_vals(const gran_t* g, unsigned epoch, float (&v)[N
 }
 // the same with 16-byte loads (two granules each; the 8-byte halves are what the producers store: observed untorn on gfx950,
 // MI355X_MICROARCH.md "Valid forms"): half the load instructions of a sweep.  `off` = byte offset of g in the granule buffer.
-template <int NV>
-__device__ inline void gather_vals16(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned epoch, float (&v)[NV], PsSpin& sp) {
+// `after_first_issue` runs between the first sweep's loads and their first use: whatever it requests (the operands of a LATER
+// operator) is younger than the sweep, so the sweep does not wait for it -- a wave's loads return in order, and requests issued
+// BEFORE a sweep delay it by their whole HBM round trip.
+struct PsNoop {
+  __device__ void operator()() const {}
+};
+template <int NV, typename F>
+__device__ inline void gather_vals16(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned epoch, float (&v)[NV], PsSpin& sp, F&& after_first_issue) {
   static_assert(NV % 2 == 0, "pairs of granules");
-  sp.passes = 0;
+  sp.passes = 1;
+  {
+    u32x4_t raw[NV / 2];
+#pragma unroll
+    for (int k = 0; k < NV / 2; ++k) raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 16 * k), 0, 16 /* sc1 */);
+    after_first_issue();
+    bool ok = true;
+#pragma unroll
+    for (int k = 0; k < NV / 2; ++k) {
+      ok &= raw[k].y == epoch && raw[k].w == epoch;
+      v[2 * k] = __uint_as_float(raw[k].x);
+      v[2 * k + 1] = __uint_as_float(raw[k].z);
+    }
+    if (__all(ok)) return;
+    if (!ps_retry(sp)) return;
+  }
   for (;;) {
     u32x4_t raw[NV / 2];
 #pragma unroll
@@ -128,15 +160,44 @@ __device__ inline void gather_vals16(__amdgpu_buffer_rsrc_t rs, unsigned off, un
   }
 }
 
-template <int NV>
-__device__ inline void ps_gather(const gran_t* gbase, __amdgpu_buffer_rsrc_t rs, bool ld16, const gran_t* g, unsigned epoch, float (&v)[NV], PsSpin& sp) {
-  if constexpr (NV % 2 == 0) {
-    if (ld16) {
-      gather_vals16<NV>(rs, (unsigned)((const char*)g - (const char*)gbase), epoch, v, sp);
-      return;
-    }
+template <int NV, typename F>
+__device__ inline void ps_gather(const gran_t* gbase, __amdgpu_buffer_rsrc_t rs, const gran_t* g, unsigned epoch, float (&v)[NV], PsSpin& sp, F&& after_first_issue) {
+  static_assert(NV % 2 == 0, "16-byte sweeps");
+  gather_vals16<NV>(rs, (unsigned)((const char*)g - (const char*)gbase), epoch, v, sp, after_first_issue);
+}
+// One granule per lane from the XCD-local copy (gl; null = none) or the write-through copy (g): PS_LOCAL_TRIES passes on the local
+// copy, one on the other, and so on -- whatever the placement, the write-through copy is found.
+constexpr int PS_LOCAL_TRIES = 6;
+template <typename F>
+__device__ inline float gather_one_dual(const gran_t* g, const gran_t* gl, unsigned epoch, PsSpin& sp, F&& after_first_issue) {
+  sp.passes = 1;
+  {
+    const gran_t raw = gran_load(gl != nullptr ? gl : g);
+    after_first_issue();
+    if (__all((unsigned)(raw >> 32) == epoch)) return __uint_as_float((unsigned)raw);
+    if (!ps_retry(sp)) return __uint_as_float((unsigned)raw);
   }
-  gather_vals<NV>(g, epoch, v, sp);
+  for (;;) {
+    const bool local = gl != nullptr && (sp.passes % (PS_LOCAL_TRIES + 1)) != PS_LOCAL_TRIES;
+    const gran_t raw = gran_load(local ? gl : g);
+    ++sp.passes;
+    if (__all((unsigned)(raw >> 32) == epoch)) return __uint_as_float((unsigned)raw);
+    if (!ps_retry(sp)) return __uint_as_float((unsigned)raw);
+  }
+}
+// two granules per lane (16 bytes), same alternation; offsets in bytes into the granule buffer
+__device__ inline void gather_two_dual(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned off_local, bool have_local, unsigned epoch, float (&v)[2],
+                                       PsSpin& sp) {
+  sp.passes = 0;
+  for (;;) {
+    const bool local = have_local && (sp.passes % (PS_LOCAL_TRIES + 1)) != PS_LOCAL_TRIES;
+    const u32x4_t raw = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(local ? off_local : off), 0, 16 /* sc1 */);
+    v[0] = __uint_as_float(raw.x);
+    v[1] = __uint_as_float(raw.z);
+    ++sp.passes;
+    if (__all(raw.y == epoch && raw.w == epoch)) return;
+    if (!ps_retry(sp)) return;
+  }
 }
 
 // timeline (option "persist_trace"): per hand-off {wall clock when the wave began to wait, polling passes, wall clock when it had the data}
@@ -156,9 +217,15 @@ __device__ inline void pt_end(PsTrace& t, unsigned passes) {
 }  // namespace
 
 // granules of one layer
-__host__ __device__ inline int ps_gran_per_layer(int d, int H, int NS) { return d + 3 * d + H * NS * (2 + d / H) + d + d + 4 * d; }
+__host__ __device__ inline int ps_gran_per_layer(int d, int H, int NS) { return d + 3 * d + H * NS * (2 + d / H) + d + d + 4 * d + 3 * d + H * NS * (2 + d / H); }
 
-template <typename T, int D, int H, int NK, int PF>
+// PF: 0 = an operator's operands are requested right BEFORE the sweep that precedes it (they land while the edge is in flight, but
+//         the sweep cannot return before they have: a wave's loads return in order);
+//     1 = the sweep first, THEN the operands of the operator AFTER the next one (gather_vals16's functor): the sweep returns at the
+//         edge's own latency and the operands have a whole stage to land.
+// PK: bit 0 = the FFN hidden vector, bit 1 = the attention output travel as bf16 pairs (compile-time: a run-time branch around
+//     a sweep that carries requests would make hipcc merge in-flight registers, see below).
+template <typename T, int D, int H, int NK, int PF, int PK>
 __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   constexpr int VEC = Elem<T>::VEC;
   constexpr int CH = 64 * VEC;
@@ -210,8 +277,12 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   const int kvl = a.kv_len[0];  // slot of the new token; the old keys are [0, kvl)
   const int ctx_max = a.ctx_max;
   const int mode = a.mode;
-  const bool ld16 = (mode & 2) != 0, hpack = (mode & 4) != 0;
-  PsSpin sp{PS_SPINS, a.fail, 1 + ((mode >> 4) & 15), 0u};
+  constexpr bool hpack = (PK & 1) != 0, apack = (PK & 2) != 0;
+  const bool glocal = (mode & 16) != 0;
+  // s_sleep(8) units ahead of the FIRST sweep of an all-to-all edge (attention output, x, x', hidden): a sweep that comes back
+  // without the data costs a whole fabric round trip (~1.1 us) before the next one can see it -- waiting first is cheaper
+  const int nap_att = (mode >> 12) & 15, nap_x = (mode >> 16) & 15, nap_x2 = (mode >> 20) & 15, nap_hid = (mode >> 24) & 15;
+  PsSpin sp{PS_SPINS, a.fail, (mode >> 8) & 15, 0u};
   PsTrace pt{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)((a.iter[0]) & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
   pt_begin(pt);
   pt_end(pt, 0u);
@@ -221,6 +292,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc((void*)a.gran, 0, (int)((size_t)(a.L + 1) * GPL * sizeof(gran_t)), 0x00020000);
   // offsets inside a layer's granules
   constexpr int G_X = 0, G_QKV = D, G_PART = 4 * D, G_ATT = G_PART + H * NS * (2 + DH), G_X2 = G_ATT + D, G_HID = G_X2 + D;
+  constexpr int G_QKVL = G_HID + 4 * D, G_PARTL = G_QKVL + 3 * D;  // XCD-local copies of the two head-group edges
 
   // ---- register-resident operands, requested ahead -----------------------------------------------------------------------------
   u32x4_t wq[RQ][NCH], wo[NCH], w1[R1][NCH], w2[NCH2];
@@ -236,16 +308,24 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   auto wvec = [&](unsigned long long W, int64_t row, int KK, int cc) {
     return ps_load_nt(reinterpret_cast<const u32x4_t PS_GLOBAL*>(as_g<T>(W) + row * KK + lane * VEC + cc * CH));
   };
-  auto issue_wqkv = [&](const PsLayer& p) {
+  // Every request below is STRAIGHT-LINE code on selected addresses: a load under a branch or an exec mask makes hipcc merge the
+  // loaded registers with the other path's by v_mov after an s_waitcnt -- the "prefetch" then waits for its own HBM round trip
+  // (measured: 1.0 us at the end of every linear2 stage).
+  const bool extra_row = (c == 0 && w == 0 && 4 * NWG < a.V);  // wave-uniform: row 4 * 256 (the EOS row at V = 1025)
+  // the in-projection rows of layer `p`, or (pred) the predict layer's: its row 4c + w in wq[0], row 1024 in the one wave that owns
+  // it (the others re-request their own row: an L2 hit), and the final norm's affine
+  auto issue_wqkv = [&](const PsLayer& p, bool pred) {
+    const unsigned long long W = pred ? (unsigned long long)a.w_pred : p.wqkv;
 #pragma unroll
     for (int r = 0; r < RQ; ++r) {
-      const int64_t row = qkv_row(w * RQ + r);
+      const int64_t prow = (r == 1 && extra_row) ? 4 * NWG : 4 * c + w;
+      const int64_t row = pred ? prow : (int64_t)qkv_row(w * RQ + r);
 #pragma unroll
-      for (int cc = 0; cc < NCH; ++cc) wq[r][cc] = wvec(p.wqkv, row, D, cc);
+      for (int cc = 0; cc < NCH; ++cc) wq[r][cc] = wvec(W, row, D, cc);
     }
-    if (lane < RQ) bq = as_g<float>(p.bqkv)[qkv_row(w * RQ + lane)];
-    ps_load4(as_g<float>(p.g1) + tid * EPT, g1v);
-    ps_load4(as_g<float>(p.be1) + tid * EPT, be1v);
+    bq = as_g<float>(p.bqkv)[qkv_row(w * RQ + (lane < RQ ? lane : RQ - 1))];  // (unused by the predict layer: it has no bias)
+    ps_load4(as_g<float>(pred ? (unsigned long long)a.norm_g : p.g1) + tid * EPT, g1v);
+    ps_load4(as_g<float>(pred ? (unsigned long long)a.norm_b : p.be1) + tid * EPT, be1v);
   };
   auto issue_kv = [&](const PsLayer& p, int base) {
     const CT PS_GLOBAL* Kb = as_g<CT>(p.kc) + (int64_t)h * ctx_max * DH + part * CVEC;
@@ -261,7 +341,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   auto issue_wo = [&](const PsLayer& p) {
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) wo[cc] = wvec(p.wo, 4 * c + w, D, cc);
-    if (lane == 0) bo_v = as_g<float>(p.bo)[4 * c + w];
+    bo_v = as_g<float>(p.bo)[4 * c + w];
   };
   auto issue_w1 = [&](const PsLayer& p) {
 #pragma unroll
@@ -269,39 +349,27 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 #pragma unroll
       for (int cc = 0; cc < NCH; ++cc) w1[r][cc] = wvec(p.w1, 4 * R1 * c + w * R1 + r, D, cc);
     }
-    if (lane < R1) b1_v = as_g<float>(p.b1)[4 * R1 * c + w * R1 + lane];
+    b1_v = as_g<float>(p.b1)[4 * R1 * c + w * R1 + (lane < R1 ? lane : R1 - 1)];
     ps_load4(as_g<float>(p.g2) + tid * EPT, g2v);
     ps_load4(as_g<float>(p.be2) + tid * EPT, be2v);
   };
   auto issue_w2 = [&](const PsLayer& p) {
 #pragma unroll
     for (int cc = 0; cc < NCH2; ++cc) w2[cc] = wvec(p.w2, 4 * c + w, 4 * D, cc);
-    if (lane == 0) b2_v = as_g<float>(p.b2)[4 * c + w];
+    b2_v = as_g<float>(p.b2)[4 * c + w];
   };
-  // final norm + predict layer: its operands travel in the in-projection's registers (wq[0], wq[1]; g1v / be1v)
-  const bool extra_row = (c == 0 && w == 0 && 4 * NWG < a.V);  // wave-uniform: row 4 * 256 (the EOS row at V = 1025)
-  auto issue_pred = [&]() {
-    const unsigned long long Wp = (unsigned long long)a.w_pred;
-#pragma unroll
-    for (int cc = 0; cc < NCH; ++cc) wq[0][cc] = wvec(Wp, 4 * c + w, D, cc);
-    if (extra_row) {
-#pragma unroll
-      for (int cc = 0; cc < NCH; ++cc) wq[1][cc] = wvec(Wp, 4 * NWG, D, cc);
-    }
-    ps_load4(as_g<float>((unsigned long long)a.norm_g) + tid * EPT, g1v);
-    ps_load4(as_g<float>((unsigned long long)a.norm_b) + tid * EPT, be1v);
-  };
-
   // ---- x of the first layer: the sampling kernel's output (previous launch) ----------------------------------------------------
   float xv[EPT];
   load_ept<EPT>(a.x_in + tid * EPT, xv);
   {
     const PsLayer p0 = ps_layer(a.layers, 0);
-    issue_wqkv(p0);
+    issue_wqkv(p0, false);
     if constexpr (PF >= 1) issue_kv(p0, s * CHUNK);
-    if constexpr (PF >= 2) issue_wo(p0);
   }
   __builtin_amdgcn_sched_barrier(0);
+  auto nap = [&](int n) {
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+  };
 
   for (int l = 0; l < a.L; ++l) {
     const PsLayer p = ps_layer(a.layers, l);
@@ -312,14 +380,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     // ======== (1) LN1 + in-projection of this head's 3 QR rows =================================================================
     if (l > 0) {
       pt_begin(pt);
-      ps_gather<EPT>(GB, rs, ld16, G + G_X + tid * EPT, epoch, xv, sp);
+      nap(nap_x);
+      if constexpr (PF >= 1) ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, [&]() { issue_kv(p, s * CHUNK); });
+      else ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, PsNoop());
       pt_end(pt, sp.passes);
-      if constexpr (PF == 1) issue_kv(p, s * CHUNK);
-      if constexpr (PF >= 2) {
-        issue_kv(p, s * CHUNK);
-        issue_wo(p);
-      }
-      __builtin_amdgcn_sched_barrier(0);
     }
     if (tid == c) store_ept_lds<EPT>(sres, xv);  // thread c holds x[4c .. 4c+3]: the residual of the rows this workgroup owns
     g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
@@ -336,8 +400,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         const int r = w * RQ + lane, which = r / QR, e = s * QR + (r % QR);  // e: element of the head
         const float v = mine + bq;
         gran_t* gq = G + G_QKV + h * (3 * DH) + which * DH + e;
+        gran_t* gql = G + G_QKVL + h * (3 * DH) + which * DH + e;
         if (which == 0) {
           gran_store(gq, epoch, v);
+          if (glocal) gran_store_local(gql, epoch, __float_as_uint(v));
         } else {
           CT PS_GLOBAL* dst = as_gw<CT>(which == 1 ? p.kc : p.vc) + ((int64_t)h * ctx_max + kvl) * DH + e;
           if constexpr (sizeof(CT) == 2) dst->v = f32_to_bf16(v);
@@ -345,6 +411,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
           float vr = v;
           if constexpr (sizeof(CT) == 2) vr = bf16_to_f32(f32_to_bf16(v));  // what later steps will read back from the cache
           gran_store(gq, epoch, vr);
+          if (glocal) gran_store_local(gql, epoch, __float_as_uint(vr));
         }
       }
     }
@@ -352,15 +419,17 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 
     // ======== (2) q, k_new, v_new of the head; attention over this workgroup's share of the cached keys ==========================
     pt_begin(pt);
-    if (w < 3) {
-      float t[1];
-      gather_vals<1>(G + G_QKV + h * (3 * DH) + w * DH + (lane < DH ? lane : 0), epoch, t, sp);
-      if (lane < DH) (w == 0 ? sq : w == 1 ? sk : sv)[lane] = t[0];
+    {
+      // every wave sweeps (wave 3 repeats wave 0's granules and drops them): the requests the sweep carries stay straight-line code
+      const int wq_i = w < 3 ? w : 0;
+      const int gi = h * (3 * DH) + wq_i * DH + (lane < DH ? lane : 0);
+      float t;
+      if constexpr (PF >= 1) t = gather_one_dual(G + G_QKV + gi, glocal ? G + G_QKVL + gi : nullptr, epoch, sp, [&]() { issue_wo(p); });
+      else t = gather_one_dual(G + G_QKV + gi, glocal ? G + G_QKVL + gi : nullptr, epoch, sp, PsNoop());
+      if (w < 3 && lane < DH) (w == 0 ? sq : w == 1 ? sk : sv)[lane] = t;
     }
     g1_lds_barrier();
     pt_end(pt, sp.passes);
-    if constexpr (PF == 1) issue_wo(p);
-    if constexpr (PF >= 2) issue_w1(p);
     __builtin_amdgcn_sched_barrier(0);
     {
       auto widen = [&](const u32x4_t& r, float (&f)[CVEC]) {
@@ -458,12 +527,17 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 #pragma unroll
           for (int ww = 0; ww < 4; ++ww) o = fmaf(sm_o[ww * DH + tid], f[ww], o);
           gran_store(gp + 2 + tid, epoch, o);
+          if (glocal) gran_store_local(gp + (G_PARTL - G_PART) + 2 + tid, epoch, __float_as_uint(o));
         } else {
-          float L = 0.f;
+          float Ls = 0.f;
 #pragma unroll
-          for (int ww = 0; ww < 4; ++ww) L = fmaf(sm_l[ww], f[ww], L);
+          for (int ww = 0; ww < 4; ++ww) Ls = fmaf(sm_l[ww], f[ww], Ls);
           gran_store(gp + 0, epoch, M);
-          gran_store(gp + 1, epoch, L);
+          gran_store(gp + 1, epoch, Ls);
+          if (glocal) {
+            gran_store_local(gp + (G_PARTL - G_PART) + 0, epoch, __float_as_uint(M));
+            gran_store_local(gp + (G_PARTL - G_PART) + 1, epoch, __float_as_uint(Ls));
+          }
         }
       }
     }
@@ -481,10 +555,16 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         j = t / (QR / 2);
         off = 2 + s * QR + 2 * (t % (QR / 2));
       }
-      if (lane >= NL) { j = 0; off = 0; }
+      if (lane >= NL) {
+        j = 0;
+        off = 0;
+      }
       float t2[2];
       pt_begin(pt);
-      ps_gather<2>(GB, rs, ld16, gp + (size_t)j * (2 + DH) + off, epoch, t2, sp);
+      {
+        const unsigned bo = (unsigned)((const char*)(gp + (size_t)j * (2 + DH) + off) - (const char*)GB);
+        gather_two_dual(rs, bo, bo + (unsigned)(G_PARTL - G_PART) * 8u, glocal, epoch, t2, sp);
+      }
       if (lane < NS) {
         spm[lane] = t2[0];
         spl[lane] = t2[1];
@@ -507,41 +587,60 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 #pragma unroll
       for (int q = 1; q < NS; ++q) M = fmaxf(M, spm[q]);
       M = fmaxf(M, sself);
-      float L = 0.f, acc[QR];
+      float Ls = 0.f, acc[QR];
 #pragma unroll
       for (int e = 0; e < QR; ++e) acc[e] = 0.f;
 #pragma unroll
       for (int q = 0; q < NS; ++q) {
         const float f = __expf(spm[q] - M);
-        L = fmaf(spl[q], f, L);
+        Ls = fmaf(spl[q], f, Ls);
 #pragma unroll
         for (int e = 0; e < QR; ++e) acc[e] = fmaf(spo[q * QR + e], f, acc[e]);
       }
       {
         const float f = __expf(sself - M);
-        L += f;
+        Ls += f;
 #pragma unroll
         for (int e = 0; e < QR; ++e) acc[e] = fmaf(sv[s * QR + e], f, acc[e]);
       }
-      const float inv = 1.0f / L;
-      float outv = 0.f;
+      const float inv = 1.0f / Ls;
 #pragma unroll
-      for (int e = 0; e < QR; ++e) outv = lane == e ? acc[e] * inv : outv;
-      if (lane < QR) gran_store(G + G_ATT + h * DH + s * QR + lane, epoch, outv);
+      for (int e = 0; e < QR; ++e) acc[e] *= inv;
+      if constexpr (!apack) {
+        float outv = 0.f;
+#pragma unroll
+        for (int e = 0; e < QR; ++e) outv = lane == e ? acc[e] : outv;
+        if (lane < QR) gran_store(G + G_ATT + h * DH + s * QR + lane, epoch, outv);
+      } else {  // bf16 pairs (the chain with act_bf16 & 1 rounds the merged row the same way)
+        const unsigned pk = lane == 0 ? pack_bf16x2(acc[0], acc[1]) : pack_bf16x2(acc[2], acc[3]);
+        if (lane < 2) gran_store_bits(G + G_ATT + (h * DH + s * QR) / 2 + lane, epoch, pk);
+      }
     }
 
     // ======== (4) out-proj + residual of rows 4c .. 4c+3 ==========================================================================
-    if (mode & 1) g1_lds_barrier();  // waves 1 .. 3 do not sweep the attention edge while wave 0 still merges: their polls would sit
-                                     // in front of its loads in the CU's memory queue
+    g1_lds_barrier();  // waves 1 .. 3 do not sweep the attention edge while wave 0 still merges: their polls would sit in front of
+                       // its loads in the CU's memory queue (measured: 257 -> 241 us per step)
     {
-      float av[EPT];
+      constexpr int NA = apack ? EPT / 2 : EPT;
+      float av[EPT], raw[NA];
       pt_begin(pt);
-      ps_gather<EPT>(GB, rs, ld16, G + G_ATT + tid * EPT, epoch, av, sp);
+      nap(nap_att);
+      if constexpr (PF >= 1) ps_gather<NA>(GB, rs, G + G_ATT + tid * NA, epoch, raw, sp, [&]() { issue_w1(p); });
+      else ps_gather<NA>(GB, rs, G + G_ATT + tid * NA, epoch, raw, sp, PsNoop());
+      if constexpr (apack) {
+#pragma unroll
+        for (int k = 0; k < EPT / 2; ++k) {
+          const unsigned u = __float_as_uint(raw[k]);
+          av[2 * k] = __uint_as_float(u << 16);
+          av[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+        }
+      } else {
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) av[k] = raw[k];
+      }
       store_ept_lds<EPT>(sx + tid * EPT, av);
       g1_lds_barrier();
       pt_end(pt, sp.passes);
-      if constexpr (PF == 1) issue_w1(p);
-      if constexpr (PF >= 2) issue_w2(p);
       __builtin_amdgcn_sched_barrier(0);
       float x[NCH][VEC];
       g1_read_shared<T, NCH>(sx, x);
@@ -556,13 +655,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     // ======== (5) LN2 + linear1 + ReLU of rows 16c .. 16c+15 ======================================================================
     {
       pt_begin(pt);
-      ps_gather<EPT>(GB, rs, ld16, G + G_X2 + tid * EPT, epoch, xv, sp);
+      nap(nap_x2);
+      if constexpr (PF >= 1) ps_gather<EPT>(GB, rs, G + G_X2 + tid * EPT, epoch, xv, sp, [&]() { issue_w2(p); });
+      else ps_gather<EPT>(GB, rs, G + G_X2 + tid * EPT, epoch, xv, sp, PsNoop());
       pt_end(pt, sp.passes);
-      if constexpr (PF == 1) issue_w2(p);
-      if constexpr (PF >= 2) {
-        if (!last) issue_wqkv(pn);
-        else issue_pred();
-      }
       __builtin_amdgcn_sched_barrier(0);
       if (tid == c) store_ept_lds<EPT>(sres, xv);
       g1_block_layernorm<D, PS_T>(xv, g2v, be2v, sx, red);
@@ -575,39 +671,37 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         mine = lane == r ? t : mine;
       }
       const float hval = fmaxf(mine + b1_v, 0.f);
-      if (!hpack) {
+      if constexpr (!hpack) {
         if (lane < R1) gran_store(G + G_HID + 4 * R1 * c + w * R1 + lane, epoch, hval);
       } else {  // two bf16 values per granule: half the bytes of the widest edge (the batched path keeps the hidden rows in bf16 too)
         const float nb = dpp_f32<0xB1>(hval);  // lane ^ 1
-        const unsigned pk = (unsigned)f32_to_bf16(hval) | ((unsigned)f32_to_bf16(nb) << 16);
-        if (lane < R1 && (lane & 1) == 0) gran_store(G + G_HID + (4 * R1 * c + w * R1 + lane) / 2, epoch, __uint_as_float(pk));
+        if (lane < R1 && (lane & 1) == 0) gran_store_bits(G + G_HID + (4 * R1 * c + w * R1 + lane) / 2, epoch, pack_bf16x2(hval, nb));
       }
     }
     if constexpr (PF == 0) issue_w2(p);
 
     // ======== (6) linear2 + residual of rows 4c .. 4c+3 ===========================================================================
     {
-      float hv[EPT2];
+      constexpr int NHG = hpack ? EPT2 / 2 : EPT2;
+      float hv[EPT2], raw[NHG];
       pt_begin(pt);
-      if (!hpack) {
-        ps_gather<EPT2>(GB, rs, ld16, G + G_HID + tid * EPT2, epoch, hv, sp);
-      } else {
-        float pk[EPT2 / 2];
-        ps_gather<EPT2 / 2>(GB, rs, ld16, G + G_HID + tid * (EPT2 / 2), epoch, pk, sp);
+      nap(nap_hid);
+      if constexpr (PF >= 1) ps_gather<NHG>(GB, rs, G + G_HID + tid * NHG, epoch, raw, sp, [&]() { issue_wqkv(pn, last); });
+      else ps_gather<NHG>(GB, rs, G + G_HID + tid * NHG, epoch, raw, sp, PsNoop());
+      if constexpr (hpack) {
 #pragma unroll
         for (int k = 0; k < EPT2 / 2; ++k) {
-          const unsigned u = __float_as_uint(pk[k]);
+          const unsigned u = __float_as_uint(raw[k]);
           hv[2 * k] = __uint_as_float(u << 16);
           hv[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
         }
+      } else {
+#pragma unroll
+        for (int k = 0; k < EPT2; ++k) hv[k] = raw[k];
       }
       store_ept_lds<EPT2>(sx + tid * EPT2, hv);
       g1_lds_barrier();
       pt_end(pt, sp.passes);
-      if constexpr (PF == 1) {
-        if (!last) issue_wqkv(pn);
-        else issue_pred();
-      }
       __builtin_amdgcn_sched_barrier(0);
       float x[NCH2][VEC];
       g1_read_shared<T, NCH2>(sx, x);
@@ -617,17 +711,15 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         gran_store(G + GPL + G_X + 4 * c + w, epoch, sres[w] + v);  // the next layer's x edge (layer L: the final norm's)
       }
     }
-    if constexpr (PF == 0) {
-      if (!last) issue_wqkv(pn);
-      else issue_pred();
-    }
+    if constexpr (PF == 0) issue_wqkv(pn, last);
   }
 
   // ======== final norm + predict layer: rows 4c .. 4c+3 (+ row 1024) ================================================================
   {
     gran_t* const G = a.gran + (size_t)a.L * GPL;
     pt_begin(pt);
-    ps_gather<EPT>(GB, rs, ld16, G + G_X + tid * EPT, epoch, xv, sp);
+    nap(nap_x);
+    ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, PsNoop());
     pt_end(pt, sp.passes);
     g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
     float x[NCH][VEC];
@@ -649,16 +741,14 @@ bool pstep_supports(int dtype, int d, int nhead, int dh, int V) {
 
 size_t pstep_gran_count(int d, int nhead, int L) { return (size_t)(L + 1) * ps_gran_per_layer(d, nhead, 256 / nhead); }
 
-int g_ps_pf = 2;  // "persist_pf": how far ahead the operands are requested (0 = at use, 1 = one operator, 2 = two)
-int g_ps_nk = 2;  // "persist_nk": keys per lane per round of the attention share (2: 1024 keys in one round; 4: the chain's qa_nk = 4)
-
-template <int NK>
-static int ps_launch_nk(hipStream_t st, const PStepArgs& a) {
+template <int NK, int PF>
+static int ps_launch_pk(hipStream_t st, const PStepArgs& a) {
   const dim3 grid(256), block(PS_T);
-  switch (g_ps_pf) {
-    case 0: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, 0>), grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, 1>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, 2>), grid, block, 0, st, a); break;
+  switch ((a.mode >> 2) & 3) {  // mode bits 4 / 8: hidden / attention rows as bf16 pairs
+    case 0: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 0>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 1>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 2>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 3>), grid, block, 0, st, a); break;
   }
   return 0;
 }
@@ -667,7 +757,8 @@ static int ps_launch_nk(hipStream_t st, const PStepArgs& a) {
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
   if (!a.layers || !a.x_in || !a.norm_g || !a.norm_b || !a.w_pred || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
-  return g_ps_nk == 4 ? ps_launch_nk<4>(st, a) : ps_launch_nk<2>(st, a);
+  if (a.nk == 4) return a.pf == 0 ? ps_launch_pk<4, 0>(st, a) : ps_launch_pk<4, 1>(st, a);
+  return a.pf == 0 ? ps_launch_pk<2, 0>(st, a) : ps_launch_pk<2, 1>(st, a);
 }
 
 }  // namespace vle

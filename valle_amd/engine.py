@@ -284,7 +284,7 @@ class Engine:
     def fetch_persist_trace(self) -> torch.Tensor:
         """(8 step slots, 256 workgroups, 96) int64 wall-clock stamps (10 ns ticks) of the persistent step's edges (option
         "persist_trace"): slot 0 = workgroup entry, then one stamp after every completed hand-off; 0 where nothing was stamped."""
-        raw = torch.zeros(8, 256, 256, dtype=torch.int64)
+        raw = torch.zeros(8, 256, 512, dtype=torch.int64)
         n = self.lib.vle_debug_fetch(self.h, b"persist_trace", C.c_void_p(raw.data_ptr()), raw.numel() * 8)
         if n < 0:
             _lib.check(int(n), self.h)

@@ -19,6 +19,12 @@ Scaling.  Per-GPU work is the SAME at every N ("scaling": "weak"): `value` is BA
 at N = 1, 2, 4, 8, and every line also carries `c3_batch64`: 64 utterances per GPU (configs[2] at N = 1, configs[3] at
 N = 8), run by all ranks under the same barrier-bracketed timing, with its own AR (HBM) and NAR (MFMA) roofline fractions.
 Scaling efficiency of either workload = its value at N / (N x its value at N = 1), from the lines alone (`scale_ref`).
+Timed region = the reference's own seam (SURVEY.md 8d "wall-time from inference() entry"): every decode goes through
+`model.inference_batch()` -- the method `VALLE.inference()` is a batch-1 wrapper of (valle/models/valle.py:961) -- with its
+asserts, length conversions, engine lookup and EOS prints inside the number (prints redirected to stderr).
+`sampled` (N = 1) is the headline workload at the reference's own default sampling (top_k = -100, temperature = 1.0,
+valle/models/valle.py:967-968); `s200` (N = 1) a realistic text length (S = 200 -> 3201 frames = 42.7 s of audio).
+`frames_per_s` / `rtf` (wall seconds per second of generated audio at 75 frames/s) accompany every tokens/s figure.
 `fp32_exact` (N = 1) is the same decode in engine mode fp32 -- the mode whose greedy token ids are bit-identical to the
 reference (tests/test_parity_sizes_gpu.py) -- timed in the same process; `c5_share_fp8` (N = 1) is the per-GPU share of BASELINE
 configs[4] (d1536-L24-h16, fp8 weights, fp8 MFMA in prefill / NAR, 32 utterances).
@@ -41,7 +47,9 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 S_TEXT, P_PROMPT = 47, 225  # 47 phonemes, 3 s x 75 Hz prompt
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "ar_step_traffic.json")    # tools/make_traffic.py from the PMC passes
 CPU_CACHE_FILE = os.path.join(ROOT, "profiles", "cpu_baseline_n1.json")  # the N = 1 line's cpu_baseline, committed
-AR_STEP_KERNEL_SOURCES = ("gemv1.hip", "decode_attn.hip", "sampling.hip", "skinny.hip", "common.h")  # the batch-1 AR step's kernels
+AR_STEP_KERNEL_SOURCES = ("persist.hip", "gemv1_dev.h", "gemv1.hip", "sampling.hip", "common.h")  # the batch-1 AR step's kernels
+N1_REF_FILE = os.path.join(ROOT, "profiles", "bench_n1_reference.json")  # value / c3_batch64.value of the committed N = 1 line (scale_ref)
+FRAME_RATE = 75.0  # EnCodec frames per second of audio (valle/data/tokenizer.py: 24 kHz / 320)
 
 
 def kernel_set_hash() -> str:
@@ -114,6 +122,11 @@ def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
         value=round(n_tok / dt, 3), unit="audio-tokens/s", cores=cores, kind="port",
         sample=f"first {n_frames} of {G_full} frames of utterance 0 (ctx {ctx0}..{ctx0 + frames}) "
                f"+ 7 NAR stages, fp32, {dt:.1f} s (AR {t_ar:.1f} s, NAR {t_nar:.1f} s)",
+        reference_full=dict(
+            value=9.8, unit="audio-tokens/s", cores=8, kind="reference", seconds=614.7, frames_per_s=1.22, rtf=61.0,
+            source="BASELINE.md section 2: the UNMODIFIED valle/models/valle.py::VALLE.inference at this workload's full length "
+                   "(S=47, P=225 -> 753 frames), fp32, greedy, 8 threads of the survey container's Xeon (the reference tree does not "
+                   "travel to the GPU box, so it cannot be re-timed there; the port above is what runs on this box's cores)"),
         full_length_estimate=dict(
             value=round(G_full * 8 / est, 3), unit="audio-tokens/s", seconds=round(est, 1),
             method="row-count extrapolation of the sample (AR: sum over steps of S+P+t rows; NAR: S+P+G rows); "
@@ -146,26 +159,41 @@ def eager_gpu_baseline(sd_cpu, d_model, nhead, num_layers, frames, dev):
 MFMA_PEAK_TFS = 2500.0  # dense bf16 MFMA peak (/opt/skills/guides/MI355X_MICROARCH.md)
 
 
-def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label=""):
-    """A second workload measured beside the headline under the SAME rules (inputs resident, whole decode calls incl. the
-    gather, barrier + device sync on both sides, MAX over ranks, tokens summed over ranks): `c3_batch64` = BASELINE
-    configs[2] / [3] (64 utterances per GPU), `fp32_exact` = the headline workload in the token-exact engine mode.
-    An extra object of the JSON line, never `value`."""
+def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label="", S=S_TEXT, top_k=None, model=None):
+    """A second workload measured beside the headline under the SAME rules (inputs resident, whole decode calls through
+    model.inference_batch() incl. the gather, barrier + device sync on both sides, MAX over ranks, tokens summed over ranks):
+    `c3_batch64` = BASELINE configs[2] / [3] (64 utterances per GPU), `fp32_exact` = the headline workload in the token-exact
+    engine mode, `sampled` / `s200` = the headline model at the reference's default sampling / at a realistic text length.
+    An extra object of the JSON line, never `value`.  N > 1: the ranks agree that every one of them built its model before any
+    of them enters a collective (a rank that failed would leave the others waiting in the barrier for ever)."""
     import valle_amd
 
-    model = valle_amd.VALLE(args.d_model, args.nhead, args.layers, prefix_mode=1, engine_dtype=dtype, max_batch=B)
-    model.load_state_dict(sd)
-    model = model.to(dev).eval()
-    eng = model.engine_for(B, S_TEXT, P_PROMPT)
-    if B > 1:
-        eng.set_option("ignore_eos", 1)  # every utterance runs to the reference's length cap, like the batch-1 line
-    X = torch.stack([synth_inputs(rank * B + b)[0] for b in range(B)]).to(dev)
-    Y = torch.stack([synth_inputs(rank * B + b)[1] for b in range(B)]).to(dev)
-    s_lens, p_lens = [S_TEXT] * B, [P_PROMPT] * B
+    top_k = args.top_k if top_k is None else top_k
+    err = None
+    own = model is None
+    try:
+        if own:
+            model = valle_amd.VALLE(args.d_model, args.nhead, args.layers, prefix_mode=1, engine_dtype=dtype, max_batch=B)
+            model.load_state_dict(sd)
+            model = model.to(dev).eval()
+        eng = model.engine_for(B, S, P_PROMPT)
+        eng.set_option("ignore_eos", 1)  # every utterance runs to the reference's length cap (random-init weights emit EOS at arbitrary steps)
+    except Exception as e:  # noqa: BLE001
+        err = e
+    if world > 1:
+        flag = torch.tensor([0 if err is None else 1], dtype=torch.int32, device=dev)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MAX)
+        if int(flag.item()) and err is None:
+            err = RuntimeError("another rank failed to build this leg's model")
+    if err is not None:
+        raise err
+    X = torch.stack([synth_inputs(rank * B + b, S)[0] for b in range(B)]).to(dev)
+    Y = torch.stack([synth_inputs(rank * B + b, S)[1] for b in range(B)]).to(dev)
+    s_lens, p_lens = [S] * B, [P_PROMPT] * B
     acc = dict(tokens=0, pre=0.0, ar=0.0, nar=0.0, ar_steps=0, ar_bytes=0, gl=None)
 
     def step():
-        return decode_step(eng, X, s_lens, Y, p_lens, args.top_k, world, world * B, dev)
+        return decode_step(model, X, s_lens, Y, p_lens, top_k, world, world * B, dev)
 
     def on_step(r):
         gl, _ = r
@@ -175,7 +203,7 @@ def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label=""):
         acc["pre"] += tm["prefill_ms"]; acc["ar"] += tm["ar_ms"]; acc["nar"] += tm["nar_ms"]; acc["ar_steps"] += int(tm["ar_steps"])
         for t in range(1, max(gl) + 1):
             live = sum(1 for b in range(B) if gl[b] >= t)
-            acc["ar_bytes"] += eng.ar_step_bytes(live, live * (S_TEXT + P_PROMPT + t))
+            acc["ar_bytes"] += eng.ar_step_bytes(live, live * (S + P_PROMPT + t))
 
     elapsed = timed_loop(step, steps, warmup, world, dev, on_step)
     tokens = acc["tokens"]
@@ -184,16 +212,17 @@ def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label=""):
         torch.distributed.all_reduce(tk, op=torch.distributed.ReduceOp.SUM)
         tokens = int(tk.item())
     gl, pre, ar, nar, ar_steps, ar_bytes = acc["gl"], acc["pre"], acc["ar"], acc["nar"], acc["ar_steps"], acc["ar_bytes"]
-    d, L, N, G = args.d_model, args.layers, S_TEXT + P_PROMPT + gl[0], gl[0]
+    d, L, N, G = args.d_model, args.layers, S + P_PROMPT + gl[0], gl[0]
     nar_flops = B * (7 * (2 * N * 12 * L * d * d + 4 * L * N * N * d) + 14 * G * d * 1024)  # SURVEY.md 8(d), this rank
     hbm = (ar_bytes / 1e9) / (ar / 1e3)
     tfs = nar_flops * steps / 1e12 / (nar / 1e3)
-    model._invalidate()
-    del model
+    if own:
+        model._invalidate()
+        del model
     mfma_peak = MFMA_PEAK_TFS if dtype != "fp32" else 157.0  # fp32 mode: v_mfma_f32_16x16x4_f32 runs at the vector rate
-    return {
-        "workload": f"dim{d}-L{L}-h{args.nhead} {dtype}, batch={B} per GPU x {world} GPU(s), S={S_TEXT}, P={P_PROMPT} -> G={G}, "
-                    f"greedy{', ignore_eos' if B > 1 else ''}{label}",
+    res = {
+        "workload": f"dim{d}-L{L}-h{args.nhead} {dtype}, batch={B} per GPU x {world} GPU(s), S={S}, P={P_PROMPT} -> G={G} frames ({G / FRAME_RATE:.2f} s), "
+                    f"{'greedy (top_k=1)' if top_k == 1 else f'sampled: top_k={top_k}, temperature=1.0'}, ignore_eos, random-init weights{label}",
         "value": round(tokens / elapsed, 1), "unit": "audio-tokens/s", "n_gpus": world, "per_gpu_value": round(tokens / elapsed / world, 1),
         "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
         "phase_ms": {"prefill": round(pre / steps, 3), "ar": round(ar / steps, 3), "nar": round(nar / steps, 3)},
@@ -201,26 +230,27 @@ def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label=""):
                         "launch_us": round(ar / ar_steps * 1e3, 2), "bytes_per_launch": int(ar_bytes / ar_steps), "rank": 0},
         "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tfs / mfma_peak, 4), "rank": 0},
     }
+    res.update(rates(tokens, elapsed, steps * B * world, G))
+    return res
 
 
-def c5_leg(args, dev, B=32, steps=2, warmup=1):
-    """BASELINE.json configs[4]'s per-GPU share on one GPU: d1536-L24-h16 (dh 96), fp8 weights, fp8 activations on the
-    block-scaled fp8 MFMA in the prefill / NAR passes (engine mode "fp8"), 32 utterances.  Extra object, not `value`."""
+def c5_leg(args, dev, dtype="fp8", B=32, steps=2, warmup=1):
+    """BASELINE.json configs[4]'s per-GPU share on one GPU: d1536-L24-h16 (dh 96), fp8 weights, 32 utterances -- engine mode
+    "fp8w" (the config's weight format: e4m3 weights, bf16 activations; holds the 5 % sigma parity bar at this architecture) or
+    "fp8" (+ fp8 activations on the block-scaled fp8 MFMA in the prefill / NAR passes).  Extra object, not `value`."""
     import valle_amd
 
     torch.manual_seed(0)
     d, L, H = 1536, 24, 16
-    model = valle_amd.VALLE(d, H, L, prefix_mode=1, engine_dtype="fp8", max_batch=B).to(dev).eval()
+    model = valle_amd.VALLE(d, H, L, prefix_mode=1, engine_dtype=dtype, max_batch=B).to(dev).eval()
     eng = model.engine_for(B, S_TEXT, P_PROMPT)
     eng.set_option("ignore_eos", 1)
     X = torch.stack([synth_inputs(b)[0] for b in range(B)]).to(dev)
     Y = torch.stack([synth_inputs(b)[1] for b in range(B)]).to(dev)
+    s_lens, p_lens = [S_TEXT] * B, [P_PROMPT] * B
 
     def step():
-        eng.prefill(X, [S_TEXT] * B, Y, [P_PROMPT] * B)
-        _, gl = eng.generate(top_k=1, temperature=1.0, seed=0, allow_empty=True)
-        eng.nar(None)
-        return gl
+        return decode_step(model, X, s_lens, Y, p_lens, 1, 1, B, dev)[0]
 
     for _ in range(warmup):
         step()
@@ -241,30 +271,53 @@ def c5_leg(args, dev, B=32, steps=2, warmup=1):
     hbm = (ar_bytes / 1e9) / (ar / 1e3)
     tfs = nar_flops * steps / 1e12 / (nar / 1e3)
     model._invalidate()
-    return {
-        "workload": f"dim{d}-L{L}-h{H} fp8 weights + fp8-MFMA prefill/NAR, batch={B}, S={S_TEXT}, P={P_PROMPT} -> G={G}, greedy, ignore_eos",
+    nar_peak = 5000.0 if dtype == "fp8" else MFMA_PEAK_TFS
+    what = "fp8 weights + fp8 activations on the block-scaled fp8 MFMA in prefill / NAR" if dtype == "fp8" else "fp8 (e4m3) weights, bf16 activations and MFMA"
+    res = {
+        "workload": f"dim{d}-L{L}-h{H} engine mode {dtype} ({what}), batch={B}, S={S_TEXT}, P={P_PROMPT} -> G={G}, greedy, ignore_eos, "
+                    f"random-init weights (the reference's init distributions, torch.manual_seed(0))",
         "value": round(tokens / elapsed, 1), "unit": "audio-tokens/s", "steps": steps, "warmup": warmup,
         "phase_ms": {"prefill": round(pre / steps, 3), "ar": round(ar / steps, 3), "nar": round(nar / steps, 3)},
         "roofline_ar": {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
                         "launch_us": round(ar / ar_steps * 1e3, 2), "bytes_per_launch": int(ar_bytes / ar_steps)},
-        "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": 5000.0, "unit": "TFLOP/s (vs the dense fp8 MX peak)", "frac": round(tfs / 5000.0, 4)},
+        "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": nar_peak,
+                         "unit": "TFLOP/s (vs the dense fp8 MX peak)" if dtype == "fp8" else "TFLOP/s (vs the dense bf16 peak)", "frac": round(tfs / nar_peak, 4)},
     }
+    res.update(rates(tokens, elapsed, steps * B, G))
+    return res
 
 
-def decode_step(eng, X, s_lens, Y, p_lens, top_k, world, n_total, dev):
-    """One "step" of the benchmark on this rank: whole decode of its B utterances (prefill + AR loop + 7 NAR stages)
-    and, for N > 1, the all_gather of the result codes (the path's only collective).  Returns (generated lengths of the
+def decode_step(runner, X, s_lens, Y, p_lens, top_k, world, n_total, dev, temperature=1.0, seed=0):
+    """One "step" of the benchmark on this rank: whole decode of its B utterances and, for N > 1, the all_gather of the
+    result codes (the path's only collective).  `runner` is the MODEL: the decode goes through `model.inference_batch()`, the
+    method `VALLE.inference()` wraps (seam B2; its per-utterance EOS prints go to stderr) -- or, for the CPU tests of the
+    step / timing contract, any object with the engine's prefill / generate / nar methods.  Returns (generated lengths of the
     local utterances, the gathered list of (G, 8) code matrices in global order)."""
     from valle_amd import dist as vdist
 
     B = X.shape[0]
-    eng.prefill(X, s_lens, Y, p_lens)
-    _, gl = eng.generate(top_k=top_k, temperature=1.0, seed=0, allow_empty=B > 1)
-    codes = eng.nar(None)
-    out = [codes[b, : gl[b]] for b in range(B)]
+    if hasattr(runner, "inference_batch"):
+        import contextlib
+
+        with contextlib.redirect_stdout(sys.stderr):
+            out = runner.inference_batch(X, torch.tensor(s_lens, dtype=torch.int32), Y, p_lens, None, top_k=top_k,
+                                         temperature=temperature, seed=seed)
+        gl = [int(o.shape[0]) for o in out]
+    else:
+        runner.prefill(X, s_lens, Y, p_lens)
+        _, gl = runner.generate(top_k=top_k, temperature=temperature, seed=seed, allow_empty=B > 1)
+        codes = runner.nar(None)
+        out = [codes[b, : gl[b]] for b in range(B)]
     if world > 1:
         out = vdist.gather_codes(out, n_total, 8, dev)
     return gl, out
+
+
+def rates(tokens, elapsed, n_utt_steps, frames_per_utt):
+    """frames/s and the real-time factor next to a tokens/s figure: rtf = wall seconds per second of generated audio, per
+    utterance stream (elapsed x streams / audio seconds); `n_utt_steps` utterance-decodes of `frames_per_utt` frames each."""
+    audio_s = n_utt_steps * frames_per_utt / FRAME_RATE
+    return {"frames_per_s": round(tokens / 8.0 / elapsed, 1), "audio_s_per_wall_s": round(audio_s / elapsed, 2), "rtf": round(elapsed / audio_s, 6)}
 
 
 def timed_loop(step_fn, steps, warmup, world, dev, on_step=None):
@@ -347,6 +400,8 @@ def main():
                                                          "now that the host-side weight preparation is multi-threaded)")
     ap.add_argument("--c5", action="store_true", help=argparse.SUPPRESS)  # round-2 spelling: the leg is on by default now
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine tuning option (vle_set_option), repeatable")
+    ap.add_argument("--dump-codes", default="", metavar="FILE", help="rank 0 saves the last step's gathered codes (list of (G, 8) int64 tensors, "
+                                                                       "global utterance order) with torch.save: the N > 1 test compares them with N = 1 decodes")
     ap.add_argument("--profile-kernels", type=int, default=0, help="extra untimed pass: hipEvent time per AR-step kernel family over n steps")
     args = ap.parse_args()
     if args.no_side:
@@ -381,10 +436,9 @@ def main():
     for kv in args.opt:
         name, val = kv.split("=")
         eng.set_option(name, int(val))
-    if B > 1:
-        # random-init weights emit EOS at arbitrary steps for some seeds (utterance 23 at step 0); the batched
-        # configs time every utterance to the reference's length cap, like the batch-1 run (which never hits EOS)
-        eng.set_option("ignore_eos", 1)
+    # random-init weights emit EOS at arbitrary steps for some seeds (utterance 23 at step 0); every configuration is timed to the
+    # reference's length cap (16 S + 1 frames; the greedy batch-1 run reaches it anyway)
+    eng.set_option("ignore_eos", 1)
 
     X = torch.zeros(B, S_TEXT, dtype=torch.int64)
     Y = torch.zeros(B, P_PROMPT, 8, dtype=torch.int64)
@@ -396,11 +450,12 @@ def main():
     acc = dict(tokens=0, pre=0.0, ar=0.0, nar=0.0, ar_steps=0, ar_bytes=0, gl=None, n_out=0)
 
     def step():
-        return decode_step(eng, X, s_lens, Y, p_lens, args.top_k, world, world * B, dev)
+        return decode_step(model, X, s_lens, Y, p_lens, args.top_k, world, world * B, dev)
 
     def on_step(r):
         gl, out = r
         acc["gl"], acc["n_out"] = gl, len(out)
+        acc["out"] = out
         acc["tokens"] += sum(gl) * 8
         tm = eng.timings()
         acc["pre"] += tm["prefill_ms"]; acc["ar"] += tm["ar_ms"]; acc["nar"] += tm["nar_ms"]; acc["ar_steps"] += int(tm["ar_steps"])
@@ -413,6 +468,8 @@ def main():
     tokens, gl = acc["tokens"], acc["gl"]
     pre_ms, ar_ms, nar_ms, ar_steps, ar_bytes = acc["pre"], acc["ar"], acc["nar"], acc["ar_steps"], acc["ar_bytes"]
     assert acc["n_out"] == world * B, "the gather did not return every rank's utterances"
+    if args.dump_codes and rank == 0:
+        torch.save([o.cpu() for o in acc["out"]], args.dump_codes)
     if world > 1:
         tk = torch.tensor([tokens], dtype=torch.float64, device=dev)
         torch.distributed.all_reduce(tk, op=torch.distributed.ReduceOp.SUM)
@@ -432,6 +489,13 @@ def main():
         achieved = (ar_bytes / 1e9) / (ar_ms / 1e3) if ar_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic(args, B)
         fused = args.d_model // args.nhead in (64, 128) and B == 1 and "qkv_attn=0" not in args.opt
+        persist = eng.fetch_u32("persist_active") == 1 if B == 1 else False
+        n1_ref = None
+        try:
+            with open(N1_REF_FILE) as f:
+                n1_ref = json.load(f)
+        except OSError:
+            pass
         out = {
             "metric": "audio-tokens/sec (AR+NAR decode, 3 s prompt -> 10 s target)",
             "value": round(tokens / elapsed, 1),
@@ -456,13 +520,21 @@ def main():
                 "hip_graph": not args.no_graph,
             },
             "per_gpu_value": round(tokens / elapsed / args.gpus, 1),
+            **rates(tokens, elapsed, args.steps * B * world, gl[0]),
+            # weak scaling in numbers: per-GPU work is fixed at every N; efficiency = value(N) / (N x value(1)) against the committed
+            # N = 1 line (profiles/bench_n1_reference.json) -- 1.0 by definition at N = 1; the c3_batch64 efficiency is filled in below
             "scale_ref": {
-                "per_gpu_work": f"{B} utterance(s) per GPU at every N (`value`); 64 utterances per GPU at every N (`c3_batch64.value`)",
-                "efficiency": "value(N) / (N * value(1)), and c3_batch64.value(N) / (N * c3_batch64.value(1)): both from the N = 1, 2, 4, 8 lines alone",
+                "n_gpus": args.gpus, "utterances_per_gpu": B, "c3_utterances_per_gpu": 64,
+                "value_n1": (n1_ref or {}).get("value"), "c3_value_n1": (n1_ref or {}).get("c3_value"),
+                "n1_source": (n1_ref or {}).get("source"),
+                "efficiency": 1.0 if args.gpus == 1 else (round(tokens / elapsed / (args.gpus * n1_ref["value"]), 4) if n1_ref and n1_ref.get("value") else None),
+                "c3_efficiency": None,
             },
             "phase_ms": {"prefill": round(pre_ms / args.steps, 3), "ar": round(ar_ms / args.steps, 3), "nar": round(nar_ms / args.steps, 3)},
             "roofline": {
-                "kernel": ("AR decode step (hipGraph replay: 4 launches/layer x L -- fused LN1+QKV+attention, out-proj, FFN1, FFN2 -- + logits + sample; "
+                "kernel": ("AR decode step = ONE persistent launch (pstep_kernel: 256 workgroups, L layers + final norm + predict layer, in-launch "
+                           "granule hand-offs) + the sampling launch, hipGraph replay; weights + KV streamed once") if persist else
+                          ("AR decode step (hipGraph replay: 4 launches/layer x L -- fused LN1+QKV+attention, out-proj, FFN1, FFN2 -- + logits + sample; "
                            "weights + KV streamed once)") if fused else
                           "AR decode step (hipGraph replay: launches/layer x L + logits + sample; weights + KV streamed once)",
                 "bound": "hbm",
@@ -503,28 +575,39 @@ def main():
                 out["eager_gpu_baseline"] = {"error": repr(err)[:200]}
     # ---- side legs: every rank takes part (same timing contract as the headline) ---------------------------------------
     plain = B == 1 and not args.opt and args.profile_kernels == 0 and args.dtype == "bf16"
+
+    def leg(name, fn, need_all_ranks):
+        """world = 1: a failing leg is reported, never raised (it must not cost the headline line).  N > 1: legs with collectives let
+        the exception propagate -- the launcher then ends every rank instead of leaving the others in a barrier."""
+        if need_all_ranks and world > 1:
+            res = fn()
+        else:
+            try:
+                res = fn()
+            except Exception as err:  # noqa: BLE001
+                res = {"error": repr(err)[:200]}
+        if out is not None:
+            out[name] = res
+        return res
+
+    if plain and world == 1 and not args.no_side:
+        # the reference's own default sampling (valle/models/valle.py:967-968) and a realistic text length, on the headline model
+        leg("sampled", lambda: side_leg(sd_all, args, dev, rank, world, 1, args.dtype, steps=3, warmup=1, top_k=-100, model=model), False)
+        leg("s200", lambda: side_leg(sd_all, args, dev, rank, world, 1, args.dtype, steps=2, warmup=1, S=200, model=model,
+                                     label="; SURVEY.md 8(d) 'realistic text' row"), False)
     model._invalidate()
     if plain and not args.no_c3:
-        try:
-            leg = side_leg(sd_all, args, dev, rank, world, 64, args.dtype)
-        except Exception as err:  # noqa: BLE001
-            leg = {"error": repr(err)[:200]}
-        if out is not None:
-            out["c3_batch64"] = leg
+        c3 = leg("c3_batch64", lambda: side_leg(sd_all, args, dev, rank, world, 64, args.dtype), True)
+        if out is not None and isinstance(c3, dict) and "value" in c3:
+            ref = out["scale_ref"].get("c3_value_n1")
+            out["scale_ref"]["c3_efficiency"] = 1.0 if args.gpus == 1 else (round(c3["value"] / (args.gpus * ref), 4) if ref else None)
     if plain and not args.no_fp32 and world == 1:
-        try:
-            leg = side_leg(sd_all, args, dev, rank, world, 1, "fp32", steps=3, warmup=1,
-                           label="; engine mode fp32 = greedy token ids bit-identical to the reference (tests/test_parity_sizes_gpu.py)")
-        except Exception as err:  # noqa: BLE001
-            leg = {"error": repr(err)[:200]}
-        if out is not None:
-            out["fp32_exact"] = leg
+        leg("fp32_exact", lambda: side_leg(sd_all, args, dev, rank, world, 1, "fp32", steps=3, warmup=1,
+                                           label="; engine mode fp32 = greedy token ids bit-identical to the reference (tests/test_parity_sizes_gpu.py)"), False)
     if plain and world == 1 and not args.no_c5 and (args.d_model, args.layers, args.nhead) == (1024, 12, 16):
-        try:
-            del model
-            out["c5_share_fp8"] = c5_leg(args, dev)
-        except Exception as err:  # noqa: BLE001
-            out["c5_share_fp8"] = {"error": repr(err)[:200]}
+        del model
+        leg("c5_share_fp8w", lambda: c5_leg(args, dev, "fp8w"), False)
+        leg("c5_share_fp8", lambda: c5_leg(args, dev, "fp8"), False)
     if out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:

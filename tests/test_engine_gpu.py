@@ -583,3 +583,32 @@ def test_fused_qkv_attention_launch_and_its_q_handoff_agree_with_the_separate_la
             assert (other - base).abs().max().item() <= tol * sigma, (dtype, opts, (other - base).abs().max().item(), sigma)
         fails = C.c_uint(0)
         assert eng.lib.vle_debug_fetch(eng.h, b"qa_spin_fail", C.byref(fails), 4) == 4 and fails.value == 0
+
+
+@pytest.mark.parametrize("d,h,dtype", [(256, 2, "fp32"), (256, 2, "bf16"), (512, 4, "fp32"), (2048, 16, "bf16")])
+def test_batch1_step_where_the_fused_launch_lacks_its_out_proj_gemv(d, h, dtype):
+    """Shapes the fused QKV + attention launch covers but whose follow-up out-proj GEMV (the PRO_ATTN_SELF prologue) is not
+    instantiated (fp32 d256-h2: 128-wide heads over one-element thread slices) must take the two separate launches, and every
+    accepted qa_nsplit must decode: fp32 token ids equal to the oracle's, bf16 teacher-forced within 5 % of sigma."""
+    cfg = vo.OracleConfig(d_model=d, nhead=h, num_layers=2, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 31)
+    x, xl, y = vo.make_inputs(6, 14, seed=5)
+    tr = {}
+    want = vo.inference(sd, cfg, x, xl, y, None, top_k=1, kv_cache=True, trace=tr)
+    ref = torch.stack(tr["ar_logits"])
+    m = build_model(cfg, sd, dtype)
+    eng = m.engine_for(1, 6, 14)
+    eng.set_option("trace_ar_logits", 1)
+    for ns in (4, 8, 16):
+        eng.set_option("qa_nsplit", ns)
+        eng.prefill(x.to(DEV), [6], y.to(DEV), [14])
+        G = want.shape[1]
+        if dtype == "fp32":
+            codes0, gl = eng.generate(top_k=1)
+            assert gl == [G] and torch.equal(codes0[0, :G].cpu(), want[0, :, 0]), (d, h, ns)
+        else:
+            _, gl = eng.generate(top_k=1, forced=want[:, :, 0].to(DEV), forced_lens=[G])
+            assert gl == [G]
+            mine = eng.fetch_ar_logits()[:, 0]
+            err = (mine - ref).abs().max().item()
+            assert err <= 0.05 * ref.std().item(), (d, h, ns, err)

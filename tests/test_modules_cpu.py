@@ -57,6 +57,36 @@ def test_classify_attn_mask():
         M.classify_attn_mask(torch.zeros(2, T, T, dtype=torch.bool), T)
 
 
+def test_key_padding_mask_shapes_outside_the_collater_pattern_raise():
+    """Padded query rows get every valid key of their sequence, which equals the reference only for trailing padding per segment
+    ([text | pad | audio | pad]) and bool masks: anything else must raise instead of diverging silently (checked before any kernel)."""
+    mha = M.MultiheadAttention(64, 4, batch_first=True)
+    B, T, S = 2, 8, 3
+    xn = torch.zeros(B * T, 64)
+    mask = prefix_lm_mask(S, T)
+    hole = torch.zeros(B, T, dtype=torch.bool)
+    hole[0, 5] = True  # a padded audio frame followed by valid ones
+    with pytest.raises(NotImplementedError, match="trailing"):
+        mha._attend(xn, B, T, mask, hole)
+    thole = torch.zeros(B, T, dtype=torch.bool)
+    thole[1, 0] = True  # a padded text position followed by a valid one
+    with pytest.raises(NotImplementedError, match="trailing"):
+        mha._attend(xn, B, T, mask, thole)
+    fm = torch.zeros(B, T)
+    fm[0, -1] = float("-inf")
+    with pytest.raises(NotImplementedError, match="bool"):
+        mha._attend(xn, B, T, mask, fm)
+    empty = torch.zeros(B, T, dtype=torch.bool)
+    empty[1] = True
+    with pytest.raises(ValueError):
+        mha._attend(xn, B, T, mask, empty)
+    ok = torch.zeros(B, T, dtype=torch.bool)
+    ok[0, 2] = ok[0, 6:] = True  # [text pad | audio pad]: accepted -- the call then needs the GPU
+    if not torch.cuda.is_available():
+        with pytest.raises((RuntimeError, AssertionError)):
+            mha._attend(xn, B, T, mask, ok)
+
+
 def test_configurations_outside_the_decode_path_raise():
     assert not M.TransformerEncoderLayer(64, 4, norm_first=False).norm_first  # post-norm layers are implemented
     with pytest.raises(NotImplementedError):

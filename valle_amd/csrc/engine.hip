@@ -24,6 +24,10 @@
 namespace vle {
 
 static std::mutex g_err_mu;
+// live engines of this process: the kernel-selection knobs of vle_set_option that are process-wide (gs_*, g1_shared, qa_waves,
+// attn_nt, ...) change what EVERY engine would capture, so they drop the captured AR-step graphs of all of them
+static std::mutex g_engines_mu;
+static std::vector<struct ::vle_engine*> g_engines;
 static std::string g_last_error;
 
 void set_global_error(const char* msg) {
@@ -263,11 +267,18 @@ void parallel_rows(int64_t n, int64_t work_per_row, F f) {
   }
   std::vector<std::thread> th;
   const int64_t per = (n + nt - 1) / nt;
+  int64_t done_to = 0;  // rows [0, done_to) are owned by started threads
   for (int t = 0; t < nt; ++t) {
     const int64_t a = t * per, b = std::min<int64_t>(n, a + per);
     if (a >= b) break;
-    th.emplace_back([=]() { f(a, b); });
+    try {
+      th.emplace_back([=]() { f(a, b); });
+    } catch (const std::system_error&) {  // no more threads (container limits): nothing may escape through the C ABI
+      break;
+    }
+    done_to = b;
   }
+  if (done_to < n) f(done_to, n);  // the rest on this thread
   for (auto& t : th) t.join();
 }
 
@@ -512,6 +523,10 @@ extern "C" int vle_create(const vle_config* c, vle_engine** out) {
     vle_destroy(e);
     return VLE_EHIP;
   }
+  {
+    std::lock_guard<std::mutex> lk(g_engines_mu);
+    g_engines.push_back(e);
+  }
   *out = e;
   return VLE_OK;
 }
@@ -544,8 +559,29 @@ static void release_buffers(vle_engine* e) {
   e->slot_mode = false;
 }
 
+static void drop_graphs(vle_engine* e) {
+  (void)hipSetDevice(e->cfg.device);
+  if (e->st) (void)hipStreamSynchronize(e->st);
+  for (auto& kv : e->graphs) {
+    if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
+    if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
+  }
+  e->graphs.clear();
+}
+// a PROCESS-WIDE kernel-selection knob changed: no engine may keep a graph captured under the old selection.  (Not thread-safe
+// against a concurrent vle_ar_generate of ANOTHER engine: the knobs are tuning / A-B tools, set between calls.)
+static void drop_all_graphs(vle_engine* caller) {
+  std::lock_guard<std::mutex> lk(g_engines_mu);
+  for (vle_engine* o : g_engines) drop_graphs(o);
+  if (caller) (void)hipSetDevice(caller->cfg.device);
+}
+
 extern "C" void vle_destroy(vle_engine* e) {
   if (!e) return;
+  {
+    std::lock_guard<std::mutex> lk(g_engines_mu);
+    g_engines.erase(std::remove(g_engines.begin(), g_engines.end(), e), g_engines.end());
+  }
   (void)hipSetDevice(e->cfg.device);
   if (e->st) (void)hipStreamSynchronize(e->st);
   for (auto& kv : e->graphs) {
@@ -1227,7 +1263,10 @@ int enqueue_ar_step(vle_engine* e) {
     if (sk && e->B == 1 && e->opt_qkv_attn && !e->opt_no_gemv1) {
       const bool codes = e->w8 && w.wqkv8 != nullptr;
       const int qdt = codes ? DT_FP8W : e->dtype;
-      if (qkv_attn1_supports(qdt, d, e->H, e->dh) && (e->opt_qa_nsplit == 4 || e->opt_qa_nsplit == 8 || e->opt_qa_nsplit == 16)) {
+      // the out-proj GEMV merges the new token's own term (PRO_ATTN_SELF): only gemv1 has that prologue, so the fused launch is
+      // taken only where that GEMV exists too (e.g. not at fp32 d256-h2: 128-wide heads over 1-element thread slices)
+      if (qkv_attn1_supports(qdt, d, e->H, e->dh) && (e->opt_qa_nsplit == 4 || e->opt_qa_nsplit == 8 || e->opt_qa_nsplit == 16) &&
+          gemv1_attn_self_supports(codes ? DT_FP8W : e->dtype, d, e->dh, e->opt_qa_nsplit)) {
         ProfScope ps(e, 0);
         QkvAttnArgs q;
         q.w = codes ? w.wqkv8 : w.wqkv; q.wscale = codes ? w.sqkv : nullptr; q.bias = w.bqkv;
@@ -2209,6 +2248,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
   }
   if (n == "qkv_attn" || n == "qa_nsplit" || n == "qa_qtemporal" || n == "qa_handoff" || n == "qa_nk") {  // changes the captured graphs: drop them
     if (n == "qa_nsplit" && !(value == 4 || value == 8 || value == 16)) return e->fail(VLE_EINVAL, "qa_nsplit must be 4, 8 or 16");
+    if (n == "qa_nk" && !(value == 2 || value == 4 || value == 8)) return e->fail(VLE_EINVAL, "qa_nk must be 2, 4 or 8");
     (n == "qkv_attn" ? e->opt_qkv_attn : n == "qa_nsplit" ? e->opt_qa_nsplit : n == "qa_handoff" ? e->opt_qa_handoff : n == "qa_nk" ? e->opt_qa_nk : e->opt_qa_qtemporal) = (int)value;
     (void)hipStreamSynchronize(e->st);
     for (auto& kv : e->graphs) {
@@ -2268,12 +2308,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
       else if (n == "gs_nf") g_gs_nf = value != 0;
       else (n == "gs_formal" ? g_gs_formal : g_g1_shared) = value != 0;
     }
-    (void)hipStreamSynchronize(e->st);
-    for (auto& kv : e->graphs) {
-      if (kv.second.first) (void)hipGraphExecDestroy(kv.second.first);
-      if (kv.second.second) (void)hipGraphExecDestroy(kv.second.second);
-    }
-    e->graphs.clear();
+    drop_all_graphs(e);  // every live engine of the process, not only the caller
     return VLE_OK;
   }
   if (n == "g8_nt") {

@@ -543,6 +543,25 @@ static int g1_dispatch_nch(hipStream_t st, const SkinnyArgs& a) {
   }
 }
 
+// Whether launch_gemv1 covers the out-proj GEMV with the PRO_ATTN_SELF prologue at this shape (K = N = d): the fused QKV +
+// attention launch leaves the new token's own softmax term to that prologue, and skinny.hip has no such prologue -- the engine
+// must not pick the fused launch where this is false.  Mirrors launch_gemv1 / g1_dispatch_nch / g1_dispatch_pe.
+bool gemv1_attn_self_supports(int dtype, int d, int dh, int nsplit) {
+  const int vec = dtype == DT_F32 ? 4 : 8, ch = 64 * vec;
+  if (d <= 0 || dh <= 0 || d % ch != 0 || dh % vec != 0) return false;
+  const int nch = d / ch;
+  if (!(nch == 1 || nch == 2 || nch == 3 || nch == 4)) return false;  // the K = d family of g1_dispatch_pe
+  if (!(nsplit == 4 || nsplit == 8 || (nsplit == 16 && nch * vec <= 16))) return false;
+  if (g_g1_shared) {
+    const int ept = d / G1_T;
+    if (d % G1_T != 0 || ept < 1 || dh % ept != 0) return false;
+    const int lpk = dh / ept;
+    return lpk >= 1 && lpk <= 64 && (lpk & (lpk - 1)) == 0;
+  }
+  const int lpk = dh / vec;
+  return lpk >= 1 && lpk <= 32 && (lpk & (lpk - 1)) == 0;
+}
+
 // returns 0 = launched, 1 = shape not covered (caller falls back to launch_skinny), < 0 = error
 int launch_gemv1(hipStream_t st, int dtype, const SkinnyArgs& a) {
   if (a.B != 1 || a.N <= 0) return 1;

@@ -207,6 +207,7 @@ struct QkvAttnArgs {
   KTrace kt;
 };
 bool qkv_attn1_supports(int dtype, int d, int nhead, int dh);
+bool gemv1_attn_self_supports(int dtype, int d, int dh, int nsplit);  // the out-proj GEMV that must follow the fused launch
 int launch_qkv_attn1(hipStream_t st, int dtype, const QkvAttnArgs& a);
 
 // ---- persist.hip: the batch-1 AR step as ONE persistent launch (256 workgroups, one per CU; option "persist") -------------------

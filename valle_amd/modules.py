@@ -351,7 +351,7 @@ class MultiheadAttention(_HipModule):
         """xn (B*T, d) in the compute dtype -> attention output (B*T, d), before out_proj.
 
         ``key_padding_mask`` (B, T) bool, True = padded position (``src_key_padding_mask`` of the teacher-forced forward,
-        valle.py:846-856, :908-926; any pattern -- VALL-E's is [text | text pad | audio | audio pad]): padded KEYS are invisible to
+        valle.py:846-856, :908-926; trailing padding per segment -- VALL-E's [text | text pad | audio | audio pad] -- anything else raises): padded KEYS are invisible to
         everyone.  Valid rows are packed per sequence and attend under ``attn_mask`` restricted to the valid keys (the ragged
         packed-row kernel: positions keep their order, the prefix-LM text length counts valid text rows).  Padded QUERY rows are
         real rows of the reference's batch (its AR loss sums over them): each sees exactly the valid keys of its sequence -- every
@@ -359,15 +359,25 @@ class MultiheadAttention(_HipModule):
         (never read by anyone: masked as keys, not part of the logits) it is merely finite -- computed by the un-masked
         cross-attention kernel against the sequence's valid K / V."""
         text_len, causal = classify_attn_mask(attn_mask, T)
+        pad = None
+        if key_padding_mask is not None and bool(key_padding_mask.any()):
+            if key_padding_mask.dtype != torch.bool:
+                raise NotImplementedError("key_padding_mask must be a bool mask (True = padded); float masks are not implemented")
+            pad = key_padding_mask.to(xn.device)
+            assert tuple(pad.shape) == (B, T), (tuple(pad.shape), B, T)
+            if bool(pad.all(dim=1).any()):
+                raise ValueError("key_padding_mask leaves a sequence without any key")
+            # padded QUERY rows are given every valid key of their sequence: that is what the reference computes only when padding
+            # is TRAILING inside each segment ([text | pad | audio | pad], the collater's shape); anything else would diverge silently
+            for lo, hi in (((0, text_len), (text_len, T)) if text_len > 0 else ((0, T),)):
+                seg = pad[:, lo:hi]
+                if seg.shape[1] > 1 and bool((seg[:, :-1] & ~seg[:, 1:]).any()):
+                    raise NotImplementedError("key_padding_mask: only trailing padding per segment ([text | pad | audio | pad]) is implemented")
         qkv = ops.linear(xn, self._w(self.in_proj_weight), self.in_proj_bias.detach())
-        if key_padding_mask is None or not bool(key_padding_mask.to(torch.bool).any()):
+        if pad is None:
             seq_off = torch.arange(0, (B + 1) * T, T, dtype=torch.int32, device=xn.device)
             tl = torch.full((B,), text_len, dtype=torch.int32, device=xn.device)
             return ops.attention(qkv, seq_off, tl, self.num_heads, causal)
-        pad = key_padding_mask.to(torch.bool).to(xn.device)
-        assert tuple(pad.shape) == (B, T), (tuple(pad.shape), B, T)
-        if bool(pad.all(dim=1).any()):
-            raise ValueError("key_padding_mask leaves a sequence without any key")
         d = qkv.shape[1] // 3
         valid = ~pad
         flat_valid = valid.reshape(-1).nonzero(as_tuple=False).squeeze(1)

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/ar_step_traffic.json -- HBM bytes per batch-1 AR step from the rocprofv3 PMC passes (tools/gpu_pmc.sh: FETCH_SIZE and
+"""profiles/ar_step_traffic.json -- HBM bytes per batch-1 AR step from the rocprofv3 PMC passes (tools/gpu_r4_collect.sh: FETCH_SIZE and
 WRITE_SIZE in SEPARATE runs over `bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-graph --no-c3 --no-fp32`), keyed by the hash of
 the step's kernel sources (bench.kernel_set_hash) so that bench.py stops reporting it once the kernels change.
 
@@ -17,7 +17,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import bench  # noqa: E402
 
-STEP_KERNELS = ("gemv1s_kernel", "gemv1_kernel", "qkv_attn1_kernel", "decode_attn_kernel", "ar_sample_kernel", "skinny_kernel")
+STEP_KERNELS = ("pstep_kernel", "gemv1s_kernel", "gemv1_kernel", "qkv_attn1_kernel", "decode_attn_kernel", "ar_sample_kernel", "skinny_kernel")
 
 
 def total(path):
@@ -43,7 +43,10 @@ def main():
         "write_kib_per_step": round(write / steps, 1),
         "steps": steps,
         "source": f"{os.path.relpath(sys.argv[1], ROOT)} + {os.path.relpath(sys.argv[2], ROOT)} (rocprofv3 --pmc, separate passes; FETCH_SIZE x 2 per the gfx950 correction)",
-        "note": "the AR step's kernels only (prefill / NAR launches excluded); algorithmic bytes at the mean context: 336.4 MB",
+        "note": "the AR step's kernels only (prefill / NAR launches excluded); algorithmic bytes at the mean context: 336.4 MB.  With the "
+                "persistent step the counter also sees every sweep of the in-launch hand-offs (L1-bypassing loads, served by the "
+                "memory-side cache / HBM: ~40 KB per workgroup and layer per successful sweep, more when a sweep is repeated)",
+        "by_kernel_fetch_kib": {k: round(v, 1) for k, v in sorted(frows.items(), key=lambda kv: -kv[1])[:6]},
     }
     with open(os.path.join(ROOT, "profiles", "ar_step_traffic.json"), "w") as f:
         json.dump(out, f, indent=1)

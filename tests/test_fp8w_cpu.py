@@ -56,3 +56,37 @@ def test_fp8w_state_dict_touches_only_linear_weights():
     changed = {k for k in sd if not torch.equal(sd[k], sq[k])}
     assert changed and all(("proj" in k or "linear" in k or "predict" in k) and k.endswith("weight") and "project_layer" not in k for k in changed)
     assert "nar_audio_embeddings.2.word_embeddings.weight" not in changed  # tied to nar_predict_layers.0, stays fp32
+
+
+def test_block_scaled_mx_e4m3_is_no_more_accurate_than_per_row_scaling():
+    """Why engine mode "fp8" keeps per-row activation scales (and its 15 % sigma bar at 24 layers): e4m3 is a FLOATING format --
+    3 mantissa bits, a constant ~2.7 % relative rounding error over 15 binades -- so a per-32-column (MX, e8m0) scale buys nothing
+    over a per-row power-of-two scale unless elements fall below max / 2^15 of their row.  On Gaussian, outlier-laden, post-ReLU
+    and heavy-tailed rows the two quantisers have the same error, element-wise and through a Linear (VERDICT r3 next #3)."""
+    torch.manual_seed(0)
+
+    def q(x):
+        return x.to(torch.float8_e4m3fn).to(torch.float32)
+
+    def per_row(x):
+        s = 2.0 ** torch.ceil(torch.log2(x.abs().amax(-1, keepdim=True) / 448.0))
+        return q(x / s) * s
+
+    def per_block(x, blk=32):
+        xb = x.reshape(*x.shape[:-1], x.shape[-1] // blk, blk)
+        s = 2.0 ** torch.ceil(torch.log2(xb.abs().amax(-1, keepdim=True).clamp_min(1e-30) / 448.0))
+        return (q(xb / s) * s).reshape(x.shape)
+
+    rows = {
+        "gaussian": torch.randn(512, 1536),
+        "1 % outliers x10": torch.randn(512, 1536) * (1 + 9 * (torch.rand(512, 1536) < 0.01)),
+        "post-ReLU": torch.relu(torch.randn(512, 6144)),
+        "student-t (3 dof)": torch.distributions.StudentT(3.0).sample((512, 1536)),
+    }
+    for name, x in rows.items():
+        w = torch.randn(x.shape[-1], 128) / x.shape[-1] ** 0.5
+        y = x @ w
+        e_row = ((per_row(x) @ w - y).norm() / y.norm()).item()
+        e_blk = ((per_block(x) @ w - y).norm() / y.norm()).item()
+        assert 0.02 < e_row < 0.035, (name, e_row)           # ~2.65 %: the format's mantissa, not the scale's granularity
+        assert e_blk > 0.97 * e_row, (name, e_row, e_blk)    # block scales are not better

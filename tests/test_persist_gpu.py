@@ -31,7 +31,7 @@ def c2_model():
 
 
 def _decode(eng, X, Y, S, P, steps, opts, top_k=1, seed=0):
-    base = {"persist": 0, "persist_pf": 0, "persist_nk": 2, "persist_mode": 0x33114, "act_bf16": 2, "qa_nsplit": 8, "qa_nk": 4,
+    base = {"persist": 0, "persist_pf": 3, "persist_nk": 2, "persist_mode": 0x114, "persist_naps": 0x6864, "act_bf16": 2, "qa_nsplit": 8, "qa_nk": 4,
             "steps_per_graph": 0, "ignore_eos": 1}
     base.update(opts)
     for k, v in base.items():
@@ -46,7 +46,7 @@ def _mode_to_act(mode):
     return (2 if mode & 4 else 0) | (1 if mode & 8 else 0)
 
 
-@pytest.mark.parametrize("nk,pf,mode", [(2, 0, 0x33114), (2, 0, 0), (2, 0, 0x1c), (4, 0, 0x33114), (2, 1, 0x33114), (2, 1, 0x18)])
+@pytest.mark.parametrize("nk,pf,mode", [(2, 3, 0x114), (2, 0, 0x114), (2, 3, 0), (2, 3, 0x1c), (4, 3, 0x114), (2, 1, 0x114), (2, 2, 0x118)])
 def test_persistent_step_is_bit_identical_to_the_launch_chain(c2_model, nk, pf, mode):
     S, P, steps = 20, 60, 40
     eng = c2_model.engine_for(1, S, P)
@@ -119,3 +119,22 @@ def test_persistent_step_is_the_default_where_covered_and_only_there():
     assert e3.fetch_u32("persist_active") == 1
     codes, gl = e3.generate(top_k=1, max_new=6)
     assert e3.fetch_u32("persist_fail") == 0 and gl[0] >= 1
+
+
+def test_persistent_step_repeated_decodes_under_changing_timing_stay_identical(c2_model):
+    """The hand-offs are correct by protocol (every payload word carries the step's epoch), not by timing: decodes with every
+    request schedule, with the first sweeps timed well, badly (no wait) and very late, must give the same bits -- a timing-
+    dependent hand-off bug would show as a differing logit or a give-up."""
+    S, P, steps = 30, 100, 60
+    eng = c2_model.engine_for(1, S, P)
+    X, Y = _inputs(S, P, seed=3)
+    ref_codes, ref = _decode(eng, X, Y, S, P, steps, {"persist": 1})
+    n = 0
+    for rep in range(3):
+        for pf in (3, 0, 1, 2):
+            for naps in (0x6864, 0, 0xFFFFFF, 0x0F0F0F, 0x123456):
+                codes, lg = _decode(eng, X, Y, S, P, steps, {"persist": 1, "persist_pf": pf, "persist_naps": naps})
+                assert eng.fetch_u32("persist_fail") == 0, (pf, hex(naps))
+                assert torch.equal(ref, lg) and torch.equal(ref_codes, codes), (rep, pf, hex(naps))
+                n += 1
+    assert n == 60

@@ -24,7 +24,7 @@ def reset(eng):
     for k in ("nsplit", "gemv1_rpw", "gemv1_rpw_qkv", "gemv1_rpw_ffn1", "no_gemv1", "attn_nk", "steps_per_graph"):
         eng.set_option(k, 0)
     for k, v in (("qkv_attn", 1), ("qa_nsplit", 8), ("g1_shared", 1), ("qa_waves", 4), ("qa_qtemporal", 1), ("qa_handoff", 1), ("qa_nk", 4),
-                 ("persist", 0), ("persist_pf", 2), ("persist_nk", 2), ("persist_mode", 0), ("act_bf16", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
+                 ("persist", 0), ("persist_pf", 3), ("persist_nk", 2), ("persist_mode", 0x114), ("persist_naps", 0x6864), ("act_bf16", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
         eng.set_option(k, v)
 
 
@@ -49,9 +49,9 @@ def main():
     ap.add_argument("--check-steps", type=int, default=96)
     ap.add_argument("--out", default="gpurun_out/persist_probe")
     ap.add_argument("--skip-check", action="store_true")
-    ap.add_argument("--variants", nargs="*", default=["pf=0,mode=0", "pf=0,mode=4", "pf=0,mode=12", "pf=0,mode=16", "pf=0,mode=28", "pf=0,mode=28,nk=4", "pf=1,mode=28"],
+    ap.add_argument("--variants", nargs="*", default=["pf=3", "pf=0", "pf=3,naps=0", "pf=3,mode=0x104", "pf=3,mode=0x110", "pf=3,mode=0x11c"],
                     help="persistent variants to time: comma-separated persist_* options, e.g. pf=0,mode=3,nk=2")
-    ap.add_argument("--trace", nargs="*", default=["pf=0,mode=28", "pf=0,mode=0x1001c"])
+    ap.add_argument("--trace", nargs="*", default=["pf=3"])
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     dev = torch.device("cuda", 0)
@@ -66,7 +66,7 @@ def main():
     # ---- 1. bit-identity with the chain --------------------------------------------------------------------------------------
     if not args.skip_check:
         checks = []
-        for nk, pf, md in ((2, 1, 0), (2, 1, 4), (2, 1, 12), (2, 1, 16), (2, 1, 28), (4, 1, 28), (2, 0, 28), (2, 1, 0x201c)):
+        for nk, pf, md in ((2, 3, 0x114), (2, 0, 0x114), (2, 3, 0), (2, 3, 0x1c), (2, 3, 0x10), (4, 3, 0x114), (2, 1, 0x114), (2, 2, 0x118)):
             if True:
                 ab = (2 if md & 4 else 0) | (1 if md & 8 else 0)
                 ref = decode(eng, X, Y, args.check_steps, {"qa_nsplit": 16, "qa_nk": nk, "act_bf16": ab}, trace=True)
@@ -146,7 +146,7 @@ def main():
                "entry_spread_us": round(float((t0[..., 0].amax(-1) - t0[..., 0].amin(-1)).mean()), 3),
                "final_x": {"compute_us": round(float(comp[..., -2].mean()), 3), "wait_us": round(float(wait[..., -2].mean()), 3)},
                "tail_us": round(float(comp[..., -1].mean()), 3)}
-        if opts.get("persist_mode", 0) & 0x10000:  # finer stamps: per layer 5 (out-proj stage) + 5 (linear2 stage)
+        if False:  # finer stamps: per layer 5 (out-proj stage) + 5 (linear2 stage)
             half = raw.shape[-1] // 2
             sb = raw[:, :, half: half + 10 * L].reshape(8, 256, L, 10)[ok].double() / 100.0
             lab = ["lds_read", "dot_reduce", "publish", "next_weights_issue"]

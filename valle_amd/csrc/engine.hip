@@ -176,7 +176,8 @@ struct vle_engine {
   int opt_qa_qtemporal = 1;   // option "qa_qtemporal": its query-row loads with the default cache policy (shared by a head's splits through L2)
   // ---- the batch-1 step as one persistent launch (persist.hip; option "persist") ----
   int opt_persist = 1;        // option "persist": 1 = batch-1 AR steps run pstep_kernel (+ the sampling launch) where the shape is covered
-  int opt_ps_nk = 2, opt_ps_pf = 0;  // options "persist_nk", "persist_pf" (PStepArgs)
+  int opt_ps_nk = 2, opt_ps_pf = 3;  // options "persist_nk", "persist_pf" (PStepArgs)
+  int opt_ps_naps = PS_NAPS_DEFAULT; // option "persist_naps"
   bool ps_device_ok = false;  // the device has the 256 CUs the persistent grid needs
   PLayer* ps_table = nullptr;               // device [L] operand table (rebuilt when the KV cache moves)
   unsigned long long* ps_gran = nullptr;    // {epoch, value} granules of the step's edges (zeroed at every prefill)
@@ -1153,7 +1154,7 @@ int enqueue_persist_step(vle_engine* e) {
   a.kv_len = e->S.kv_len; a.iter = e->S.iter; a.done = e->S.done; a.gran = e->ps_gran;
   a.fail = e->qa_spin_fail ? e->qa_spin_fail + 2 : nullptr;
   a.ptrace = e->opt_ps_trace ? e->ps_ptrace : nullptr;
-  a.mode = e->opt_ps_mode; a.nk = e->opt_ps_nk; a.pf = e->opt_ps_pf;
+  a.mode = e->opt_ps_mode; a.nk = e->opt_ps_nk; a.pf = e->opt_ps_pf; a.naps = e->opt_ps_naps;
   const int r = launch_pstep(e->st, e->dtype, a);
   if (r != 0) return e->fail(VLE_EINVAL, "launch_pstep rejected the step");
   return 0;
@@ -2323,12 +2324,13 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     (n == "glds_big" ? g_glds_big : n == "glds_w8" ? g_glds_w8 : g_glds_prio) = (int)value;
     return VLE_OK;
   }
-  if (n == "persist" || n == "persist_pf" || n == "persist_nk" || n == "persist_trace" || n == "persist_mode" || n == "act_bf16") {  // change the captured graphs: drop them
+  if (n == "persist" || n == "persist_pf" || n == "persist_nk" || n == "persist_trace" || n == "persist_mode" || n == "persist_naps" || n == "act_bf16") {  // change the captured graphs: drop them
     if (n == "persist") e->opt_persist = value != 0;
     else if (n == "act_bf16") e->opt_act_bf16 = (int)value & 3;
     else if (n == "persist_mode") e->opt_ps_mode = (int)value;
+    else if (n == "persist_naps") e->opt_ps_naps = (int)value;
     else if (n == "persist_pf") {
-      if (value < 0 || value > 1) return e->fail(VLE_EINVAL, "persist_pf must be 0 or 1");
+      if (value < 0 || value > 3) return e->fail(VLE_EINVAL, "persist_pf must be 0 .. 3");
       e->opt_ps_pf = (int)value;
     } else if (n == "persist_nk") {
       if (!(value == 2 || value == 4)) return e->fail(VLE_EINVAL, "persist_nk must be 2 or 4");

@@ -218,7 +218,8 @@ struct PLayer {  // one decoder layer's operands (device table, one entry per la
   void *kc = nullptr, *vc = nullptr;  // this layer's KV cache [H][ctx_max][dh] (batch 1)
 };
 constexpr int PS_PT_SLOTS = 512;
-constexpr int PS_MODE_DEFAULT = 0x33114;  // hidden as bf16 pairs, XCD-local group edges, 1 sleep unit, 3 x 8 units ahead of the attention / x sweeps (tools/persist_probe.py)  // wall-clock stamps per workgroup and step of the in-kernel timeline (option "persist_trace")
+constexpr int PS_MODE_DEFAULT = 0x114;    // hidden vector as bf16 pairs, XCD-local group edges, 1 sleep unit between sweeps
+constexpr int PS_NAPS_DEFAULT = 0x6864;   // att 4, x 6, x' 8, hidden 6 units of s_sleep(4) (tools/persist_probe.py, persist_pf = 3)  // wall-clock stamps per workgroup and step of the in-kernel timeline (option "persist_trace")
 struct PStepArgs {
   const PLayer* layers = nullptr;  // device [L]
   int L = 0, d = 0, nhead = 0, dh = 0, V = 0, ctx_max = 0;
@@ -234,11 +235,15 @@ struct PStepArgs {
   unsigned long long* ptrace = nullptr;  // [8][256][PS_PT_SLOTS] optional timeline
   int never = 0;                   // always 0 (keeps the LDS carve allocated)
   // "persist_mode": bit 2 (4) the FFN hidden vector, bit 3 (8) the attention output travel as bf16 pairs; bit 4 (16) the two
-  // head-group edges also through XCD-local (default-policy) granules; bits 8..11 s_sleep units between two sweeps of an edge;
-  // bits 12..15 / 16..19 / 20..23 / 24..27 s_sleep(8) units ahead of the first sweep of the attention-output / x / x' / hidden edge
+  // head-group edges also through XCD-local (default-policy) granules; bits 8..11 s_sleep units between two sweeps of an edge
   int mode = PS_MODE_DEFAULT;
+  // "persist_naps": s_sleep(4) units (~0.1 us each) ahead of the FIRST sweep of an edge, 4 bits each: attention output, x, x',
+  // hidden, q/k/v, partials.  A sweep that comes back without the data costs a fabric round trip (~1.1 us) before the next one
+  // can see it; the values time the first sweep to land just after the producers' stores (tools/persist_probe.py sweeps)
+  int naps = PS_NAPS_DEFAULT;
   int nk = 2;                      // "persist_nk": keys per lane per round of the attention share (2: 1024 keys in one round; 4)
-  int pf = 0;                      // "persist_pf": 0 = an operator's operands are requested ahead of the sweep that precedes it; 1 = behind it
+  int pf = 3;                      // "persist_pf": when the compute waves request an operator's operands (persist.hip): 0 = in one burst right
+                                   // before the sweep that precedes the operator, 3 = linear1 / linear2 spread over three sweeps (default)
 };
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V);
 size_t pstep_gran_count(int d, int nhead, int L);

@@ -221,8 +221,10 @@ __host__ __device__ inline int ps_gran_per_layer(int d, int H, int NS) { return 
 
 // PF: 0 = an operator's operands are requested right BEFORE the sweep that precedes it (they land while the edge is in flight, but
 //         the sweep cannot return before they have: a wave's loads return in order);
-//     1 = the sweep first, THEN the operands of the operator AFTER the next one (gather_vals16's functor): the sweep returns at the
-//         edge's own latency and the operands have a whole stage to land.
+//     1 = the sweep first, THEN the operands of the operator AFTER the next one (gather_vals16's functor): measured 240-280 us per
+//         step -- the requests of all 256 workgroups fill the memory system right when everybody's sweep is in flight;
+//     2 = at the START of the previous stage (right after its own sweep): they land under that stage's arithmetic, publish and
+//         hand-off latency.
 // PK: bit 0 = the FFN hidden vector, bit 1 = the attention output travel as bf16 pairs (compile-time: a run-time branch around
 //     a sweep that carries requests would make hipcc merge in-flight registers, see below).
 template <typename T, int D, int H, int NK, int PF, int PK>
@@ -281,7 +283,9 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   const bool glocal = (mode & 16) != 0;
   // s_sleep(8) units ahead of the FIRST sweep of an all-to-all edge (attention output, x, x', hidden): a sweep that comes back
   // without the data costs a whole fabric round trip (~1.1 us) before the next one can see it -- waiting first is cheaper
-  const int nap_att = (mode >> 12) & 15, nap_x = (mode >> 16) & 15, nap_x2 = (mode >> 20) & 15, nap_hid = (mode >> 24) & 15;
+  const int naps = a.naps;  // "persist_naps": s_sleep(4) units (~0.1 us), 4 bits per edge
+  const int nap_att = naps & 15, nap_x = (naps >> 4) & 15, nap_x2 = (naps >> 8) & 15, nap_hid = (naps >> 12) & 15, nap_qkv = (naps >> 16) & 15,
+            nap_part = (naps >> 20) & 15;
   PsSpin sp{PS_SPINS, a.fail, (mode >> 8) & 15, 0u};
   PsTrace pt{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)((a.iter[0]) & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
   pt_begin(pt);
@@ -343,21 +347,30 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     for (int cc = 0; cc < NCH; ++cc) wo[cc] = wvec(p.wo, 4 * c + w, D, cc);
     bo_v = as_g<float>(p.bo)[4 * c + w];
   };
-  auto issue_w1 = [&](const PsLayer& p) {
+  // linear1's rows [r0, r1) of this wave (+ its bias and norm2's affine with the first part); linear2's chunks [c0, c1)
+  auto issue_w1_rows = [&](const PsLayer& p, int r0, int r1) {
 #pragma unroll
     for (int r = 0; r < R1; ++r) {
+      if (r < r0 || r >= r1) continue;
 #pragma unroll
       for (int cc = 0; cc < NCH; ++cc) w1[r][cc] = wvec(p.w1, 4 * R1 * c + w * R1 + r, D, cc);
     }
-    b1_v = as_g<float>(p.b1)[4 * R1 * c + w * R1 + (lane < R1 ? lane : R1 - 1)];
-    ps_load4(as_g<float>(p.g2) + tid * EPT, g2v);
-    ps_load4(as_g<float>(p.be2) + tid * EPT, be2v);
+    if (r0 == 0) {
+      b1_v = as_g<float>(p.b1)[4 * R1 * c + w * R1 + (lane < R1 ? lane : R1 - 1)];
+      ps_load4(as_g<float>(p.g2) + tid * EPT, g2v);
+      ps_load4(as_g<float>(p.be2) + tid * EPT, be2v);
+    }
   };
-  auto issue_w2 = [&](const PsLayer& p) {
+  auto issue_w1 = [&](const PsLayer& p) { issue_w1_rows(p, 0, R1); };
+  auto issue_w2_chunks = [&](const PsLayer& p, int c0, int c1) {
 #pragma unroll
-    for (int cc = 0; cc < NCH2; ++cc) w2[cc] = wvec(p.w2, 4 * c + w, 4 * D, cc);
-    b2_v = as_g<float>(p.b2)[4 * c + w];
+    for (int cc = 0; cc < NCH2; ++cc) {
+      if (cc < c0 || cc >= c1) continue;
+      w2[cc] = wvec(p.w2, 4 * c + w, 4 * D, cc);
+    }
+    if (c0 == 0) b2_v = as_g<float>(p.b2)[4 * c + w];
   };
+  auto issue_w2 = [&](const PsLayer& p) { issue_w2_chunks(p, 0, NCH2); };
   // ---- x of the first layer: the sampling kernel's output (previous launch) ----------------------------------------------------
   float xv[EPT];
   load_ept<EPT>(a.x_in + tid * EPT, xv);
@@ -368,7 +381,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   }
   __builtin_amdgcn_sched_barrier(0);
   auto nap = [&](int n) {
-    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(8);
+    for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
   };
 
   for (int l = 0; l < a.L; ++l) {
@@ -381,9 +394,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     if (l > 0) {
       pt_begin(pt);
       nap(nap_x);
-      if constexpr (PF >= 1) ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, [&]() { issue_kv(p, s * CHUNK); });
+      if constexpr (PF == 1) ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, [&]() { issue_kv(p, s * CHUNK); });
       else ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, PsNoop());
       pt_end(pt, sp.passes);
+      if constexpr (PF == 2) issue_kv(p, s * CHUNK);
     }
     if (tid == c) store_ept_lds<EPT>(sres, xv);  // thread c holds x[4c .. 4c+3]: the residual of the rows this workgroup owns
     g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
@@ -415,21 +429,23 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         }
       }
     }
-    if constexpr (PF == 0) issue_kv(p, s * CHUNK);
+    if constexpr (PF == 0 || PF == 3) issue_kv(p, s * CHUNK);
 
     // ======== (2) q, k_new, v_new of the head; attention over this workgroup's share of the cached keys ==========================
     pt_begin(pt);
     {
       // every wave sweeps (wave 3 repeats wave 0's granules and drops them): the requests the sweep carries stay straight-line code
+      nap(nap_qkv);
       const int wq_i = w < 3 ? w : 0;
       const int gi = h * (3 * DH) + wq_i * DH + (lane < DH ? lane : 0);
       float t;
-      if constexpr (PF >= 1) t = gather_one_dual(G + G_QKV + gi, glocal ? G + G_QKVL + gi : nullptr, epoch, sp, [&]() { issue_wo(p); });
+      if constexpr (PF == 1) t = gather_one_dual(G + G_QKV + gi, glocal ? G + G_QKVL + gi : nullptr, epoch, sp, [&]() { issue_wo(p); });
       else t = gather_one_dual(G + G_QKV + gi, glocal ? G + G_QKVL + gi : nullptr, epoch, sp, PsNoop());
       if (w < 3 && lane < DH) (w == 0 ? sq : w == 1 ? sk : sv)[lane] = t;
     }
     g1_lds_barrier();
     pt_end(pt, sp.passes);
+    if constexpr (PF == 2) issue_wo(p);
     __builtin_amdgcn_sched_barrier(0);
     {
       auto widen = [&](const u32x4_t& r, float (&f)[CVEC]) {
@@ -541,7 +557,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         }
       }
     }
-    if constexpr (PF == 0) issue_wo(p);
+    if constexpr (PF == 0 || PF == 3) issue_wo(p);
 
     // ======== (3) merge of the head's NS partials + the new token's own key, for this workgroup's QR output columns (wave 0) =====
     if (w == 0) {
@@ -561,6 +577,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       }
       float t2[2];
       pt_begin(pt);
+      nap(nap_part);
       {
         const unsigned bo = (unsigned)((const char*)(gp + (size_t)j * (2 + DH) + off) - (const char*)GB);
         gather_two_dual(rs, bo, bo + (unsigned)(G_PARTL - G_PART) * 8u, glocal, epoch, t2, sp);
@@ -624,8 +641,9 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       constexpr int NA = apack ? EPT / 2 : EPT;
       float av[EPT], raw[NA];
       pt_begin(pt);
+      if constexpr (PF == 3) issue_w1_rows(p, 0, R1 - 1);  // in place of most of the nap: ~6 MB chip-wide land inside the edge's own latency
       nap(nap_att);
-      if constexpr (PF >= 1) ps_gather<NA>(GB, rs, G + G_ATT + tid * NA, epoch, raw, sp, [&]() { issue_w1(p); });
+      if constexpr (PF == 1) ps_gather<NA>(GB, rs, G + G_ATT + tid * NA, epoch, raw, sp, [&]() { issue_w1(p); });
       else ps_gather<NA>(GB, rs, G + G_ATT + tid * NA, epoch, raw, sp, PsNoop());
       if constexpr (apack) {
 #pragma unroll
@@ -641,6 +659,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       store_ept_lds<EPT>(sx + tid * EPT, av);
       g1_lds_barrier();
       pt_end(pt, sp.passes);
+      if constexpr (PF == 2) issue_w1(p);
       __builtin_amdgcn_sched_barrier(0);
       float x[NCH][VEC];
       g1_read_shared<T, NCH>(sx, x);
@@ -651,14 +670,19 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       }
     }
     if constexpr (PF == 0) issue_w1(p);
+    if constexpr (PF == 3) {
+      issue_w1_rows(p, R1 - 1, R1);
+      issue_w2_chunks(p, 0, NCH2 / 2);
+    }
 
     // ======== (5) LN2 + linear1 + ReLU of rows 16c .. 16c+15 ======================================================================
     {
       pt_begin(pt);
       nap(nap_x2);
-      if constexpr (PF >= 1) ps_gather<EPT>(GB, rs, G + G_X2 + tid * EPT, epoch, xv, sp, [&]() { issue_w2(p); });
+      if constexpr (PF == 1) ps_gather<EPT>(GB, rs, G + G_X2 + tid * EPT, epoch, xv, sp, [&]() { issue_w2(p); });
       else ps_gather<EPT>(GB, rs, G + G_X2 + tid * EPT, epoch, xv, sp, PsNoop());
       pt_end(pt, sp.passes);
+      if constexpr (PF == 2) issue_w2(p);
       __builtin_amdgcn_sched_barrier(0);
       if (tid == c) store_ept_lds<EPT>(sres, xv);
       g1_block_layernorm<D, PS_T>(xv, g2v, be2v, sx, red);
@@ -679,6 +703,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       }
     }
     if constexpr (PF == 0) issue_w2(p);
+    if constexpr (PF == 3) issue_w2_chunks(p, NCH2 / 2, NCH2);
 
     // ======== (6) linear2 + residual of rows 4c .. 4c+3 ===========================================================================
     {
@@ -686,7 +711,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       float hv[EPT2], raw[NHG];
       pt_begin(pt);
       nap(nap_hid);
-      if constexpr (PF >= 1) ps_gather<NHG>(GB, rs, G + G_HID + tid * NHG, epoch, raw, sp, [&]() { issue_wqkv(pn, last); });
+      if constexpr (PF == 1) ps_gather<NHG>(GB, rs, G + G_HID + tid * NHG, epoch, raw, sp, [&]() { issue_wqkv(pn, last); });
       else ps_gather<NHG>(GB, rs, G + G_HID + tid * NHG, epoch, raw, sp, PsNoop());
       if constexpr (hpack) {
 #pragma unroll
@@ -702,6 +727,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       store_ept_lds<EPT2>(sx + tid * EPT2, hv);
       g1_lds_barrier();
       pt_end(pt, sp.passes);
+      if constexpr (PF == 2) issue_wqkv(pn, last);
       __builtin_amdgcn_sched_barrier(0);
       float x[NCH2][VEC];
       g1_read_shared<T, NCH2>(sx, x);
@@ -711,7 +737,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         gran_store(G + GPL + G_X + 4 * c + w, epoch, sres[w] + v);  // the next layer's x edge (layer L: the final norm's)
       }
     }
-    if constexpr (PF == 0) issue_wqkv(pn, last);
+    if constexpr (PF == 0 || PF == 3) issue_wqkv(pn, last);
   }
 
   // ======== final norm + predict layer: rows 4c .. 4c+3 (+ row 1024) ================================================================
@@ -757,8 +783,8 @@ static int ps_launch_pk(hipStream_t st, const PStepArgs& a) {
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
   if (!a.layers || !a.x_in || !a.norm_g || !a.norm_b || !a.w_pred || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
-  if (a.nk == 4) return a.pf == 0 ? ps_launch_pk<4, 0>(st, a) : ps_launch_pk<4, 1>(st, a);
-  return a.pf == 0 ? ps_launch_pk<2, 0>(st, a) : ps_launch_pk<2, 1>(st, a);
+  if (a.nk == 4) return a.pf == 0 ? ps_launch_pk<4, 0>(st, a) : a.pf == 1 ? ps_launch_pk<4, 1>(st, a) : a.pf == 2 ? ps_launch_pk<4, 2>(st, a) : ps_launch_pk<4, 3>(st, a);
+  return a.pf == 0 ? ps_launch_pk<2, 0>(st, a) : a.pf == 1 ? ps_launch_pk<2, 1>(st, a) : a.pf == 2 ? ps_launch_pk<2, 2>(st, a) : ps_launch_pk<2, 3>(st, a);
 }
 
 }  // namespace vle

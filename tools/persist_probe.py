@@ -24,7 +24,7 @@ def reset(eng):
     for k in ("nsplit", "gemv1_rpw", "gemv1_rpw_qkv", "gemv1_rpw_ffn1", "no_gemv1", "attn_nk", "steps_per_graph"):
         eng.set_option(k, 0)
     for k, v in (("qkv_attn", 1), ("qa_nsplit", 8), ("g1_shared", 1), ("qa_waves", 4), ("qa_qtemporal", 1), ("qa_handoff", 1), ("qa_nk", 4),
-                 ("persist", 0), ("persist_pf", 3), ("persist_nk", 2), ("persist_mode", 0x114), ("persist_naps", 0x6864), ("act_bf16", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
+                 ("persist", 0), ("persist_pf", 3), ("persist_nk", 2), ("persist_mode", 0x134), ("persist_naps", 0x6864), ("act_bf16", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
         eng.set_option(k, v)
 
 
@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--check-steps", type=int, default=96)
     ap.add_argument("--out", default="gpurun_out/persist_probe")
     ap.add_argument("--skip-check", action="store_true")
-    ap.add_argument("--variants", nargs="*", default=["pf=3", "pf=0", "pf=3,naps=0", "pf=3,mode=0x104", "pf=3,mode=0x110", "pf=3,mode=0x11c"],
+    ap.add_argument("--variants", nargs="*", default=["pf=3", "pf=3,mode=0x114", "pf=0", "pf=3,naps=0", "pf=3,mode=0x124", "pf=3,mode=0x130", "pf=3,mode=0x13c"],
                     help="persistent variants to time: comma-separated persist_* options, e.g. pf=0,mode=3,nk=2")
     ap.add_argument("--trace", nargs="*", default=["pf=3"])
     args = ap.parse_args()
@@ -66,10 +66,13 @@ def main():
     # ---- 1. bit-identity with the chain --------------------------------------------------------------------------------------
     if not args.skip_check:
         checks = []
-        for nk, pf, md in ((2, 3, 0x114), (2, 0, 0x114), (2, 3, 0), (2, 3, 0x1c), (2, 3, 0x10), (4, 3, 0x114), (2, 1, 0x114), (2, 2, 0x118)):
+        for nk, pf, md in ((2, 3, 0x134), (2, 0, 0x134), (4, 3, 0x13c), (2, 3, 0x114), (2, 0, 0x114), (2, 3, 0), (2, 3, 0x1c), (2, 3, 0x10), (4, 3, 0x114), (2, 1, 0x114), (2, 2, 0x118)):
             if True:
                 ab = (2 if md & 4 else 0) | (1 if md & 8 else 0)
-                ref = decode(eng, X, Y, args.check_steps, {"qa_nsplit": 16, "qa_nk": nk, "act_bf16": ab}, trace=True)
+                if md & 32:  # folded LayerNorm: against the three-barrier form of the same launch (fp32 re-association apart)
+                    ref = decode(eng, X, Y, args.check_steps, {"persist": 1, "persist_nk": nk, "persist_pf": pf, "persist_mode": md & ~32}, trace=True)
+                else:
+                    ref = decode(eng, X, Y, args.check_steps, {"qa_nsplit": 16, "qa_nk": nk, "act_bf16": ab}, trace=True)
                 got = decode(eng, X, Y, args.check_steps, {"persist": 1, "persist_nk": nk, "persist_pf": pf, "persist_mode": md, "qa_nsplit": 16, "qa_nk": nk}, trace=True)
                 active = eng.fetch_u32("persist_active")
                 fail = eng.fetch_u32("persist_fail")

@@ -1,7 +1,17 @@
-import sys, os, torch, time
-sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", "/root/repo"))
-import valle_amd
-from bench import S_TEXT, P_PROMPT, synth_inputs
+#!/usr/bin/env python
+"""Soak test of the persistent batch-1 AR step's hand-offs:  python tools/persist_stress.py SECONDS [STEPS]
+Decodes the same utterance over and over with the shipped persist_mode under every request schedule and a set of hand-off timings
+(persist_naps); every logit of every decode must equal the first decode's, bit for bit, and no wave may give up waiting."""
+import os
+import sys
+import time
+
+import torch
+
+sys.path.insert(0, os.environ.get("GRAFT_REPO_ROOT", os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+import valle_amd  # noqa: E402
+from bench import P_PROMPT, S_TEXT, synth_inputs  # noqa: E402
+
 dev = torch.device("cuda", 0)
 torch.manual_seed(0)
 model = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16").to(dev).eval()
@@ -9,22 +19,27 @@ eng = model.engine_for(1, S_TEXT, P_PROMPT)
 eng.set_option("ignore_eos", 1)
 x, y = synth_inputs(0)
 X, Y = x[None].to(dev), y[None].to(dev)
+steps = int(sys.argv[2]) if len(sys.argv) > 2 else 120
+MODE = 0x134
+variants = [(3, 0x6864), (0, 0x6864), (3, 0), (3, 0xFFFFFF), (1, 0x6864), (2, 0x6864), (3, 0x123456), (0, 0x0F0F0F)]
 ref = None
 t0 = time.time()
-n = 0
-variants = [(0, 0x33114), (3, 0x2431114), (3, 0x230114), (0, 0x114), (3, 0x1330114), (1, 0x33114), (2, 0x33114)]
+n = bad = 0
 while time.time() - t0 < float(sys.argv[1]):
-    pf, mode = variants[n % len(variants)]
-    eng.set_option("persist", 1); eng.set_option("persist_pf", pf); eng.set_option("persist_mode", mode)
-    eng.set_option("trace_ar_logits", 1)
+    pf, naps = variants[n % len(variants)]
+    for k, v in (("persist", 1), ("persist_pf", pf), ("persist_mode", MODE), ("persist_naps", naps), ("trace_ar_logits", 1)):
+        eng.set_option(k, v)
     eng.prefill(X, [S_TEXT], Y, [P_PROMPT])
-    codes, gl = eng.generate(top_k=1, max_new=120)
+    codes, gl = eng.generate(top_k=1, max_new=steps)
     lg = eng.fetch_ar_logits()[:, 0].clone()
     fail = eng.fetch_u32("persist_fail")
-    if ref is None: ref = lg
-    ok = torch.equal(ref, lg)
-    if not ok or fail:
-        print("MISMATCH", n, pf, hex(mode), fail, (ref - lg).abs().max().item(), flush=True)
+    if ref is None:
+        ref = lg
+    if not torch.equal(ref, lg) or fail:
+        bad += 1
+        print("MISMATCH", n, pf, hex(naps), fail, (ref - lg).abs().max().item(), flush=True)
     n += 1
-    if n % 50 == 0: print("iter", n, flush=True)
-print("done", n, "decodes")
+    if n % 100 == 0:
+        print("iter", n, flush=True)
+print("done", n, "decodes x", steps, "steps;", bad, "mismatches")
+sys.exit(1 if bad else 0)

@@ -180,6 +180,7 @@ struct vle_engine {
   int opt_ps_naps = PS_NAPS_DEFAULT; // option "persist_naps"
   bool ps_device_ok = false;  // the device has the 256 CUs the persistent grid needs
   PLayer* ps_table = nullptr;               // device [L] operand table (rebuilt when the KV cache moves)
+  float* ps_fold = nullptr;                 // [L][14 d] + [2][V_AR + 3]: row constants of the folded LayerNorm (launch_ps_fold)
   unsigned long long* ps_gran = nullptr;    // {epoch, value} granules of the step's edges (zeroed at every prefill)
   size_t ps_gran_n = 0;
   unsigned long long* ps_ptrace = nullptr;  // [8][256][PS_PT_SLOTS] in-kernel timeline (option "persist_trace")
@@ -544,7 +545,7 @@ static void release_buffers(vle_engine* e) {
   e->kcache = e->vcache = nullptr;
   e->x_step = e->q_step = e->h_step = e->part_o = e->part_ml = e->logits = nullptr;
   e->k_new = e->v_new = nullptr; e->qgran = nullptr; e->qa_spin_fail = nullptr;
-  e->ps_table = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0;
+  e->ps_table = nullptr; e->ps_fold = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0;
   e->xn_step = e->qkv_step = e->att_step = e->hT_step = nullptr;
   e->gs_ws = nullptr; e->ln_stats = nullptr; e->ao_part = nullptr; e->ao_cnt = nullptr;
   e->state_dev = nullptr; e->S = ArState{}; e->dyn_dev = nullptr;
@@ -861,6 +862,7 @@ static int alloc_buffers(vle_engine* e) {
     if ((r = dev_alloc(e, &e->ps_gran, e->ps_gran_n))) return r;
     E_HIP(e, hipMemset(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long)));
     if ((r = dev_alloc(e, &e->ps_table, (size_t)e->L))) return r;
+    if ((r = dev_alloc(e, &e->ps_fold, (size_t)e->L * 14 * d + 2 * (V_AR + 3)))) return r;
   }
   if ((r = dev_alloc(e, &e->part_o, (size_t)B * e->H * 16 * e->dh))) return r;
   if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
@@ -1128,16 +1130,25 @@ bool persist_ready(const vle_engine* e) {
 // (re)build the operand table for a batch-1 call and forget the granules' old tags (the iteration counter restarts at every
 // prefill).  Called from vle_ar_prefill: never inside a stream capture.
 int persist_prepare(vle_engine* e) {
-  if (!e->ps_table || !e->ps_gran || e->B != 1 || e->w8) return 0;
+  if (!e->ps_table || !e->ps_gran || !e->ps_fold || e->B != 1 || e->w8) return 0;
   if (e->ps_table_kc != e->kcache || e->ps_table_ctx != e->ctx_max) {
     std::vector<PLayer> tab(e->L);
+    const int64_t d = e->d;
     for (int l = 0; l < e->L; ++l) {
       const LayerW& w = e->ar[l];
       PLayer& t = tab[l];
+      float* f = e->ps_fold + (size_t)l * 14 * d;
+      t.sgqkv = f; t.tbqkv = f + 3 * d; t.sg1 = f + 6 * d; t.tb1 = f + 10 * d;
+      E_LAUNCH(e, launch_ps_fold(e->st, w.wqkv, w.g1, w.be1, w.bqkv, f, f + 3 * d, (int)(3 * d), (int)d));
+      E_LAUNCH(e, launch_ps_fold(e->st, w.w1, w.g2, w.be2, w.b1, f + 6 * d, f + 10 * d, (int)(4 * d), (int)d));
       t.wqkv = w.wqkv; t.wo = w.wo; t.w1 = w.w1; t.w2 = w.w2;
       t.bqkv = w.bqkv; t.bo = w.bo; t.b1 = w.b1; t.b2 = w.b2;
       t.g1 = w.g1; t.be1 = w.be1; t.g2 = w.g2; t.be2 = w.be2;
       t.kc = cache_layer(e, e->kcache, l); t.vc = cache_layer(e, e->vcache, l);
+    }
+    {
+      float* f = e->ps_fold + (size_t)e->L * 14 * d;
+      E_LAUNCH(e, launch_ps_fold(e->st, e->ar_predict, e->ar_norm_g, e->ar_norm_b, nullptr, f, f + V_AR + 3, V_AR, (int)d));
     }
     E_HIP(e, hipStreamSynchronize(e->st));
     E_HIP(e, hipMemcpy(e->ps_table, tab.data(), tab.size() * sizeof(PLayer), hipMemcpyHostToDevice));
@@ -1151,6 +1162,7 @@ int enqueue_persist_step(vle_engine* e) {
   PStepArgs a;
   a.layers = e->ps_table; a.L = e->L; a.d = e->d; a.nhead = e->H; a.dh = e->dh; a.V = V_AR; a.ctx_max = e->ctx_max;
   a.x_in = e->x_step; a.norm_g = e->ar_norm_g; a.norm_b = e->ar_norm_b; a.w_pred = e->ar_predict; a.logits = e->logits;
+  a.sg_pred = e->ps_fold + (size_t)e->L * 14 * e->d; a.tb_pred = a.sg_pred + V_AR + 3;
   a.kv_len = e->S.kv_len; a.iter = e->S.iter; a.done = e->S.done; a.gran = e->ps_gran;
   a.fail = e->qa_spin_fail ? e->qa_spin_fail + 2 : nullptr;
   a.ptrace = e->opt_ps_trace ? e->ps_ptrace : nullptr;

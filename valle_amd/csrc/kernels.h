@@ -216,9 +216,12 @@ struct PLayer {  // one decoder layer's operands (device table, one entry per la
   const float *bqkv = nullptr, *bo = nullptr, *b1 = nullptr, *b2 = nullptr;
   const float *g1 = nullptr, *be1 = nullptr, *g2 = nullptr, *be2 = nullptr;
   void *kc = nullptr, *vc = nullptr;  // this layer's KV cache [H][ctx_max][dh] (batch 1)
+  // folded LayerNorm (persist_mode bit 5): per output row n of the in-projection / linear1, sg[n] = sum_k W[n][k] gamma[k] and
+  // tb[n] = sum_k W[n][k] beta[k] + bias[n]  (launch_ps_fold)
+  const float *sgqkv = nullptr, *tbqkv = nullptr, *sg1 = nullptr, *tb1 = nullptr;
 };
 constexpr int PS_PT_SLOTS = 512;
-constexpr int PS_MODE_DEFAULT = 0x114;    // hidden vector as bf16 pairs, XCD-local group edges, 1 sleep unit between sweeps
+constexpr int PS_MODE_DEFAULT = 0x134;    // hidden vector as bf16 pairs, XCD-local group edges, folded LayerNorm, 1 sleep unit between sweeps
 constexpr int PS_NAPS_DEFAULT = 0x6864;   // att 4, x 6, x' 8, hidden 6 units of s_sleep(4) (tools/persist_probe.py, persist_pf = 3)  // wall-clock stamps per workgroup and step of the in-kernel timeline (option "persist_trace")
 struct PStepArgs {
   const PLayer* layers = nullptr;  // device [L]
@@ -226,6 +229,7 @@ struct PStepArgs {
   const float* x_in = nullptr;     // f32 [d]: the token's embedding + position (sampling kernel)
   const float *norm_g = nullptr, *norm_b = nullptr;  // final LayerNorm
   const void* w_pred = nullptr;    // bf16 [V][d]
+  const float *sg_pred = nullptr, *tb_pred = nullptr;  // f32 [V]: the folded final norm's row constants (mode bit 5)
   float* logits = nullptr;         // f32 [V]
   const int32_t* kv_len = nullptr; // [1] cache slot of the new token
   const int32_t* iter = nullptr;   // [1] AR iteration counter: epoch = iter + 1
@@ -235,7 +239,10 @@ struct PStepArgs {
   unsigned long long* ptrace = nullptr;  // [8][256][PS_PT_SLOTS] optional timeline
   int never = 0;                   // always 0 (keeps the LDS carve allocated)
   // "persist_mode": bit 2 (4) the FFN hidden vector, bit 3 (8) the attention output travel as bf16 pairs; bit 4 (16) the two
-  // head-group edges also through XCD-local (default-policy) granules; bits 8..11 s_sleep units between two sweeps of an edge
+  // head-group edges also through XCD-local (default-policy) granules; bit 5 (32) folded LayerNorm: the dot products run on
+  // x * gamma while the row statistics are still being combined, rstd * (dot - mean * sg) + tb afterwards -- one workgroup barrier
+  // per LayerNorm instead of three (not bit-identical to the launch chain: fp32 re-association); bits 8..11 s_sleep units between
+  // two sweeps of an edge
   int mode = PS_MODE_DEFAULT;
   // "persist_naps": s_sleep(4) units (~0.1 us each) ahead of the FIRST sweep of an edge, 4 bits each: attention output, x, x',
   // hidden, q/k/v, partials.  A sweep that comes back without the data costs a fabric round trip (~1.1 us) before the next one
@@ -248,6 +255,8 @@ struct PStepArgs {
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V);
 size_t pstep_gran_count(int d, int nhead, int L);
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched, 1 shape not covered, < 0 error
+// sg[n] = sum_k W[n][k] gamma[k], tb[n] = sum_k W[n][k] beta[k] + (bias ? bias[n] : 0) for the N rows of bf16 W[N][K] (fp64 sums)
+int launch_ps_fold(hipStream_t st, const void* W, const float* gamma, const float* beta, const float* bias, float* sg, float* tb, int N, int K);
 
 // ---- attention.hip --------------------------------------------------------------------------
 // prefill (causal=1: prefix-LM mask) / NAR (causal=0) attention over packed sequences

@@ -53,14 +53,15 @@ __device__ inline void ps_load4(const float PS_GLOBAL* p, float (&f)[4]) {
   f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
 }
 struct PsLayer {  // one entry of the table, as addresses
-  unsigned long long wqkv, wo, w1, w2, bqkv, bo, b1, b2, g1, be1, g2, be2, kc, vc;
+  unsigned long long wqkv, wo, w1, w2, bqkv, bo, b1, b2, g1, be1, g2, be2, kc, vc, sgqkv, tbqkv, sg1, tb1;
 };
 __device__ inline PsLayer ps_layer(const PLayer* tab, int l) {
-  static_assert(sizeof(PLayer) == 14 * 8, "PLayer is 14 pointers");
-  const unsigned long long PS_CONST* t = (const unsigned long long PS_CONST*)tab + (size_t)l * 14;
+  static_assert(sizeof(PLayer) == 18 * 8, "PLayer is 18 pointers");
+  const unsigned long long PS_CONST* t = (const unsigned long long PS_CONST*)tab + (size_t)l * 18;
   PsLayer p;
   p.wqkv = t[0]; p.wo = t[1]; p.w1 = t[2]; p.w2 = t[3]; p.bqkv = t[4]; p.bo = t[5]; p.b1 = t[6]; p.b2 = t[7];
   p.g1 = t[8]; p.be1 = t[9]; p.g2 = t[10]; p.be2 = t[11]; p.kc = t[12]; p.vc = t[13];
+  p.sgqkv = t[14]; p.tbqkv = t[15]; p.sg1 = t[16]; p.tb1 = t[17];
   return p;
 }
 
@@ -227,6 +228,13 @@ __host__ __device__ inline int ps_gran_per_layer(int d, int H, int NS) { return 
 //         hand-off latency.
 // PK: bit 0 = the FFN hidden vector, bit 1 = the attention output travel as bf16 pairs (compile-time: a run-time branch around
 //     a sweep that carries requests would make hipcc merge in-flight registers, see below).
+//     bit 2 = folded LayerNorm: LN(x) . W[n] = rstd * (sum_k W[n][k] gamma[k] x[k] - mean * sg[n]) + tb[n] with the row constants
+//     sg, tb of launch_ps_fold.  The dot products need only x * gamma, which a thread has as soon as its gather returns; the row
+//     statistics travel as one (mean, M2) pair per wave through the SAME barrier that publishes x * gamma to the other waves and are
+//     combined afterwards (Chan's update: exact two-pass statistics per wave, no cancellation in the combination) -- one workgroup
+//     barrier per LayerNorm instead of three.  Same arithmetic as the reference's LayerNorm + Linear up to fp32 re-association
+//     (valle/modules/transformer.py:57-74 then F.linear), so NOT bit-identical to the launch chain: tests/test_persist_gpu.py holds
+//     it to 1e-4 of the logits' spread against the three-barrier form and to bit-reproducibility against itself.
 template <typename T, int D, int H, int NK, int PF, int PK>
 __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   constexpr int VEC = Elem<T>::VEC;
@@ -279,7 +287,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   const int kvl = a.kv_len[0];  // slot of the new token; the old keys are [0, kvl)
   const int ctx_max = a.ctx_max;
   const int mode = a.mode;
-  constexpr bool hpack = (PK & 1) != 0, apack = (PK & 2) != 0;
+  constexpr bool hpack = (PK & 1) != 0, apack = (PK & 2) != 0, LF = (PK & 4) != 0;
   const bool glocal = (mode & 16) != 0;
   // s_sleep(8) units ahead of the FIRST sweep of an all-to-all edge (attention output, x, x', hidden): a sweep that comes back
   // without the data costs a whole fabric round trip (~1.1 us) before the next one can see it -- waiting first is cheaper
@@ -301,6 +309,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   // ---- register-resident operands, requested ahead -----------------------------------------------------------------------------
   u32x4_t wq[RQ][NCH], wo[NCH], w1[R1][NCH], w2[NCH2];
   float bq = 0.f, bo_v = 0.f, b1_v = 0.f, b2_v = 0.f;
+  float sgq = 0.f, sg1_v = 0.f, sgx = 0.f, tbx = 0.f;  // folded LayerNorm: sg of the rows whose tb sits in bq / b1_v; row 1024's pair
   float g1v[EPT], be1v[EPT], g2v[EPT], be2v[EPT];
   u32x4_t kraw[NK], vraw[NK];
 
@@ -327,9 +336,18 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 #pragma unroll
       for (int cc = 0; cc < NCH; ++cc) wq[r][cc] = wvec(W, row, D, cc);
     }
-    bq = as_g<float>(p.bqkv)[qkv_row(w * RQ + (lane < RQ ? lane : RQ - 1))];  // (unused by the predict layer: it has no bias)
+    if constexpr (!LF) {
+      bq = as_g<float>(p.bqkv)[qkv_row(w * RQ + (lane < RQ ? lane : RQ - 1))];  // (unused by the predict layer: it has no bias)
+    } else {  // the row's (sg, tb): in-projection row of lane r, or the predict layer's row 4c + w (and row 1024 for its one wave)
+      const int rq = qkv_row(w * RQ + (lane < RQ ? lane : RQ - 1));
+      const int ri = pred ? 4 * c + w : rq;
+      sgq = as_g<float>(pred ? (unsigned long long)a.sg_pred : p.sgqkv)[ri];
+      bq = as_g<float>(pred ? (unsigned long long)a.tb_pred : p.tbqkv)[ri];
+      sgx = as_g<float>((unsigned long long)a.sg_pred)[a.V - 1];
+      tbx = as_g<float>((unsigned long long)a.tb_pred)[a.V - 1];
+    }
     ps_load4(as_g<float>(pred ? (unsigned long long)a.norm_g : p.g1) + tid * EPT, g1v);
-    ps_load4(as_g<float>(pred ? (unsigned long long)a.norm_b : p.be1) + tid * EPT, be1v);
+    if constexpr (!LF) ps_load4(as_g<float>(pred ? (unsigned long long)a.norm_b : p.be1) + tid * EPT, be1v);
   };
   auto issue_kv = [&](const PsLayer& p, int base) {
     const CT PS_GLOBAL* Kb = as_g<CT>(p.kc) + (int64_t)h * ctx_max * DH + part * CVEC;
@@ -356,9 +374,15 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       for (int cc = 0; cc < NCH; ++cc) w1[r][cc] = wvec(p.w1, 4 * R1 * c + w * R1 + r, D, cc);
     }
     if (r0 == 0) {
-      b1_v = as_g<float>(p.b1)[4 * R1 * c + w * R1 + (lane < R1 ? lane : R1 - 1)];
+      const int r1i = 4 * R1 * c + w * R1 + (lane < R1 ? lane : R1 - 1);
+      if constexpr (!LF) {
+        b1_v = as_g<float>(p.b1)[r1i];
+      } else {
+        sg1_v = as_g<float>(p.sg1)[r1i];
+        b1_v = as_g<float>(p.tb1)[r1i];
+      }
       ps_load4(as_g<float>(p.g2) + tid * EPT, g2v);
-      ps_load4(as_g<float>(p.be2) + tid * EPT, be2v);
+      if constexpr (!LF) ps_load4(as_g<float>(p.be2) + tid * EPT, be2v);
     }
   };
   auto issue_w1 = [&](const PsLayer& p) { issue_w1_rows(p, 0, R1); };
@@ -383,6 +407,40 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   auto nap = [&](int n) {
     for (int i = 0; i < n; ++i) __builtin_amdgcn_s_sleep(4);
   };
+  // folded LayerNorm, the row side: x * gamma into sx, this wave's (mean, M2) of its 256 elements into red, ONE barrier, then the
+  // row's mean and 1 / sqrt(var + eps) from the four pairs.  (valle/modules/transformer.py:57-74: biased variance, eps 1e-5)
+  auto fold_stats = [&](const float (&xr)[EPT], const float (&gv)[EPT], float& mean, float& rstd) {
+    float xg[EPT];
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) xg[k] = xr[k] * gv[k];
+    store_ept_lds<EPT>(sx + tid * EPT, xg);
+    float sw = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) sw += xr[k];
+    const float mw = wave_sum_dpp(sw) * (1.0f / (64.0f * EPT));
+    float qw = 0.f;
+#pragma unroll
+    for (int k = 0; k < EPT; ++k) {
+      const float t = xr[k] - mw;
+      qw = fmaf(t, t, qw);
+    }
+    qw = wave_sum_dpp(qw);
+    if (lane == 0) {
+      red[w] = mw;
+      red[4 + w] = qw;
+    }
+    g1_lds_barrier();
+    mean = ((red[0] + red[1]) + (red[2] + red[3])) * 0.25f;
+    float m2 = (red[4] + red[5]) + (red[6] + red[7]);
+    float dm = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const float t = red[i] - mean;
+      dm = fmaf(t, t, dm);
+    }
+    m2 = fmaf(dm, 64.0f * EPT, m2);
+    rstd = 1.0f / sqrtf(m2 * (1.0f / (float)D) + LN_EPS);
+  };
 
   for (int l = 0; l < a.L; ++l) {
     const PsLayer p = ps_layer(a.layers, l);
@@ -400,7 +458,9 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if constexpr (PF == 2) issue_kv(p, s * CHUNK);
     }
     if (tid == c) store_ept_lds<EPT>(sres, xv);  // thread c holds x[4c .. 4c+3]: the residual of the rows this workgroup owns
-    g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if constexpr (LF) fold_stats(xv, g1v, ln_mean, ln_rstd);
+    else g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
     {
       float x[NCH][VEC];
       g1_read_shared<T, NCH>(sx, x);
@@ -412,7 +472,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       }
       if (lane < RQ) {
         const int r = w * RQ + lane, which = r / QR, e = s * QR + (r % QR);  // e: element of the head
-        const float v = mine + bq;
+        const float v = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgq, mine), bq) : mine + bq;
         gran_t* gq = G + G_QKV + h * (3 * DH) + which * DH + e;
         gran_t* gql = G + G_QKVL + h * (3 * DH) + which * DH + e;
         if (which == 0) {
@@ -685,7 +745,9 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if constexpr (PF == 2) issue_w2(p);
       __builtin_amdgcn_sched_barrier(0);
       if (tid == c) store_ept_lds<EPT>(sres, xv);
-      g1_block_layernorm<D, PS_T>(xv, g2v, be2v, sx, red);
+      float ln_mean = 0.f, ln_rstd = 1.f;
+      if constexpr (LF) fold_stats(xv, g2v, ln_mean, ln_rstd);
+      else g1_block_layernorm<D, PS_T>(xv, g2v, be2v, sx, red);
       float x[NCH][VEC];
       g1_read_shared<T, NCH>(sx, x);
       float mine = 0.f;
@@ -694,7 +756,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         const float t = wave_sum_dpp(g1_dot<T, NCH>(w1[r], x));
         mine = lane == r ? t : mine;
       }
-      const float hval = fmaxf(mine + b1_v, 0.f);
+      const float hval = fmaxf(LF ? fmaf(ln_rstd, fmaf(-ln_mean, sg1_v, mine), b1_v) : mine + b1_v, 0.f);
       if constexpr (!hpack) {
         if (lane < R1) gran_store(G + G_HID + 4 * R1 * c + w * R1 + lane, epoch, hval);
       } else {  // two bf16 values per granule: half the bytes of the widest edge (the batched path keeps the hidden rows in bf16 too)
@@ -747,18 +809,50 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     nap(nap_x);
     ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, PsNoop());
     pt_end(pt, sp.passes);
-    g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
+    float ln_mean = 0.f, ln_rstd = 1.f;
+    if constexpr (LF) fold_stats(xv, g1v, ln_mean, ln_rstd);
+    else g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
     float x[NCH][VEC];
     g1_read_shared<T, NCH>(sx, x);
     const float t0 = wave_sum_dpp(g1_dot<T, NCH>(wq[0], x));
-    if (lane == 0) a.logits[4 * c + w] = t0 + 0.f;
+    if (lane == 0) a.logits[4 * c + w] = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgq, t0), bq) : t0 + 0.f;
     if (extra_row) {
       const float t1 = wave_sum_dpp(g1_dot<T, NCH>(wq[1], x));
-      if (lane == 0) a.logits[4 * NWG] = t1 + 0.f;
+      if (lane == 0) a.logits[4 * NWG] = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgx, t1), tbx) : t1 + 0.f;
     }
     pt_begin(pt);
     pt_end(pt, 0u);
   }
+}
+
+// Row constants of the folded LayerNorm: one wave per row of bf16 W[N][K]; fp64 sums (one-time work at engine set-up).
+__global__ __launch_bounds__(256) void ps_fold_kernel(const bf16_t* __restrict__ W, const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                       const float* __restrict__ bias, float* __restrict__ sg, float* __restrict__ tb, int N, int K) {
+  const int lane = threadIdx.x & 63;
+  const int n = (int)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (n >= N) return;
+  const bf16_t* wr = W + (int64_t)n * K;
+  double s = 0.0, t = 0.0;
+  for (int k = lane; k < K; k += 64) {
+    const double wv = (double)bf16_to_f32(wr[k].v);
+    s += wv * (double)gamma[k];
+    t += wv * (double)beta[k];
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    s += __shfl_xor(s, o, 64);
+    t += __shfl_xor(t, o, 64);
+  }
+  if (lane == 0) {
+    sg[n] = (float)s;
+    tb[n] = (float)(t + (bias ? (double)bias[n] : 0.0));
+  }
+}
+
+int launch_ps_fold(hipStream_t st, const void* W, const float* gamma, const float* beta, const float* bias, float* sg, float* tb, int N, int K) {
+  if (!W || !gamma || !beta || !sg || !tb || N < 1 || K < 1) return -1;
+  hipLaunchKernelGGL(ps_fold_kernel, dim3((N + 3) / 4), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(W), gamma, beta, bias, sg, tb, N, K);
+  return 0;
 }
 
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V) {
@@ -770,11 +864,15 @@ size_t pstep_gran_count(int d, int nhead, int L) { return (size_t)(L + 1) * ps_g
 template <int NK, int PF>
 static int ps_launch_pk(hipStream_t st, const PStepArgs& a) {
   const dim3 grid(256), block(PS_T);
-  switch ((a.mode >> 2) & 3) {  // mode bits 4 / 8: hidden / attention rows as bf16 pairs
+  switch (((a.mode >> 2) & 3) | ((a.mode >> 3) & 4)) {  // mode bits 4 / 8: hidden / attention rows as bf16 pairs; 32: folded LayerNorm
     case 0: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 0>), grid, block, 0, st, a); break;
     case 1: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 1>), grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 2>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 3>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 3>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 4>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 5>), grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 6>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 7>), grid, block, 0, st, a); break;
   }
   return 0;
 }
@@ -783,6 +881,7 @@ static int ps_launch_pk(hipStream_t st, const PStepArgs& a) {
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
   if (!a.layers || !a.x_in || !a.norm_g || !a.norm_b || !a.w_pred || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
+  if ((a.mode & 32) && (!a.sg_pred || !a.tb_pred)) return -1;
   if (a.nk == 4) return a.pf == 0 ? ps_launch_pk<4, 0>(st, a) : a.pf == 1 ? ps_launch_pk<4, 1>(st, a) : a.pf == 2 ? ps_launch_pk<4, 2>(st, a) : ps_launch_pk<4, 3>(st, a);
   return a.pf == 0 ? ps_launch_pk<2, 0>(st, a) : a.pf == 1 ? ps_launch_pk<2, 1>(st, a) : a.pf == 2 ? ps_launch_pk<2, 2>(st, a) : ps_launch_pk<2, 3>(st, a);
 }

@@ -47,7 +47,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 S_TEXT, P_PROMPT = 47, 225  # 47 phonemes, 3 s x 75 Hz prompt
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "ar_step_traffic.json")    # tools/make_traffic.py from the PMC passes
 CPU_CACHE_FILE = os.path.join(ROOT, "profiles", "cpu_baseline_n1.json")  # the N = 1 line's cpu_baseline, committed
-AR_STEP_KERNEL_SOURCES = ("persist.hip", "gemv1_dev.h", "gemv1.hip", "sampling.hip", "common.h")  # the batch-1 AR step's kernels
+AR_STEP_KERNEL_SOURCES = ("persist.hip", "gemv1_dev.h", "sampling_dev.h", "gemv1.hip", "sampling.hip", "common.h")  # the batch-1 AR step's kernels
 N1_REF_FILE = os.path.join(ROOT, "profiles", "bench_n1_reference.json")  # value / c3_batch64.value of the committed N = 1 line (scale_ref)
 FRAME_RATE = 75.0  # EnCodec frames per second of audio (valle/data/tokenizer.py: 24 kHz / 320)
 
@@ -227,7 +227,7 @@ def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label="", 
         "steps": steps, "warmup": warmup, "ms_per_step": round(elapsed / steps * 1e3, 3),
         "phase_ms": {"prefill": round(pre / steps, 3), "ar": round(ar / steps, 3), "nar": round(nar / steps, 3)},
         "roofline_ar": {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
-                        "launch_us": round(ar / ar_steps * 1e3, 2), "bytes_per_launch": int(ar_bytes / ar_steps), "rank": 0},
+                        "step_us": round(ar / ar_steps * 1e3, 2), "bytes_per_step": int(ar_bytes / ar_steps), "rank": 0},
         "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tfs / mfma_peak, 4), "rank": 0},
     }
     res.update(rates(tokens, elapsed, steps * B * world, G))
@@ -279,7 +279,7 @@ def c5_leg(args, dev, dtype="fp8", B=32, steps=2, warmup=1):
         "value": round(tokens / elapsed, 1), "unit": "audio-tokens/s", "steps": steps, "warmup": warmup,
         "phase_ms": {"prefill": round(pre / steps, 3), "ar": round(ar / steps, 3), "nar": round(nar / steps, 3)},
         "roofline_ar": {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),
-                        "launch_us": round(ar / ar_steps * 1e3, 2), "bytes_per_launch": int(ar_bytes / ar_steps)},
+                        "step_us": round(ar / ar_steps * 1e3, 2), "bytes_per_step": int(ar_bytes / ar_steps)},
         "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": nar_peak,
                          "unit": "TFLOP/s (vs the dense fp8 MX peak)" if dtype == "fp8" else "TFLOP/s (vs the dense bf16 peak)", "frac": round(tfs / nar_peak, 4)},
     }
@@ -490,6 +490,10 @@ def main():
         traffic, traffic_src = measured_traffic(args, B)
         fused = args.d_model // args.nhead in (64, 128) and B == 1 and "qkv_attn=0" not in args.opt
         persist = eng.fetch_u32("persist_active") == 1 if B == 1 else False
+        own_sample = persist and eng.fetch_u32("persist_sample_active") == 1
+        # kernel launches of the dominant kernel over the timed decodes: with the sampling step inside the persistent launch one launch
+        # runs several AR iterations (the engine's last call is representative: every timed decode has the same length)
+        launches = eng.fetch_u32("ar_launches") * args.steps if own_sample else ar_steps
         n1_ref = None
         try:
             with open(N1_REF_FILE) as f:
@@ -532,7 +536,10 @@ def main():
             },
             "phase_ms": {"prefill": round(pre_ms / args.steps, 3), "ar": round(ar_ms / args.steps, 3), "nar": round(nar_ms / args.steps, 3)},
             "roofline": {
-                "kernel": ("AR decode step = ONE persistent launch (pstep_kernel: 256 workgroups, L layers + final norm + predict layer, in-launch "
+                "kernel": ("pstep_kernel = persistent AR launch (256 workgroups; per iteration L layers + final norm + predict layer + sampling, stop "
+                           "rule and next-token embedding, in-launch granule hand-offs; several AR iterations per launch, hipGraph replay); per "
+                           "iteration the weights + KV are streamed once") if own_sample else
+                          ("AR decode step = ONE persistent launch (pstep_kernel: 256 workgroups, L layers + final norm + predict layer, in-launch "
                            "granule hand-offs) + the sampling launch, hipGraph replay; weights + KV streamed once") if persist else
                           ("AR decode step (hipGraph replay: 4 launches/layer x L -- fused LN1+QKV+attention, out-proj, FFN1, FFN2 -- + logits + sample; "
                            "weights + KV streamed once)") if fused else
@@ -545,11 +552,17 @@ def main():
                 # HBM bytes per AR step from the PMC passes (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate runs, FETCH_SIZE
                 # doubled per the gfx950 correction), read from profiles/ar_step_traffic.json and only reported while the step's
                 # kernels are the ones it was measured on (kernel-set hash); null + the reason otherwise
-                "traffic": traffic,
+                "traffic": None if traffic is None else int(traffic * ar_steps / max(launches, 1)),  # per launch, like `achieved`
+                "traffic_per_step": traffic,
                 "traffic_source": traffic_src,
-                "launch_us": round(step_ms * 1e3, 2),
-                "bytes_per_launch": int(ar_bytes / max(ar_steps, 1)),
-                "launches": ar_steps,
+                # per launch of the kernel (what rocprofv3's average duration is compared with) and per AR iteration
+                "launch_us": round(ar_ms / max(launches, 1) * 1e3, 2),
+                "bytes_per_launch": int(ar_bytes / max(launches, 1)),
+                "launches": launches,
+                "iterations": ar_steps,
+                "iterations_per_launch": round(ar_steps / max(launches, 1), 2),
+                "step_us": round(step_ms * 1e3, 2),
+                "bytes_per_step": int(ar_bytes / max(ar_steps, 1)),
             },
         }
         if kernel_prof is not None:

@@ -36,15 +36,25 @@ def c2_model():
     return valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()
 
 
-def _decode(eng, X, Y, S, P, steps, opts, top_k=1, seed=0):
-    base = {"persist": 0, "persist_pf": 3, "persist_nk": 2, "persist_mode": CLASSIC, "persist_naps": 0x6864, "act_bf16": 2, "qa_nsplit": 8, "qa_nk": 4,
+@pytest.fixture(scope="module")
+def eos_model():
+    """The same architecture with the EOS row of the predict layer flipped and scaled: decodes stop on EOS (arg-max or draw, valle.py:1044-1046) after a handful of steps."""
+    torch.manual_seed(12)
+    m = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16")
+    with torch.no_grad():
+        m.ar_predict_layer.weight[1024] *= -1.5  # (this init's EOS logit sits at -1 +- 0.3: now it tops the row every few steps)
+    return m.to(DEV).eval()
+
+
+def _decode(eng, X, Y, S, P, steps, opts, top_k=1, seed=0, temperature=1.0, **gen):
+    base = {"persist": 0, "persist_pf": 3, "persist_nk": 2, "persist_mode": CLASSIC, "persist_naps": 0x6864, "persist_sample": 1, "persist_steps": 32, "act_bf16": 2, "qa_nsplit": 8, "qa_nk": 4,
             "steps_per_graph": 0, "ignore_eos": 1}
     base.update(opts)
     for k, v in base.items():
         eng.set_option(k, v)
     eng.set_option("trace_ar_logits", 1)
     eng.prefill(X, [S], Y, [P])
-    codes, gl = eng.generate(top_k=top_k, seed=seed, max_new=steps)
+    codes, gl = eng.generate(top_k=top_k, seed=seed, max_new=steps, temperature=temperature, **gen)
     return codes[0, : gl[0]].cpu(), eng.fetch_ar_logits()[:, 0].clone()
 
 
@@ -104,7 +114,7 @@ def test_persistent_step_past_1024_keys_and_at_full_length(c2_model):
 
 
 def test_persistent_step_graph_replay_equals_eager_and_sampled_decode_is_reproducible(c2_model):
-    S, P, steps = 24, 50, 33  # 33 steps: four 8-step graphs and one single-step replay
+    S, P, steps = 24, 50, 67  # 67 steps: the eager first step, two 32-step launches and two single-step replays
     eng_g = c2_model.engine_for(1, S, P)
     X, Y = _inputs(S, P, seed=2)
     on = {"persist": 1, "persist_mode": FOLDED}
@@ -120,6 +130,52 @@ def test_persistent_step_graph_replay_equals_eager_and_sampled_decode_is_reprodu
     assert torch.equal(c1, c3) and torch.equal(l1, l3), "graph replay and eager launches must agree bit for bit"
     c4, _ = _decode(eng_g, X, Y, S, P, steps, on, top_k=-100, seed=8)
     assert not torch.equal(c1, c4)
+
+
+@pytest.mark.parametrize("top_k,temperature,ignore_eos", [(1, 1.0, 1), (-100, 1.0, 1), (50, 0.7, 1), (-100, 1.3, 0), (3, 1.0, 0)])
+def test_sampling_inside_the_launch_equals_the_sampling_kernel(c2_model, eos_model, top_k, temperature, ignore_eos):
+    """persist_sample = 1 (default): after the predict layer every workgroup gathers the logits and runs the sampling kernel's own
+    device code (csrc/sampling_dev.h: topk_sampling valle/models/valle.py:1287-1302, stop rule :1044-1048, next input :1013-1015),
+    several AR iterations per launch.  Tokens, per-step logits, generated length and the stopping step must equal the one-step
+    launches followed by ar_sample_kernel, for every way of cutting the steps into launches -- including utterances that stop on
+    EOS in the middle of a launch (random-init weights draw EOS within a few hundred sampled steps)."""
+    S, P, steps = 30, 80, 300
+    eng = (c2_model if ignore_eos else eos_model).engine_for(1, S, P)
+    X, Y = _inputs(S, P, seed=6)
+    common = {"persist": 1, "persist_mode": FOLDED, "ignore_eos": ignore_eos}
+    ref_codes, ref = _decode(eng, X, Y, S, P, steps, dict(common, persist_sample=0), top_k=top_k, seed=11, temperature=temperature)
+    assert eng.fetch_u32("persist_active") == 1
+    for per_launch in (32, 1, 3, 8, 300):
+        codes, lg = _decode(eng, X, Y, S, P, steps, dict(common, persist_sample=1, persist_steps=per_launch), top_k=top_k, seed=11,
+                            temperature=temperature)
+        assert eng.fetch_u32("persist_fail") == 0
+        assert codes.numel() == ref_codes.numel(), (per_launch, codes.numel(), ref_codes.numel())
+        assert torch.equal(codes, ref_codes), per_launch
+        n = ref_codes.numel() + 1  # iterations that ran, the stopping one included (the trace buffer is sized by the ENQUEUED steps)
+        assert lg.shape[0] >= n and ref.shape[0] >= n and torch.equal(lg[:n], ref[:n]), per_launch
+    if not ignore_eos:
+        assert 0 < ref_codes.numel() < steps, "model and seed were chosen to stop on EOS before the cap"
+
+
+def test_sampling_inside_the_launch_follows_forced_tokens(c2_model):
+    """Teacher forcing (the parity hook of vle_ar_generate): the fed history is the given one, the engine's own draws are still
+    recorded; an id outside the audio vocabulary is reported like the reference's nn.Embedding IndexError."""
+    S, P, steps = 20, 40, 45
+    eng = c2_model.engine_for(1, S, P)
+    X, Y = _inputs(S, P, seed=7)
+    g = torch.Generator().manual_seed(5)
+    forced = torch.randint(0, 1024, (1, steps), generator=g, dtype=torch.int64)
+    common = {"persist": 1, "persist_mode": FOLDED}
+    ref_codes, ref = _decode(eng, X, Y, S, P, 0, dict(common, persist_sample=0), forced=forced, forced_lens=[steps])
+    got_codes, got = _decode(eng, X, Y, S, P, 0, dict(common, persist_sample=1, persist_steps=7), forced=forced, forced_lens=[steps])
+    assert got_codes.numel() == steps and torch.equal(got_codes, forced[0])
+    assert torch.equal(ref_codes, got_codes) and torch.equal(ref, got)
+    bad = forced.clone()
+    bad[0, 9] = 5000
+    with pytest.raises(Exception, match="vocabulary"):
+        _decode(eng, X, Y, S, P, 0, dict(common, persist_sample=1, persist_steps=7), forced=bad, forced_lens=[steps])
+    got2, _ = _decode(eng, X, Y, S, P, 0, dict(common, persist_sample=1), forced=forced, forced_lens=[steps])  # the engine recovers
+    assert torch.equal(got2, forced[0])
 
 
 def test_persistent_step_is_the_default_where_covered_and_only_there():

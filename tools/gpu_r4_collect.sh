@@ -30,5 +30,6 @@ for SET in "FETCH_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES GRBM_GUI_ACTIVE SQ_BUSY_CYCLES
   (cd /tmp && rm -rf /tmp/pmc_run && timeout 500 rocprofv3 --pmc $SET --kernel-trace -d /tmp/pmc_run -o p --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --batch 64 --steps 1 --warmup 0 --cpu-frames 0 --no-graph --no-side > $GRAFT_REPO_ROOT/$D/pmc_b64_$TAG.log 2>&1); echo "pmc b64 $TAG rc=$?"
   python tools/pmc_summary.py /tmp/pmc_run/p_counter_collection.csv $D/pmc_b64_${TAG}_by_kernel.csv
 done
-timeout 600 python tools/persist_probe.py --out $D --steps 300 --rounds 2 --check-steps 64 --variants pf=0,mode=0x33114 pf=0,mode=0x114 pf=0,mode=0x33104 pf=0,mode=0x33110 --trace pf=0,mode=0x33114 > $D/persist_probe.log 2>&1; echo "persist probe rc=$?"
+timeout 600 python tools/persist_probe.py --out $D --steps 300 --rounds 2 --check-steps 64 --variants pf=3 pf=3,sample=0 pf=3,steps=8 pf=3,mode=0x114 pf=0 --trace pf=3 > $D/persist_probe.log 2>&1; echo "persist probe rc=$?"
+timeout 200 python tools/persist_stress.py 60 > $D/persist_stress.log 2>&1; echo "persist stress rc=$?"; tail -n 1 $D/persist_stress.log
 timeout 600 python tools/ktrace_step.py --out $D/ktrace_b64 --spg 8 --batch 64 > $D/ktrace_b64.log 2>&1; echo "ktrace b64 rc=$?"

@@ -24,7 +24,7 @@ def reset(eng):
     for k in ("nsplit", "gemv1_rpw", "gemv1_rpw_qkv", "gemv1_rpw_ffn1", "no_gemv1", "attn_nk", "steps_per_graph"):
         eng.set_option(k, 0)
     for k, v in (("qkv_attn", 1), ("qa_nsplit", 8), ("g1_shared", 1), ("qa_waves", 4), ("qa_qtemporal", 1), ("qa_handoff", 1), ("qa_nk", 4),
-                 ("persist", 0), ("persist_pf", 3), ("persist_nk", 2), ("persist_mode", 0x134), ("persist_naps", 0x6864), ("act_bf16", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
+                 ("persist", 0), ("persist_pf", 3), ("persist_nk", 2), ("persist_mode", 0x134), ("persist_naps", 0x6864), ("persist_sample", 1), ("act_bf16", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
         eng.set_option(k, v)
 
 
@@ -49,7 +49,7 @@ def main():
     ap.add_argument("--check-steps", type=int, default=96)
     ap.add_argument("--out", default="gpurun_out/persist_probe")
     ap.add_argument("--skip-check", action="store_true")
-    ap.add_argument("--variants", nargs="*", default=["pf=3", "pf=3,mode=0x114", "pf=0", "pf=3,naps=0", "pf=3,mode=0x124", "pf=3,mode=0x130", "pf=3,mode=0x13c"],
+    ap.add_argument("--variants", nargs="*", default=["pf=3", "pf=3,sample=0", "pf=3,steps=8", "pf=3,mode=0x114", "pf=0", "pf=3,naps=0"],
                     help="persistent variants to time: comma-separated persist_* options, e.g. pf=0,mode=3,nk=2")
     ap.add_argument("--trace", nargs="*", default=["pf=3"])
     args = ap.parse_args()
@@ -98,7 +98,7 @@ def main():
         opts = {"persist": 1}
         for kv in name.split(","):
             k, v = kv.split("=")
-            opts["persist_" + k] = int(v, 0)
+            opts[k if k == "steps_per_graph" else "persist_" + k] = int(v, 0)
         variants.append((name, opts))
     res = {name: [] for name, _ in variants}
     for r in range(args.rounds):
@@ -114,12 +114,14 @@ def main():
     # ---- 3. timeline (option "persist_trace"): thread 0 of every workgroup records, per hand-off, {wall clock when it began to wait,
     #         polling passes, wall clock when it had the data} -------------------------------------------------------------------
     L = 12
-    names = ["entry"] + ["L0." + n for n in STAGES[1:]] + [f"L{l}.{n}" for l in range(1, L) for n in STAGES] + ["final.x", "exit"]
     for name in args.trace:
         opts = {"persist": 1, "persist_trace": 1}
         for kv in name.split(","):
             k, v = kv.split("=")
-            opts["persist_" + k] = int(v, 0)
+            opts[k if k == "steps_per_graph" else "persist_" + k] = int(v, 0)
+        own = opts.get("persist_sample", 1) != 0  # the sampling step inside the launch: one more hand-off (the logits) per step
+        names = (["entry"] + ["L0." + n for n in STAGES[1:]] + [f"L{l}.{n}" for l in range(1, L) for n in STAGES] + ["final.x"] +
+                 (["logits"] if own else []) + ["exit"])
         reset(eng)
         for k, v in opts.items():
             eng.set_option(k, v)
@@ -147,8 +149,11 @@ def main():
         body = (t1[..., -1].amax(-1) - t0[..., 0].amin(-1))
         rec = {"variant": name, "steps_seen": int(ok.sum()), "per_stage": summ, "layer_us": round(layer, 3), "kernel_body_us": round(float(body.mean()), 2),
                "entry_spread_us": round(float((t0[..., 0].amax(-1) - t0[..., 0].amin(-1)).mean()), 3),
-               "final_x": {"compute_us": round(float(comp[..., -2].mean()), 3), "wait_us": round(float(wait[..., -2].mean()), 3)},
+               "final_x": {"compute_us": round(float(comp[..., names.index("final.x")].mean()), 3), "wait_us": round(float(wait[..., names.index("final.x")].mean()), 3)},
                "tail_us": round(float(comp[..., -1].mean()), 3)}
+        if own:
+            i = names.index("logits")
+            rec["logits"] = {"compute_us": round(float(comp[..., i].mean()), 3), "wait_us": round(float(wait[..., i].mean()), 3), "passes": round(float(passes[..., i].mean()), 2)}
         if False:  # finer stamps: per layer 5 (out-proj stage) + 5 (linear2 stage)
             half = raw.shape[-1] // 2
             sb = raw[:, :, half: half + 10 * L].reshape(8, 256, L, 10)[ok].double() / 100.0

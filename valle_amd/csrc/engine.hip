@@ -15,6 +15,7 @@
 #include <mutex>
 #include <string>
 #include <thread>
+#include <atomic>
 #include <vector>
 
 #include "common.h"
@@ -180,12 +181,17 @@ struct vle_engine {
   int opt_ps_naps = PS_NAPS_DEFAULT; // option "persist_naps"
   bool ps_device_ok = false;  // the device has the 256 CUs the persistent grid needs
   PLayer* ps_table = nullptr;               // device [L] operand table (rebuilt when the KV cache moves)
+  PStepSample* ps_sample = nullptr;         // device copy of the in-launch sampling step's operands (PStepArgs::smp)
   float* ps_fold = nullptr;                 // [L][14 d] + [2][V_AR + 3]: row constants of the folded LayerNorm (launch_ps_fold)
   unsigned long long* ps_gran = nullptr;    // {epoch, value} granules of the step's edges (zeroed at every prefill)
   size_t ps_gran_n = 0;
   unsigned long long* ps_ptrace = nullptr;  // [8][256][PS_PT_SLOTS] in-kernel timeline (option "persist_trace")
   bool opt_ps_trace = false;
   int opt_ps_mode = PS_MODE_DEFAULT;  // option "persist_mode": PStepArgs::mode
+  bool opt_ps_sample = true;          // option "persist_sample": the sampling step inside the persistent launch, several AR iterations
+                                      // per launch (0: one step per launch + the sampling kernel, as the launch chain does)
+  int opt_ps_steps = 32;              // option "persist_steps": AR iterations per persistent launch ("steps_per_graph" > 0 overrides):
+                                      // 146.7 us per step at 8, 145.6 at 32 (a launch's first step starts with cold operands)
   int opt_act_bf16 = 2;       // option "act_bf16" (bf16 engines only): batch-1 chain, 1 = merged attention row, 2 = FFN hidden row rounded to
                               // bf16 -- what the persistent step's packed edges carry (persist_mode bits 8 / 4), so that the chain (profiling,
                               // slot mode, shapes the persistent step lacks) and the persistent step compute the same numbers
@@ -210,6 +216,7 @@ struct vle_engine {
   int nsplit = 1;
   std::map<int, std::pair<hipGraphExec_t, hipGraphExec_t>> graphs;  // B -> (multi, single)
   double t_prefill = 0, t_ar = 0, t_nar = 0, n_steps = 0;
+  int n_ar_launches = 0;  // AR-loop submissions of the last vle_ar_generate (graph replays / eager steps), debug item "ar_launches"
 
   int fail(int code, const std::string& m) {
     err = m;
@@ -240,9 +247,52 @@ namespace {
     }                                                                                            \
   } while (0)
 
+// Debugging aid (environment VLE_GUARD_ALLOC=1): every device allocation of the engine gets its own virtual-memory mapping and ENDS at
+// the end of it, with an unmapped granule behind -- a kernel that reads or writes past the end of any engine buffer faults at once and
+// deterministically instead of once in twenty processes (hipMalloc sub-allocates: an overrun usually lands in somebody's mapped
+// memory).  Each mapping is listed on stderr so the faulting address names its buffer.  VLE_GUARD_ALLOC=2 puts the buffer at the
+// START of its mapping behind an unmapped granule instead (under-runs).  Nothing is freed in this mode.
+static bool guard_alloc_enabled() {
+  static const int on = [] { const char* v = getenv("VLE_GUARD_ALLOC"); return v ? atoi(v) : 0; }();
+  return on != 0;
+}
+static int guard_alloc(int device, void** out, size_t bytes, const char* tag) {
+  static const int mode = [] { const char* v = getenv("VLE_GUARD_ALLOC"); return v ? atoi(v) : 0; }();
+  static std::atomic<int> seq{0};
+  hipMemAllocationProp prop{};
+  prop.type = hipMemAllocationTypePinned;
+  prop.location.type = hipMemLocationTypeDevice;
+  prop.location.id = device;
+  size_t gran = 0;
+  if (hipMemGetAllocationGranularity(&gran, &prop, hipMemAllocationGranularityMinimum) != hipSuccess || gran == 0) return -1;
+  const size_t mapped = (bytes + gran - 1) / gran * gran;
+  void* va = nullptr;
+  if (hipMemAddressReserve(&va, mapped + 2 * gran, gran, nullptr, 0) != hipSuccess) return -1;
+  char* base = (char*)va + gran;  // one unmapped granule on either side
+  hipMemGenericAllocationHandle_t h;
+  if (hipMemCreate(&h, mapped, &prop, 0) != hipSuccess) return -1;
+  if (hipMemMap(base, mapped, 0, h, 0) != hipSuccess) return -1;
+  hipMemAccessDesc acc{};
+  acc.location = prop.location;
+  acc.flags = hipMemAccessFlagsProtReadWrite;
+  if (hipMemSetAccess(base, mapped, &acc, 1) != hipSuccess) return -1;
+  const size_t off = mode == 2 ? 0 : ((mapped - bytes) & ~(size_t)255);
+  *out = base + off;
+  fprintf(stderr, "[guard] #%d %s %zu bytes at %p .. %p (mapping %p .. %p)\n", seq.fetch_add(1), tag, bytes, (void*)(base + off), (void*)(base + off + bytes),
+          (void*)base, (void*)(base + mapped));
+  fflush(stderr);
+  return 0;
+}
+
 template <typename T>
 int dev_alloc(vle_engine* e, T** p, size_t count) {
   void* q = nullptr;
+  if (guard_alloc_enabled()) {
+    const int gr = guard_alloc(e->cfg.device, &q, std::max<size_t>(count, 1) * sizeof(T), e->in_buffers ? "buffer" : "weight");
+    if (gr != 0) return e->fail(VLE_EHIP, "guard allocation failed (VLE_GUARD_ALLOC)");
+    *p = (T*)q;  // never freed: a debugging mode
+    return 0;
+  }
   E_HIP(e, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
   (e->in_buffers ? e->buf_allocs : e->allocs).push_back(q);
   *p = (T*)q;
@@ -545,7 +595,7 @@ static void release_buffers(vle_engine* e) {
   e->kcache = e->vcache = nullptr;
   e->x_step = e->q_step = e->h_step = e->part_o = e->part_ml = e->logits = nullptr;
   e->k_new = e->v_new = nullptr; e->qgran = nullptr; e->qa_spin_fail = nullptr;
-  e->ps_table = nullptr; e->ps_fold = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0;
+  e->ps_table = nullptr; e->ps_sample = nullptr; e->ps_fold = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0;
   e->xn_step = e->qkv_step = e->att_step = e->hT_step = nullptr;
   e->gs_ws = nullptr; e->ln_stats = nullptr; e->ao_part = nullptr; e->ao_cnt = nullptr;
   e->state_dev = nullptr; e->S = ArState{}; e->dyn_dev = nullptr;
@@ -863,6 +913,7 @@ static int alloc_buffers(vle_engine* e) {
     E_HIP(e, hipMemset(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long)));
     if ((r = dev_alloc(e, &e->ps_table, (size_t)e->L))) return r;
     if ((r = dev_alloc(e, &e->ps_fold, (size_t)e->L * 14 * d + 2 * (V_AR + 3)))) return r;
+    if ((r = dev_alloc(e, &e->ps_sample, (size_t)1))) return r;
   }
   if ((r = dev_alloc(e, &e->part_o, (size_t)B * e->H * 16 * e->dh))) return r;
   if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
@@ -1130,7 +1181,7 @@ bool persist_ready(const vle_engine* e) {
 // (re)build the operand table for a batch-1 call and forget the granules' old tags (the iteration counter restarts at every
 // prefill).  Called from vle_ar_prefill: never inside a stream capture.
 int persist_prepare(vle_engine* e) {
-  if (!e->ps_table || !e->ps_gran || !e->ps_fold || e->B != 1 || e->w8) return 0;
+  if (!e->ps_table || !e->ps_gran || !e->ps_fold || !e->ps_sample || e->B != 1 || e->w8) return 0;
   if (e->ps_table_kc != e->kcache || e->ps_table_ctx != e->ctx_max) {
     std::vector<PLayer> tab(e->L);
     const int64_t d = e->d;
@@ -1154,11 +1205,21 @@ int persist_prepare(vle_engine* e) {
     E_HIP(e, hipMemcpy(e->ps_table, tab.data(), tab.size() * sizeof(PLayer), hipMemcpyHostToDevice));
     e->ps_table_kc = e->kcache; e->ps_table_ctx = e->ctx_max;
   }
+  {
+    PStepSample q;
+    q.s = e->S; q.dyn = e->dyn_dev; q.bos = e->bos;
+    q.tokens = e->tokens; q.sampled = e->sampled; q.g_stride = e->max_G;
+    q.audio_emb = e->ar_audio_emb; q.pe = e->pe; q.alpha_audio = e->alphas + 1; q.x = e->x_step;
+    q.id_err = e->id_err_dev;
+    q.host_prog = e->opt_host_prog ? e->prog_dev : nullptr;
+    E_HIP(e, hipStreamSynchronize(e->st));
+    E_HIP(e, hipMemcpy(e->ps_sample, &q, sizeof(q), hipMemcpyHostToDevice));
+  }
   E_HIP(e, hipMemsetAsync(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long), e->st));
   return 0;
 }
 
-int enqueue_persist_step(vle_engine* e) {
+int enqueue_persist_step(vle_engine* e, int nsteps = 1) {
   PStepArgs a;
   a.layers = e->ps_table; a.L = e->L; a.d = e->d; a.nhead = e->H; a.dh = e->dh; a.V = V_AR; a.ctx_max = e->ctx_max;
   a.x_in = e->x_step; a.norm_g = e->ar_norm_g; a.norm_b = e->ar_norm_b; a.w_pred = e->ar_predict; a.logits = e->logits;
@@ -1167,6 +1228,10 @@ int enqueue_persist_step(vle_engine* e) {
   a.fail = e->qa_spin_fail ? e->qa_spin_fail + 2 : nullptr;
   a.ptrace = e->opt_ps_trace ? e->ps_ptrace : nullptr;
   a.mode = e->opt_ps_mode; a.nk = e->opt_ps_nk; a.pf = e->opt_ps_pf; a.naps = e->opt_ps_naps;
+  if (e->opt_ps_sample) {
+    a.nsteps = nsteps;
+    a.smp = e->ps_sample;
+  }
   const int r = launch_pstep(e->st, e->dtype, a);
   if (r != 0) return e->fail(VLE_EINVAL, "launch_pstep rejected the step");
   return 0;
@@ -1180,7 +1245,7 @@ int enqueue_ar_step(vle_engine* e) {
   if (persist_ready(e)) {
     int pr = enqueue_persist_step(e);
     if (pr) return pr;
-    return enqueue_ar_sample(e, 0, nullptr, 0);
+    return e->opt_ps_sample ? 0 : enqueue_ar_sample(e, 0, nullptr, 0);
   }
   const bool sk = use_skinny(e);
   const bool gs = use_mfma_skinny(e);
@@ -1373,7 +1438,12 @@ int capture_graph(vle_engine* e, int steps, hipGraphExec_t* out) {
   hipGraph_t g = nullptr;
   E_HIP(e, hipStreamBeginCapture(e->st, hipStreamCaptureModeThreadLocal));
   int r = 0;
-  for (int i = 0; i < steps && r == 0; ++i) r = enqueue_ar_step(e);
+  if (persist_ready(e) && e->opt_ps_sample) {
+    e->kt_idx = 0;
+    r = enqueue_persist_step(e, steps);  // ONE launch runs all `steps` iterations, sampling included
+  } else {
+    for (int i = 0; i < steps && r == 0; ++i) r = enqueue_ar_step(e);
+  }
   hipError_t ce = hipStreamEndCapture(e->st, &g);
   if (r) {
     if (g) (void)hipGraphDestroy(g);
@@ -1548,7 +1618,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   // iteration 0: sample from the prefill's logits
   if ((r = enqueue_ar_sample(e, 1))) return r;
   int steps_done = 0;
-  const int spg = e->opt_spg > 0 ? e->opt_spg : (e->cfg.steps_per_graph > 0 ? e->cfg.steps_per_graph : 8);
+  const int spg = e->opt_spg > 0 ? e->opt_spg : (persist_ready(e) && e->opt_ps_sample) ? e->opt_ps_steps : (e->cfg.steps_per_graph > 0 ? e->cfg.steps_per_graph : 8);
   const bool use_graph = e->cfg.use_graph != 0 && !e->opt_profile;
   if (e->opt_profile) {
     e->prof_used = 0;
@@ -1580,9 +1650,13 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   volatile int32_t* hprog = e->prog_host;
   int launches = 0;
   bool all_done = false, stalled = false;
+  // with the sampling step inside the persistent launch a launch ends by itself at the stop rule (length cap, max_new, forced
+  // length, capacities: pstep_kernel applies ar_sample_kernel's rule): the tail of the loop is one more multi-step launch, not up to
+  // spg - 1 single steps
+  const bool self_stopping = use_graph && persist_ready(e) && e->opt_ps_sample;
   while (steps_done < bound && !all_done) {
     if (use_graph) {
-      if (bound - steps_done >= spg) {
+      if (bound - steps_done >= spg || self_stopping) {
         E_HIP(e, hipGraphLaunch(g_multi, st));
         steps_done += spg;
       } else {
@@ -1655,7 +1729,8 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
     if (e->G_len[b] == 0 && !e->bos && !forced && max_new <= 0) no_token = true;
     if (!st_host[3 * e->max_B + b]) not_done = true;
   }
-  e->n_steps = steps_done;
+  e->n_steps = std::min(steps_done, bound);
+  e->n_ar_launches = launches;
   float ms = 0.f;
   if (hipEventElapsedTime(&ms, e->ev_t[2], e->ev_t[3]) == hipSuccess) e->t_ar = ms;
   if (hipEventElapsedTime(&ms, e->ev_t[0], e->ev_t[1]) == hipSuccess) e->t_prefill = ms;
@@ -2336,8 +2411,14 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     (n == "glds_big" ? g_glds_big : n == "glds_w8" ? g_glds_w8 : g_glds_prio) = (int)value;
     return VLE_OK;
   }
-  if (n == "persist" || n == "persist_pf" || n == "persist_nk" || n == "persist_trace" || n == "persist_mode" || n == "persist_naps" || n == "act_bf16") {  // change the captured graphs: drop them
+  if (n == "persist" || n == "persist_pf" || n == "persist_nk" || n == "persist_trace" || n == "persist_mode" || n == "persist_naps" || n == "act_bf16" ||
+      n == "persist_sample" || n == "persist_steps") {  // change the captured graphs: drop them
     if (n == "persist") e->opt_persist = value != 0;
+    else if (n == "persist_sample") e->opt_ps_sample = value != 0;
+    else if (n == "persist_steps") {
+      if (value < 1 || value > 4096) return e->fail(VLE_EINVAL, "persist_steps must be 1 .. 4096");
+      e->opt_ps_steps = (int)value;
+    }
     else if (n == "act_bf16") e->opt_act_bf16 = (int)value & 3;
     else if (n == "persist_mode") e->opt_ps_mode = (int)value;
     else if (n == "persist_naps") e->opt_ps_naps = (int)value;
@@ -2446,6 +2527,13 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
     if (!e->qa_spin_fail) return e->fail(VLE_ESTATE, "no hand-off counter");
     src = e->qa_spin_fail + 2;
     n = sizeof(unsigned);
+  } else if (w == "ar_launches" || w == "persist_sample_active") {
+    // ar_launches: stream submissions of the last AR loop after the first (eager) step -- with the sampling step inside the persistent
+    // launch each is ONE pstep_kernel launch of several iterations; persist_sample_active: 1 when that is how the next call would run
+    const int32_t v = w == "ar_launches" ? e->n_ar_launches : (persist_ready(e) && e->opt_ps_sample ? 1 : 0);
+    const size_t nb = std::min(bytes, sizeof(v));
+    memcpy(host_dst, &v, nb);
+    return (int64_t)nb;
   } else if (w == "persist_active") {  // 1 when the next batch-1 step would run the persistent launch
     const int32_t v = persist_ready(e) ? 1 : 0;
     const size_t nb = std::min(bytes, sizeof(v));

@@ -248,6 +248,10 @@ struct PStepArgs {
   // hidden, q/k/v, partials.  A sweep that comes back without the data costs a fabric round trip (~1.1 us) before the next one
   // can see it; the values time the first sweep to land just after the producers' stores (tools/persist_probe.py sweeps)
   int naps = PS_NAPS_DEFAULT;
+  // the sampling step inside the launch: nsteps > 0 AR iterations per launch, `smp` = DEVICE copy of the PStepSample block (read with
+  // scalar loads where it is needed -- as kernel arguments its 30 words stayed live through the whole step and spilled)
+  int nsteps = 0;
+  const struct PStepSample* smp = nullptr;
   int nk = 2;                      // "persist_nk": keys per lane per round of the attention share (2: 1024 keys in one round; 4)
   int pf = 3;                      // "persist_pf": when the compute waves request an operator's operands (persist.hip): 0 = in one burst right
                                    // before the sweep that precedes the operator, 3 = linear1 / linear2 spread over three sweeps (default)
@@ -369,6 +373,20 @@ struct ArSampleArgs {
 // VALL-F cross-attention (block API): q [Tq x d], kv [S x 2d] = [K | V] of the memory sequence, no mask; dtype DT_F32 / DT_BF16
 int launch_cross_attention(hipStream_t st, int dtype, const void* q, const void* kv, void* out, int Tq, int S, int d, int nhead);
 int launch_ar_sample(hipStream_t st, const ArSampleArgs& a);
+// The persistent batch-1 step with the sampling step INSIDE the launch (persist.hip): nsteps AR iterations per launch.  After the
+// predict layer every workgroup gathers the 1025 logits, draws the token with the sampling kernel's own code (sampling_dev.h: the
+// same Philox stream, so every workgroup draws the same token), applies the stop rule and builds the next step's input row itself;
+// workgroup 0 alone writes the utterance's state, the token history and the host progress words (ar_sample_kernel's stores).
+struct PStepSample {  // PStepArgs::smp (device memory); PStepArgs::nsteps = 0: the launch ends with the logits of one step and launch_ar_sample follows
+  ArState s{};
+  const ArDyn* dyn = nullptr;
+  int bos = 0;
+  int64_t* tokens = nullptr; int64_t* sampled = nullptr; int64_t g_stride = 0;
+  const float* audio_emb = nullptr; const float* pe = nullptr; const float* alpha_audio = nullptr;
+  float* x = nullptr;                      // [d] the input row of the step after this launch's last
+  int32_t* id_err = nullptr;
+  int32_t* host_prog = nullptr;
+};
 // stand-alone topk_sampling (valle.py:1287-1302) per row of logits[rows][V]: out[row] = draw with Philox(request_seed(seed, row), it),
 // argmax_out[row] (nullable) = arg-max of the raw row
 int launch_topk_sample_rows(hipStream_t st, const float* logits, int64_t rows, int V, int top_k, float temperature, unsigned long long seed,

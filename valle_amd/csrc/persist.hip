@@ -28,6 +28,7 @@
 #include "common.h"
 #include "kernels.h"
 #include "gemv1_dev.h"
+#include "sampling_dev.h"
 
 namespace vle {
 
@@ -63,6 +64,18 @@ __device__ inline PsLayer ps_layer(const PLayer* tab, int l) {
   p.g1 = t[8]; p.be1 = t[9]; p.g2 = t[10]; p.be2 = t[11]; p.kc = t[12]; p.vc = t[13];
   p.sgqkv = t[14]; p.tbqkv = t[15]; p.sg1 = t[16]; p.tb1 = t[17];
   return p;
+}
+
+// the in-launch sampling step's operand block (device memory) through scalar loads
+__device__ inline PStepSample ps_sample_load(const PStepSample* p) {
+  static_assert(sizeof(PStepSample) == 18 * 8, "PStepSample is 18 eight-byte words");
+  const unsigned long long PS_CONST* t = (const unsigned long long PS_CONST*)p;
+  unsigned long long wds[18];
+#pragma unroll
+  for (int i = 0; i < 18; ++i) wds[i] = t[i];
+  PStepSample q;
+  __builtin_memcpy(&q, wds, sizeof(q));
+  return q;
 }
 
 __device__ inline gran_t gran_load(const gran_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
@@ -161,6 +174,31 @@ __device__ inline void gather_vals16(__amdgpu_buffer_rsrc_t rs, unsigned off, un
   }
 }
 
+// NV granules per lane (16-byte loads) + ONE more granule at byte offset off1 (the same for every lane), all in the same pass
+template <int NV>
+__device__ inline void gather_vals16_plus1(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned off1, unsigned epoch, float (&v)[NV], float& v1, PsSpin& sp) {
+  static_assert(NV % 2 == 0, "pairs of granules");
+  sp.passes = 0;
+  for (;;) {
+    u32x4_t raw[NV / 2];
+#pragma unroll
+    for (int k = 0; k < NV / 2; ++k) raw[k] = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)(off + 16 * k), 0, 16 /* sc1 */);
+    typedef unsigned u32x2_t __attribute__((ext_vector_type(2)));
+    const u32x2_t r1 = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)off1, 0, 16 /* sc1 */);
+    bool ok = r1.y == epoch;
+    v1 = __uint_as_float(r1.x);
+#pragma unroll
+    for (int k = 0; k < NV / 2; ++k) {
+      ok &= raw[k].y == epoch && raw[k].w == epoch;
+      v[2 * k] = __uint_as_float(raw[k].x);
+      v[2 * k + 1] = __uint_as_float(raw[k].z);
+    }
+    ++sp.passes;
+    if (__all(ok)) return;
+    if (!ps_retry(sp)) return;
+  }
+}
+
 template <int NV, typename F>
 __device__ inline void ps_gather(const gran_t* gbase, __amdgpu_buffer_rsrc_t rs, const gran_t* g, unsigned epoch, float (&v)[NV], PsSpin& sp, F&& after_first_issue) {
   static_assert(NV % 2 == 0, "16-byte sweeps");
@@ -237,6 +275,7 @@ __host__ __device__ inline int ps_gran_per_layer(int d, int H, int NS) { return 
 //     it to 1e-4 of the logits' spread against the three-barrier form and to bit-reproducibility against itself.
 template <typename T, int D, int H, int NK, int PF, int PK>
 __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
+
   constexpr int VEC = Elem<T>::VEC;
   constexpr int CH = 64 * VEC;
   constexpr int NCH = D / CH;        // K = d
@@ -280,11 +319,23 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   // the NS workgroups of a head on ONE XCD (block b runs on XCD b % 8: speed only)
   const int jj = c >> 3;
   const int h = (c & 7) * (H / 8) + jj / NS, s = jj % NS;
-  if (a.done[0]) return;  // the utterance has stopped: the remaining steps of the captured graph are no-ops
+  if (a.done[0]) {  // the utterance has stopped: the remaining launches of the host's queue are no-ops
+    if (a.nsteps > 0 && c == 0 && tid == 0) {  // ... that still report (ar_sample_kernel's progress words)
+      const PStepSample q = ps_sample_load(a.smp);
+      if (q.host_prog != nullptr) {
+        const int sc = q.s.done_count[1] + a.nsteps;
+        q.s.done_count[1] = sc;
+        __hip_atomic_store(q.host_prog + 0, q.s.done_count[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        __hip_atomic_store(q.host_prog + 1, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+      }
+    }
+    return;
+  }
   if (c == 0 && tid == 0 && a.never) smem[SM_FLOATS - 1] = 0.f;  // keeps the whole array allocated
 
-  const unsigned epoch = (unsigned)(a.iter[0] + 1);
-  const int kvl = a.kv_len[0];  // slot of the new token; the old keys are [0, kvl)
+  int it = a.iter[0];               // AR iteration of the step being computed (advances inside a multi-step launch)
+  unsigned epoch = (unsigned)(it + 1);
+  int kvl = a.kv_len[0];            // slot of the new token; the old keys are [0, kvl)
   const int ctx_max = a.ctx_max;
   const int mode = a.mode;
   constexpr bool hpack = (PK & 1) != 0, apack = (PK & 2) != 0, LF = (PK & 4) != 0;
@@ -295,7 +346,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   const int nap_att = naps & 15, nap_x = (naps >> 4) & 15, nap_x2 = (naps >> 8) & 15, nap_hid = (naps >> 12) & 15, nap_qkv = (naps >> 16) & 15,
             nap_part = (naps >> 20) & 15;
   PsSpin sp{PS_SPINS, a.fail, (mode >> 8) & 15, 0u};
-  PsTrace pt{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)((a.iter[0]) & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
+  PsTrace pt{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)(it & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
   pt_begin(pt);
   pt_end(pt, 0u);
 
@@ -349,13 +400,19 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     ps_load4(as_g<float>(pred ? (unsigned long long)a.norm_g : p.g1) + tid * EPT, g1v);
     if constexpr (!LF) ps_load4(as_g<float>(pred ? (unsigned long long)a.norm_b : p.be1) + tid * EPT, be1v);
   };
-  auto issue_kv = [&](const PsLayer& p, int base) {
+  // Cache rows inside a multi-step launch: the row a step appends (stage 1, another workgroup, possibly another XCD whose L2 is not
+  // coherent with this one's) must be readable one step later without a kernel boundary in between.  The writer stores it
+  // write-through (agent scope), and NO load of this launch touches a row before it is written -- lanes beyond the valid length
+  // `nvalid` re-read row nvalid - 1 instead of running ahead into unwritten rows -- so the first touch of the row's 128-byte line by
+  // any L1 / L2 comes after the data is in memory, and ordinary cached loads see it.  (L2-bypassing loads would do too: measured
+  // +0.3 us per layer, the cache is partly L2-resident from step to step.)
+  auto issue_kv = [&](const PsLayer& p, int base, int nvalid) {
     const CT PS_GLOBAL* Kb = as_g<CT>(p.kc) + (int64_t)h * ctx_max * DH + part * CVEC;
     const CT PS_GLOBAL* Vb = as_g<CT>(p.vc) + (int64_t)h * ctx_max * DH + part * CVEC;
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       int key = base + w * WCH + i * KPW + slot;
-      key = key < ctx_max ? key : ctx_max - 1;
+      key = key < nvalid ? key : nvalid - 1;
       kraw[i] = *reinterpret_cast<const u32x4_t PS_GLOBAL*>(Kb + (int64_t)key * DH);
       vraw[i] = *reinterpret_cast<const u32x4_t PS_GLOBAL*>(Vb + (int64_t)key * DH);
     }
@@ -401,7 +458,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   {
     const PsLayer p0 = ps_layer(a.layers, 0);
     issue_wqkv(p0, false);
-    if constexpr (PF >= 1) issue_kv(p0, s * CHUNK);
+    if constexpr (PF >= 1) issue_kv(p0, s * CHUNK, kvl);
   }
   __builtin_amdgcn_sched_barrier(0);
   auto nap = [&](int n) {
@@ -442,6 +499,24 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     rstd = 1.0f / sqrtf(m2 * (1.0f / (float)D) + LN_EPS);
   };
 
+  // ---- sampling inside the launch: the utterance's state, carried in registers by every workgroup ------------------------------
+  const bool own_sample = a.nsteps > 0;
+  int n_gen = 0, apos = 0, s_cap = 0;
+  if (own_sample) {
+    const PStepSample q = ps_sample_load(a.smp);
+    n_gen = q.s.n_gen[0];
+    apos = q.s.audio_pos[0];
+    s_cap = q.s.cap[0];
+  }
+  const int nsteps = own_sample ? a.nsteps : 1;
+
+  for (int step = 0; step < nsteps; ++step) {
+  if (step > 0) {
+    sp.budget = sp.budget ? PS_SPINS : 0u;  // a wave that gave up stays out; the others get a fresh budget per step
+    pt = PsTrace{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)(it & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
+    pt_begin(pt);
+    pt_end(pt, 0u);
+  }
   for (int l = 0; l < a.L; ++l) {
     const PsLayer p = ps_layer(a.layers, l);
     const PsLayer pn = ps_layer(a.layers, l + 1 < a.L ? l + 1 : l);  // the next layer's entry, long before its operands are requested
@@ -452,12 +527,13 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     if (l > 0) {
       pt_begin(pt);
       nap(nap_x);
-      if constexpr (PF == 1) ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, [&]() { issue_kv(p, s * CHUNK); });
+      if constexpr (PF == 1) ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, [&]() { issue_kv(p, s * CHUNK, kvl); });
       else ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, PsNoop());
       pt_end(pt, sp.passes);
-      if constexpr (PF == 2) issue_kv(p, s * CHUNK);
+      if constexpr (PF == 2) issue_kv(p, s * CHUNK, kvl);
     }
     if (tid == c) store_ept_lds<EPT>(sres, xv);  // thread c holds x[4c .. 4c+3]: the residual of the rows this workgroup owns
+    float kv_new = 0.f;  // lanes < RQ: this lane's K or V element of the new token (stored into the cache further down)
     float ln_mean = 0.f, ln_rstd = 1.f;
     if constexpr (LF) fold_stats(xv, g1v, ln_mean, ln_rstd);
     else g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
@@ -479,9 +555,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
           gran_store(gq, epoch, v);
           if (glocal) gran_store_local(gql, epoch, __float_as_uint(v));
         } else {
-          CT PS_GLOBAL* dst = as_gw<CT>(which == 1 ? p.kc : p.vc) + ((int64_t)h * ctx_max + kvl) * DH + e;
-          if constexpr (sizeof(CT) == 2) dst->v = f32_to_bf16(v);
-          else *reinterpret_cast<float PS_GLOBAL*>(dst) = v;
+          kv_new = v;
           float vr = v;
           if constexpr (sizeof(CT) == 2) vr = bf16_to_f32(f32_to_bf16(v));  // what later steps will read back from the cache
           gran_store(gq, epoch, vr);
@@ -489,7 +563,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         }
       }
     }
-    if constexpr (PF == 0 || PF == 3) issue_kv(p, s * CHUNK);
+    if constexpr (PF == 0 || PF == 3) issue_kv(p, s * CHUNK, kvl);
 
     // ======== (2) q, k_new, v_new of the head; attention over this workgroup's share of the cached keys ==========================
     pt_begin(pt);
@@ -560,7 +634,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         m = mn;
         base += NS * CHUNK;
         if (base >= ctx) break;  // block-uniform
-        issue_kv(p, base);
+        issue_kv(p, base, kvl);
       }
       // merge the KPW key slots of the wave, then the 4 waves through LDS (qkv_attn1_kernel's order)
 #pragma unroll
@@ -694,6 +768,19 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       }
     }
 
+    // The new token's K / V elements go into the cache HERE, write-through (agent scope: readable by the next step of a multi-step
+    // launch, see issue_kv): the store's acknowledgement from memory (~1 us) counts in this wave's vmcnt like a load, and the next
+    // wait is the attention-output sweep, an all-to-all edge that takes longer than that anyway.  Right after the in-projection
+    // (where the launch chain stores them) it sat in front of the q/k/v sweep, an XCD-local edge of 0.5 us: +0.2 us per layer.
+    if (lane < RQ) {
+      const int r = w * RQ + lane, which = r / QR, e = s * QR + (r % QR);
+      if (which != 0) {
+        CT PS_GLOBAL* dst = as_gw<CT>(which == 1 ? p.kc : p.vc) + ((int64_t)h * ctx_max + kvl) * DH + e;
+        if constexpr (sizeof(CT) == 2) __hip_atomic_store(reinterpret_cast<uint16_t*>((unsigned long long)dst), f32_to_bf16(kv_new), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        else __hip_atomic_store(reinterpret_cast<float*>((unsigned long long)dst), kv_new, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      }
+    }
+
     // ======== (4) out-proj + residual of rows 4c .. 4c+3 ==========================================================================
     g1_lds_barrier();  // waves 1 .. 3 do not sweep the attention edge while wave 0 still merges: their polls would sit in front of
                        // its loads in the CU's memory queue (measured: 257 -> 241 us per step)
@@ -815,14 +902,123 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     float x[NCH][VEC];
     g1_read_shared<T, NCH>(sx, x);
     const float t0 = wave_sum_dpp(g1_dot<T, NCH>(wq[0], x));
-    if (lane == 0) a.logits[4 * c + w] = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgq, t0), bq) : t0 + 0.f;
+    constexpr int G_LOG = G_QKV;  // the final block's q/k/v slots carry the logits edge (V <= 3 D)
+    if (lane == 0) {
+      const float lg = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgq, t0), bq) : t0 + 0.f;
+      a.logits[4 * c + w] = lg;
+      if (own_sample) gran_store(G + G_LOG + 4 * c + w, epoch, lg);
+    }
     if (extra_row) {
       const float t1 = wave_sum_dpp(g1_dot<T, NCH>(wq[1], x));
-      if (lane == 0) a.logits[4 * NWG] = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgx, t1), tbx) : t1 + 0.f;
+      if (lane == 0) {
+        const float lg = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgx, t1), tbx) : t1 + 0.f;
+        a.logits[4 * NWG] = lg;
+        if (own_sample) gran_store(G + G_LOG + 4 * NWG, epoch, lg);
+      }
+    }
+    if (own_sample) {
+      // ======== sampling, stop rule, next input row (ar_sample_kernel, sampling.hip; valle/models/valle.py:1039-1057) ==============
+      // Every workgroup gathers the V logits and draws the SAME token (same logits, same Philox counter), so nobody waits for a
+      // "sampler": the step-to-step dependence costs one all-to-all edge.  The next step's first operands are requested first.
+      float* const slog = smem + 8 * 1024;   // [V] the row, then regrouped SAMP_PER per thread
+      unsigned long long* const red64 = reinterpret_cast<unsigned long long*>(smem + 10 * 1024);
+      int* const redi = reinterpret_cast<int*>(smem + 10 * 1024 + 16);
+      float* const redf = smem + 10 * 1024 + 32;
+      float* const wave_tot = smem + 10 * 1024 + 48;
+      static_assert(SAMP_T == PS_T && SAMP_T * SAMP_PER >= 4 * NWG + 1, "the sampling code's block shape");
+      const PStepSample q = ps_sample_load(a.smp);
+      const ArDyn dyn = *q.dyn;
+      const PsLayer p0 = ps_layer(a.layers, 0);
+      issue_wqkv(p0, false);
+      if constexpr (PF == 1 || PF == 2) issue_kv(p0, s * CHUNK, kvl + 1);  // (these schedules request a layer's keys during its x sweep)
+      const int apos1 = apos + 1, kvl1 = kvl + 1;
+      float pev[EPT];
+      ps_load4(as_g<float>((unsigned long long)q.pe) + (int64_t)apos1 * D + tid * EPT, pev);
+      const float alpha = *q.alpha_audio;
+      float lg4[EPT], lgx;
+      pt_begin(pt);
+      nap(nap_x);
+      gather_vals16_plus1<EPT>(rs, (unsigned)((const char*)(G + G_LOG + tid * EPT) - (const char*)GB),
+                               (unsigned)((const char*)(G + G_LOG + 4 * NWG) - (const char*)GB), epoch, lg4, lgx, sp);
+      pt_end(pt, sp.passes);
+      store_ept_lds<EPT>(slog + tid * EPT, lg4);
+      if (tid == 0) slog[4 * NWG] = lgx;
+      __syncthreads();
+      const int V = a.V;
+      float raw[SAMP_PER];
+#pragma unroll
+      for (int j = 0; j < SAMP_PER; ++j) {
+        const int idx = tid * SAMP_PER + j;
+        raw[j] = idx < V ? slog[idx] : -INFINITY;
+      }
+      if (c == 0 && dyn.trace != nullptr && it < dyn.trace_cap) {
+        float* tr = dyn.trace + (int64_t)it * V;
+#pragma unroll
+        for (int j = 0; j < SAMP_PER; ++j) {
+          const int idx = tid * SAMP_PER + j;
+          if (idx < V) tr[idx] = raw[j];
+        }
+      }
+      const int argmax = argmax_row(raw, V, red64);
+      const int sample = sample_row(raw, V, dyn.top_k, dyn.temperature, request_seed(dyn.seed, 0ull), (uint32_t)it, argmax,
+                                    SampScratch{red64, redi, redf, wave_tot});
+      // stop rule (valle.py:1044-1048) and bookkeeping: the same integers in every workgroup; workgroup 0 stores them
+      int stop = (!dyn.ignore_eos && ((argmax == 1024) || (sample == 1024))) || (n_gen + q.bos > s_cap);
+      if (dyn.max_new > 0 && n_gen >= dyn.max_new) stop = 1;
+      if (dyn.has_forced) stop = n_gen >= dyn.forced_len[0];
+      if (n_gen >= (int)q.g_stride || kvl1 >= ctx_max) stop = 1;  // capacity guard
+      int next = sample;
+      bool bad_id = false;
+      if (!stop && dyn.has_forced) {
+        const int64_t f = dyn.forced[n_gen];
+        next = (int)f;
+        if (f < 0 || f >= (int64_t)V + q.bos) {  // outside ar_audio_embedding: the reference's nn.Embedding raises IndexError
+          next = 0;
+          bad_id = true;
+        }
+      }
+      if (c == 0 && tid == 0) {
+        if (q.host_prog != nullptr) {  // [0] utterances done before this step, [1] sampling steps so far (ar_sample_kernel's words)
+          const int sc = q.s.done_count[1] + (stop ? nsteps - step : 1);
+          q.s.done_count[1] = sc;
+          __hip_atomic_store(q.host_prog + 0, q.s.done_count[0] + (stop ? 1 : 0), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+          __hip_atomic_store(q.host_prog + 1, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+        if (!stop) {
+          if (bad_id && q.id_err) atomicOr(q.id_err, 4);
+          q.tokens[n_gen] = next;
+          q.sampled[n_gen] = sample;
+          q.s.n_gen[0] = n_gen + 1;
+          q.s.kv_len[0] = kvl1;
+          q.s.audio_pos[0] = apos1;
+        } else {
+          if (n_gen < (int)q.g_stride) q.sampled[n_gen] = sample;  // the stopping iteration's own draw (e.g. EOS), for the hooks
+          q.s.done[0] = 1;
+          atomicAdd(q.s.done_count, 1);
+        }
+        q.s.iter[0] = it + 1;
+      }
+      if (stop) return;
+      // next step's input: ar_audio_position(ar_audio_embedding(token))  (valle.py:1013-1015), the sampling kernel's roundings
+      float ev[EPT];
+      load_ept<EPT>(q.audio_emb + (int64_t)next * D + tid * EPT, ev);
+#pragma unroll
+      for (int k = 0; k < EPT; ++k) xv[k] = __fadd_rn(ev[k], __fmul_rn(alpha, pev[k]));
+      if (c == 0) {
+        float* xo = q.x + tid * EPT;
+#pragma unroll
+        for (int k = 0; k < EPT; ++k) xo[k] = xv[k];
+      }
+      n_gen += 1;
+      apos = apos1;
+      kvl = kvl1;
+      it += 1;
+      epoch = (unsigned)(it + 1);
     }
     pt_begin(pt);
     pt_end(pt, 0u);
   }
+  }  // step
 }
 
 // Row constants of the folded LayerNorm: one wave per row of bf16 W[N][K]; fp64 sums (one-time work at engine set-up).
@@ -882,6 +1078,7 @@ int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
   if (!a.layers || !a.x_in || !a.norm_g || !a.norm_b || !a.w_pred || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
   if ((a.mode & 32) && (!a.sg_pred || !a.tb_pred)) return -1;
+  if (a.nsteps < 0 || a.nsteps > 4096 || (a.nsteps > 0 && !a.smp)) return -1;
   if (a.nk == 4) return a.pf == 0 ? ps_launch_pk<4, 0>(st, a) : a.pf == 1 ? ps_launch_pk<4, 1>(st, a) : a.pf == 2 ? ps_launch_pk<4, 2>(st, a) : ps_launch_pk<4, 3>(st, a);
   return a.pf == 0 ? ps_launch_pk<2, 0>(st, a) : a.pf == 1 ? ps_launch_pk<2, 1>(st, a) : a.pf == 2 ? ps_launch_pk<2, 2>(st, a) : ps_launch_pk<2, 3>(st, a);
 }

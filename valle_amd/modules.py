@@ -369,7 +369,9 @@ class MultiheadAttention(_HipModule):
                 raise ValueError("key_padding_mask leaves a sequence without any key")
             # padded QUERY rows are given every valid key of their sequence: that is what the reference computes only when padding
             # is TRAILING inside each segment ([text | pad | audio | pad], the collater's shape); anything else would diverge silently
-            for lo, hi in (((0, text_len), (text_len, T)) if text_len > 0 else ((0, T),)):
+            # (without an attention mask -- the NAR decoder -- every query sees every valid key whatever the pattern: nothing to check)
+            segments = () if (not causal and text_len == 0) else (((0, text_len), (text_len, T)) if text_len > 0 else ((0, T),))
+            for lo, hi in segments:
                 seg = pad[:, lo:hi]
                 if seg.shape[1] > 1 and bool((seg[:, :-1] & ~seg[:, 1:]).any()):
                     raise NotImplementedError("key_padding_mask: only trailing padding per segment ([text | pad | audio | pad]) is implemented")

@@ -47,7 +47,7 @@ def eos_model():
 
 
 def _decode(eng, X, Y, S, P, steps, opts, top_k=1, seed=0, temperature=1.0, **gen):
-    base = {"persist": 0, "persist_pf": 3, "persist_nk": 2, "persist_mode": CLASSIC, "persist_naps": 0x6864, "persist_sample": 1, "persist_steps": 32, "act_bf16": 2, "qa_nsplit": 8, "qa_nk": 4,
+    base = {"persist": 0, "persist_pf": 3, "persist_nk": 2, "persist_mode": CLASSIC, "persist_naps": 0x335854, "persist_sample": 1, "persist_steps": 32, "act_bf16": 2, "qa_nsplit": 8, "qa_nk": 4,
             "steps_per_graph": 0, "ignore_eos": 1}
     base.update(opts)
     for k, v in base.items():
@@ -217,7 +217,7 @@ def test_persistent_step_repeated_decodes_under_changing_timing_stay_identical(c
         ref_codes, ref = _decode(eng, X, Y, S, P, steps, {"persist": 1, "persist_mode": mode})
         for rep in range(3 if mode == FOLDED else 1):
             for pf in (3, 0, 1, 2):
-                for naps in (0x6864, 0, 0xFFFFFF, 0x0F0F0F, 0x123456):
+                for naps in (0x335854, 0, 0xFFFFFF, 0x0F0F0F, 0x123456):
                     codes, lg = _decode(eng, X, Y, S, P, steps, {"persist": 1, "persist_mode": mode, "persist_pf": pf, "persist_naps": naps})
                     assert eng.fetch_u32("persist_fail") == 0, (pf, hex(naps))
                     assert torch.equal(ref, lg) and torch.equal(ref_codes, codes), (hex(mode), rep, pf, hex(naps))

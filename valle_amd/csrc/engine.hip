@@ -911,7 +911,7 @@ static int alloc_buffers(vle_engine* e) {
     e->ps_gran_n = pstep_gran_count(e->d, e->H, e->L);
     if ((r = dev_alloc(e, &e->ps_gran, e->ps_gran_n))) return r;
     E_HIP(e, hipMemset(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long)));
-    if ((r = dev_alloc(e, &e->ps_table, (size_t)e->L))) return r;
+    if ((r = dev_alloc(e, &e->ps_table, (size_t)e->L + 1))) return r;
     if ((r = dev_alloc(e, &e->ps_fold, (size_t)e->L * 14 * d + 2 * (V_AR + 3)))) return r;
     if ((r = dev_alloc(e, &e->ps_sample, (size_t)1))) return r;
   }
@@ -1183,7 +1183,7 @@ bool persist_ready(const vle_engine* e) {
 int persist_prepare(vle_engine* e) {
   if (!e->ps_table || !e->ps_gran || !e->ps_fold || !e->ps_sample || e->B != 1 || e->w8) return 0;
   if (e->ps_table_kc != e->kcache || e->ps_table_ctx != e->ctx_max) {
-    std::vector<PLayer> tab(e->L);
+    std::vector<PLayer> tab(e->L + 1);
     const int64_t d = e->d;
     for (int l = 0; l < e->L; ++l) {
       const LayerW& w = e->ar[l];
@@ -1197,9 +1197,12 @@ int persist_prepare(vle_engine* e) {
       t.g1 = w.g1; t.be1 = w.be1; t.g2 = w.g2; t.be2 = w.be2;
       t.kc = cache_layer(e, e->kcache, l); t.vc = cache_layer(e, e->vcache, l);
     }
-    {
+    {  // entry L: the predict layer behind the final norm
       float* f = e->ps_fold + (size_t)e->L * 14 * d;
       E_LAUNCH(e, launch_ps_fold(e->st, e->ar_predict, e->ar_norm_g, e->ar_norm_b, nullptr, f, f + V_AR + 3, V_AR, (int)d));
+      PLayer& t = tab[e->L];
+      t = tab[e->L - 1];  // every pointer valid
+      t.wqkv = e->ar_predict; t.g1 = e->ar_norm_g; t.be1 = e->ar_norm_b; t.sgqkv = f; t.tbqkv = f + V_AR + 3;
     }
     E_HIP(e, hipStreamSynchronize(e->st));
     E_HIP(e, hipMemcpy(e->ps_table, tab.data(), tab.size() * sizeof(PLayer), hipMemcpyHostToDevice));
@@ -1222,8 +1225,7 @@ int persist_prepare(vle_engine* e) {
 int enqueue_persist_step(vle_engine* e, int nsteps = 1) {
   PStepArgs a;
   a.layers = e->ps_table; a.L = e->L; a.d = e->d; a.nhead = e->H; a.dh = e->dh; a.V = V_AR; a.ctx_max = e->ctx_max;
-  a.x_in = e->x_step; a.norm_g = e->ar_norm_g; a.norm_b = e->ar_norm_b; a.w_pred = e->ar_predict; a.logits = e->logits;
-  a.sg_pred = e->ps_fold + (size_t)e->L * 14 * e->d; a.tb_pred = a.sg_pred + V_AR + 3;
+  a.x_in = e->x_step; a.logits = e->logits;
   a.kv_len = e->S.kv_len; a.iter = e->S.iter; a.done = e->S.done; a.gran = e->ps_gran;
   a.fail = e->qa_spin_fail ? e->qa_spin_fail + 2 : nullptr;
   a.ptrace = e->opt_ps_trace ? e->ps_ptrace : nullptr;

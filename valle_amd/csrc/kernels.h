@@ -222,14 +222,12 @@ struct PLayer {  // one decoder layer's operands (device table, one entry per la
 };
 constexpr int PS_PT_SLOTS = 512;
 constexpr int PS_MODE_DEFAULT = 0x134;    // hidden vector as bf16 pairs, XCD-local group edges, folded LayerNorm, 1 sleep unit between sweeps
-constexpr int PS_NAPS_DEFAULT = 0x6864;   // att 4, x 6, x' 8, hidden 6 units of s_sleep(4) (tools/persist_probe.py, persist_pf = 3)  // wall-clock stamps per workgroup and step of the in-kernel timeline (option "persist_trace")
+constexpr int PS_NAPS_DEFAULT = 0x335854;  // units of s_sleep(4) ahead of the first sweep: att 4, x 5, x' 8, hidden 5, q/k/v 3, partials 3 (tools/persist_probe.py sweeps, persist_pf = 3)
 struct PStepArgs {
-  const PLayer* layers = nullptr;  // device [L]
+  const PLayer* layers = nullptr;  // device [L + 1]: the decoder layers, then the predict layer as a pseudo-layer (wqkv = ar_predict_layer.weight
+                                   // bf16 [V][d], g1 / be1 = the final LayerNorm, sgqkv / tbqkv = its folded row constants [V], bqkv = any valid [3 d])
   int L = 0, d = 0, nhead = 0, dh = 0, V = 0, ctx_max = 0;
   const float* x_in = nullptr;     // f32 [d]: the token's embedding + position (sampling kernel)
-  const float *norm_g = nullptr, *norm_b = nullptr;  // final LayerNorm
-  const void* w_pred = nullptr;    // bf16 [V][d]
-  const float *sg_pred = nullptr, *tb_pred = nullptr;  // f32 [V]: the folded final norm's row constants (mode bit 5)
   float* logits = nullptr;         // f32 [V]
   const int32_t* kv_len = nullptr; // [1] cache slot of the new token
   const int32_t* iter = nullptr;   // [1] AR iteration counter: epoch = iter + 1

@@ -224,6 +224,8 @@ __device__ inline float gather_one_dual(const gran_t* g, const gran_t* gl, unsig
     if (!ps_retry(sp)) return __uint_as_float((unsigned)raw);
   }
 }
+// (Measured and dropped: a producer wave storing only the XCD-local copy before its own sweep and the write-through copy once it has
+// its data -- the q/k/v edge went 0.74 -> 0.63 us but the deferred acknowledgement then sat in front of the next stage: 144.5 -> 145.5 us.)
 // two granules per lane (16 bytes), same alternation; offsets in bytes into the granule buffer
 __device__ inline void gather_two_dual(__amdgpu_buffer_rsrc_t rs, unsigned off, unsigned off_local, bool have_local, unsigned epoch, float (&v)[2],
                                        PsSpin& sp) {
@@ -378,8 +380,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   const bool extra_row = (c == 0 && w == 0 && 4 * NWG < a.V);  // wave-uniform: row 4 * 256 (the EOS row at V = 1025)
   // the in-projection rows of layer `p`, or (pred) the predict layer's: its row 4c + w in wq[0], row 1024 in the one wave that owns
   // it (the others re-request their own row: an L2 hit), and the final norm's affine
+  // (the predict layer is entry L of the operand table: wqkv = its weight, g1 / be1 = the final norm's affine, sgqkv / tbqkv = its
+  //  folded row constants -- no kernel argument stays live through the layers for it)
   auto issue_wqkv = [&](const PsLayer& p, bool pred) {
-    const unsigned long long W = pred ? (unsigned long long)a.w_pred : p.wqkv;
+    const unsigned long long W = p.wqkv;
 #pragma unroll
     for (int r = 0; r < RQ; ++r) {
       const int64_t prow = (r == 1 && extra_row) ? 4 * NWG : 4 * c + w;
@@ -392,13 +396,13 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     } else {  // the row's (sg, tb): in-projection row of lane r, or the predict layer's row 4c + w (and row 1024 for its one wave)
       const int rq = qkv_row(w * RQ + (lane < RQ ? lane : RQ - 1));
       const int ri = pred ? 4 * c + w : rq;
-      sgq = as_g<float>(pred ? (unsigned long long)a.sg_pred : p.sgqkv)[ri];
-      bq = as_g<float>(pred ? (unsigned long long)a.tb_pred : p.tbqkv)[ri];
-      sgx = as_g<float>((unsigned long long)a.sg_pred)[a.V - 1];
-      tbx = as_g<float>((unsigned long long)a.tb_pred)[a.V - 1];
+      sgq = as_g<float>(p.sgqkv)[ri];
+      bq = as_g<float>(p.tbqkv)[ri];
+      sgx = as_g<float>(p.sgqkv)[pred ? 4 * NWG : 0];  // row 1024's pair (used by the one wave that owns the row)
+      tbx = as_g<float>(p.tbqkv)[pred ? 4 * NWG : 0];
     }
-    ps_load4(as_g<float>(pred ? (unsigned long long)a.norm_g : p.g1) + tid * EPT, g1v);
-    if constexpr (!LF) ps_load4(as_g<float>(pred ? (unsigned long long)a.norm_b : p.be1) + tid * EPT, be1v);
+    ps_load4(as_g<float>(p.g1) + tid * EPT, g1v);
+    if constexpr (!LF) ps_load4(as_g<float>(p.be1) + tid * EPT, be1v);
   };
   // Cache rows inside a multi-step launch: the row a step appends (stage 1, another workgroup, possibly another XCD whose L2 is not
   // coherent with this one's) must be readable one step later without a kernel boundary in between.  The writer stores it
@@ -519,7 +523,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   }
   for (int l = 0; l < a.L; ++l) {
     const PsLayer p = ps_layer(a.layers, l);
-    const PsLayer pn = ps_layer(a.layers, l + 1 < a.L ? l + 1 : l);  // the next layer's entry, long before its operands are requested
+    const PsLayer pn = ps_layer(a.layers, l + 1);  // the next layer's entry (entry L: the predict layer), long before its operands are requested
     gran_t* const G = a.gran + (size_t)l * GPL;
     const bool last = l + 1 == a.L;
 
@@ -1076,8 +1080,7 @@ static int ps_launch_pk(hipStream_t st, const PStepArgs& a) {
 // returns 0 = launched, 1 = shape not covered, < 0 = error
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
-  if (!a.layers || !a.x_in || !a.norm_g || !a.norm_b || !a.w_pred || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
-  if ((a.mode & 32) && (!a.sg_pred || !a.tb_pred)) return -1;
+  if (!a.layers || !a.x_in || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
   if (a.nsteps < 0 || a.nsteps > 4096 || (a.nsteps > 0 && !a.smp)) return -1;
   if (a.nk == 4) return a.pf == 0 ? ps_launch_pk<4, 0>(st, a) : a.pf == 1 ? ps_launch_pk<4, 1>(st, a) : a.pf == 2 ? ps_launch_pk<4, 2>(st, a) : ps_launch_pk<4, 3>(st, a);
   return a.pf == 0 ? ps_launch_pk<2, 0>(st, a) : a.pf == 1 ? ps_launch_pk<2, 1>(st, a) : a.pf == 2 ? ps_launch_pk<2, 2>(st, a) : ps_launch_pk<2, 3>(st, a);

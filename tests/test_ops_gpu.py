@@ -430,6 +430,41 @@ def test_linear_gemm_tile_policy_knobs(M, N, K, knob):
         assert (relu.double() - ref.clamp_min(0)).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(64 * 256 + 64, 1024, 1024), (64 * 256 + 37, 1024, 4096), (32 * 256 + 200, 2048, 1024), (21 * 256 + 1, 3072, 1024),
+                                   (1025, 4096, 1024), (2 * 1024 + 2, 2048, 1024)])  # the last two: the 128 x 128 tiles (one / two utterances' linear1)
+def test_linear_gemm_leftover_rows_as_a_second_launch(M, N, K):
+    """Knob "glds_tail" (gemm_glds.hip): the rows past the last full 256-row tile of a 256 x 256-tile launch run as a second, small
+    launch when the ragged tile row would cost a whole extra round over the 256 CUs (the NAR stages' M = 1024 B + B).  Rows are
+    independent: with and without the split every epilogue gives the same bits, and the leftover rows are right."""
+    a = _rand(M, K, seed=80).to(torch.bfloat16)
+    w = (_rand(N, K, seed=81) / math.sqrt(K)).to(torch.bfloat16)
+    bias = _rand(N, seed=82) * 0.1
+    r0 = _rand(M, N, seed=83)
+    ref = a.double() @ w.double().t() + bias.double()
+    if (M // 256) * (N // 256) >= 128:
+        assert -(-(M // 256) * (N // 256) // 256) < -(-((M + 255) // 256) * (N // 256) // 256), "a shape the split applies to"
+    else:
+        assert 0 < M % 128 <= 64 and -(-(M // 128) * (N // 128) // 256) < -(-((M + 127) // 128) * (N // 128) // 256), "a shape the split applies to"
+
+    def run():
+        return (ops.linear(a, w, bias, ops.EPI_F32, ksplit=None), ops.linear(a, w, bias, ops.EPI_STORE, ksplit=None),
+                ops.linear(a, w, bias, ops.EPI_RELU, ksplit=None), ops.linear(a, w, bias, ops.EPI_RESID, resid=r0.clone(), ksplit=None))
+
+    ops.tune("glds_tail", 0)
+    try:
+        whole = run()
+    finally:
+        ops.tune("glds_tail", 1)
+    split = run()
+    for x, y in zip(whole, split):
+        assert torch.equal(x, y)
+    tol = 3e-5 * math.sqrt(K / 64) * max(1.0, ref.abs().max().item())
+    assert (split[0].double() - ref).abs().max().item() < tol
+    assert (split[3].double() - (ref + r0.double())).abs().max().item() < tol
+    tail = slice(M - M % (256 if (M // 256) * (N // 256) >= 128 else 128), M)
+    assert (split[1][tail].double() - ref[tail]).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("formal", [0, 1])
 def test_skinny_gemm_split_k_handoff_under_memory_pressure(formal):
     """`formal` = 1: the same hand-off with explicit agent-scope release / acquire fences around the ticket (knob "gs_formal").

@@ -342,6 +342,13 @@ static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const flo
 }
 
 // returns 0 = launched, 1 = shape not covered (caller uses gemm.hip)
+// "glds_tail" (default 1): rows beyond the last full 256-row tile of a gemm_8ph.hip launch go to a second, small launch when that
+// saves a whole round of 256 x 256 tiles over the 256 CUs.  The NAR stages of B utterances of T = 1025 rows have M = 1024 B + B: the
+// B leftover rows made a 257th tile row whose N / 256 tiles ran alone in an extra round -- 1028 tiles = 4 rounds + 4 tiles for
+// linear2 / out-proj at 64 utterances (a fifth of the launch), 13 rounds instead of 12 for the in-projection, 17 instead of 16 for
+// linear1.  Rows are independent, so the split changes no number.
+int g_glds_tail = 1;
+
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
                      int K, int epi) {
   if (K % 64 != 0 || K < 64 || M < 1 || N < 1 || N % 4 != 0) return 1;
@@ -354,10 +361,33 @@ int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* 
   // many tiles (batched prefill / NAR rows): 256 x 128 with 8 waves -- two waves per SIMD cover each other's
   // ds_read -> MFMA latency, and the W panel is re-read half as often
   // enough 256 x 256 tiles: the 4-phase-per-K-tile schedule of gemm_8ph.hip
-  if (g_glds_8ph != 0 && (M / 256) * (N / 256) >= (g_glds_8ph > 0 ? g_glds_8ph : 128) && launch_gemm_8ph(st, A, W, bias, out, resid, M, N, K, epi) == 0)
-    return 0;
+  if (g_glds_8ph != 0 && (M / 256) * (N / 256) >= (g_glds_8ph > 0 ? g_glds_8ph : 128)) {
+    const int64_t rem = M % 256, ncol = N / 256, cus = 256;
+    const bool split = g_glds_tail != 0 && rem > 0 && N % 256 == 0 && ((M / 256) * ncol + cus - 1) / cus < (((M + 255) / 256) * ncol + cus - 1) / cus;
+    const int64_t Mmain = split ? M - rem : M;
+    if (launch_gemm_8ph(st, A, W, bias, out, resid, Mmain, N, K, epi) == 0) {
+      if (!split) return 0;
+      const bf16_t* a2 = a + Mmain * K;
+      void* out2 = out == nullptr ? nullptr : (epi == EPI_F32 || epi == EPI_RESID) ? (void*)((float*)out + Mmain * N) : (void*)((bf16_t*)out + Mmain * N);
+      float* resid2 = resid == nullptr ? nullptr : resid + Mmain * N;
+      if (rem >= 128) return launch_gemm_glds(st, a2, W, bias, out2, resid2, rem, N, K, epi);
+      return gg_launch<64, 64>(st, a2, w, bias, out2, resid2, rem, N, K, epi);
+    }
+  }
   const int64_t t256 = (M / 256) * ((N + 127) / 128);
   if (g_glds_big != 0 && t256 >= (g_glds_big > 0 ? g_glds_big : 512)) return gg_launch<256, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi);
+  if (full128 >= 160 && g_glds_tail != 0) {
+    // the same for the 128 x 128 tiles: one utterance's NAR rows (M = 1025 = 8 x 128 + 1) made linear1 9 x 32 = 288 tiles, a second
+    // round for 32 one-row tiles
+    const int64_t rem = M % 128, ncol = (N + 127) / 128, cus = 256;
+    if (rem > 0 && rem <= 64 && M >= 256 && ((M / 128) * ncol + cus - 1) / cus < (((M + 127) / 128) * ncol + cus - 1) / cus) {
+      const int64_t Mmain = M - rem;
+      const int r = launch_gemm_glds(st, A, W, bias, out, resid, Mmain, N, K, epi);
+      if (r != 0) return r;
+      void* out2 = out == nullptr ? nullptr : (epi == EPI_F32 || epi == EPI_RESID) ? (void*)((float*)out + Mmain * N) : (void*)((bf16_t*)out + Mmain * N);
+      return gg_launch<64, 64>(st, a + Mmain * K, w, bias, out2, resid == nullptr ? nullptr : resid + Mmain * N, rem, N, K, epi);
+    }
+  }
   if (g_glds_w8) {  // 8 waves on the one-tile-per-CU shapes too (wave tile 32 x 64 / 32 x 32)
     if (full128 >= 160) return gg_launch<128, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi);
     if (t128x64 >= 96) return gg_launch<128, 64, 8>(st, a, w, bias, out, resid, M, N, K, epi);

@@ -161,11 +161,17 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   constexpr bool kVec = VEC * sizeof(T) == 16;
   uint4 kraw[kVec ? NK : 1], vraw[kVec ? NK : 1];  // 16-byte vectors stay raw until they are consumed
   float kf1[kVec ? 1 : NK][VEC], vf1[kVec ? 1 : NK][VEC];
+  // Lanes whose key lies beyond the context are masked afterwards; what they load is clamped into the cache.  The streaming variant
+  // (NT: many utterances, HBM-bound) reads the context length FIRST and clamps to the last valid row, so those lanes re-read a line
+  // the wave fetches anyway -- at 64 utterances the rows past the context were 10 % of the kernel's HBM traffic (r04 PMC: 186.8 MB
+  // per launch against 170 MB of valid rows).  The batch-1 variant keeps the length in the same burst as the first keys (latency).
+  int key_hi = ctx_max - 1;
+  if constexpr (NT) key_hi = kv_len[b];
   auto issue = [&](int base) {  // loads of the NK keys base + w*WCH + i*KPW + slot (clamped into the cache)
 #pragma unroll
     for (int i = 0; i < NK; ++i) {
       int key = base + w * WCH + i * KPW + slot;
-      key = key < ctx_max ? key : ctx_max - 1;
+      key = key < key_hi ? key : key_hi;
       if constexpr (kVec) {
         if constexpr (NT) {  // a KV stream far larger than the 256 MB memory-side cache: read once per step, do not allocate
           typedef unsigned int da_u32x4 __attribute__((ext_vector_type(4)));

@@ -182,6 +182,8 @@ struct vle_engine {
   bool ps_device_ok = false;  // the device has the 256 CUs the persistent grid needs
   PLayer* ps_table = nullptr;               // device [L] operand table (rebuilt when the KV cache moves)
   PStepSample* ps_sample = nullptr;         // device copy of the in-launch sampling step's operands (PStepArgs::smp)
+  unsigned char* ps_host = nullptr;         // pinned staging of both: they reach the device by stream-ordered copies on the engine's stream
+  size_t ps_host_bytes = 0;
   float* ps_fold = nullptr;                 // [L][14 d] + [2][V_AR + 3]: row constants of the folded LayerNorm (launch_ps_fold)
   unsigned long long* ps_gran = nullptr;    // {epoch, value} granules of the step's edges (zeroed at every prefill)
   size_t ps_gran_n = 0;
@@ -588,6 +590,8 @@ static void release_buffers(vle_engine* e) {
   for (void* p : e->buf_allocs) (void)hipFree(p);
   e->buf_allocs.clear();
   if (e->tables_host) (void)hipHostFree(e->tables_host);
+  if (e->ps_host) (void)hipHostFree(e->ps_host);
+  e->ps_host = nullptr; e->ps_host_bytes = 0;
   if (e->poll_host) (void)hipHostFree(e->poll_host);
   if (e->prog_host) (void)hipHostFree(e->prog_host);
   e->tables_host = e->poll_host = e->prog_host = nullptr;
@@ -914,6 +918,8 @@ static int alloc_buffers(vle_engine* e) {
     if ((r = dev_alloc(e, &e->ps_table, (size_t)e->L + 1))) return r;
     if ((r = dev_alloc(e, &e->ps_fold, (size_t)e->L * 14 * d + 2 * (V_AR + 3)))) return r;
     if ((r = dev_alloc(e, &e->ps_sample, (size_t)1))) return r;
+    e->ps_host_bytes = ((size_t)e->L + 1) * sizeof(PLayer) + sizeof(PStepSample);
+    E_HIP(e, hipHostMalloc((void**)&e->ps_host, e->ps_host_bytes, hipHostMallocDefault));
   }
   if ((r = dev_alloc(e, &e->part_o, (size_t)B * e->H * 16 * e->dh))) return r;
   if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
@@ -1181,7 +1187,7 @@ bool persist_ready(const vle_engine* e) {
 // (re)build the operand table for a batch-1 call and forget the granules' old tags (the iteration counter restarts at every
 // prefill).  Called from vle_ar_prefill: never inside a stream capture.
 int persist_prepare(vle_engine* e) {
-  if (!e->ps_table || !e->ps_gran || !e->ps_fold || !e->ps_sample || e->B != 1 || e->w8) return 0;
+  if (!e->ps_table || !e->ps_gran || !e->ps_fold || !e->ps_sample || !e->ps_host || e->B != 1 || e->w8) return 0;
   if (e->ps_table_kc != e->kcache || e->ps_table_ctx != e->ctx_max) {
     std::vector<PLayer> tab(e->L + 1);
     const int64_t d = e->d;
@@ -1204,8 +1210,11 @@ int persist_prepare(vle_engine* e) {
       t = tab[e->L - 1];  // every pointer valid
       t.wqkv = e->ar_predict; t.g1 = e->ar_norm_g; t.be1 = e->ar_norm_b; t.sgqkv = f; t.tbqkv = f + V_AR + 3;
     }
-    E_HIP(e, hipStreamSynchronize(e->st));
-    E_HIP(e, hipMemcpy(e->ps_table, tab.data(), tab.size() * sizeof(PLayer), hipMemcpyHostToDevice));
+    // pinned staging + a copy ON THE ENGINE'S STREAM: the kernels that read the table through scalar loads are ordered behind it by
+    // the stream itself (a synchronous copy from pageable memory may be a host write through the PCIe aperture)
+    E_HIP(e, hipStreamSynchronize(e->st));  // no earlier copy still reads the staging area
+    memcpy(e->ps_host, tab.data(), tab.size() * sizeof(PLayer));
+    E_HIP(e, hipMemcpyAsync(e->ps_table, e->ps_host, tab.size() * sizeof(PLayer), hipMemcpyHostToDevice, e->st));
     e->ps_table_kc = e->kcache; e->ps_table_ctx = e->ctx_max;
   }
   {
@@ -1215,8 +1224,10 @@ int persist_prepare(vle_engine* e) {
     q.audio_emb = e->ar_audio_emb; q.pe = e->pe; q.alpha_audio = e->alphas + 1; q.x = e->x_step;
     q.id_err = e->id_err_dev;
     q.host_prog = e->opt_host_prog ? e->prog_dev : nullptr;
+    unsigned char* hq = e->ps_host + ((size_t)e->L + 1) * sizeof(PLayer);
     E_HIP(e, hipStreamSynchronize(e->st));
-    E_HIP(e, hipMemcpy(e->ps_sample, &q, sizeof(q), hipMemcpyHostToDevice));
+    memcpy(hq, &q, sizeof(q));
+    E_HIP(e, hipMemcpyAsync(e->ps_sample, hq, sizeof(q), hipMemcpyHostToDevice, e->st));
   }
   E_HIP(e, hipMemsetAsync(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long), e->st));
   return 0;

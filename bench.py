@@ -52,15 +52,24 @@ N1_REF_FILE = os.path.join(ROOT, "profiles", "bench_n1_reference.json")  # value
 FRAME_RATE = 75.0  # EnCodec frames per second of audio (valle/data/tokenizer.py: 24 kHz / 320)
 
 
+def _code_only(src: str) -> str:
+    """C++ source without comments and blank space: what the compiler sees (string literals in these files contain no `//`)."""
+    import re
+
+    src = re.sub(r"/\*.*?\*/", " ", src, flags=re.S)
+    src = re.sub(r"//[^\n]*", "", src)
+    return "\n".join(" ".join(line.split()) for line in src.splitlines() if line.strip())
+
+
 def kernel_set_hash() -> str:
-    """sha256[:16] over the sources of the kernels one batch-1 AR step launches: `roofline.traffic` (HBM bytes per step from the
-    PMC counters) is only reported while the kernels are the ones it was measured on."""
+    """sha256[:16] over the CODE (comments and white space stripped) of the sources of the kernels one batch-1 AR step launches:
+    `roofline.traffic` (HBM bytes per step from the PMC counters) is only reported while the kernels are the ones it was measured on."""
     import hashlib
 
     h = hashlib.sha256()
     for name in AR_STEP_KERNEL_SOURCES:
-        with open(os.path.join(ROOT, "valle_amd", "csrc", name), "rb") as f:
-            h.update(f.read())
+        with open(os.path.join(ROOT, "valle_amd", "csrc", name), "r", encoding="utf-8") as f:
+            h.update(_code_only(f.read()).encode())
     return h.hexdigest()[:16]
 
 

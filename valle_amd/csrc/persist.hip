@@ -1,14 +1,17 @@
-// The batch-1 AR decode step as ONE persistent launch (option "persist"; kernels.h PStepArgs).
-//   reference: one iteration of the AR loop of VALLE.inference (valle/models/valle.py:1012-1057) through the L pre-norm decoder
-//   layers (valle/modules/transformer.py:296-302, 332-334; attention valle/modules/activation.py:408-427 on the last row of the
-//   prefix-LM mask valle.py:1019-1033), the final norm and ar_predict_layer (valle.py:1035-1039).
+// The batch-1 AR decode loop as persistent launches of several steps each (options "persist", "persist_sample", "persist_steps";
+// kernels.h PStepArgs / PStepSample).
+//   reference: the AR loop of VALLE.inference (valle/models/valle.py:1012-1057), per iteration: the L pre-norm decoder layers
+//   (valle/modules/transformer.py:296-302, 332-334; attention valle/modules/activation.py:408-427 on the last row of the prefix-LM
+//   mask valle.py:1019-1033), the final norm and ar_predict_layer (valle.py:1035-1039), topk_sampling (:1287-1302), the stop rule
+//   (:1044-1048) and the next token's embedding + position (:1013-1015, :1057).
 //
-// Why.  As a launch chain the step is 4 dependent launches per layer (gemv1.hip): 50 boundaries of ~1.66 us plus 50 bodies that
-// each begin with one un-hidden HBM round trip -- 211 us per step for 336 MB (0.198 of the HBM roofline, traffic
-// ratio 1.10: latency, not bytes).  Here the whole step is one grid of 256 workgroups, ONE per CU, that never leaves the chip:
+// Why.  As a launch chain the step is 4 dependent launches per layer (gemv1.hip) + logits + sampling: 50 boundaries of ~1.66 us plus
+// 50 bodies that each begin with one un-hidden HBM round trip -- 211 us per step for 336 MB (0.198 of the HBM
+// roofline, traffic ratio 1.10: latency, not bytes).  Here a launch is one grid of 256 workgroups, ONE per CU, that never leaves
+// the chip for up to `nsteps` AR iterations:
 //   * every workgroup owns the same slice of every operator (rows of W: 12 of the in-projection = 4 query + 4 key + 4 value rows
 //     of ITS head, 4 of out-proj, 16 of linear1, 4 of linear2, 4 of the predict layer; and one (head, 1/16 of the keys) share of
-//     the attention), so its weights never move: they are requested one or two operators AHEAD, straight into registers (a layer's
+//     the attention), so its weights never move: they are requested one operator AHEAD, straight into registers (a layer's
 //     share is 96 KB per workgroup = 96 VGPRs per lane of the 512 a one-wave-per-SIMD workgroup owns), and have landed when the
 //     operator's input arrives -- the HBM round trip that opens every kernel of the chain is gone from the critical path;
 //   * an operator's output vector travels producer -> consumers as 8-byte {epoch, value} granules (the guide's recipe R2: the data
@@ -18,13 +21,18 @@
 //        -> (16 split partials of head h, same 16 workgroups, 96 granules each) -> [merge + the new token's own key]
 //        -> (attention output, 1024 granules, all) -> [out-proj + residual] -> (x', 1024, all) -> [LN2, linear1, ReLU]
 //        -> (hidden, 4096, all) -> [linear2 + residual] -> (x'', 1024, all) -> next layer;
-//   * every arithmetic step is the launch chain's own device function on the same lane <-> element mapping (gemv1_dev.h), and the
-//     attention share is qkv_attn1_kernel's code with 16 splits: the step is BIT-IDENTICAL to the chain run with
-//     qa_nsplit = 16, qa_nk = NK (tests/test_persist_gpu.py asserts equality of every logit of a whole decode).
+//     and per step: (x of the final norm, 1024, all) -> [final norm, predict layer] -> (logits, 1025, all) -> [draw, stop rule,
+//     embedding: the same in every workgroup] -> layer 0 of the next step.  Buffers are per (layer, edge) and reused from step to
+//     step: a granule of step t + 1 is stored only behind an all-to-all edge of step t + 1, i.e. after everybody read step t;
+//   * every arithmetic step is the launch chain's own device function on the same lane <-> element mapping (gemv1_dev.h), the
+//     attention share is qkv_attn1_kernel's code with 16 splits and the draw is ar_sample_kernel's code (sampling_dev.h): with the
+//     three-barrier LayerNorm (mode bit 5 off) the step is BIT-IDENTICAL to the chain run with qa_nsplit = 16, qa_nk = NK
+//     (tests/test_persist_gpu.py asserts equality of every logit and token of whole decodes); the folded LayerNorm (bit 5, default)
+//     is the same arithmetic up to fp32 re-association.
 // Spins are bounded: a wave that gives up marks the launch failed (PStepArgs::fail, reported by the engine as an error), stops
 // waiting for the rest of the launch and lets every other workgroup run through, so a lost granule cannot hang the device.
 // Co-residency: 256 workgroups of 256 threads with > 80 KB of LDS each = one per CU on an otherwise idle MI355X (the engine
-// owns its stream; the step's neighbours in the graph are ordinary dependent launches).
+// owns its stream; a launch's neighbours in the graph are ordinary dependent launches).
 #include "common.h"
 #include "kernels.h"
 #include "gemv1_dev.h"

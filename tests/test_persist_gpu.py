@@ -178,6 +178,36 @@ def test_sampling_inside_the_launch_follows_forced_tokens(c2_model):
     assert torch.equal(got2, forced[0])
 
 
+def test_model_falls_back_to_the_launch_chain_when_the_persistent_launch_gives_up(monkeypatch, capfd):
+    """The persistent launch needs the whole GPU; a launch that could not get it reports VLE_EHIP "... gave up ...".  The model API
+    (VALLE.inference_batch, the seam bench.py times) then repeats the decode from the prefill on the launch chain and keeps the
+    engine there -- a shared GPU costs speed, not the request."""
+    torch.manual_seed(5)
+    m = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()
+    S, P = 12, 20
+    X, Y = _inputs(S, P, seed=9)
+    eng = m.engine_for(1, S, P)
+    eng.set_option("ignore_eos", 1)
+    want = m.inference_batch(X, torch.tensor([S]), Y, [P], top_k=1, max_new=24)[0]
+    assert eng.fetch_u32("persist_active") == 1
+    real, calls = eng.generate, []
+
+    def flaky(*a, **k):
+        calls.append(1)
+        if len(calls) == 1:
+            real(*a, **k)  # the decode runs (and leaves the engine's state where a failed run leaves it) ...
+            raise valle_amd._lib.VleError(valle_amd._lib.VLE_EHIP, "the persistent AR step gave up waiting for an in-launch hand-off")
+        return real(*a, **k)
+
+    monkeypatch.setattr(eng, "generate", flaky)
+    got = m.inference_batch(X, torch.tensor([S]), Y, [P], top_k=1, max_new=24)[0]
+    assert len(calls) == 2 and eng.fetch_u32("persist_active") == 0
+    assert "launch chain" in capfd.readouterr().err
+    assert got.shape == want.shape and torch.equal(got[:, 0], want[:, 0]), "greedy first-codebook tokens of the two paths"
+    monkeypatch.setattr(eng, "generate", real)
+    eng.set_option("persist", 1)
+
+
 def test_persistent_step_is_the_default_where_covered_and_only_there():
     torch.manual_seed(3)
     m = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()

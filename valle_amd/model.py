@@ -260,10 +260,25 @@ class VALLE(nn.Module):
             # the reference samples from torch's global generator (valle.py:1301): draw the engine's RNG seed
             # from it, so torch.manual_seed() makes sampled decodes reproducible and successive calls differ
             seed = 0 if top_k == 1 else int(torch.randint(0, 2**62, (1,)).item())
-        eng.prefill(x.to(dev, torch.int64), xl, y.to(dev, torch.int64)[..., : self.num_quantizers], yl)
+        xd, yd = x.to(dev, torch.int64), y.to(dev, torch.int64)[..., : self.num_quantizers]
+        eng.prefill(xd, xl, yd, yl)
         try:
             # batch 1 keeps the reference's SyntaxError; in a batch an utterance that hits EOS at step 0 returns 0 frames
-            _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
+            try:
+                _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
+            except _lib.VleError as err:
+                # The persistent batch-1 launch needs every CU of the GPU; when another workload holds some for > 0.1 s it gives up and
+                # says so.  The decode is then repeated from the prefill on the launch chain (same sampling stream, same tokens up to
+                # the fp32 re-association of the folded LayerNorm) and this engine stays on the chain.
+                if not (err.code == _lib.VLE_EHIP and "persistent AR step gave up" in str(err)):
+                    raise
+                import sys
+
+                print("valle_amd: the persistent AR launch could not hold the whole GPU; this engine continues on the launch chain "
+                      "(option persist = 0)", file=sys.stderr)
+                eng.set_option("persist", 0)
+                eng.prefill(xd, xl, yd, yl)
+                _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
         except _lib.VleError as err:
             if err.code == _lib.VLE_ENOTOKEN:
                 raise SyntaxError("well trained model shouldn't reach here.") from None  # valle.py:1049-1052

@@ -177,7 +177,14 @@ int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slo
  *          "qkv_attn", "qa_handoff", "qa_nsplit", "g1_shared" (batch-1 step); "gs_fast" (compile-time-layout bodies of the
  *          batched GEMMs, default 1), "gs_nf" (two W fragments per workgroup where the grid exceeds the chip, default 1), "gs_msplit",
  *          "gs_formal", "gs_gran" (split-K hand-off through granules, default 0),
- *          "gs_fuse_ln", "attn_oproj", "attn_nt", "attn_lds_pad" (batched step); "ktrace" (in-kernel timeline) */
+ *          "gs_fuse_ln", "attn_oproj", "attn_nt", "attn_lds_pad" (batched step); "ktrace" (in-kernel timeline);
+ *          the persistent batch-1 AR launch (valle_amd/csrc/persist.hip): "persist" (default 1: bf16 d1024-h16 at one
+ *          utterance runs it; 0 = the launch chain), "persist_sample" (default 1: topk_sampling, the stop rule and the next token's
+ *          embedding inside the launch) with "persist_steps" (default 32 AR iterations per launch), "persist_mode" (bit field: 4 / 8
+ *          hidden / attention rows as bf16 pairs, 16 XCD-local copies of the head-group edges, 32 folded LayerNorm; default 0x134),
+ *          "persist_pf" (0..3 operand request schedule), "persist_nk" (2 | 4 keys per lane), "persist_naps" (first-sweep waits, 4 bits
+ *          per edge), "persist_trace" (in-kernel timeline), "act_bf16" (the chain's matching roundings).
+ *   debug words of vle_debug_fetch for it: "persist_active", "persist_sample_active", "persist_fail", "ar_launches", "persist_trace". */
 int vle_set_option(vle_engine* e, const char* name, int64_t value);
 /* what: "ar_logits"  -> fp32 [n_steps, B, 1025] (row t = logits of AR loop iteration t)
  *       "nar_logits:<stage>" -> fp32 [sum_b G_b, 1024]

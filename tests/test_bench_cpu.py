@@ -25,6 +25,15 @@ def test_kernel_set_hash_follows_the_step_kernels_sources():
         assert os.path.exists(os.path.join(ROOT, "valle_amd", "csrc", name)), name
 
 
+def test_kernel_set_hash_sees_code_not_comments():
+    """The traffic record must survive a comment or white-space edit of the kernel sources and go stale with any change of code."""
+    a = "int f(int x) {  // doubles\n  return 2 * x; /* twice\n   as much */\n}\n"
+    b = "int f(int x) {\n\n    return 2 * x;\n}  // same function, other words\n"
+    c = "int f(int x) {\n  return 3 * x;\n}\n"
+    assert bench._code_only(a) == bench._code_only(b) != bench._code_only(c)
+    assert "//" not in bench._code_only(a) and "/*" not in bench._code_only(a)
+
+
 def test_measured_traffic_is_gated_on_workload_and_kernel_set(tmp_path, monkeypatch):
     # other workloads never get the C2 batch-1 figure
     for a, B in ((_args(dtype="fp8w"), 1), (_args(), 64), (_args(d_model=1536), 1), (_args(opt=["qkv_attn=0"]), 1)):

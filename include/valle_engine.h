@@ -236,7 +236,7 @@ int vle_op_linear_fp8w(void* stream, const void* a, const void* w8, const float*
                        int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit);
 /* Kernel-selection knobs of the stand-alone operators, process-global (tests and microbenchmarks):
  * "glds_big" -1 default | 0 never | n: full-tile count from which the bf16 GEMM uses its 8-wave 256 x 128 tile;
- * "glds_8ph" 0 never | -1 | n: tile count from which it uses the phase-split 256 x 256 kernel; "glds_tail" 1 | 0: the rows past
+ * "glds_8ph" 0 never | -1 | n: tile count from which it uses the phase-split 256 x 256 kernel; "glds_t64" n: 128 x 64 tiles from n of them, 64 x 64 below (default 160); "glds_tail" 1 | 0: the rows past
  * its last full 256-row tile as a second small launch when that saves a round of tiles; "glds_w8", "glds_swz",
  * "glds_prio" 0 | 1: A/B switches of the tile kernels. */
 int vle_op_tune(const char* name, int64_t value);

@@ -99,7 +99,7 @@ def test_op_tune_knows_the_batched_gemm_knobs_and_rejects_the_rest():
     batched GEMMs is accepted inside its range -- set to its default here, so nothing changes for later tests -- and an unknown
     name or a value outside the range is an error, not a silent no-op."""
     lib = valle_amd._lib.load()
-    for name, default in (("gs_fast", 1), ("gs_nf", 1), ("gs_gran", 0), ("gs_msplit", 1), ("gs_formal", 0), ("g1_shared", 1), ("glds_tail", 1)):
+    for name, default in (("gs_fast", 1), ("gs_nf", 1), ("gs_gran", 0), ("gs_msplit", 1), ("gs_formal", 0), ("g1_shared", 1), ("glds_tail", 1), ("glds_t64", 160)):
         assert lib.vle_op_tune(name.encode(), default) == 0, name
     assert lib.vle_op_tune(b"gs_fast", 2) != 0
     assert lib.vle_op_tune(b"gs_nf", -1) != 0

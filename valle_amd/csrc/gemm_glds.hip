@@ -348,6 +348,9 @@ static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const flo
 // linear2 / out-proj at 64 utterances (a fifth of the launch), 13 rounds instead of 12 for the in-projection, 17 instead of 16 for
 // linear1.  Rows are independent, so the split changes no number.
 int g_glds_tail = 1;
+// "glds_t64": 128 x 64 tiles from this many of them, 64 x 64 tiles below.  96 until round 4; at 144 tiles of 128 x 64 (the N = 1024
+// GEMMs of one utterance's NAR rows, M = 1025: 56 % of the CUs) the 272 tiles of 64 x 64 are faster -- NAR 8.52 -> 8.21 ms.
+int g_glds_t64 = 160;
 
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
                      int K, int epi) {
@@ -390,10 +393,10 @@ int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* 
   }
   if (g_glds_w8) {  // 8 waves on the one-tile-per-CU shapes too (wave tile 32 x 64 / 32 x 32)
     if (full128 >= 160) return gg_launch<128, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi);
-    if (t128x64 >= 96) return gg_launch<128, 64, 8>(st, a, w, bias, out, resid, M, N, K, epi);
+    if (t128x64 >= g_glds_t64) return gg_launch<128, 64, 8>(st, a, w, bias, out, resid, M, N, K, epi);
   }
   if (full128 >= 160) return gg_launch<128, 128>(st, a, w, bias, out, resid, M, N, K, epi);
-  if (t128x64 >= 96) return gg_launch<128, 64>(st, a, w, bias, out, resid, M, N, K, epi);
+  if (t128x64 >= g_glds_t64) return gg_launch<128, 64>(st, a, w, bias, out, resid, M, N, K, epi);
   return gg_launch<64, 64>(st, a, w, bias, out, resid, M, N, K, epi);
 }
 

@@ -48,6 +48,7 @@ extern int g_attn_qw;
 extern int g_g8_colgroup;
 extern int g_g8_stagger;
 extern int g_glds_8ph;
+extern int g_glds_t64;
 extern int g_glds_tail;  // gemm_glds.hip: 1 = the rows past the last full 256-row tile of a gemm_8ph launch as a second small launch when that saves a round
 extern int g_glds_swz;
 // gemm_8ph.hip: bf16, 256 x 256 tile, phase-split schedule; returns 1 when the shape is not covered

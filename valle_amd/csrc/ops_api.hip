@@ -37,6 +37,7 @@ extern "C" int vle_op_tune(const char* name, int64_t value) {
   else if (n == "glds_swz" && value >= 0 && value <= 1) vle::g_glds_swz = (int)value;
   else if (n == "glds_8ph" && value >= -1) vle::g_glds_8ph = (int)value;
   else if (n == "glds_tail" && value >= 0 && value <= 1) vle::g_glds_tail = (int)value;
+  else if (n == "glds_t64" && value >= 0 && value <= 100000) vle::g_glds_t64 = (int)value;
   else if (n == "g8_stagger" && value >= 0 && value <= 1) vle::g_g8_stagger = (int)value;
   else if (n == "g8_colgroup" && value >= 0 && value <= 16) vle::g_g8_colgroup = (int)value;
   else if (n == "attn_qw" && value >= 0 && value <= 2) vle::g_attn_qw = (int)value;

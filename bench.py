@@ -221,6 +221,7 @@ def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label="", 
         torch.distributed.all_reduce(tk, op=torch.distributed.ReduceOp.SUM)
         tokens = int(tk.item())
     gl, pre, ar, nar, ar_steps, ar_bytes = acc["gl"], acc["pre"], acc["ar"], acc["nar"], acc["ar_steps"], acc["ar_bytes"]
+    ps_health = {k: eng.fetch_u32("persist_" + k) for k in ("ran", "fail", "fallbacks")}
     d, L, N, G = args.d_model, args.layers, S + P_PROMPT + gl[0], gl[0]
     nar_flops = B * (7 * (2 * N * 12 * L * d * d + 4 * L * N * N * d) + 14 * G * d * 1024)  # SURVEY.md 8(d), this rank
     hbm = (ar_bytes / 1e9) / (ar / 1e3)
@@ -239,6 +240,7 @@ def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label="", 
                         "step_us": round(ar / ar_steps * 1e3, 2), "bytes_per_step": int(ar_bytes / ar_steps), "rank": 0},
         "roofline_nar": {"bound": "mfma", "achieved": round(tfs, 1), "peak": mfma_peak, "unit": "TFLOP/s", "frac": round(tfs / mfma_peak, 4), "rank": 0},
     }
+    res["persist"] = ps_health
     res.update(rates(tokens, elapsed, steps * B * world, G))
     return res
 
@@ -498,7 +500,11 @@ def main():
         achieved = (ar_bytes / 1e9) / (ar_ms / 1e3) if ar_ms > 0 else 0.0
         traffic, traffic_src = measured_traffic(args, B)
         fused = args.d_model // args.nhead in (64, 128) and B == 1 and "qkv_attn=0" not in args.opt
-        persist = eng.fetch_u32("persist_active") == 1 if B == 1 else False
+        # the persistent launch's health over the timed decodes: `ran` = the last AR loop ran pstep_kernel (not merely "would"), `fail` =
+        # waves that gave up in it, `fallbacks` = calls since engine creation that ended with VLE_EBUSY and were repeated on the chain
+        ps_health = {"active": eng.fetch_u32("persist_active"), "ran": eng.fetch_u32("persist_ran"), "fail": eng.fetch_u32("persist_fail"),
+                     "fallbacks": eng.fetch_u32("persist_fallbacks"), "backoff": eng.fetch_u32("persist_backoff")}
+        persist = ps_health["ran"] == 1 if B == 1 else False
         own_sample = persist and eng.fetch_u32("persist_sample_active") == 1
         # kernel launches of the dominant kernel over the timed decodes: with the sampling step inside the persistent launch one launch
         # runs several AR iterations (the engine's last call is representative: every timed decode has the same length)
@@ -531,6 +537,7 @@ def main():
                 "world_size": world_seen,
                 "backend": "nccl (RCCL)" if world > 1 else "none (single process)",
                 "hip_graph": not args.no_graph,
+                "persist": ps_health,
             },
             "per_gpu_value": round(tokens / elapsed / args.gpus, 1),
             **rates(tokens, elapsed, args.steps * B * world, gl[0]),

@@ -38,6 +38,11 @@ extern "C" {
 #define VLE_EINDEX (-6)   /* a token id is outside its vocabulary (text >= 512, first codebook > 1024, other codebooks
                              >= 1024, or negative): the reference's nn.Embedding raises IndexError
                              (valle/modules/embedding.py:34,44).  The engine replaced the id by 0 before using it. */
+#define VLE_EBUSY (-7)    /* vle_ar_generate: the persistent batch-1 launch (one workgroup per CU for the whole AR loop) could
+                             not keep the whole GPU -- another workload held CUs for > 0.1 s and a wave gave up waiting.  This
+                             call's tokens are invalid.  Repeat vle_ar_prefill + vle_ar_generate: the engine runs its next
+                             batch-1 calls on the launch chain (2, then 4 ... 64 calls while it keeps happening) and re-arms
+                             the persistent launch by itself.  valle_amd.VALLE.inference does the repeat (valle_amd/model.py). */
 
 /* arithmetic mode of the whole path */
 #define VLE_DTYPE_F32 0  /* fp32 weights / KV / accumulate: token-id-exact vs the reference */
@@ -184,7 +189,16 @@ int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slo
  *          hidden / attention rows as bf16 pairs, 16 XCD-local copies of the head-group edges, 32 folded LayerNorm; default 0x134),
  *          "persist_pf" (0..3 operand request schedule), "persist_nk" (2 | 4 keys per lane), "persist_naps" (first-sweep waits, 4 bits
  *          per edge), "persist_trace" (in-kernel timeline), "act_bf16" (the chain's matching roundings).
- *   debug words of vle_debug_fetch for it: "persist_active", "persist_sample_active", "persist_fail", "ar_launches", "persist_trace". */
+ *          "persist_rearm" (any value: forget the back-off after VLE_EBUSY), "persist_inject_fail" (n: the next n persistent calls
+ *          end as if a wave had given up -- the test hook of the VLE_EBUSY path).
+ *   debug words of vle_debug_fetch for it: "persist_active" (the next batch-1 call would run it), "persist_ran" (the LAST
+ *   vle_ar_generate did), "persist_fail" (waves that gave up in the last call; 0 in a healthy run), "persist_fallbacks" (calls that
+ *   ended with VLE_EBUSY since vle_create), "persist_backoff" (batch-1 calls left on the launch chain before it is re-armed),
+ *   "persist_sample_active", "ar_launches", "persist_trace".
+ *   Environment (debugging, read once per process): VLE_GUARD_ALLOC=1|2 every engine allocation in its own virtual-memory mapping,
+ *   ending (1) / starting (2) at the mapping's edge with an unmapped granule behind / in front; VLE_ALLOC_LOG=1 lists every engine
+ *   allocation on stderr (a GPU memory-access fault's address then names its buffer); VLE_POISON_ALLOC=<byte> fills every engine
+ *   allocation with that byte first (memory of a fresh box is not zero: reads of never-written state behave the same everywhere). */
 int vle_set_option(vle_engine* e, const char* name, int64_t value);
 /* what: "ar_logits"  -> fp32 [n_steps, B, 1025] (row t = logits of AR loop iteration t)
  *       "nar_logits:<stage>" -> fp32 [sum_b G_b, 1024]
@@ -197,6 +211,11 @@ int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_dst, size_t 
 /* phase timings of the last call, milliseconds measured with hipEvents on the engine's stream:
  * out[0] prefill, out[1] AR steps, out[2] NAR, out[3] number of AR steps executed */
 int vle_last_timings(vle_engine* e, double* out4);
+/* Debugging aid for CALLER-owned buffers (inputs, forced tokens, outputs): `bytes` of device memory in a virtual-memory mapping of
+ * their own, ENDING at the mapping's end (at_start = 0) or starting at its start (1), with an unmapped granule on either side -- an
+ * overrun by any kernel of the path faults at once instead of landing in a neighbour's memory.  Never freed.  (No reference
+ * counterpart: the reference's tensors are bounds-checked by ATen.) */
+int vle_debug_guard_alloc(int32_t device, size_t bytes, int32_t at_start, void** out);
 /* algorithmic bytes moved per AR step for the current batch at context length ctx */
 int64_t vle_ar_step_bytes(const vle_engine* e, int32_t B, int64_t sum_ctx);
 

@@ -28,3 +28,10 @@ def load_case(name):
         mode=bytes(z["mode"]).decode(), top_k=int(z["top_k"]),
         codes=torch.from_numpy(z["codes"].astype(np.int64))[None],
     )
+
+
+def assert_persistent_launch_ran(eng):
+    """The headline path is the persistent batch-1 launch (valle_amd/csrc/persist.hip): a parity claim about it must fail when the
+    last AR loop silently ran the launch chain instead (CU count, table mismatch, back-off after VLE_EBUSY) or when a wave gave up."""
+    ran, fail, fb = eng.fetch_u32("persist_ran"), eng.fetch_u32("persist_fail"), eng.fetch_u32("persist_fallbacks")
+    assert ran == 1 and fail == 0 and fb == 0, f"persistent launch: ran={ran} give-ups={fail} fallbacks={fb}"

@@ -14,7 +14,7 @@ pytestmark = pytest.mark.gpu
 
 import valle_amd  # noqa: E402
 from oracle import valle_oracle as vo  # noqa: E402
-from tests.golden_util import list_cases, load_case  # noqa: E402
+from tests.golden_util import assert_persistent_launch_ran, list_cases, load_case  # noqa: E402
 
 DEV = "cuda:0"
 SMALL = [c for c in list_cases() if not c.startswith(("c1_", "c2_", "opt_", "vallf_"))]  # opt_* / vallf_*: tests/test_options_gpu.py (block-module decode)
@@ -88,6 +88,7 @@ def test_c2_architecture_fp32_exact_and_bf16_teacher_forced():
     eng.prefill(case["x"].to(DEV), [S], case["y"].to(DEV), [P])
     _, gl = eng.generate(top_k=1, forced=ref_tokens[None].to(DEV), forced_lens=[ref_tokens.numel()])
     assert gl == [ref_tokens.numel()]
+    assert_persistent_launch_ran(eng)  # bf16 at the C2 shape: the bars below are about the persistent launch
     stride = int(z["ar_stride"])
     mine = eng.fetch_ar_logits()[:, 0]
     sigma = float(z["ar_logit_std"])
@@ -193,6 +194,7 @@ def test_c2_full_size_properties_bf16():
     x, y = _bench_inputs(0)
     X, XL, Y = x[None].to(DEV), torch.tensor([47], dtype=torch.int32, device=DEV), y[None].to(DEV)
     a = m.inference(X, XL, Y, None, top_k=1).cpu()
+    assert_persistent_launch_ran(m.engine_for(1, 47, 225))
     assert a.shape == (1, 753, 8) and a.dtype == torch.int64            # valle.py:1047 cap: 16 * 47 + 1 frames
     assert int(a.min()) >= 0 and int(a[..., 1:].max()) < 1024 and int(a[..., 0].max()) <= 1024
     b = m.inference(X, XL, Y, None, top_k=1).cpu()

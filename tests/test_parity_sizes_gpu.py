@@ -22,7 +22,7 @@ pytestmark = pytest.mark.gpu
 import valle_amd  # noqa: E402
 from oracle import valle_oracle as vo  # noqa: E402
 from oracle.make_fixtures_oracle import SPECS, utterance_shapes  # noqa: E402
-from tests.golden_util import GOLDEN_DIR, load_case  # noqa: E402
+from tests.golden_util import GOLDEN_DIR, assert_persistent_launch_ran, load_case  # noqa: E402
 
 DEV = "cuda:0"
 TAU = 0.05  # fraction of sigma_logit (max); mean bar 0.01
@@ -110,6 +110,7 @@ def test_c2_full_size_bf16_teacher_forced_all_steps(c2_full):
     eng.prefill(case["x"].to(DEV), [47], case["y"].to(DEV), [225])
     _, gl = eng.generate(top_k=1, forced=ref_tokens[None].to(DEV), forced_lens=[753])
     assert gl == [753]
+    assert_persistent_launch_ran(eng)  # these bars are about the shipped default path: the persistent launch, healthy
     mine = eng.fetch_ar_logits()[:, 0]
     ref = torch.from_numpy(z["ar_logits_all_f16"].astype(np.float32))
     sigma = float(z["ar_logit_std"])

@@ -178,34 +178,86 @@ def test_sampling_inside_the_launch_follows_forced_tokens(c2_model):
     assert torch.equal(got2, forced[0])
 
 
-def test_model_falls_back_to_the_launch_chain_when_the_persistent_launch_gives_up(monkeypatch, capfd):
-    """The persistent launch needs the whole GPU; a launch that could not get it reports VLE_EHIP "... gave up ...".  The model API
-    (VALLE.inference_batch, the seam bench.py times) then repeats the decode from the prefill on the launch chain and keeps the
-    engine there -- a shared GPU costs speed, not the request."""
+def test_model_falls_back_to_the_launch_chain_when_the_persistent_launch_gives_up_and_rearms(capfd):
+    """The persistent launch needs the whole GPU; a call in which a wave gave up ends with VLE_EBUSY (the DEVICE counter is what
+    decides: option persist_inject_fail sets it as a wave that gives up does).  The model API (VALLE.inference_batch, the seam
+    bench.py times) repeats the decode from the prefill; the engine keeps its next batch-1 calls on the launch chain and re-arms
+    the persistent launch by itself after the back-off -- a shared GPU costs speed for a while, not the request."""
     torch.manual_seed(5)
     m = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()
     S, P = 12, 20
     X, Y = _inputs(S, P, seed=9)
     eng = m.engine_for(1, S, P)
     eng.set_option("ignore_eos", 1)
-    want = m.inference_batch(X, torch.tensor([S]), Y, [P], top_k=1, max_new=24)[0]
-    assert eng.fetch_u32("persist_active") == 1
-    real, calls = eng.generate, []
-
-    def flaky(*a, **k):
-        calls.append(1)
-        if len(calls) == 1:
-            real(*a, **k)  # the decode runs (and leaves the engine's state where a failed run leaves it) ...
-            raise valle_amd._lib.VleError(valle_amd._lib.VLE_EHIP, "the persistent AR step gave up waiting for an in-launch hand-off")
-        return real(*a, **k)
-
-    monkeypatch.setattr(eng, "generate", flaky)
-    got = m.inference_batch(X, torch.tensor([S]), Y, [P], top_k=1, max_new=24)[0]
-    assert len(calls) == 2 and eng.fetch_u32("persist_active") == 0
+    lens = torch.tensor([S])
+    want = m.inference_batch(X, lens, Y, [P], top_k=1, max_new=24)[0]
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0 and eng.fetch_u32("persist_fallbacks") == 0
+    # the C ABI's own answer: VLE_EBUSY, and the engine refuses to hand out the void call's state
+    eng.set_option("persist_inject_fail", 1)
+    eng.prefill(X, [S], Y, [P])
+    with pytest.raises(valle_amd._lib.VleError) as ei:
+        eng.generate(top_k=1, max_new=24)
+    assert ei.value.code == valle_amd._lib.VLE_EBUSY
+    assert eng.fetch_u32("persist_fallbacks") == 1 and eng.fetch_u32("persist_backoff") == 2 and eng.fetch_u32("persist_active") == 0
+    with pytest.raises(valle_amd._lib.VleError):
+        eng.nar(None)  # needs a completed generate
+    # the next calls run the chain (the counter of the void call does not poison them), then the persistent launch is back
+    for left in (1, 0):
+        got = m.inference_batch(X, lens, Y, [P], top_k=1, max_new=24)[0]
+        assert eng.fetch_u32("persist_ran") == 0 and eng.fetch_u32("persist_backoff") == left
+        assert torch.equal(got[:, 0], want[:, 0]), "greedy first-codebook tokens of the two paths"
+    got = m.inference_batch(X, lens, Y, [P], top_k=1, max_new=24)[0]
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+    assert torch.equal(got, want)
+    # through the model API: the request survives, the message names the fallback, the back-off doubles while it keeps happening
+    capfd.readouterr()
+    eng.set_option("persist_inject_fail", 1)
+    got = m.inference_batch(X, lens, Y, [P], top_k=1, max_new=24)[0]
     assert "launch chain" in capfd.readouterr().err
-    assert got.shape == want.shape and torch.equal(got[:, 0], want[:, 0]), "greedy first-codebook tokens of the two paths"
-    monkeypatch.setattr(eng, "generate", real)
-    eng.set_option("persist", 1)
+    assert torch.equal(got[:, 0], want[:, 0])
+    assert eng.fetch_u32("persist_fallbacks") == 2 and eng.fetch_u32("persist_ran") == 0 and eng.fetch_u32("persist_backoff") == 1
+    got = m.inference_batch(X, lens, Y, [P], top_k=1, max_new=24)[0]  # back-off 1 -> 0: still the chain
+    assert eng.fetch_u32("persist_ran") == 0
+    eng.set_option("persist_inject_fail", 1)
+    got = m.inference_batch(X, lens, Y, [P], top_k=1, max_new=24)[0]  # re-armed, fails again: the back-off is now 4
+    assert eng.fetch_u32("persist_fallbacks") == 3 and eng.fetch_u32("persist_backoff") == 3
+    eng.set_option("persist_rearm", 1)
+    got = m.inference_batch(X, lens, Y, [P], top_k=1, max_new=24)[0]
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0 and torch.equal(got, want)
+
+
+def test_decode_with_caller_buffers_at_the_edge_of_their_mappings():
+    """Every caller-owned input of the decode path (text, prompt codes, forced tokens, forced NAR history) in a virtual-memory
+    mapping of its own that ENDS (then: starts) at the buffer's last (first) byte, an unmapped page behind (in front): a kernel of
+    the path that reads past either end of a caller buffer faults here, deterministically, instead of once in forty fresh boxes.
+    (The engine's own buffers get the same treatment from VLE_GUARD_ALLOC=1|2 -- tools/fresh_box_probe.py runs both.)"""
+    from valle_amd._lib import guarded_like
+
+    torch.manual_seed(11)
+    m = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()
+    S, P = 13, 21
+    X, Y = _inputs(S, P, seed=4)
+    eng = m.engine_for(1, S, P)
+    eng.set_option("ignore_eos", 1)
+    eng.prefill(X, [S], Y, [P])
+    want0, gl = eng.generate(top_k=1, max_new=40)
+    want = eng.nar(None).clone()
+    forced = want0[:, : gl[0]].clone()
+    for at_start in (False, True):
+        Xg, Yg, Fg, Ng = (guarded_like(t, at_start) for t in (X, Y, forced, want))
+        eng.prefill(Xg, [S], Yg, [P])
+        got0, gl2 = eng.generate(top_k=1, max_new=40)
+        assert gl2 == gl and eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+        assert torch.equal(eng.nar(None), want)
+        eng.prefill(Xg, [S], Yg, [P])
+        got1, gl3 = eng.generate(top_k=1, forced=Fg, forced_lens=[gl[0]])
+        assert gl3 == gl and torch.equal(got1[:, : gl[0]], forced)
+        assert torch.equal(eng.nar(None, forced=Ng), want)
+        eng.set_option("persist", 0)  # the launch chain reads the same caller buffers
+        eng.prefill(Xg, [S], Yg, [P])
+        got2, gl4 = eng.generate(top_k=1, forced=Fg, forced_lens=[gl[0]])
+        assert gl4 == gl and torch.equal(got2[:, : gl[0]], forced)
+        eng.set_option("persist", 1)
 
 
 def test_persistent_step_is_the_default_where_covered_and_only_there():

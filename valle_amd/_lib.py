@@ -12,7 +12,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libvalle_engine.so")
 
 VLE_OK = 0
-VLE_EINVAL, VLE_ESTATE, VLE_EHIP, VLE_EKEY, VLE_ENOTOKEN, VLE_EINDEX = -1, -2, -3, -4, -5, -6
+VLE_EINVAL, VLE_ESTATE, VLE_EHIP, VLE_EKEY, VLE_ENOTOKEN, VLE_EINDEX, VLE_EBUSY = -1, -2, -3, -4, -5, -6, -7
 DTYPE_F32, DTYPE_BF16, DTYPE_FP8W, DTYPE_FP8 = 0, 1, 2, 3
 
 
@@ -49,6 +49,7 @@ SIGNATURES = {
     "vle_set_option": (C.c_int, [_P, C.c_char_p, C.c_int64]),
     "vle_debug_fetch": (C.c_int64, [_P, C.c_char_p, _P, C.c_size_t]),
     "vle_last_timings": (C.c_int, [_P, C.POINTER(C.c_double)]),
+    "vle_debug_guard_alloc": (C.c_int, [C.c_int32, C.c_size_t, C.c_int32, C.POINTER(_P)]),
     "vle_ar_step_bytes": (C.c_int64, [_P, C.c_int32, C.c_int64]),
     "vle_op_layernorm": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, C.c_int64, C.c_int32]),
     "vle_op_linear": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int]),
@@ -120,3 +121,28 @@ def check(code: int, handle=None):
     if code == VLE_EINDEX:  # what nn.Embedding raises in the reference (valle/modules/embedding.py:34,44)
         raise IndexError(msg.decode() if msg else "token id out of range")
     raise VleError(code, msg.decode() if msg else "?")
+
+
+class _GuardedMemory:
+    """`bytes` of device memory from vle_debug_guard_alloc, exposed through __cuda_array_interface__ (torch.as_tensor wraps it)."""
+
+    def __init__(self, nbytes: int, device: int, at_start: bool):
+        p = _P()
+        check(load().vle_debug_guard_alloc(device, nbytes, int(at_start), C.byref(p)))
+        self.ptr = p.value
+        self.__cuda_array_interface__ = {"shape": (nbytes,), "typestr": "|u1", "data": (self.ptr, False), "version": 2}
+
+
+def guarded_like(t, at_start: bool = False):
+    """Debugging aid: a copy of the CUDA tensor `t` whose storage ends (starts) at the edge of its own virtual-memory mapping, an
+    unmapped page behind (in front of) it -- see vle_debug_guard_alloc.  The memory is never freed."""
+    import torch
+
+    t = t.contiguous()
+    nbytes = max(t.numel() * t.element_size(), 1)
+    mem = _GuardedMemory(nbytes, t.device.index or 0, at_start)
+    raw = torch.as_tensor(mem, device=t.device)
+    out = raw[: t.numel() * t.element_size()].view(t.dtype).view(t.shape) if t.numel() else t.clone()
+    out.copy_(t)
+    out._vle_guard = mem
+    return out

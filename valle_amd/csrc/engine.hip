@@ -198,6 +198,15 @@ struct vle_engine {
                               // bf16 -- what the persistent step's packed edges carry (persist_mode bits 8 / 4), so that the chain (profiling,
                               // slot mode, shapes the persistent step lacks) and the persistent step compute the same numbers
   const void* ps_table_kc = nullptr; int ps_table_ctx = 0;  // what the table was built for
+  PStepSample ps_sample_sent{}; bool ps_sample_valid = false;  // what ps_sample holds (re-uploaded only when it changes)
+  // A persistent launch that could not keep the whole GPU (a wave gave up waiting, PStepArgs::fail) ends the call with VLE_EBUSY;
+  // the engine then stays on the launch chain for `ps_backoff` batch-1 prefills (2, 4, ... 64: doubling while it keeps happening,
+  // back to 2 after a clean persistent decode) and re-arms the persistent launch by itself.
+  int ps_backoff = 0, ps_backoff_next = 2;
+  unsigned ps_fallbacks = 0;   // calls that ended with VLE_EBUSY since vle_create (debug item "persist_fallbacks")
+  unsigned ps_last_fail = 0;   // give-up count of the last call that ran the persistent launch (debug item "persist_fail")
+  bool ps_last_call = false;   // the last vle_ar_generate ran the persistent launch (debug item "persist_ran")
+  int dbg_inject_psfail = 0;   // option "persist_inject_fail": the next n persistent calls get a non-zero give-up counter (tests)
   int opt_rpw = 0;            // option "gemv1_rpw": rows per wave override of gemv1 (tuning)
   int opt_rpw_qkv = 0;        // option "gemv1_rpw_qkv": the same for the QKV GEMV only
   int opt_rpw_ffn1 = 0;       // option "gemv1_rpw_ffn1": ... for the FFN1 GEMV only
@@ -258,8 +267,9 @@ static bool guard_alloc_enabled() {
   static const int on = [] { const char* v = getenv("VLE_GUARD_ALLOC"); return v ? atoi(v) : 0; }();
   return on != 0;
 }
-static int guard_alloc(int device, void** out, size_t bytes, const char* tag) {
-  static const int mode = [] { const char* v = getenv("VLE_GUARD_ALLOC"); return v ? atoi(v) : 0; }();
+static int guard_alloc(int device, void** out, size_t bytes, const char* tag, int mode_override = 0) {
+  static const int env_mode = [] { const char* v = getenv("VLE_GUARD_ALLOC"); return v ? atoi(v) : 0; }();
+  const int mode = mode_override ? mode_override : env_mode;
   static std::atomic<int> seq{0};
   hipMemAllocationProp prop{};
   prop.type = hipMemAllocationTypePinned;
@@ -278,12 +288,37 @@ static int guard_alloc(int device, void** out, size_t bytes, const char* tag) {
   acc.location = prop.location;
   acc.flags = hipMemAccessFlagsProtReadWrite;
   if (hipMemSetAccess(base, mapped, &acc, 1) != hipSuccess) return -1;
-  const size_t off = mode == 2 ? 0 : ((mapped - bytes) & ~(size_t)255);
+  const size_t off = mode == 2 ? 0 : ((mapped - bytes) & ~(size_t)(mode_override ? 15 : 255));  // caller buffers: 16-byte aligned like torch's
   *out = base + off;
   fprintf(stderr, "[guard] #%d %s %zu bytes at %p .. %p (mapping %p .. %p)\n", seq.fetch_add(1), tag, bytes, (void*)(base + off), (void*)(base + off + bytes),
           (void*)base, (void*)(base + mapped));
   fflush(stderr);
   return 0;
+}
+
+// Two more debugging aids for ordinary hipMalloc allocations.  VLE_ALLOC_LOG=1: every engine allocation is listed on stderr
+// (sequence number, kind, bytes, address range) so that the address of a GPU memory-access fault names its buffer.
+// VLE_POISON_ALLOC=<byte>: every engine allocation is filled with that byte before the engine initialises what it means to
+// initialise -- a fresh box hands out memory that holds whatever the last tenant left (the driver wipes on release, so a
+// second process on the same box sees zeros): a read of something the engine forgot to write then behaves the same in every
+// process instead of once per box (0xff: NaN floats, -1 integers, non-canonical pointers; 0x7f: huge finite floats / integers).
+static void debug_alloc_note(void* q, size_t bytes, const char* tag) {
+  static const int log_on = [] { const char* v = getenv("VLE_ALLOC_LOG"); return v ? atoi(v) : 0; }();
+  static const int poison = [] { const char* v = getenv("VLE_POISON_ALLOC"); return v ? (int)strtol(v, nullptr, 0) : -1; }();
+  static std::atomic<int> seq{0};
+  if (poison >= 0) (void)hipMemset(q, poison & 0xff, bytes);
+  if (log_on) {
+    fprintf(stderr, "[alloc] #%d %s %zu bytes at %p .. %p\n", seq.fetch_add(1), tag, bytes, q, (void*)((char*)q + bytes));
+    fflush(stderr);
+  }
+}
+
+static void debug_host_note(void* q, size_t bytes, const char* tag) {
+  static const int log_on = [] { const char* v = getenv("VLE_ALLOC_LOG"); return v ? atoi(v) : 0; }();
+  if (log_on) {
+    fprintf(stderr, "[alloc] host %s %zu bytes at %p .. %p\n", tag, bytes, q, (void*)((char*)q + bytes));
+    fflush(stderr);
+  }
 }
 
 template <typename T>
@@ -295,9 +330,11 @@ int dev_alloc(vle_engine* e, T** p, size_t count) {
     *p = (T*)q;  // never freed: a debugging mode
     return 0;
   }
-  E_HIP(e, hipMalloc(&q, std::max<size_t>(count, 1) * sizeof(T)));
+  const size_t bytes = std::max<size_t>(count, 1) * sizeof(T);
+  E_HIP(e, hipMalloc(&q, bytes));
   (e->in_buffers ? e->buf_allocs : e->allocs).push_back(q);
   *p = (T*)q;
+  debug_alloc_note(q, bytes, e->in_buffers ? "buffer" : "weight");
   return 0;
 }
 
@@ -558,7 +595,7 @@ extern "C" int vle_create(const vle_config* c, vle_engine** out) {
   {  // the persistent batch-1 step is a grid of 256 co-resident workgroups, one per CU (persist.hip)
     int cus = 0;
     if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device) != hipSuccess) (void)hipGetLastError();
-    e->ps_device_ok = cus >= 256;
+    e->ps_device_ok = cus >= 256 && pstep_fits_one_per_cu();
   }
   auto chk = [&](hipError_t r, const char* what) {
     if (r != hipSuccess) {
@@ -599,6 +636,7 @@ static void release_buffers(vle_engine* e) {
   e->kcache = e->vcache = nullptr;
   e->x_step = e->q_step = e->h_step = e->part_o = e->part_ml = e->logits = nullptr;
   e->k_new = e->v_new = nullptr; e->qgran = nullptr; e->qa_spin_fail = nullptr;
+  e->ps_sample_valid = false;
   e->ps_table = nullptr; e->ps_sample = nullptr; e->ps_fold = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0;
   e->xn_step = e->qkv_step = e->att_step = e->hT_step = nullptr;
   e->gs_ws = nullptr; e->ln_stats = nullptr; e->ao_part = nullptr; e->ao_cnt = nullptr;
@@ -920,6 +958,7 @@ static int alloc_buffers(vle_engine* e) {
     if ((r = dev_alloc(e, &e->ps_sample, (size_t)1))) return r;
     e->ps_host_bytes = ((size_t)e->L + 1) * sizeof(PLayer) + sizeof(PStepSample);
     E_HIP(e, hipHostMalloc((void**)&e->ps_host, e->ps_host_bytes, hipHostMallocDefault));
+    debug_host_note(e->ps_host, e->ps_host_bytes, "pinned ps_host");
   }
   if ((r = dev_alloc(e, &e->part_o, (size_t)B * e->H * 16 * e->dh))) return r;
   if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
@@ -988,12 +1027,16 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->tables_dev, e->tables_cap))) return r;
   E_HIP(e, hipHostMalloc((void**)&e->tables_host, e->tables_cap * sizeof(int32_t), hipHostMallocDefault));
   E_HIP(e, hipHostMalloc((void**)&e->poll_host, 64 * sizeof(int32_t), hipHostMallocDefault));
+  debug_host_note(e->tables_host, e->tables_cap * sizeof(int32_t), "pinned tables_host");
+  debug_host_note(e->poll_host, 64 * sizeof(int32_t), "pinned poll_host");
   // progress words the sampling kernel writes while graphs are in flight: they must be COHERENT (fine-grained) host memory or the
   // host sees nothing until a synchronisation; without a device mapping the AR loop falls back to the event / D2H poll
   e->prog_dev = nullptr;
   if (hipHostMalloc((void**)&e->prog_host, 16 * sizeof(int32_t), hipHostMallocMapped | hipHostMallocCoherent) == hipSuccess) {
     memset(e->prog_host, 0, 16 * sizeof(int32_t));
     if (hipHostGetDevicePointer((void**)&e->prog_dev, e->prog_host, 0) != hipSuccess) e->prog_dev = nullptr;
+    debug_host_note(e->prog_host, 16 * sizeof(int32_t), "pinned+mapped prog_host");
+    debug_host_note(e->prog_dev, 16 * sizeof(int32_t), "device alias of prog_host");
   } else {
     (void)hipGetLastError();
     e->prog_host = nullptr;
@@ -1180,7 +1223,7 @@ int kv_stream_nt(const vle_engine* e) {
 
 // The persistent step (persist.hip) covers this call: batch 1, the covered shape, bf16 weights, its table built for this cache
 bool persist_ready(const vle_engine* e) {
-  return e->opt_persist && e->ps_device_ok && e->B == 1 && !e->slot_mode && !e->w8 && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
+  return e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && e->B == 1 && !e->slot_mode && !e->w8 && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
          e->ps_table_kc == e->kcache && e->ps_table_ctx == e->ctx_max && (int)e->ar.size() == e->L;
 }
 
@@ -1219,15 +1262,20 @@ int persist_prepare(vle_engine* e) {
   }
   {
     PStepSample q;
-    q.s = e->S; q.dyn = e->dyn_dev; q.bos = e->bos;
+    memset(&q, 0, sizeof(q));  // padding bytes too: the block is compared with what was uploaded last
+    q.s = e->S; q.dyn = e->dyn_dev; q.bos = e->bos; q.pe_rows = e->max_pos;
     q.tokens = e->tokens; q.sampled = e->sampled; q.g_stride = e->max_G;
     q.audio_emb = e->ar_audio_emb; q.pe = e->pe; q.alpha_audio = e->alphas + 1; q.x = e->x_step;
     q.id_err = e->id_err_dev;
     q.host_prog = e->opt_host_prog ? e->prog_dev : nullptr;
-    unsigned char* hq = e->ps_host + ((size_t)e->L + 1) * sizeof(PLayer);
-    E_HIP(e, hipStreamSynchronize(e->st));
-    memcpy(hq, &q, sizeof(q));
-    E_HIP(e, hipMemcpyAsync(e->ps_sample, hq, sizeof(q), hipMemcpyHostToDevice, e->st));
+    if (!e->ps_sample_valid || memcmp(&q, &e->ps_sample_sent, sizeof(q)) != 0) {  // unchanged between prefills: no stall of the stream
+      unsigned char* hq = e->ps_host + ((size_t)e->L + 1) * sizeof(PLayer);
+      E_HIP(e, hipStreamSynchronize(e->st));
+      memcpy(hq, &q, sizeof(q));
+      E_HIP(e, hipMemcpyAsync(e->ps_sample, hq, sizeof(q), hipMemcpyHostToDevice, e->st));
+      memcpy(&e->ps_sample_sent, &q, sizeof(q));
+      e->ps_sample_valid = true;
+    }
   }
   E_HIP(e, hipMemsetAsync(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long), e->st));
   return 0;
@@ -1626,6 +1674,10 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
     E_HIP(e, hipMemcpyAsync(e->forced_len_dev, hf, B * sizeof(int32_t), hipMemcpyHostToDevice, st));
   }
   E_HIP(e, hipMemsetAsync(e->id_err_dev, 0, sizeof(int32_t), st));
+  // the persistent launch's give-up counter belongs to THIS call (a launch that finds it non-zero ends at once: pstep_kernel)
+  const bool ps_call = persist_ready(e);
+  e->ps_last_call = ps_call;
+  if (e->qa_spin_fail) E_HIP(e, hipMemsetAsync(e->qa_spin_fail + 2, 0, sizeof(unsigned), st));
   E_HIP(e, hipEventRecord(e->ev_t[2], st));
 
   // iteration 0: sample from the prefill's logits
@@ -1640,14 +1692,15 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   }
   hipGraphExec_t g_multi = nullptr, g_single = nullptr;
   if (use_graph && bound > 0) {
-    auto it = e->graphs.find(B * 64 + e->nsplit);
+    const int gkey = B * 64 + e->nsplit + (ps_call ? 1 << 20 : 0);  // the persistent launch and the chain are different graphs
+    auto it = e->graphs.find(gkey);
     if (it == e->graphs.end()) {
       // first step runs eagerly (sets kernel attributes outside capture), then capture
       if ((r = enqueue_ar_step(e))) return r;
       steps_done = 1;
       if ((r = capture_graph(e, spg, &g_multi))) return r;
       if ((r = capture_graph(e, 1, &g_single))) return r;
-      e->graphs[B * 64 + e->nsplit] = {g_multi, g_single};
+      e->graphs[gkey] = {g_multi, g_single};
     } else {
       g_multi = it->second.first;
       g_single = it->second.second;
@@ -1717,7 +1770,11 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   E_HIP(e, hipMemcpyAsync(e->tables_host, e->state_dev, st_host.size() * sizeof(int32_t), hipMemcpyDeviceToHost, st));
   E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_IDERR, e->id_err_dev, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   e->poll_host[POLL_PSFAIL] = 0;
-  if (e->qa_spin_fail) E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_PSFAIL, e->qa_spin_fail + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  if (ps_call && e->dbg_inject_psfail > 0 && e->qa_spin_fail) {  // test hook: as if one wave had given up
+    --e->dbg_inject_psfail;
+    E_HIP(e, hipMemsetAsync(e->qa_spin_fail + 2, 1, 1, st));
+  }
+  if (ps_call && e->qa_spin_fail) E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_PSFAIL, e->qa_spin_fail + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   if (codes0)
     E_HIP(e, hipMemcpy2DAsync(codes0, g_stride * sizeof(int64_t), e->tokens, e->max_G * sizeof(int64_t),
                               std::min<int64_t>(g_stride, e->max_G) * sizeof(int64_t), B, hipMemcpyDeviceToDevice, st));
@@ -1750,9 +1807,21 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
   e->have_gen = true;
   if ((r = leave(e, stream))) return r;
   if (e->poll_host[POLL_IDERR] != 0) return e->fail(VLE_EINDEX, "forced token id outside the audio vocabulary (the reference's nn.Embedding raises IndexError)");
-  if (e->poll_host[POLL_PSFAIL] != 0)
-    return e->fail(VLE_EHIP, "the persistent AR step gave up waiting for an in-launch hand-off (GPU shared with another workload?): results are invalid; set option persist = 0");
+  if (ps_call) {
+    e->ps_last_fail = (unsigned)e->poll_host[POLL_PSFAIL];
+    if (e->ps_last_fail != 0) {
+      ++e->ps_fallbacks;
+      e->ps_backoff = e->ps_backoff_next;
+      e->ps_backoff_next = std::min(64, 2 * e->ps_backoff_next);
+      e->have_prefill = e->have_gen = false;  // the KV cache and the token history of this call are not to be used
+      return e->fail(VLE_EBUSY, "the persistent AR launch could not keep the whole GPU (a wave gave up waiting for an in-launch hand-off: GPU shared "
+                                "with another workload?): this call's results are invalid; repeat vle_ar_prefill + vle_ar_generate -- the engine "
+                                "runs the launch chain for its next batch-1 calls and re-arms the persistent launch by itself");
+    }
+    e->ps_backoff_next = 2;
+  }
   if (not_done) return e->fail(VLE_ESTATE, "AR loop ended with unfinished utterances (capacity too small?)");
+  if (!ps_call && B == 1 && !e->slot_mode && e->ps_backoff > 0) --e->ps_backoff;  // one more batch-1 call on the chain after VLE_EBUSY; at 0 the persistent launch is re-armed
   if (no_token) return e->fail(VLE_ENOTOKEN, "well trained model shouldn't reach here.");
   return VLE_OK;
 }
@@ -2476,6 +2545,14 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     e->graphs.clear();
     return VLE_OK;
   }
+  if (n == "persist_inject_fail") {  // test hook: the next `value` persistent calls end as if a wave had given up (VLE_EBUSY)
+    e->dbg_inject_psfail = (int)std::max<int64_t>(0, value);
+    return VLE_OK;
+  }
+  if (n == "persist_rearm") {  // forget the back-off: the next batch-1 prefill may take the persistent launch again
+    e->ps_backoff = 0; e->ps_backoff_next = 2;
+    return VLE_OK;
+  }
   if (n == "fp8_gemm") {
     e->opt_fp8_gemm = value != 0;
     return VLE_OK;
@@ -2547,6 +2624,13 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
     const size_t nb = std::min(bytes, sizeof(v));
     memcpy(host_dst, &v, nb);
     return (int64_t)nb;
+  } else if (w == "persist_ran" || w == "persist_fallbacks" || w == "persist_backoff") {
+    // persist_ran: 1 when the last vle_ar_generate ran the persistent launch; persist_fallbacks: calls that ended with VLE_EBUSY since
+    // vle_create; persist_backoff: batch-1 prefills left on the launch chain before the persistent launch is re-armed
+    const int32_t v = w == "persist_ran" ? (e->ps_last_call ? 1 : 0) : w == "persist_fallbacks" ? (int32_t)e->ps_fallbacks : e->ps_backoff;
+    const size_t nb = std::min(bytes, sizeof(v));
+    memcpy(host_dst, &v, nb);
+    return (int64_t)nb;
   } else if (w == "persist_active") {  // 1 when the next batch-1 step would run the persistent launch
     const int32_t v = persist_ready(e) ? 1 : 0;
     const size_t nb = std::min(bytes, sizeof(v));
@@ -2565,6 +2649,23 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
   n = std::min(n, bytes);
   if (hipMemcpy(host_dst, src, n, hipMemcpyDeviceToHost) != hipSuccess) return e->fail(VLE_EHIP, "debug copy failed");
   return (int64_t)n;
+}
+
+// Debugging aid for CALLER-owned buffers (the engine's own go through VLE_GUARD_ALLOC): a device allocation in its own virtual-memory
+// mapping with an unmapped granule on either side.  at_start = 0: the buffer ENDS at the end of its mapping (a kernel that reads or
+// writes past the end of x / y / forced tokens / codes faults at once); 1: it STARTS at the mapping's start (under-runs).  Never freed.
+extern "C" int vle_debug_guard_alloc(int32_t device, size_t bytes, int32_t at_start, void** out) {
+  if (!out || bytes == 0) return VLE_EINVAL;
+  if (hipSetDevice(device) != hipSuccess) {
+    (void)hipGetLastError();
+    return VLE_EHIP;
+  }
+  if (guard_alloc(device, out, bytes, "caller", at_start ? 2 : 1) != 0) {
+    (void)hipGetLastError();
+    set_global_error("vle_debug_guard_alloc: virtual-memory allocation failed");
+    return VLE_EHIP;
+  }
+  return VLE_OK;
 }
 
 extern "C" int vle_last_timings(vle_engine* e, double* out4) {

@@ -257,6 +257,8 @@ struct PStepArgs {
                                    // before the sweep that precedes the operator, 3 = linear1 / linear2 spread over three sweeps (default)
 };
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V);
+// the persistent grid needs one workgroup per CU: the occupancy calculator must place (at least) one pstep_kernel workgroup on a CU
+bool pstep_fits_one_per_cu();
 size_t pstep_gran_count(int d, int nhead, int L);
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched, 1 shape not covered, < 0 error
 // sg[n] = sum_k W[n][k] gamma[k], tb[n] = sum_k W[n][k] beta[k] + (bias ? bias[n] : 0) for the N rows of bf16 W[N][K] (fp64 sums)
@@ -381,6 +383,7 @@ struct PStepSample {  // PStepArgs::smp (device memory); PStepArgs::nsteps = 0: 
   ArState s{};
   const ArDyn* dyn = nullptr;
   int bos = 0;
+  int pe_rows = 0;                         // rows of the position table `pe` (requests are kept inside it)
   int64_t* tokens = nullptr; int64_t* sampled = nullptr; int64_t g_stride = 0;
   const float* audio_emb = nullptr; const float* pe = nullptr; const float* alpha_audio = nullptr;
   float* x = nullptr;                      // [d] the input row of the step after this launch's last

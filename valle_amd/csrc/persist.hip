@@ -341,6 +341,11 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     }
     return;
   }
+  // An earlier launch of this call gave up (the GPU is shared): its results are void and the call will end with VLE_EBUSY -- the
+  // launches still queued behind it end at once instead of each waiting out its own budget.  The counter is zeroed on the stream
+  // at the start of every vle_ar_generate and only ever grows inside one, so every workgroup of a launch reads the same answer
+  // unless the give-up happens inside THIS launch (then the others' bounded spins end it).
+  if (a.fail != nullptr && __hip_atomic_load(a.fail, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0u) return;
   if (c == 0 && tid == 0 && a.never) smem[SM_FLOATS - 1] = 0.f;  // keeps the whole array allocated
 
   int it = a.iter[0];               // AR iteration of the step being computed (advances inside a multi-step launch)
@@ -425,6 +430,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     for (int i = 0; i < NK; ++i) {
       int key = base + w * WCH + i * KPW + slot;
       key = key < nvalid ? key : nvalid - 1;
+      key = key > 0 ? key : 0;  // nvalid = 0 (nothing cached yet) must not reach in front of the cache
       kraw[i] = *reinterpret_cast<const u32x4_t PS_GLOBAL*>(Kb + (int64_t)key * DH);
       vraw[i] = *reinterpret_cast<const u32x4_t PS_GLOBAL*>(Vb + (int64_t)key * DH);
     }
@@ -945,7 +951,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if constexpr (PF == 1 || PF == 2) issue_kv(p0, s * CHUNK, kvl + 1);  // (these schedules request a layer's keys during its x sweep)
       const int apos1 = apos + 1, kvl1 = kvl + 1;
       float pev[EPT];
-      ps_load4(as_g<float>((unsigned long long)q.pe) + (int64_t)apos1 * D + tid * EPT, pev);
+      // (at the capacity guard apos1 can be one row past the table -- prepend_bos, full prompt, n_gen == max_gen --: that step stops
+      //  and never uses the row, but the request is issued before the stop rule is known: keep it inside the table)
+      const int pe_row = apos1 < q.pe_rows ? apos1 : q.pe_rows - 1;
+      ps_load4(as_g<float>((unsigned long long)q.pe) + (int64_t)pe_row * D + tid * EPT, pev);
       const float alpha = *q.alpha_audio;
       float lg4[EPT], lgx;
       pt_begin(pt);
@@ -1061,6 +1070,16 @@ int launch_ps_fold(hipStream_t st, const void* W, const float* gamma, const floa
   if (!W || !gamma || !beta || !sg || !tb || N < 1 || K < 1) return -1;
   hipLaunchKernelGGL(ps_fold_kernel, dim3((N + 3) / 4), dim3(256), 0, st, reinterpret_cast<const bf16_t*>(W), gamma, beta, bias, sg, tb, N, K);
   return 0;
+}
+
+bool pstep_fits_one_per_cu() {
+  int per_cu = 0;
+  const hipError_t r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (pstep_kernel<bf16_t, 1024, 16, 2, 3, 5>), PS_T, 0);
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    return false;
+  }
+  return per_cu >= 1;
 }
 
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V) {

@@ -267,16 +267,18 @@ class VALLE(nn.Module):
             try:
                 _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
             except _lib.VleError as err:
-                # The persistent batch-1 launch needs every CU of the GPU; when another workload holds some for > 0.1 s it gives up and
-                # says so.  The decode is then repeated from the prefill on the launch chain (same sampling stream, same tokens up to
-                # the fp32 re-association of the folded LayerNorm) and this engine stays on the chain.
-                if not (err.code == _lib.VLE_EHIP and "persistent AR step gave up" in str(err)):
+                # The persistent batch-1 launch needs every CU of the GPU; when another workload holds some for > 0.1 s a wave gives up
+                # and the call ends with VLE_EBUSY.  The decode is repeated from the prefill: the engine itself keeps its next batch-1
+                # calls on the launch chain (same sampling stream, same tokens up to the fp32 re-association of the folded LayerNorm)
+                # and re-arms the persistent launch after a back-off (2, 4 ... 64 calls) -- a busy neighbour costs speed for a
+                # while, not the request and not the engine's fast path for good.
+                if err.code != _lib.VLE_EBUSY:
                     raise
                 import sys
 
-                print("valle_amd: the persistent AR launch could not hold the whole GPU; this engine continues on the launch chain "
-                      "(option persist = 0)", file=sys.stderr)
-                eng.set_option("persist", 0)
+                print("valle_amd: the persistent AR launch could not hold the whole GPU; this decode is repeated on the launch chain "
+                      f"(fallback #{eng.fetch_u32('persist_fallbacks')}, persistent launch re-armed after {eng.fetch_u32('persist_backoff')} calls)",
+                      file=sys.stderr)
                 eng.prefill(xd, xl, yd, yl)
                 _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
         except _lib.VleError as err:

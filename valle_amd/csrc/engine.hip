@@ -124,6 +124,10 @@ struct vle_engine {
   int32_t* id_err_dev = nullptr;  // token-id range flag (1 text, 2 prompt / continuation codes, 4 forced tokens): VLE_EINDEX
   hipEvent_t ev_chk = nullptr;
   float *X = nullptr, *yemb = nullptr, *nar_logits = nullptr;
+  // LayerNorm folded into the packed-row GEMMs of the prefill / NAR passes (kernels.h GemmLn; option "ln_fold", default 1):
+  float* ln_rows_stats = nullptr;  // [max_rows][d / 64][2] (mean, M2) of every 64-column group of the residual rows (buffer)
+  float* nar_fold = nullptr;       // [Q - 1][L][14 d]: per (stage, layer) sg / tb of the in-projection (3 d each) and of linear1 (4 d each)
+  bool opt_ln_fold = true;
   void *Xn = nullptr, *QKV = nullptr, *ATT = nullptr, *Hb = nullptr;
   int32_t* tables_dev = nullptr;  // row tables
   int32_t* tables_host = nullptr; // pinned mirror
@@ -643,7 +647,7 @@ static void release_buffers(vle_engine* e) {
   e->state_dev = nullptr; e->S = ArState{}; e->dyn_dev = nullptr;
   e->tokens = e->sampled = e->text_ids = e->prompt_codes = nullptr;
   e->forced_len_dev = nullptr; e->slot_seed_dev = nullptr; e->id_err_dev = nullptr;
-  e->X = e->yemb = e->nar_logits = nullptr;
+  e->X = e->yemb = e->nar_logits = nullptr; e->ln_rows_stats = nullptr;
   e->Xn = e->QKV = e->ATT = e->Hb = nullptr;
   e->A8 = nullptr; e->a8_scale = nullptr;
   e->tables_dev = nullptr; e->tables_cap = 0;
@@ -922,6 +926,18 @@ extern "C" int vle_finalize_weights(vle_engine* e) {
   e->in_buffers = false;
   if (r) return r;
   if ((r = make_weight_packs(e))) return r;
+  if (e->Q > 1 && e->dtype == DT_BF16 && d % 256 == 0 && d <= 1536) {
+    // row constants of the folded (Ada)LayerNorm of the NAR passes: per stage and layer, sg = W gamma_s, tb = W beta_s + b of the
+    // in-projection and of linear1 on the folded AdaLN affine of that stage (fold_adaln above), fp64 sums on the device
+    if ((r = dev_alloc(e, &e->nar_fold, (size_t)(e->Q - 1) * e->L * 14 * d))) return r;
+    for (int i = 0; i < e->Q - 1; ++i)
+      for (int l = 0; l < e->L; ++l) {
+        float* f = e->nar_fold + ((size_t)i * e->L + l) * 14 * d;
+        E_LAUNCH(e, launch_ps_fold(e->st, e->nar[l].wqkv, e->nar_gamma[i][2 * l], e->nar_beta[i][2 * l], e->nar[l].bqkv, f, f + 3 * d, (int)(3 * d), (int)d));
+        E_LAUNCH(e, launch_ps_fold(e->st, e->nar[l].w1, e->nar_gamma[i][2 * l + 1], e->nar_beta[i][2 * l + 1], e->nar[l].b1, f + 6 * d, f + 10 * d, (int)(4 * d), (int)d));
+      }
+    E_HIP(e, hipStreamSynchronize(e->st));
+  }
   e->in_buffers = true;  // from here on dev_alloc serves capacity-dependent buffers (traces, diagnostics)
   e->finalized = true;
   return VLE_OK;
@@ -963,6 +979,14 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->part_o, (size_t)B * e->H * 16 * e->dh))) return r;
   if ((r = dev_alloc(e, &e->part_ml, (size_t)B * e->H * 16 * 2))) return r;
   if ((r = dev_alloc(e, &e->logits, B * V_AR))) return r;
+  E_HIP(e, hipMemset(e->x_step, 0, (size_t)B * d * sizeof(float)));
+  E_HIP(e, hipMemset(e->q_step, 0, (size_t)B * d * sizeof(float)));
+  E_HIP(e, hipMemset(e->h_step, 0, (size_t)B * 4 * d * sizeof(float)));
+  E_HIP(e, hipMemset(e->k_new, 0, (size_t)B * d * sizeof(float)));
+  E_HIP(e, hipMemset(e->v_new, 0, (size_t)B * d * sizeof(float)));
+  E_HIP(e, hipMemset(e->part_o, 0, (size_t)B * e->H * 16 * e->dh * sizeof(float)));
+  E_HIP(e, hipMemset(e->part_ml, 0, (size_t)B * e->H * 16 * 2 * sizeof(float)));
+  E_HIP(e, hipMemset(e->logits, 0, (size_t)B * V_AR * sizeof(float)));
   if (B > SKINNY_MAX_B || true) {  // GEMM-path step buffers (also used when the GEMV path cannot hold B rows in LDS)
     const size_t Bp = (size_t)(B + 15) / 16 * 16;  // the fragment-major layout (common.h xf_index) holds whole 16-row fragments
     if ((r = dev_alloc(e, &p, Bp * d * es))) return r;
@@ -976,11 +1000,17 @@ static int alloc_buffers(vle_engine* e) {
     if ((r = dev_alloc(e, &p, gemm_skinny_workspace_bytes()))) return r;
     E_HIP(e, hipMemset(p, 0, gemm_skinny_workspace_bytes()));
     e->gs_ws = p;
-    // free / finished slots keep whatever they held: start from finite values
+    // free / finished slots and the rows that pad the batch to whole 16-row fragments keep whatever they held: start from finite
+    // values everywhere (VLE_POISON_ALLOC=0xff, round 5: the fused-LayerNorm step at 33 utterances, d 1536, fp8w produced NaN logits
+    // from never-written padding rows -- harmless only as long as fresh memory happens to hold zeros)
     E_HIP(e, hipMemset(e->xn_step, 0, Bp * d * es));
+    E_HIP(e, hipMemset(e->qkv_step, 0, (size_t)B * 3 * d * es));
+    E_HIP(e, hipMemset(e->att_step, 0, Bp * d * es));
+    E_HIP(e, hipMemset(e->hT_step, 0, Bp * 4 * d * es));
     if ((r = dev_alloc(e, &e->ln_stats, (size_t)64 * (d / 16 + 1) * 2))) return r;
     E_HIP(e, hipMemset(e->ln_stats, 0, (size_t)64 * (d / 16 + 1) * 2 * sizeof(float)));
     if ((r = dev_alloc(e, &e->ao_part, (size_t)B * e->H * d))) return r;
+    E_HIP(e, hipMemset(e->ao_part, 0, (size_t)B * e->H * d * sizeof(float)));
     if ((r = dev_alloc(e, &p, (size_t)B * sizeof(int)))) return r;
     E_HIP(e, hipMemset(p, 0, (size_t)B * sizeof(int)));
     e->ao_cnt = (int*)p;
@@ -1006,6 +1036,9 @@ static int alloc_buffers(vle_engine* e) {
   E_HIP(e, hipMemset(e->id_err_dev, 0, 4 * sizeof(int32_t)));
   const int64_t R = e->max_rows;
   if ((r = dev_alloc(e, &e->X, (size_t)R * d))) return r;
+  if (e->dtype == DT_BF16 && d % 256 == 0 && d <= 1536) {
+    if ((r = dev_alloc(e, &e->ln_rows_stats, (size_t)R * (d / LN_GROUP) * 2))) return r;
+  }
   if ((r = dev_alloc(e, &p, (size_t)R * d * es))) return r;
   e->Xn = p;
   if ((r = dev_alloc(e, &p, (size_t)R * 3 * d * es))) return r;
@@ -1099,11 +1132,51 @@ int gemm_rows(vle_engine* e, const void* A, const void* w, const void* w8, const
   return launch_gemm(e->st, e->dtype, A, w, bias, out, resid, rows, N, K, epi);
 }
 
+// LayerNorm folded into the GEMMs of one layer over packed rows (kernels.h GemmLn): row constants of this layer's two norm sites,
+// whether X's norm1 operand (bf16(x * gamma1) in Xn + group statistics) was left by the previous layer's linear2, and the gamma of
+// the NEXT layer's norm1 (null: this is the last layer -- its linear2 is a plain residual GEMM)
+struct LnFoldLayer {
+  const float *sg_qkv = nullptr, *tb_qkv = nullptr, *sg_1 = nullptr, *tb_1 = nullptr;
+  bool in_folded = false;
+  const float* next_g1 = nullptr;
+};
+bool use_ln_fold(const vle_engine* e, int64_t rows) {
+  return e->opt_ln_fold && !e->a8 && e->ln_rows_stats != nullptr && gemm_ln_supports(e->dtype, rows, e->d);
+}
+
 int enqueue_layer_rows(vle_engine* e, const LayerW& w, const float* g1, const float* b1, const float* g2, const float* b2,
                        int64_t rows, const int32_t* seq_off, const int32_t* text_len, int max_len, int causal,
-                       void* kc, void* vc, const int32_t* row_seq, const int32_t* row_pos) {
+                       void* kc, void* vc, const int32_t* row_seq, const int32_t* row_pos, const LnFoldLayer* f = nullptr) {
   const int d = e->d;
   hipStream_t st = e->st;
+  if (f != nullptr) {
+    // 5 launches instead of 7: the two LayerNorm passes over the rows (read 4 d + write 2 d bytes per row each, and at one
+    // utterance 5 us + a launch boundary each) ride on the residual GEMMs' epilogues
+    GemmLn ln;
+    if (f->in_folded) {
+      ln.stats_in = e->ln_rows_stats; ln.sg = f->sg_qkv;
+      E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.wqkv, f->tb_qkv, e->QKV, nullptr, rows, 3 * d, d, EPI_STORE_LNC, &ln));
+    } else {
+      E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, nullptr, g1, b1, e->Xn, rows, d));
+      E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.wqkv, w.bqkv, e->QKV, nullptr, rows, 3 * d, d, EPI_STORE));
+    }
+    if (kc) E_LAUNCH(e, launch_kv_scatter(st, e->dtype, e->QKV, kc, vc, row_seq, row_pos, rows, d, e->H, e->ctx_max));
+    E_LAUNCH(e, launch_attention(st, e->dtype, e->QKV, e->ATT, seq_off, text_len, e->nseq > 0 ? e->nseq : e->B, max_len, d, e->H, causal));
+    ln = GemmLn();
+    ln.gamma = g2; ln.xg = e->Xn; ln.stats_out = e->ln_rows_stats;
+    E_LAUNCH(e, launch_gemm(st, e->dtype, e->ATT, w.wo, w.bo, nullptr, e->X, rows, d, d, EPI_RESID_LNP, &ln));
+    ln = GemmLn();
+    ln.stats_in = e->ln_rows_stats; ln.sg = f->sg_1;
+    E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.w1, f->tb_1, e->Hb, nullptr, rows, 4 * d, d, EPI_RELU_LNC, &ln));
+    if (f->next_g1 != nullptr) {
+      ln = GemmLn();
+      ln.gamma = f->next_g1; ln.xg = e->Xn; ln.stats_out = e->ln_rows_stats;
+      E_LAUNCH(e, launch_gemm(st, e->dtype, e->Hb, w.w2, w.b2, nullptr, e->X, rows, d, 4 * d, EPI_RESID_LNP, &ln));
+    } else {
+      E_LAUNCH(e, launch_gemm(st, e->dtype, e->Hb, w.w2, w.b2, nullptr, e->X, rows, d, 4 * d, EPI_RESID));
+    }
+    return 0;
+  }
   E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, nullptr, g1, b1, e->Xn, rows, d));
   E_LAUNCH(e, gemm_rows(e, e->Xn, w.wqkv, w.wqkv8, w.sqkv, w.bqkv, e->QKV, nullptr, rows, 3 * d, d, EPI_STORE));
   if (kc) E_LAUNCH(e, launch_kv_scatter(st, e->dtype, e->QKV, kc, vc, row_seq, row_pos, rows, d, e->H, e->ctx_max));
@@ -1604,10 +1677,15 @@ extern "C" int vle_ar_prefill(vle_engine* e, void* stream, const int64_t* text, 
   pa.text_emb = e->ar_text_emb; pa.audio_emb = e->ar_audio_emb; pa.pe = e->pe;
   pa.alpha_text = e->alphas + 0; pa.alpha_audio = e->alphas + 1; pa.bos = e->bos; pa.d = e->d; pa.rows = rows; pa.x = e->X;
   E_LAUNCH(e, launch_prefill_embed(st, pa));
+  const bool pf_fold = use_ln_fold(e, rows) && !e->ar.empty() && e->ar[0].wg_qkv != nullptr;
   for (int l = 0; l < e->L; ++l) {
     const LayerW& w = e->ar[l];
+    LnFoldLayer f;
+    f.sg_qkv = w.wg_qkv; f.tb_qkv = w.wb_qkv; f.sg_1 = w.wg_1; f.tb_1 = w.wb_1;
+    f.in_folded = l > 0;
+    f.next_g1 = l + 1 < e->L ? e->ar[l + 1].g1 : nullptr;
     if ((r = enqueue_layer_rows(e, w, w.g1, w.be1, w.g2, w.be2, rows, d_seq_off, d_text_len, max_len, 1,
-                                cache_layer(e, e->kcache, l), cache_layer(e, e->vcache, l), d_row_seq, d_row_pos)))
+                                cache_layer(e, e->kcache, l), cache_layer(e, e->vcache, l), d_row_seq, d_row_pos, pf_fold ? &f : nullptr)))
       return r;
   }
   E_LAUNCH(e, launch_gather_rows(st, e->X, d_last, e->x_step, B, e->d));
@@ -1937,9 +2015,16 @@ static int run_nar(vle_engine* e, const std::vector<int32_t>& drop, int mode, in
   E_LAUNCH(e, launch_nar_yemb_init(st, na, mode != 0 ? 1 : 0));
   for (int i = 0; i < Q - 1; ++i) {
     E_LAUNCH(e, launch_nar_assemble(st, na));
+    const bool nar_fold = use_ln_fold(e, xrows) && e->nar_fold != nullptr;
     for (int l = 0; l < e->L; ++l) {
+      LnFoldLayer f;
+      const float* fc = nar_fold ? e->nar_fold + ((size_t)i * e->L + l) * 14 * d : nullptr;
+      f.sg_qkv = fc; f.tb_qkv = fc + 3 * d; f.sg_1 = fc + 6 * d; f.tb_1 = fc + 10 * d;
+      f.in_folded = l > 0;
+      f.next_g1 = l + 1 < e->L ? e->nar_gamma[i][2 * (l + 1)] : nullptr;
       if ((r = enqueue_layer_rows(e, e->nar[l], e->nar_gamma[i][2 * l], e->nar_beta[i][2 * l], e->nar_gamma[i][2 * l + 1],
-                                  e->nar_beta[i][2 * l + 1], xrows, d_xoff, d_tl_zero, max_len, 0, nullptr, nullptr, nullptr, nullptr)))
+                                  e->nar_beta[i][2 * l + 1], xrows, d_xoff, d_tl_zero, max_len, 0, nullptr, nullptr, nullptr, nullptr,
+                                  nar_fold ? &f : nullptr)))
         return r;
     }
     // final AdaLN only on the generated rows, then nar_predict_layers[i] (valle.py:1128)
@@ -2551,6 +2636,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
   }
   if (n == "persist_rearm") {  // forget the back-off: the next batch-1 prefill may take the persistent launch again
     e->ps_backoff = 0; e->ps_backoff_next = 2;
+    return VLE_OK;
+  }
+  if (n == "ln_fold") {  // 0: the prefill / NAR passes run their LayerNorm launches (A/B, tests)
+    e->opt_ln_fold = value != 0;
     return VLE_OK;
   }
   if (n == "fp8_gemm") {

@@ -181,8 +181,12 @@ static int gemm_dispatch(hipStream_t st, const void* A, const void* W, const flo
 }
 
 int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const float* bias, void* out, float* resid,
-                int64_t M, int N, int K, int epi) {
+                int64_t M, int N, int K, int epi, const GemmLn* ln) {
   if (M <= 0 || N <= 0) return 0;
+  if (epi >= EPI_RESID_LNP) {  // LayerNorm folded into the GEMM: gemm_glds.hip / gemm_8ph.hip only (callers ask gemm_ln_supports first)
+    if (dtype != DT_BF16 || ln == nullptr) return -1;
+    return launch_gemm_glds(st, A, W, bias, out, resid, M, N, K, epi, ln) == 0 ? 0 : -1;
+  }
   if (dtype == DT_F32) return gemm_dispatch<float>(st, A, W, bias, out, resid, M, N, K, epi);
   // bf16: the LDS-DMA pipelined kernel (gemm_glds.hip) when it has the shape
   if (launch_gemm_glds(st, A, W, bias, out, resid, M, N, K, epi) == 0) return 0;

@@ -59,9 +59,15 @@ __device__ inline int g8_key(int row) {
 template <int EPI, bool STAGGER, int SWZ>
 __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                        const float* __restrict__ bias, void* __restrict__ out_,
-                                                       float* __restrict__ resid, int64_t M, int N, int K, int GC, int dbg) {
-  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G8_BUF];  // the ONLY LDS object (a second one makes
-                                                                           // hipcc drain vmcnt before every ds_read)
+                                                       float* __restrict__ resid, int64_t M, int N, int K, int GC, int dbg, GemmLn ln) {
+  // LayerNorm folded into the GEMMs (kernels.h GemmLn; same scheme as gemm_glds.hip): LNP = this launch completes the residual stream
+  // and leaves bf16(x * gamma) + group statistics for the next norm site; LNC = this launch reads x * gamma and applies
+  // rstd * (acc - mean * sg) + tb in its epilogue
+  constexpr bool LNP = EPI == EPI_RESID_LNP, LNC = EPI == EPI_STORE_LNC || EPI == EPI_RELU_LNC;
+  constexpr bool RESID = EPI == EPI_RESID || LNP, RELU = EPI == EPI_RELU || EPI == EPI_RELU_LNC, BF16OUT = EPI == EPI_STORE || RELU || LNC;
+  constexpr int LN_LDS = LNC ? 256 * 16 : 0;  // (mean, M2) of the two halves of the tile's rows, behind the two buffers: never a DMA target
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G8_BUF + LN_LDS];  // the ONLY LDS object (a second one makes
+                                                                                    // hipcc drain vmcnt before every ds_read)
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wr = wave >> 2, wc = wave & 3;
@@ -174,6 +180,19 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
   };
 
   const int KT = (dbg & 2) ? 2 : K / 64;  // diagnostic (g8_dbg bit 1): prologue + two K-tiles + epilogue only
+  // LNC: the row statistics, as in gemm_glds.hip: thread t owns HALF of row m0 + t % 256 (half t / 256 of its K / 64 group pairs); the
+  // pairs are requested AHEAD of the DMA queue (in-order return: the wait for them never drains the pipeline), on clamped addresses,
+  // and combined once the DMA prologue is on its way; the two halves meet in the epilogue
+  constexpr int LNV = 6;
+  g8_f32x4 lnp[LNC ? LNV : 1];
+  const int ln_np = K / 256;  // 16-byte loads (two groups each) per half row
+  if constexpr (LNC) {
+    int64_t m = m0 + (tid & 255);
+    m = m < M ? m : M - 1;
+    const g8_f32x4* sp = reinterpret_cast<const g8_f32x4*>(ln.stats_in + m * (int64_t)(K / 32)) + (tid >> 8) * ln_np;
+#pragma unroll
+    for (int g = 0; g < LNV; ++g) lnp[g] = sp[g < ln_np ? g : ln_np - 1];
+  }
   // Issue schedule (one half-tile per phase, in order of first use, into a half whose last read lies >= 2 phases back,
   // so it also holds when the two wave groups are half a phase apart):
   //   phase 1: A-bot of tile t+1      phase 2: B-right of tile t+1     (other buffer)
@@ -182,6 +201,22 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
   // tile t+1; it precedes phase 4's first barrier, the data is first read in the next phase.
   issue(G8_BLEFT, 0); issue(G8_ATOP, 0); issue(G8_BRIGHT, 0); issue(G8_ABOT, 0);
   issue(G8_BLEFT, 1); issue(G8_ATOP, 1);
+  float ln_mean = 0.f, ln_m2 = 0.f;  // of this thread's half row
+  if constexpr (LNC) {
+    const float ref = lnp[0][0];
+    float s1 = 0.f, s2 = 0.f, q = 0.f;
+#pragma unroll
+    for (int g = 0; g < LNV; ++g) {
+      const bool on = g < ln_np;
+      const float d0 = on ? lnp[g][0] - ref : 0.f, d1 = on ? lnp[g][2] - ref : 0.f;
+      s1 += d0 + d1;
+      s2 = fmaf(d0, d0, fmaf(d1, d1, s2));
+      q += on ? lnp[g][1] + lnp[g][3] : 0.f;
+    }
+    const float sm = s1 / (float)(2 * ln_np);  // mean_h - ref
+    ln_mean = ref + sm;
+    ln_m2 = q + (float)LN_GROUP * (s2 - s1 * sm);
+  }
   g8_wait_vm<4>();  // tile 0 landed (this wave's pieces)
   __builtin_amdgcn_s_barrier();
   if (STAGGER && wr == 1) __builtin_amdgcn_s_barrier();  // pairs with the first in-loop barrier of waves 0-3
@@ -231,19 +266,43 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
   //   fp32 image  [128][256], one row half of the tile per pass: chunk c of row r at c ^ (r & 7) (ds_write_b128 groups of 8 rows).
   if (!(dbg & 4)) {
     unsigned char* const E = smem;
-    if constexpr (EPI == EPI_STORE || EPI == EPI_RELU) {
+    if constexpr (BF16OUT) {
+      g8_f32x4 sg4[LNC ? 2 : 1][LNC ? 2 : 1];
+      if constexpr (LNC) {
+#pragma unroll
+        for (int h = 0; h < 2; ++h)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) sg4[h][j] = *reinterpret_cast<const g8_f32x4*>(ln.sg + n0 + h * 128 + wc * 32 + j * 16 + fg * 4);
+        float* const S = reinterpret_cast<float*>(smem + 2 * G8_BUF);  // the rows' (mean, rstd): owner threads -> fragment layout
+        S[4 * (tid & 255) + 2 * (tid >> 8)] = ln_mean;
+        S[4 * (tid & 255) + 2 * (tid >> 8) + 1] = ln_m2;
+        __syncthreads();
+      }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
         for (int i = 0; i < 4; ++i) {
           const int row = a * 128 + wr * 64 + i * 16 + fr;
+          float mean = 0.f, rstd = 1.f;
+          if constexpr (LNC) {  // the row's two halves (K / 2 elements each): mean = (m0 + m1) / 2, M2 = q0 + q1 + (K / 4) (m0 - m1)^2
+            const g8_f32x4 hh = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + row * 16);
+            const float dm = hh[0] - hh[2];
+            mean = 0.5f * (hh[0] + hh[2]);
+            rstd = 1.0f / sqrtf((hh[1] + hh[3] + 0.25f * (float)K * dm * dm) / (float)K + LN_EPS);
+          }
 #pragma unroll
           for (int b = 0; b < 2; ++b)
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int c = b * 16 + wc * 4 + j * 2 + (fg >> 1);
-              g8_f32x4 v = acc[a][b][i][j] + bias4[b][j];
-              if constexpr (EPI == EPI_RELU) {
+              g8_f32x4 v;
+              if constexpr (LNC) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sg4[b][j][r], acc[a][b][i][j][r]), bias4[b][j][r]);
+              } else {
+                v = acc[a][b][i][j] + bias4[b][j];
+              }
+              if constexpr (RELU) {
 #pragma unroll
                 for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
               }
@@ -282,9 +341,11 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
               *reinterpret_cast<g8_f32x4*>(E + row * 1024 + ((c ^ (fr & 7)) << 4)) = acc[a][b][i][j] + bias4[b][j];
             }
         }
-        float* const base = (EPI == EPI_RESID ? resid : reinterpret_cast<float*>(out_)) + n0 + lane * 4;
+        float* const base = (RESID ? resid : reinterpret_cast<float*>(out_)) + n0 + lane * 4;
         g8_f32x4 old[16];
-        if constexpr (EPI == EPI_RESID) {  // the 16 rows' old values: requested before the barrier
+        g8_f32x4 gamma4 = g8_f32x4{0.f, 0.f, 0.f, 0.f};
+        if constexpr (LNP) gamma4 = *reinterpret_cast<const g8_f32x4*>(ln.gamma + n0 + lane * 4);
+        if constexpr (RESID) {  // the 16 rows' old values: requested before the barrier
 #pragma unroll
           for (int it = 0; it < 16; ++it) {
             const int64_t m = m0 + a * 128 + wave * 16 + it;
@@ -297,11 +358,27 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
         for (int it = 0; it < 16; ++it) {
           const int r = wave * 16 + it;
           g8_f32x4 v = *reinterpret_cast<const g8_f32x4*>(E + r * 1024 + ((lane ^ (r & 7)) << 4));
-          if constexpr (EPI == EPI_RESID) v = old[it] + v;
+          if constexpr (RESID) v = old[it] + v;
           const int64_t m = m0 + a * 128 + r;
+          float gmean = 0.f, gm2 = 0.f;
+          if constexpr (LNP) {  // (mean, M2) of this lane row's 64-column group of the completed residual row: exact two-pass, one DPP row
+            gmean = row16_sum_dpp((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / (float)LN_GROUP);
+            const float d0 = v[0] - gmean, d1 = v[1] - gmean, d2 = v[2] - gmean, d3 = v[3] - gmean;
+            gm2 = row16_sum_dpp(fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0))));
+          }
           if (m < M && !(dbg & 1)) {
             if (dbg & 16) __builtin_nontemporal_store(v, reinterpret_cast<g8_f32x4*>(base + m * N));
             else *reinterpret_cast<g8_f32x4*>(base + m * N) = v;
+            if constexpr (LNP) {
+              g8_bf16x4 o4;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o4[q] = (__bf16)(v[q] * gamma4[q]);
+              *reinterpret_cast<g8_bf16x4*>(reinterpret_cast<bf16_t*>(ln.xg) + m * N + n0 + lane * 4) = o4;
+              if ((lane & 15) == 0) {
+                typedef float g8_f32x2 __attribute__((ext_vector_type(2)));
+                *reinterpret_cast<g8_f32x2*>(ln.stats_out + (m * (int64_t)(N / LN_GROUP) + (n0 + lane * 4) / LN_GROUP) * 2) = g8_f32x2{gmean, gm2};
+              }
+            }
           }
         }
       }
@@ -348,12 +425,23 @@ int g_g8_stagger = 1;  // "g8_stagger": waves 4-7 half a phase behind waves 0-3 
 
 // returns 0 = launched, 1 = shape not covered
 int launch_gemm_8ph(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
-                    int K, int epi) {
+                    int K, int epi, const GemmLn* lnp) {
   if (N % 256 != 0 || K % 128 != 0 || K < 256 || M < 256) return 1;
   const dim3 grid(N / 256, (unsigned)((M + 255) / 256)), block(512);
   const bf16_t* a = (const bf16_t*)A;
   const bf16_t* w = (const bf16_t*)W;
-#define VLE_G8(E, ST, SW) hipLaunchKernelGGL((gemm_8ph_kernel<E, ST, SW>), grid, block, 0, st, a, w, bias, out, resid, M, N, K, g_g8_colgroup, g_g8_dbg | (g_g8_nt << 3))
+  const GemmLn ln = lnp ? *lnp : GemmLn();
+#define VLE_G8(E, ST, SW) hipLaunchKernelGGL((gemm_8ph_kernel<E, ST, SW>), grid, block, 0, st, a, w, bias, out, resid, M, N, K, g_g8_colgroup, g_g8_dbg | (g_g8_nt << 3), ln)
+  if (epi >= EPI_RESID_LNP) {  // LayerNorm folded into the GEMM (kernels.h GemmLn): the default schedule only (staggered, row & 7 swizzle)
+    if ((g_g8_dbg & 7) != 0) return -1;
+    switch (epi) {
+      case EPI_RESID_LNP: if (!ln.gamma || !ln.xg || !ln.stats_out) return -1; VLE_G8(EPI_RESID_LNP, true, 0); break;
+      case EPI_STORE_LNC: if (!ln.stats_in || !ln.sg || K > 1536) return -1; VLE_G8(EPI_STORE_LNC, true, 0); break;
+      case EPI_RELU_LNC: if (!ln.stats_in || !ln.sg || K > 1536) return -1; VLE_G8(EPI_RELU_LNC, true, 0); break;
+      default: return -1;
+    }
+    return 0;
+  }
 #define VLE_G8E(ST, SW)                           \
   switch (epi) {                                  \
     case EPI_STORE: VLE_G8(EPI_STORE, ST, SW); break; \

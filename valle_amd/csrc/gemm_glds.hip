@@ -43,7 +43,11 @@ __device__ inline int gg_key(int row) {
 template <int BM, int BN, int EPI, int NW, bool PRIO = false, int SWZ = 0>
 __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                         const float* __restrict__ bias, void* __restrict__ out_,
-                                                        float* __restrict__ resid, int64_t M, int N, int K, int glds_legacy_epilogue) {
+                                                        float* __restrict__ resid, int64_t M, int N, int K, int glds_legacy_epilogue, GemmLn ln) {
+  // LayerNorm folded into the GEMMs (kernels.h GemmLn): LNP = this launch completes the residual stream and leaves bf16(x * gamma) +
+  // group statistics for the next norm site; LNC = this launch reads x * gamma and applies rstd * (acc - mean * sg) + tb
+  constexpr bool LNP = EPI == EPI_RESID_LNP, LNC = EPI == EPI_STORE_LNC || EPI == EPI_RELU_LNC;
+  constexpr bool RESID = EPI == EPI_RESID || LNP, RELU = EPI == EPI_RELU || EPI == EPI_RELU_LNC;
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int STAGES = (4 * STAGE_BYTES <= 144 * 1024) ? 4 : 3;
   constexpr int D = STAGES - 1;                 // k-steps in flight
@@ -51,7 +55,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   constexpr int NI = NIA + NIB;
   constexpr int WMW = NW / 2;                   // waves along M (x 2 along N): 2 x 2, or 4 x 2 for the 8-wave 256-row tile
   constexpr int WM = BM / WMW, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES];
+  constexpr int LN_LDS = LNC ? BM * 16 : 0;  // (mean, M2) of the two halves of the tile's rows, behind the ring: never a DMA target
+  __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES + LN_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);  // provably wave-uniform: scalar branches / LDS bases
@@ -122,9 +127,42 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   nlive = nlive < 0 ? 0 : (nlive > FM ? FM : nlive);
 
   const int KT = K / 64;
+  // LNC: the row statistics.  Thread t < 2 BM owns HALF of row m0 + t % BM (half t / BM of its K / 64 group pairs (mean, M2)): the
+  // pairs are requested AHEAD of the DMA queue (a wave's loads return in order: the wait for them never drains the pipeline),
+  // straight-line and on clamped addresses (no branch around a request), and combined after the DMA prologue is on its way:
+  //   mean_h = avg(mean_g),  M2_h = sum(M2_g) + 64 * sum((mean_g - mean_h)^2)   (Chan; the squares taken around the half's first group)
+  // The two halves meet in the epilogue (LDS behind the ring).  Two threads per row keep the request at 6 registers x 4.
+  constexpr int LNV = 6;  // 16-byte loads (two groups each) per half row: K <= 1536
+  static_assert(!LNC || NW * 64 >= 2 * BM, "two threads per tile row");
+  gg_f32x4 lnp[LNC ? LNV : 1];
+  const int ln_np = K / 256;  // loads per half row
+  if constexpr (LNC) {
+    int64_t m = m0 + tid % BM;
+    m = m < M ? m : M - 1;
+    const int half = (tid / BM) & 1;
+    const gg_f32x4* sp = reinterpret_cast<const gg_f32x4*>(ln.stats_in + m * (int64_t)(KT * 2)) + half * ln_np;  // KT = K / 64 groups
+#pragma unroll
+    for (int g = 0; g < LNV; ++g) lnp[g] = sp[g < ln_np ? g : ln_np - 1];
+  }
 #pragma unroll
   for (int s = 0; s < D; ++s)
     if (s < KT) issue(s);
+  float ln_mean = 0.f, ln_m2 = 0.f;  // of this thread's half row
+  if constexpr (LNC) {
+    const float ref = lnp[0][0];
+    float s1 = 0.f, s2 = 0.f, q = 0.f;
+#pragma unroll
+    for (int g = 0; g < LNV; ++g) {
+      const bool on = g < ln_np;
+      const float d0 = on ? lnp[g][0] - ref : 0.f, d1 = on ? lnp[g][2] - ref : 0.f;
+      s1 += d0 + d1;
+      s2 = fmaf(d0, d0, fmaf(d1, d1, s2));
+      q += on ? lnp[g][1] + lnp[g][3] : 0.f;
+    }
+    const float sm = s1 / (float)(2 * ln_np);  // mean_h - ref
+    ln_mean = ref + sm;
+    ln_m2 = q + (float)LN_GROUP * (s2 - s1 * sm);
+  }
 
   for (int kt = 0; kt < KT; ++kt) {
     // tile kt has landed once at most min(D-1, KT-1-kt) younger tiles of this wave are outstanding
@@ -192,19 +230,44 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   // elements the two 8-byte halves of a chunk swapped when (r >> 3) & 1: conflict-free for the fragment writes -- and read back
   // as whole rows: every global access is BN x element-size contiguous bytes of one output row, 16 bytes per lane; the
   // residual's old values are loaded in that row form too (requested before the barrier).
-  if (n0 + BN <= N && !glds_legacy_epilogue) {
-    constexpr bool F32OUT = EPI == EPI_RESID || EPI == EPI_F32;
+  if ((n0 + BN <= N && !glds_legacy_epilogue) || LNP || LNC) {  // (the LN epilogues exist in this form only: gemm_ln_supports)
+    constexpr bool F32OUT = RESID || EPI == EPI_F32;
     constexpr int ES = F32OUT ? 4 : 2, RB = BN * ES, CPR = RB / 16, RPI = 64 / CPR, IT = BM / NW / RPI;
     static_assert(BM * RB <= STAGES * STAGE_BYTES && (BM / NW) % RPI == 0, "epilogue image must fit the LDS ring");
+    static_assert(!LNP || CPR % 16 == 0, "a 16-lane row of the row-form pass covers one 64-column group");
+    gg_f32x4 sg4[LNC ? FN : 1];
+    if constexpr (LNC) {
+#pragma unroll
+      for (int j = 0; j < FN; ++j) sg4[j] = *reinterpret_cast<const gg_f32x4*>(ln.sg + min(n0 + wn0 + j * 16 + fg * 4, N - 4));
+    }
     __syncthreads();  // every wave has consumed the last k-step
     unsigned char* const E = smem;
+    if constexpr (LNC) {  // the rows' (mean, rstd) from their owner threads to the fragment layout
+      float* const S = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);
+      if (tid < 2 * BM) {
+        S[4 * (tid % BM) + 2 * (tid / BM)] = ln_mean;
+        S[4 * (tid % BM) + 2 * (tid / BM) + 1] = ln_m2;
+      }
+      __syncthreads();
+    }
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int row = wm0 + i * 16 + fr, col = wn0 + j * 16 + fg * 4;
-        gg_f32x4 v = acc[i][j] + bias4[j];
-        if constexpr (EPI == EPI_RELU) {
+        gg_f32x4 v;
+        if constexpr (LNC) {
+          // the row's two halves (K / 2 elements each): mean = (m0 + m1) / 2, M2 = q0 + q1 + (K / 4) (m0 - m1)^2
+          const gg_f32x4 hh = *reinterpret_cast<const gg_f32x4*>(smem + STAGES * STAGE_BYTES + row * 16);
+          const float dm = hh[0] - hh[2];
+          const float mean = 0.5f * (hh[0] + hh[2]);
+          const float rstd = 1.0f / sqrtf((hh[1] + hh[3] + 0.25f * (float)K * dm * dm) / (float)K + LN_EPS);
+#pragma unroll
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sg4[j][r], acc[i][j][r]), bias4[j][r]);
+        } else {
+          v = acc[i][j] + bias4[j];
+        }
+        if constexpr (RELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
         }
@@ -218,13 +281,15 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
         }
       }
     const int l = lane % CPR, rsub = lane / CPR;
-    gg_f32x4 old[EPI == EPI_RESID ? IT : 1];
-    if constexpr (EPI == EPI_RESID) {
+    gg_f32x4 old[RESID ? IT : 1];
+    gg_f32x4 gamma4 = gg_f32x4{0.f, 0.f, 0.f, 0.f};
+    if constexpr (RESID) {
 #pragma unroll
       for (int it = 0; it < IT; ++it) {
         const int64_t m = m0 + wave * (BM / NW) + it * RPI + rsub;
         old[it] = *reinterpret_cast<const gg_f32x4*>(resid + (m < M ? m : M - 1) * N + n0 + l * 4);
       }
+      if constexpr (LNP) gamma4 = *reinterpret_cast<const gg_f32x4*>(ln.gamma + n0 + l * 4);
     }
     __syncthreads();
 #pragma unroll
@@ -235,7 +300,25 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
       if constexpr (!F32OUT) {
         if ((r >> 3) & 1) v = gg_u32x4{v[2], v[3], v[0], v[1]};
       }
-      if (m < M) {
+      if constexpr (LNP) {
+        // the completed residual row x: store it, and leave the next norm site's operand bf16(x * gamma) and this 64-column group's
+        // (mean, M2) -- exact two-pass over the group's 64 fp32 values (16 lanes x 4: one DPP row), before any guard (whole rows of lanes)
+        const gg_f32x4 x = old[it] + gg_f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
+        const float gmean = row16_sum_dpp((x[0] + x[1]) + (x[2] + x[3])) * (1.0f / (float)LN_GROUP);
+        const float d0 = x[0] - gmean, d1 = x[1] - gmean, d2 = x[2] - gmean, d3 = x[3] - gmean;
+        const float gm2 = row16_sum_dpp(fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0))));
+        if (m < M) {
+          *reinterpret_cast<gg_f32x4*>(resid + m * N + n0 + l * 4) = x;
+          gg_bf16x4 o4;
+#pragma unroll
+          for (int r = 0; r < 4; ++r) o4[r] = (__bf16)(x[r] * gamma4[r]);
+          *reinterpret_cast<gg_bf16x4*>(reinterpret_cast<bf16_t*>(ln.xg) + m * N + n0 + l * 4) = o4;
+          if ((l & 15) == 0) {
+            typedef float gg_f32x2 __attribute__((ext_vector_type(2)));
+            *reinterpret_cast<gg_f32x2*>(ln.stats_out + (m * (int64_t)(N / LN_GROUP) + (n0 + l * 4) / LN_GROUP) * 2) = gg_f32x2{gmean, gm2};
+          }
+        }
+      } else if (m < M) {
         if constexpr (EPI == EPI_RESID) {
           const gg_f32x4 f = gg_f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
           *reinterpret_cast<gg_f32x4*>(resid + m * N + n0 + l * 4) = old[it] + f;
@@ -317,26 +400,42 @@ int g_glds_swz = 0;   // "glds_swz": 1 = slot key (row >> 1) & 7 on the 8-wave t
 int g_glds_prio = 0;  // "glds_prio": s_setprio(1) around the MFMA cluster of the 8-wave tiles (A/B knob)
 int g_glds_w8 = 1;  // "glds_w8": 8-wave workgroups on the 128-row tiles as well (batch-1 NAR 12.0 -> 10.0 ms); 0 = 4 waves
 
+// the per-row pointers of a GemmLn, `rows` rows further down (leftover-row launches)
+static GemmLn gg_ln_rows(const GemmLn* ln, int64_t rows, int N, int K) {
+  GemmLn o = ln ? *ln : GemmLn();
+  if (o.xg) o.xg = (bf16_t*)o.xg + rows * N;
+  if (o.stats_out) o.stats_out += rows * (N / LN_GROUP) * 2;
+  if (o.stats_in) o.stats_in += rows * (K / LN_GROUP) * 2;
+  return o;
+}
+
 template <int BM, int BN, int NW = 4>
 static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const float* bias, void* out, float* resid, int64_t M,
-                     int N, int K, int epi) {
+                     int N, int K, int epi, const GemmLn* lnp = nullptr) {
   const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM)), block(NW * 64);
+  const GemmLn ln = lnp ? *lnp : GemmLn();
 #define VLE_GG(E)                                                                                                       \
   do {                                                                                                                  \
     if (NW == 8 && g_glds_swz)                                                                                          \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, (NW == 8) ? 1 : 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0); \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, (NW == 8) ? 1 : 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0, ln); \
     else if (NW == 8 && g_glds_prio)                                                                                    \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, (NW == 8), 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0); \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, (NW == 8), 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0, ln); \
     else                                                                                                                \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0);  \
+      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0, ln);  \
   } while (0)
+#define VLE_GG_LN(E) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, 0, ln)
   switch (epi) {
     case EPI_STORE: VLE_GG(EPI_STORE); break;
     case EPI_RELU: VLE_GG(EPI_RELU); break;
     case EPI_RESID: VLE_GG(EPI_RESID); break;
     case EPI_F32: VLE_GG(EPI_F32); break;
+    // LayerNorm folded into the GEMM (kernels.h GemmLn): the default body only (the swizzle / priority A-B variants stay un-folded)
+    case EPI_RESID_LNP: if (!ln.gamma || !ln.xg || !ln.stats_out || N % BN) return -1; VLE_GG_LN(EPI_RESID_LNP); break;
+    case EPI_STORE_LNC: if (!ln.stats_in || !ln.sg || N % BN || K > 1536 || K % 128) return -1; VLE_GG_LN(EPI_STORE_LNC); break;
+    case EPI_RELU_LNC: if (!ln.stats_in || !ln.sg || N % BN || K > 1536 || K % 128) return -1; VLE_GG_LN(EPI_RELU_LNC); break;
     default: return -1;
   }
+#undef VLE_GG_LN
 #undef VLE_GG
   return 0;
 }
@@ -352,9 +451,14 @@ int g_glds_tail = 1;
 // GEMMs of one utterance's NAR rows, M = 1025: 56 % of the CUs) the 272 tiles of 64 x 64 are faster -- NAR 8.52 -> 8.21 ms.
 int g_glds_t64 = 160;
 
+bool gemm_ln_supports(int dtype, int64_t M, int d) {
+  return dtype == DT_BF16 && M >= 128 && d % 256 == 0 && d >= 256 && d <= 1536 && g_glds_epi != 0;
+}
+
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
-                     int K, int epi) {
+                     int K, int epi, const GemmLn* ln) {
   if (K % 64 != 0 || K < 64 || M < 1 || N < 1 || N % 4 != 0) return 1;
+  if (epi >= EPI_RESID_LNP && (ln == nullptr || N % 256 != 0)) return -1;
   if (M < 128) return 1;  // tiny-M launches (AR step at batch > 8) stay on gemm.hip for now
   // tile choice: estimated time ~ rounds of full-cost tiles over 256 CUs x per-tile cost (~ BM*BN/eff)
   const int64_t full128 = (M / 128) * ((N + 127) / 128) + ((M % 128) ? ((N + 127) / 128) : 0);
@@ -368,36 +472,38 @@ int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* 
     const int64_t rem = M % 256, ncol = N / 256, cus = 256;
     const bool split = g_glds_tail != 0 && rem > 0 && N % 256 == 0 && ((M / 256) * ncol + cus - 1) / cus < (((M + 255) / 256) * ncol + cus - 1) / cus;
     const int64_t Mmain = split ? M - rem : M;
-    if (launch_gemm_8ph(st, A, W, bias, out, resid, Mmain, N, K, epi) == 0) {
+    if (launch_gemm_8ph(st, A, W, bias, out, resid, Mmain, N, K, epi, ln) == 0) {
       if (!split) return 0;
       const bf16_t* a2 = a + Mmain * K;
-      void* out2 = out == nullptr ? nullptr : (epi == EPI_F32 || epi == EPI_RESID) ? (void*)((float*)out + Mmain * N) : (void*)((bf16_t*)out + Mmain * N);
+      void* out2 = out == nullptr ? nullptr : (epi == EPI_F32 || epi == EPI_RESID || epi == EPI_RESID_LNP) ? (void*)((float*)out + Mmain * N) : (void*)((bf16_t*)out + Mmain * N);
       float* resid2 = resid == nullptr ? nullptr : resid + Mmain * N;
-      if (rem >= 128) return launch_gemm_glds(st, a2, W, bias, out2, resid2, rem, N, K, epi);
-      return gg_launch<64, 64>(st, a2, w, bias, out2, resid2, rem, N, K, epi);
+      const GemmLn ln2 = gg_ln_rows(ln, Mmain, N, K);
+      if (rem >= 128) return launch_gemm_glds(st, a2, W, bias, out2, resid2, rem, N, K, epi, ln ? &ln2 : nullptr);
+      return gg_launch<64, 64>(st, a2, w, bias, out2, resid2, rem, N, K, epi, ln ? &ln2 : nullptr);
     }
   }
   const int64_t t256 = (M / 256) * ((N + 127) / 128);
-  if (g_glds_big != 0 && t256 >= (g_glds_big > 0 ? g_glds_big : 512)) return gg_launch<256, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi);
+  if (g_glds_big != 0 && t256 >= (g_glds_big > 0 ? g_glds_big : 512)) return gg_launch<256, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi, ln);
   if (full128 >= 160 && g_glds_tail != 0) {
     // the same for the 128 x 128 tiles: one utterance's NAR rows (M = 1025 = 8 x 128 + 1) made linear1 9 x 32 = 288 tiles, a second
     // round for 32 one-row tiles
     const int64_t rem = M % 128, ncol = (N + 127) / 128, cus = 256;
     if (rem > 0 && rem <= 64 && M >= 256 && ((M / 128) * ncol + cus - 1) / cus < (((M + 127) / 128) * ncol + cus - 1) / cus) {
       const int64_t Mmain = M - rem;
-      const int r = launch_gemm_glds(st, A, W, bias, out, resid, Mmain, N, K, epi);
+      const int r = launch_gemm_glds(st, A, W, bias, out, resid, Mmain, N, K, epi, ln);
       if (r != 0) return r;
-      void* out2 = out == nullptr ? nullptr : (epi == EPI_F32 || epi == EPI_RESID) ? (void*)((float*)out + Mmain * N) : (void*)((bf16_t*)out + Mmain * N);
-      return gg_launch<64, 64>(st, a + Mmain * K, w, bias, out2, resid == nullptr ? nullptr : resid + Mmain * N, rem, N, K, epi);
+      void* out2 = out == nullptr ? nullptr : (epi == EPI_F32 || epi == EPI_RESID || epi == EPI_RESID_LNP) ? (void*)((float*)out + Mmain * N) : (void*)((bf16_t*)out + Mmain * N);
+      const GemmLn ln2 = gg_ln_rows(ln, Mmain, N, K);
+      return gg_launch<64, 64>(st, a + Mmain * K, w, bias, out2, resid == nullptr ? nullptr : resid + Mmain * N, rem, N, K, epi, ln ? &ln2 : nullptr);
     }
   }
   if (g_glds_w8) {  // 8 waves on the one-tile-per-CU shapes too (wave tile 32 x 64 / 32 x 32)
-    if (full128 >= 160) return gg_launch<128, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi);
-    if (t128x64 >= g_glds_t64) return gg_launch<128, 64, 8>(st, a, w, bias, out, resid, M, N, K, epi);
+    if (full128 >= 160) return gg_launch<128, 128, 8>(st, a, w, bias, out, resid, M, N, K, epi, ln);
+    if (t128x64 >= g_glds_t64) return gg_launch<128, 64, 8>(st, a, w, bias, out, resid, M, N, K, epi, ln);
   }
-  if (full128 >= 160) return gg_launch<128, 128>(st, a, w, bias, out, resid, M, N, K, epi);
-  if (t128x64 >= g_glds_t64) return gg_launch<128, 64>(st, a, w, bias, out, resid, M, N, K, epi);
-  return gg_launch<64, 64>(st, a, w, bias, out, resid, M, N, K, epi);
+  if (full128 >= 160) return gg_launch<128, 128>(st, a, w, bias, out, resid, M, N, K, epi, ln);
+  if (t128x64 >= g_glds_t64) return gg_launch<128, 64>(st, a, w, bias, out, resid, M, N, K, epi, ln);
+  return gg_launch<64, 64>(st, a, w, bias, out, resid, M, N, K, epi, ln);
 }
 
 }  // namespace vle

@@ -32,17 +32,39 @@ int launch_cross_entropy(hipStream_t st, const float* logits, const int64_t* tar
                          int ignore_index, int topk);
 
 // ---- gemm.hip -------------------------------------------------------------------------------
-enum { EPI_STORE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_F32 = 3 };
+enum { EPI_STORE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_F32 = 3,
+       // LayerNorm folded into the packed-row GEMMs (GemmLn below; bf16, gemm_glds.hip / gemm_8ph.hip only)
+       EPI_RESID_LNP = 4,   // EPI_RESID + producer side: bf16(x_new * gamma) and the statistics of every 64-column group of x_new
+       EPI_STORE_LNC = 5,   // consumer side: A holds x * gamma; out = bf16(rstd * (acc - mean * sg[n]) + bias[n])
+       EPI_RELU_LNC = 6 };  // ... with ReLU
+// LayerNorm of the residual stream without a LayerNorm launch (valle/modules/transformer.py:57-74, 93-108 with the AdaLN fold):
+//   LN(x) W^T + b  =  rstd * ((x * gamma) W^T - mean * sg) + tb,   sg[n] = sum_k W[n][k] gamma[k],  tb[n] = sum_k W[n][k] beta[k] + b[n].
+// The GEMM that completes the residual stream x (out-proj, linear2: EPI_RESID_LNP) also writes xg = bf16(x * gamma) of the NEXT
+// norm site and, per row and 64-column group, (mean, M2) of the group (exact two-pass over the 64 fp32 values); the GEMM that
+// reads the normalised row (in-proj, linear1: EPI_*_LNC) multiplies xg, combines the row's K / 64 group pairs (Chan) and applies
+// the affine in its epilogue -- `bias` must then be tb.  The layout of the statistics does not depend on tile sizes: any mix of
+// launches (tile policy, leftover-row launches) may produce and consume it.
+struct GemmLn {
+  const float* gamma = nullptr;   // producer: [N] of the next norm site
+  void* xg = nullptr;             // producer: bf16 [M][N]
+  float* stats_out = nullptr;     // producer: [M][N / 64][2]
+  const float* stats_in = nullptr;  // consumer: [M][K / 64][2]
+  const float* sg = nullptr;      // consumer: [N]
+};
+constexpr int LN_GROUP = 64;
 // out = epi(A[T, M x K] @ W[T, N x K]^T + bias)
 int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const float* bias, void* out, float* resid,
-                int64_t M, int N, int K, int epi);
+                int64_t M, int N, int K, int epi, const GemmLn* ln = nullptr);
+// the LNP / LNC epilogues exist for a layer of width d over M packed rows (bf16, M >= 128, every tile inside N whatever the tile
+// policy picks for N = d, 3 d, 4 d; the consumer combines up to 24 group pairs: d <= 1536)
+bool gemm_ln_supports(int dtype, int64_t M, int d);
 
 int launch_gemm_f32_strided(hipStream_t st, const float* A, int64_t lda, const float* W, const float* bias, float* out, float* resid,
                             int64_t M, int N, int K, int epi);
 
 // gemm_glds.hip: bf16, M >= 128, K % 64 == 0: LDS-DMA multi-stage pipeline; returns 1 when the shape is not covered
 int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
-                     int K, int epi);
+                     int K, int epi, const GemmLn* ln = nullptr);
 
 extern int g_attn_qw;
 extern int g_g8_colgroup;
@@ -53,7 +75,7 @@ extern int g_glds_tail;  // gemm_glds.hip: 1 = the rows past the last full 256-r
 extern int g_glds_swz;
 // gemm_8ph.hip: bf16, 256 x 256 tile, phase-split schedule; returns 1 when the shape is not covered
 int launch_gemm_8ph(hipStream_t st, const void* A, const void* W, const float* bias, void* out, float* resid, int64_t M, int N,
-                    int K, int epi);
+                    int K, int epi, const GemmLn* ln = nullptr);
 // gemm_fp8.hip: e4m3fn x e4m3fn on v_mfma_scale_f32_16x16x128_f8f6f4, per-row power-of-two scales on both operands
 // (engine mode FP8); returns 1 when the shape is not covered
 int launch_gemm_fp8(hipStream_t st, const void* A8, const float* a_scale, const void* W8, const float* w_scale, const float* bias,

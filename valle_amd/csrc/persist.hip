@@ -255,8 +255,18 @@ struct PsTrace {
   int i;
   unsigned long long t0;
 };
-__device__ inline void pt_begin(PsTrace& t) { if (t.p) t.t0 = wall_clock64(); }
+// TR (compile time): the untraced instantiations carry none of this -- a run-time `if (t.p)` at every hand-off cost 28 exec-masked
+// branches per layer and kept the trace state live in scalar registers through the whole step (layer loop 2873 -> 2500 instructions,
+// 323 -> 130 v_readlane of spilled scalars)
+template <bool TR>
+__device__ inline void pt_begin(PsTrace& t) {
+  if constexpr (TR) {
+    if (t.p) t.t0 = wall_clock64();
+  }
+}
+template <bool TR>
 __device__ inline void pt_end(PsTrace& t, unsigned passes) {
+  if constexpr (!TR) return;
   if (t.p && t.i + 3 <= PS_PT_SLOTS) {
     t.p[t.i] = t.t0; t.p[t.i + 1] = passes; t.p[t.i + 2] = wall_clock64();
     t.i += 3;
@@ -283,7 +293,7 @@ __host__ __device__ inline int ps_gran_per_layer(int d, int H, int NS) { return 
 //     barrier per LayerNorm instead of three.  Same arithmetic as the reference's LayerNorm + Linear up to fp32 re-association
 //     (valle/modules/transformer.py:57-74 then F.linear), so NOT bit-identical to the launch chain: tests/test_persist_gpu.py holds
 //     it to 1e-4 of the logits' spread against the three-barrier form and to bit-reproducibility against itself.
-template <typename T, int D, int H, int NK, int PF, int PK>
+template <typename T, int D, int H, int NK, int PF, int PK, bool TR = false>
 __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 
   constexpr int VEC = Elem<T>::VEC;
@@ -361,9 +371,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   const int nap_att = naps & 15, nap_x = (naps >> 4) & 15, nap_x2 = (naps >> 8) & 15, nap_hid = (naps >> 12) & 15, nap_qkv = (naps >> 16) & 15,
             nap_part = (naps >> 20) & 15;
   PsSpin sp{PS_SPINS, a.fail, (mode >> 8) & 15, 0u};
-  PsTrace pt{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)(it & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
-  pt_begin(pt);
-  pt_end(pt, 0u);
+  PsTrace pt{nullptr, 0, 0ull};
+  if constexpr (TR) pt.p = (a.ptrace && tid == 0) ? a.ptrace + ((size_t)(it & 7) * NWG + c) * PS_PT_SLOTS : nullptr;
+  pt_begin<TR>(pt);
+  pt_end<TR>(pt, 0u);
 
   const int GPL = ps_gran_per_layer(D, H, NS);
   const gran_t* const GB = a.gran;
@@ -531,9 +542,9 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   for (int step = 0; step < nsteps; ++step) {
   if (step > 0) {
     sp.budget = sp.budget ? PS_SPINS : 0u;  // a wave that gave up stays out; the others get a fresh budget per step
-    pt = PsTrace{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)(it & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
-    pt_begin(pt);
-    pt_end(pt, 0u);
+    if constexpr (TR) pt = PsTrace{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)(it & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
+    pt_begin<TR>(pt);
+    pt_end<TR>(pt, 0u);
   }
   for (int l = 0; l < a.L; ++l) {
     const PsLayer p = ps_layer(a.layers, l);
@@ -543,11 +554,11 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 
     // ======== (1) LN1 + in-projection of this head's 3 QR rows =================================================================
     if (l > 0) {
-      pt_begin(pt);
+      pt_begin<TR>(pt);
       nap(nap_x);
       if constexpr (PF == 1) ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, [&]() { issue_kv(p, s * CHUNK, kvl); });
       else ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, PsNoop());
-      pt_end(pt, sp.passes);
+      pt_end<TR>(pt, sp.passes);
       if constexpr (PF == 2) issue_kv(p, s * CHUNK, kvl);
     }
     if (tid == c) store_ept_lds<EPT>(sres, xv);  // thread c holds x[4c .. 4c+3]: the residual of the rows this workgroup owns
@@ -584,7 +595,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     if constexpr (PF == 0 || PF == 3) issue_kv(p, s * CHUNK, kvl);
 
     // ======== (2) q, k_new, v_new of the head; attention over this workgroup's share of the cached keys ==========================
-    pt_begin(pt);
+    pt_begin<TR>(pt);
     {
       // every wave sweeps (wave 3 repeats wave 0's granules and drops them): the requests the sweep carries stay straight-line code
       nap(nap_qkv);
@@ -596,7 +607,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if (w < 3 && lane < DH) (w == 0 ? sq : w == 1 ? sk : sv)[lane] = t;
     }
     g1_lds_barrier();
-    pt_end(pt, sp.passes);
+    pt_end<TR>(pt, sp.passes);
     if constexpr (PF == 2) issue_wo(p);
     __builtin_amdgcn_sched_barrier(0);
     {
@@ -728,7 +739,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         off = 0;
       }
       float t2[2];
-      pt_begin(pt);
+      pt_begin<TR>(pt);
       nap(nap_part);
       {
         const unsigned bo = (unsigned)((const char*)(gp + (size_t)j * (2 + DH) + off) - (const char*)GB);
@@ -743,7 +754,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         spo[j * QR + 2 * (t % (QR / 2)) + 1] = t2[1];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-      pt_end(pt, sp.passes);
+      pt_end<TR>(pt, sp.passes);
       // the chain's PRO_ATTN_SELF prologue for thread (head-local index s): gemv1.hip gemv1s_kernel, EPT = QR, NS splits
       float tq = 0.f;
       {
@@ -805,7 +816,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     {
       constexpr int NA = apack ? EPT / 2 : EPT;
       float av[EPT], raw[NA];
-      pt_begin(pt);
+      pt_begin<TR>(pt);
       if constexpr (PF == 3) issue_w1_rows(p, 0, R1 - 1);  // in place of most of the nap: ~6 MB chip-wide land inside the edge's own latency
       nap(nap_att);
       if constexpr (PF == 1) ps_gather<NA>(GB, rs, G + G_ATT + tid * NA, epoch, raw, sp, [&]() { issue_w1(p); });
@@ -823,7 +834,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       }
       store_ept_lds<EPT>(sx + tid * EPT, av);
       g1_lds_barrier();
-      pt_end(pt, sp.passes);
+      pt_end<TR>(pt, sp.passes);
       if constexpr (PF == 2) issue_w1(p);
       __builtin_amdgcn_sched_barrier(0);
       float x[NCH][VEC];
@@ -842,11 +853,11 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 
     // ======== (5) LN2 + linear1 + ReLU of rows 16c .. 16c+15 ======================================================================
     {
-      pt_begin(pt);
+      pt_begin<TR>(pt);
       nap(nap_x2);
       if constexpr (PF == 1) ps_gather<EPT>(GB, rs, G + G_X2 + tid * EPT, epoch, xv, sp, [&]() { issue_w2(p); });
       else ps_gather<EPT>(GB, rs, G + G_X2 + tid * EPT, epoch, xv, sp, PsNoop());
-      pt_end(pt, sp.passes);
+      pt_end<TR>(pt, sp.passes);
       if constexpr (PF == 2) issue_w2(p);
       __builtin_amdgcn_sched_barrier(0);
       if (tid == c) store_ept_lds<EPT>(sres, xv);
@@ -876,7 +887,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     {
       constexpr int NHG = hpack ? EPT2 / 2 : EPT2;
       float hv[EPT2], raw[NHG];
-      pt_begin(pt);
+      pt_begin<TR>(pt);
       nap(nap_hid);
       if constexpr (PF == 1) ps_gather<NHG>(GB, rs, G + G_HID + tid * NHG, epoch, raw, sp, [&]() { issue_wqkv(pn, last); });
       else ps_gather<NHG>(GB, rs, G + G_HID + tid * NHG, epoch, raw, sp, PsNoop());
@@ -893,7 +904,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       }
       store_ept_lds<EPT2>(sx + tid * EPT2, hv);
       g1_lds_barrier();
-      pt_end(pt, sp.passes);
+      pt_end<TR>(pt, sp.passes);
       if constexpr (PF == 2) issue_wqkv(pn, last);
       __builtin_amdgcn_sched_barrier(0);
       float x[NCH2][VEC];
@@ -910,10 +921,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   // ======== final norm + predict layer: rows 4c .. 4c+3 (+ row 1024) ================================================================
   {
     gran_t* const G = a.gran + (size_t)a.L * GPL;
-    pt_begin(pt);
+    pt_begin<TR>(pt);
     nap(nap_x);
     ps_gather<EPT>(GB, rs, G + G_X + tid * EPT, epoch, xv, sp, PsNoop());
-    pt_end(pt, sp.passes);
+    pt_end<TR>(pt, sp.passes);
     float ln_mean = 0.f, ln_rstd = 1.f;
     if constexpr (LF) fold_stats(xv, g1v, ln_mean, ln_rstd);
     else g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
@@ -957,11 +968,11 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       ps_load4(as_g<float>((unsigned long long)q.pe) + (int64_t)pe_row * D + tid * EPT, pev);
       const float alpha = *q.alpha_audio;
       float lg4[EPT], lgx;
-      pt_begin(pt);
+      pt_begin<TR>(pt);
       nap(nap_x);
       gather_vals16_plus1<EPT>(rs, (unsigned)((const char*)(G + G_LOG + tid * EPT) - (const char*)GB),
                                (unsigned)((const char*)(G + G_LOG + 4 * NWG) - (const char*)GB), epoch, lg4, lgx, sp);
-      pt_end(pt, sp.passes);
+      pt_end<TR>(pt, sp.passes);
       store_ept_lds<EPT>(slog + tid * EPT, lg4);
       if (tid == 0) slog[4 * NWG] = lgx;
       __syncthreads();
@@ -1036,8 +1047,8 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       it += 1;
       epoch = (unsigned)(it + 1);
     }
-    pt_begin(pt);
-    pt_end(pt, 0u);
+    pt_begin<TR>(pt);
+    pt_end<TR>(pt, 0u);
   }
   }  // step
 }
@@ -1088,6 +1099,23 @@ bool pstep_supports(int dtype, int d, int nhead, int dh, int V) {
 
 size_t pstep_gran_count(int d, int nhead, int L) { return (size_t)(L + 1) * ps_gran_per_layer(d, nhead, 256 / nhead); }
 
+// The timeline (option "persist_trace") exists for the shipped schedule (NK = 2, PF = 3), every packing mode; other schedules run
+// untraced (their trace buffer stays zero).
+static int ps_launch_traced(hipStream_t st, const PStepArgs& a) {
+  const dim3 grid(256), block(PS_T);
+  switch (((a.mode >> 2) & 3) | ((a.mode >> 3) & 4)) {
+    case 0: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 0, true>), grid, block, 0, st, a); break;
+    case 1: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 1, true>), grid, block, 0, st, a); break;
+    case 2: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 2, true>), grid, block, 0, st, a); break;
+    case 3: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 3, true>), grid, block, 0, st, a); break;
+    case 4: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 4, true>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 5, true>), grid, block, 0, st, a); break;
+    case 6: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 6, true>), grid, block, 0, st, a); break;
+    default: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 7, true>), grid, block, 0, st, a); break;
+  }
+  return 0;
+}
+
 template <int NK, int PF>
 static int ps_launch_pk(hipStream_t st, const PStepArgs& a) {
   const dim3 grid(256), block(PS_T);
@@ -1109,6 +1137,7 @@ int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
   if (!a.layers || !a.x_in || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
   if (a.nsteps < 0 || a.nsteps > 4096 || (a.nsteps > 0 && !a.smp)) return -1;
+  if (a.ptrace != nullptr && a.nk != 4 && a.pf == 3) return ps_launch_traced(st, a);
   if (a.nk == 4) return a.pf == 0 ? ps_launch_pk<4, 0>(st, a) : a.pf == 1 ? ps_launch_pk<4, 1>(st, a) : a.pf == 2 ? ps_launch_pk<4, 2>(st, a) : ps_launch_pk<4, 3>(st, a);
   return a.pf == 0 ? ps_launch_pk<2, 0>(st, a) : a.pf == 1 ? ps_launch_pk<2, 1>(st, a) : a.pf == 2 ? ps_launch_pk<2, 2>(st, a) : ps_launch_pk<2, 3>(st, a);
 }

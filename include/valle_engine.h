@@ -244,6 +244,19 @@ int vle_op_linear(void* stream, int dtype, const void* a, const void* w, const f
  * summed in slice order.  ksplit: 0 = chosen from the shape; other shapes ignore the workspace. */
 int vle_op_linear_ws(void* stream, int dtype, const void* a, const void* w, const float* bias, void* out, float* resid,
                      int64_t M, int32_t N, int32_t K, int epilogue, void* workspace, int32_t ksplit);
+/* LayerNorm folded into the packed-row GEMMs of the prefill / NAR passes (valle/modules/transformer.py:57-74 LayerNorm, :93-108
+ * AdaptiveLayerNorm, followed by F.linear): LN(x) W^T + b = rstd * ((x * gamma) W^T - mean * sg) + tb with sg = W gamma,
+ * tb = W beta + b.  The two halves as stand-alone operators, bf16 operands:
+ *   producer: resid[M][N] (fp32) += a[M][K] @ w[N][K]^T + bias; xg[M][N] = bf16(resid * gamma);
+ *             stats[M][N / 64][2] = (mean, sum of squared deviations) of every 64-column group of the completed row;
+ *   consumer: out[M][N] = bf16(act(rstd_m * (xg[M][K] @ w[N][K]^T - mean_m * sg[n]) + tb[n])), the row's mean / rstd combined
+ *             from stats[M][K / 64][2] (eps 1e-5, biased variance), act = ReLU when relu != 0.
+ * M >= 128; the normalised width (producer N, consumer K) a multiple of 256 and <= 1536; the other dimension a multiple of 256
+ * (consumer N) / of 128 (producer K). */
+int vle_op_linear_ln_producer(void* stream, const void* a, const void* w, const float* bias, float* resid, const float* gamma,
+                              void* xg, float* stats, int64_t M, int32_t N, int32_t K);
+int vle_op_linear_ln_consumer(void* stream, const void* xg, const void* w, const float* tb, const float* sg, const float* stats,
+                              void* out, int64_t M, int32_t N, int32_t K, int32_t relu);
 int64_t vle_op_linear_workspace_bytes(void);
 /* The two weight-streaming kernels of the AR step on FP8W weights (w8 e4m3fn [N x K], wscale f32 [N], DEVICE):
  * vle_op_linear_skinny_fp8w: one utterance (gemv1.hip), contract of vle_op_linear_skinny with M = 1;

@@ -614,3 +614,42 @@ def test_batch1_step_where_the_fused_launch_lacks_its_out_proj_gemv(d, h, dtype)
             mine = eng.fetch_ar_logits()[:, 0]
             err = (mine - ref).abs().max().item()
             assert err <= 0.05 * ref.std().item(), (d, h, ns, err)
+
+
+@pytest.mark.parametrize("dtype", ["bf16", "fp8w"])
+def test_layernorm_folded_into_the_packed_row_gemms_matches_the_layernorm_launches(dtype):
+    """Option "ln_fold" (default 1): the prefill and the 7 NAR passes run 5 launches per layer -- the LayerNorms ride on the residual
+    GEMMs' epilogues (kernels.h GemmLn).  Against the same engine with the LayerNorm launches (ln_fold = 0), teacher-forced on one
+    history: the prefill's logits and every NAR stage's logits within 2 % of their spread (two bf16 roundings of different
+    quantities, each within ~1 % of exact), codes equal wherever the margin allows; and deterministic run to run."""
+    cfg = vo.OracleConfig(d_model=256, nhead=4, num_layers=3, prefix_mode=1)
+    sd = vo.make_state_dict(cfg, 21)
+    S, P, G = 24, 110, 60  # 134 prefill rows, 194 NAR rows: the folded path needs >= 128 packed rows
+    x, xl, y = vo.make_inputs(S, P, seed=5)
+    m = build_model(cfg, sd, dtype)
+    eng = m.engine_for(1, S, P)
+    for k in ("trace_ar_logits", "trace_nar_logits", "ignore_eos"):
+        eng.set_option(k, 1)
+    X, Y = x.to(DEV), y.to(DEV)
+
+    def run(fold, forced=None, nar_forced=None):
+        eng.set_option("ln_fold", fold)
+        eng.prefill(X, [S], Y, [P])
+        kw = dict(forced=forced, forced_lens=[G]) if forced is not None else dict(max_new=G)
+        c0, gl = eng.generate(top_k=1, **kw)
+        ar = eng.fetch_ar_logits()[:, 0].clone()
+        codes = eng.nar(None, forced=nar_forced).clone()
+        return c0[:, : gl[0]].clone(), ar, codes, [eng.fetch_nar_logits(i).clone() for i in range(7)]
+
+    tok, ar0, codes0, nar0 = run(0)
+    _, ar1, codes1, nar1 = run(1, forced=tok, nar_forced=codes0)
+    _, ar2, codes2, nar2 = run(1, forced=tok, nar_forced=codes0)
+    assert torch.equal(ar1, ar2) and torch.equal(codes1, codes2) and all(torch.equal(a, b) for a, b in zip(nar1, nar2))
+    sig = ar0.std().item()
+    assert (ar1[0] - ar0[0]).abs().max().item() <= 0.02 * sig, "prefill logits"
+    assert (ar1 - ar0).abs().max().item() <= 0.03 * sig, "AR steps on the folded prefill's K/V cache"
+    for i in range(7):
+        s_i = nar0[i].std().item()
+        assert (nar1[i] - nar0[i]).abs().max().item() <= 0.02 * s_i, (i, (nar1[i] - nar0[i]).abs().max().item(), s_i)
+    assert (codes1 == codes0).float().mean().item() > 0.97
+    eng.set_option("ln_fold", 1)

@@ -465,6 +465,58 @@ def test_linear_gemm_leftover_rows_as_a_second_launch(M, N, K):
     assert (split[1][tail].double() - ref[tail]).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
 
 
+# (M, d): every tile policy of gemm_glds.hip / gemm_8ph.hip the prefill / NAR rows meet -- 64 x 64 (few rows), 128 x 64 / 128 x 128 with the
+# 64 x 64 leftover launch (one utterance, M = 1025), 256 x 128, 256 x 256 phase-split + leftover rows (batched NAR rows), d 1536 (24 groups)
+@pytest.mark.parametrize("M,d", [(128, 256), (272, 1024), (1025, 1024), (2 * 1025, 1024), (8 * 1025, 1024), (33 * 1025, 1024), (1025, 1536), (12 * 1025, 1536)])
+def test_layernorm_folded_into_the_gemms_equals_layernorm_then_linear(M, d):
+    """kernels.h GemmLn: the GEMM that completes the residual stream (out-proj / linear2, here K = d and K = 4 d) also leaves
+    xg = bf16(x * gamma) and per-64-column-group (mean, M2); the GEMM that reads the normalised row (in-proj / linear1) multiplies xg
+    and applies rstd * (acc - mean * sg) + tb.  Against the fp64 definition LayerNorm(x) W^T + b of valle/modules/transformer.py:57-74
+    + F.linear (biased variance, eps 1e-5), with a row mean several times the row's spread (the fold's cancellation case)."""
+    g = torch.Generator().manual_seed(5 + M + d)
+    for Kp in (d, 4 * d):  # producer K: out-proj, linear2
+        a = (torch.randn(M, Kp, generator=g) * 0.5).to(torch.bfloat16).to(DEV)
+        wp = (torch.randn(d, Kp, generator=g) / math.sqrt(Kp)).to(torch.bfloat16).to(DEV)
+        bp = (torch.randn(d, generator=g) * 0.1).to(DEV)
+        x0 = (torch.randn(M, d, generator=g) * 1.5 + torch.randn(M, 1, generator=g) * 2.0).to(DEV)  # row means up to several sigma
+        gamma = (1.0 + 0.3 * torch.randn(d, generator=g)).to(DEV)
+        beta = (0.2 * torch.randn(d, generator=g)).to(DEV)
+        x_ref = x0.double() + a.double() @ wp.double().t() + bp.double()
+        x = x0.clone()
+        xg, stats = ops.linear_ln_producer(a, wp, bp, x, gamma)
+        torch.cuda.synchronize()
+        tol = 3e-5 * math.sqrt(Kp / 64) * max(1.0, x_ref.abs().max().item())
+        assert (x.double() - x_ref).abs().max().item() < tol, "residual stream"
+        # the side products are functions of the fp32 row the kernel stored: exact definitions on x itself
+        assert torch.equal(xg, (x * gamma).to(torch.bfloat16)), "bf16(x * gamma)"
+        xg64 = x.double().view(M, d // 64, 64)
+        gm = xg64.mean(-1)
+        gm2 = ((xg64 - gm[..., None]) ** 2).sum(-1)
+        assert (stats[..., 0].double() - gm).abs().max().item() < 1e-5 * max(1.0, gm.abs().max().item())
+        assert ((stats[..., 1].double() - gm2).abs() / gm2.clamp_min(1e-3)).max().item() < 1e-4
+        for N, relu in ((3 * d, False), (4 * d, True)):  # consumers: in-projection, linear1 + ReLU
+            wc = (torch.randn(N, d, generator=g) / math.sqrt(d)).to(torch.bfloat16).to(DEV)
+            bc = (torch.randn(N, generator=g) * 0.1).to(DEV)
+            sg = (wc.double() @ gamma.double()).float()
+            tb = (wc.double() @ beta.double() + bc.double()).float()
+            out = ops.linear_ln_consumer(xg, wc, tb, sg, stats, relu=relu)
+            mean = x.double().mean(-1, keepdim=True)
+            var = ((x.double() - mean) ** 2).mean(-1, keepdim=True)
+            ln = (x.double() - mean) / torch.sqrt(var + 1e-5) * gamma.double() + beta.double()
+            ref = ln @ wc.double().t() + bc.double()
+            if relu:
+                ref = ref.clamp_min(0)
+            # what the un-folded path computes: bf16(LN(x)) @ W -- the fold must sit as close to the definition as that does
+            unf = ln.to(torch.bfloat16).double() @ wc.double().t() + bc.double()
+            if relu:
+                unf = unf.clamp_min(0)
+            scale = max(1.0, ref.abs().max().item())
+            e_fold = (out.double() - ref).abs().max().item() / scale
+            e_unf = (unf.to(torch.bfloat16).double() - ref).abs().max().item() / scale
+            assert e_fold < max(3 * e_unf, 0.02), (M, d, Kp, N, e_fold, e_unf)
+            assert (out.double() - ref).abs().mean().item() / scale < 2e-3
+
+
 @pytest.mark.parametrize("formal", [0, 1])
 def test_skinny_gemm_split_k_handoff_under_memory_pressure(formal):
     """`formal` = 1: the same hand-off with explicit agent-scope release / acquire fences around the ticket (knob "gs_formal").

@@ -55,6 +55,8 @@ SIGNATURES = {
     "vle_op_linear": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int]),
     "vle_op_linear_ws": (C.c_int, [_P, C.c_int, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int, _P, C.c_int32]),
     "vle_op_linear_workspace_bytes": (C.c_int64, []),
+    "vle_op_linear_ln_producer": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32]),
+    "vle_op_linear_ln_consumer": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, C.c_int64, C.c_int32, C.c_int32, C.c_int32]),
     "vle_op_tune": (C.c_int, [C.c_char_p, C.c_int64]),
     "vle_quantize_fp8w": (C.c_int, [_P, C.c_int64, C.c_int64, _P, _P, _P]),
     "vle_op_linear_skinny_fp8w": (C.c_int, [_P, _P, _P, _P, _P, _P, _P, _P, _P, C.c_int32, C.c_int32, C.c_int]),

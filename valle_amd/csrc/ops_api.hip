@@ -86,6 +86,26 @@ extern "C" int vle_op_linear_ws(void* stream, int dtype, const void* a, const vo
   return op_linear(stream, dtype, a, w, bias, out, resid, M, N, K, epilogue, workspace, ksplit, "vle_op_linear_ws");
 }
 
+// LayerNorm folded into the packed-row GEMMs (kernels.h GemmLn), the two halves as stand-alone operators (bf16):
+//   producer: resid[M][N] += a @ w^T + bias; xg = bf16(resid * gamma); stats[M][N / 64][2] = (mean, M2) of every 64-column group
+//   consumer: out[M][N] = bf16(act(rstd * (xg @ w^T - mean * sg) + tb)) with the rows' mean / rstd combined from stats[M][K / 64][2]
+extern "C" int vle_op_linear_ln_producer(void* stream, const void* a, const void* w, const float* bias, float* resid, const float* gamma,
+                                         void* xg, float* stats, int64_t M, int32_t N, int32_t K) {
+  if (!a || !w || !resid || !gamma || !xg || !stats) return op_fail("vle_op_linear_ln_producer: null operand");
+  if (!gemm_ln_supports(DT_BF16, M, N) || K % 128 != 0 || K < 256) return op_fail("vle_op_linear_ln_producer: shape not covered (M >= 128, N % 256 == 0, N <= 1536, K % 128 == 0)");
+  GemmLn ln;
+  ln.gamma = gamma; ln.xg = xg; ln.stats_out = stats;
+  return op_done(launch_gemm((hipStream_t)stream, DT_BF16, a, w, bias, nullptr, resid, M, N, K, EPI_RESID_LNP, &ln), "vle_op_linear_ln_producer");
+}
+extern "C" int vle_op_linear_ln_consumer(void* stream, const void* xg, const void* w, const float* tb, const float* sg, const float* stats,
+                                         void* out, int64_t M, int32_t N, int32_t K, int32_t relu) {
+  if (!xg || !w || !tb || !sg || !stats || !out) return op_fail("vle_op_linear_ln_consumer: null operand");
+  if (!gemm_ln_supports(DT_BF16, M, K) || N % 256 != 0) return op_fail("vle_op_linear_ln_consumer: shape not covered (M >= 128, K % 256 == 0, K <= 1536, N % 256 == 0)");
+  GemmLn ln;
+  ln.stats_in = stats; ln.sg = sg;
+  return op_done(launch_gemm((hipStream_t)stream, DT_BF16, xg, w, tb, out, nullptr, M, N, K, relu ? EPI_RELU_LNC : EPI_STORE_LNC, &ln), "vle_op_linear_ln_consumer");
+}
+
 extern "C" int vle_op_linear_skinny_fp8w(void* stream, const float* x, const float* gamma, const float* beta, const void* w8,
                                          const float* wscale, const float* bias, float* out, float* resid, int32_t N, int32_t K,
                                          int epilogue) {

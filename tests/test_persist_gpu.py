@@ -82,20 +82,27 @@ def test_folded_layernorm_matches_the_three_barrier_form(c2_model, nk, pf, mode)
     """LN(x) . W[n] = rstd * (sum_k W[n][k] gamma[k] x[k] - mean * sg[n]) + tb[n]: the same numbers as LayerNorm followed by the
     linear layer (valle/modules/transformer.py:57-74, :296-302) up to fp32 re-association -- which the bf16 roundings of the K/V cache
     and of the packed hidden row amplify to at most a few 1e-4 of the logits' spread (measured 6.4e-4 sigma); bar 5e-3 sigma, every
-    step, teacher-free over 96 steps, and the greedy tokens agree."""
+    step over 96 steps.  The folded form is teacher-forced on the three-barrier form's greedy history (a free-running comparison
+    measures where the first sub-noise arg-max tie falls, not the arithmetic: with round 5's folded prefill one of the four
+    parameter sets met such a tie and diverged); its own arg-max must agree wherever the margin exceeds the bar."""
     S, P, steps = 47, 225, 96
     eng = c2_model.engine_for(1, S, P)
     X, Y = _inputs(S, P, seed=5)
     opts = {"persist": 1, "persist_nk": nk, "persist_pf": pf, "act_bf16": _mode_to_act(mode)}
     ref_codes, ref = _decode(eng, X, Y, S, P, steps, dict(opts, persist_mode=mode & ~32))
-    got_codes, got = _decode(eng, X, Y, S, P, steps, dict(opts, persist_mode=mode))
-    assert eng.fetch_u32("persist_active") == 1 and eng.fetch_u32("persist_fail") == 0
+    got_codes, got = _decode(eng, X, Y, S, P, 0, dict(opts, persist_mode=mode), forced=ref_codes[None].to(DEV), forced_lens=[ref_codes.numel()])
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+    assert torch.equal(got_codes, ref_codes)  # (the forced history)
     n = min(ref.shape[0], got.shape[0])
     sigma = ref[:n].std().item()
     err = (ref[:n] - got[:n]).abs().max().item()
     assert not torch.equal(ref[:n], got[:n]), "the folded form did not run (identical bits)"
     assert err <= 5e-3 * sigma, f"max |dlogit| {err:.3e} vs sigma {sigma:.3e}"
-    assert torch.equal(ref_codes, got_codes)
+    top2 = ref[:n].topk(2, dim=-1).values
+    safe = (top2[:, 0] - top2[:, 1]) > 2 * 5e-3 * sigma
+    own = eng.fetch_sampled()[0, : ref_codes.numel()]
+    k = min(n, own.numel())
+    assert torch.equal(own[:k][safe[:k]], ref[:k].argmax(-1)[safe[:k]])
 
 
 def test_persistent_step_past_1024_keys_and_at_full_length(c2_model):

@@ -309,10 +309,18 @@ static int guard_alloc(int device, void** out, size_t bytes, const char* tag, in
 static void debug_alloc_note(void* q, size_t bytes, const char* tag) {
   static const int log_on = [] { const char* v = getenv("VLE_ALLOC_LOG"); return v ? atoi(v) : 0; }();
   static const int poison = [] { const char* v = getenv("VLE_POISON_ALLOC"); return v ? (int)strtol(v, nullptr, 0) : -1; }();
+  // VLE_POISON_RANGE=a:b restricts the poison to allocations number a .. b - 1 of the process (bisecting WHICH buffer a NaN came from)
+  static const std::pair<int, int> range = [] {
+    const char* v = getenv("VLE_POISON_RANGE");
+    int a = 0, b = 1 << 30;
+    if (v) sscanf(v, "%d:%d", &a, &b);
+    return std::make_pair(a, b);
+  }();
   static std::atomic<int> seq{0};
-  if (poison >= 0) (void)hipMemset(q, poison & 0xff, bytes);
+  const int n = seq.fetch_add(1);
+  if (poison >= 0 && n >= range.first && n < range.second) (void)hipMemset(q, poison & 0xff, bytes);
   if (log_on) {
-    fprintf(stderr, "[alloc] #%d %s %zu bytes at %p .. %p\n", seq.fetch_add(1), tag, bytes, q, (void*)((char*)q + bytes));
+    fprintf(stderr, "[alloc] #%d %s %zu bytes at %p .. %p\n", n, tag, bytes, q, (void*)((char*)q + bytes));
     fflush(stderr);
   }
 }

@@ -406,9 +406,10 @@ def main():
     ap.add_argument("--no-c3", action="store_true", help="skip the extra batch-64-per-GPU (BASELINE configs[2] / [3]) object")
     ap.add_argument("--no-side", action="store_true", help="headline only: no c3_batch64 / fp32_exact / c5_share_fp8 legs (profiling runs)")
     ap.add_argument("--no-fp32", action="store_true", help="skip the extra fp32_exact object (token-exact engine mode) of the N = 1 line")
-    ap.add_argument("--no-c5", action="store_true", help="skip the extra `c5_share_fp8` object of the N = 1 line: the per-GPU share of BASELINE "
-                                                         "configs[4] (d1536-L24-h16, fp8 weights + fp8 MFMA, 32 utterances; ~20 s on an MI355X box "
+    ap.add_argument("--no-c5", action="store_true", help="skip the extra `c5_share_fp8w` object of the N = 1 line: the per-GPU share of BASELINE "
+                                                         "configs[4] (d1536-L24-h16, fp8 weights, 32 utterances; ~20 s on an MI355X box "
                                                          "now that the host-side weight preparation is multi-threaded)")
+    ap.add_argument("--c5-fp8", action="store_true", help="also time the configs[4] share in engine mode fp8 (looser parity bar than fp8w)")
     ap.add_argument("--c5", action="store_true", help=argparse.SUPPRESS)  # round-2 spelling: the leg is on by default now
     ap.add_argument("--opt", action="append", default=[], metavar="NAME=VALUE", help="engine tuning option (vle_set_option), repeatable")
     ap.add_argument("--dump-codes", default="", metavar="FILE", help="rank 0 saves the last step's gathered codes (list of (G, 8) int64 tensors, "
@@ -635,8 +636,12 @@ def main():
                                            label="; engine mode fp32 = greedy token ids bit-identical to the reference (tests/test_parity_sizes_gpu.py)"), False)
     if plain and world == 1 and not args.no_c5 and (args.d_model, args.layers, args.nhead) == (1024, 12, 16):
         del model
+        # BASELINE configs[4] is quoted on fp8w -- the config's WEIGHT format, which holds the 5 % sigma parity bar at this architecture.
+        # Engine mode fp8 (per-row e4m3 activations on the block-scaled MFMA) is held to a looser bar (15 % sigma max / 3 % mean,
+        # tests/test_parity_sizes_gpu.py) and its MX per-32-column activation scales were not built: it is measured only on request.
         leg("c5_share_fp8w", lambda: c5_leg(args, dev, "fp8w"), False)
-        leg("c5_share_fp8", lambda: c5_leg(args, dev, "fp8"), False)
+        if args.c5_fp8:
+            leg("c5_share_fp8", lambda: c5_leg(args, dev, "fp8"), False)
     if out is not None:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -105,6 +105,39 @@ def test_folded_layernorm_matches_the_three_barrier_form(c2_model, nk, pf, mode)
     assert torch.equal(own[:k][safe[:k]], ref[:k].argmax(-1)[safe[:k]])
 
 
+@pytest.mark.parametrize("mode", [0x174, 0x17c])
+def test_bf16_activation_rows_with_dot2_match_the_fp32_rows(c2_model, mode):
+    """persist_mode bit 6 (D2): the operators' input rows sit in LDS as bf16 and the dot products run on v_dot2c_f32_bf16.  For
+    linear2 (and, with bit 3, out-proj) the row already travels as bf16 pairs -- the same products in another summation order; the
+    in-projection, linear1 and the predict layer round x * gamma to bf16 first, as the batched step's MFMA GEMMs do.  Teacher-forced
+    on the fp32-row form's greedy history over 96 steps: every logit within 3 % of the logits' spread (mean 0.5 %), the arg-max equal
+    wherever the margin exceeds that, and bit-reproducible run to run."""
+    S, P, steps = 47, 225, 96
+    eng = c2_model.engine_for(1, S, P)
+    X, Y = _inputs(S, P, seed=6)
+    opts = {"persist": 1, "persist_nk": 2, "persist_pf": 3, "act_bf16": _mode_to_act(mode)}
+    ref_codes, ref = _decode(eng, X, Y, S, P, steps, dict(opts, persist_mode=mode & ~64))
+    forced = dict(forced=ref_codes[None].to(DEV), forced_lens=[ref_codes.numel()])
+    _, got = _decode(eng, X, Y, S, P, 0, dict(opts, persist_mode=mode), **forced)
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+    own = eng.fetch_sampled()[0, : ref_codes.numel()].clone()
+    _, again = _decode(eng, X, Y, S, P, 0, dict(opts, persist_mode=mode), **forced)
+    assert torch.equal(got, again)
+    n = min(ref.shape[0], got.shape[0])
+    sigma = ref[:n].std().item()
+    diff = (ref[:n] - got[:n]).abs()
+    assert not torch.equal(ref[:n], got[:n]), "the dot2 form did not run (identical bits)"
+    print(f"D2 mode {mode:#x}: max |dlogit| {diff.max().item() / sigma:.3%} of sigma, mean {diff.mean().item() / sigma:.4%}")
+    assert diff.max().item() <= 3e-2 * sigma and diff.mean().item() <= 5e-3 * sigma
+    top2 = ref[:n].topk(2, dim=-1).values
+    k = min(n, own.numel())
+    safe = ((top2[:, 0] - top2[:, 1]) > 2 * 3e-2 * sigma)[:k]
+    assert torch.equal(own[:k][safe], ref[:k].argmax(-1)[safe])
+    # the request schedule without the spread (pf = 0) computes the same bits
+    _, pf0 = _decode(eng, X, Y, S, P, 0, dict(opts, persist_mode=mode, persist_pf=0), **forced)
+    assert torch.equal(got, pf0)
+
+
 def test_persistent_step_past_1024_keys_and_at_full_length(c2_model):
     """BASELINE configs[1]'s own lengths plus a longer text: the context passes 1024 keys, where a workgroup's attention share
     takes a second round of key chunks (16 splits x 64 keys per round at 2 keys per lane)."""

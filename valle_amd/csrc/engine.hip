@@ -318,7 +318,12 @@ static void debug_alloc_note(void* q, size_t bytes, const char* tag) {
   }();
   static std::atomic<int> seq{0};
   const int n = seq.fetch_add(1);
-  if (poison >= 0 && n >= range.first && n < range.second) (void)hipMemset(q, poison & 0xff, bytes);
+  if (poison >= 0 && n >= range.first && n < range.second) {
+    // synchronous: an allocation made inside a call (the logit trace of vle_ar_generate) is written by the engine's stream right away,
+    // and a fill still in flight on the null stream would land on top of those writes (seen: NaN "logits" that were never computed)
+    (void)hipMemset(q, poison & 0xff, bytes);
+    (void)hipDeviceSynchronize();
+  }
   if (log_on) {
     fprintf(stderr, "[alloc] #%d %s %zu bytes at %p .. %p\n", n, tag, bytes, q, (void*)((char*)q + bytes));
     fflush(stderr);
@@ -1009,8 +1014,7 @@ static int alloc_buffers(vle_engine* e) {
     E_HIP(e, hipMemset(p, 0, gemm_skinny_workspace_bytes()));
     e->gs_ws = p;
     // free / finished slots and the rows that pad the batch to whole 16-row fragments keep whatever they held: start from finite
-    // values everywhere (VLE_POISON_ALLOC=0xff, round 5: the fused-LayerNorm step at 33 utterances, d 1536, fp8w produced NaN logits
-    // from never-written padding rows -- harmless only as long as fresh memory happens to hold zeros)
+    // values everywhere (MFMA rows are independent, so a NaN there cannot reach a live row -- this is hygiene, not a fix)
     E_HIP(e, hipMemset(e->xn_step, 0, Bp * d * es));
     E_HIP(e, hipMemset(e->qkv_step, 0, (size_t)B * 3 * d * es));
     E_HIP(e, hipMemset(e->att_step, 0, Bp * d * es));

@@ -100,7 +100,42 @@ __device__ inline void gran_store_bits(gran_t* p, unsigned epoch, unsigned bits)
 __device__ inline void gran_store_local(gran_t* p, unsigned epoch, unsigned bits) {
   *reinterpret_cast<gran_t PS_GLOBAL*>((unsigned long long)p) = ((gran_t)epoch << 32) | (gran_t)bits;
 }
-__device__ inline unsigned pack_bf16x2(float lo, float hi) { return (unsigned)f32_to_bf16(lo) | ((unsigned)f32_to_bf16(hi) << 16); }
+// two fp32 -> one bf16 pair, round-to-nearest-even: v_cvt_pk_bf16_f32 (for finite values the bits of common.h f32_to_bf16, which the
+// launch chain applies to the same rows -- 10 integer instructions per pair there)
+__device__ inline unsigned pack_bf16x2(float lo, float hi) {
+  typedef __bf16 pk_bf16x2 __attribute__((ext_vector_type(2)));
+  const pk_bf16x2 v = pk_bf16x2{(__bf16)lo, (__bf16)hi};
+  return __builtin_bit_cast(unsigned, v);
+}
+
+// D2 (PK bit 3): the operator's input row sits in LDS as bf16 and the dot products run on v_dot2c_f32_bf16 -- two multiply-adds per
+// lane and instruction on the 16-byte weight vectors as they arrive, no widening of either operand (per 8 weights: 4 instructions
+// instead of 8 shifts / masks + 4 packed FMAs, and half the LDS reads).  The hidden row and (mode bit 3) the attention row already
+// travel as bf16 pairs: for linear2 / out-proj the products are the same numbers in another summation order; the in-projection,
+// linear1 and the predict layer round x * gamma (the folded LayerNorm's operand) to bf16 first -- what the batched step's MFMA
+// GEMMs do with the same rows (gemm_skinny.hip, LnProducer).
+typedef __bf16 ps_bf16x2 __attribute__((ext_vector_type(2)));
+template <int NCH>
+__device__ inline float ps_dot_bf16(const u32x4_t (&wv)[NCH], const u32x4_t (&xv)[NCH]) {
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;  // four independent chains (a dot2c accumulates in place)
+  auto bf2 = [](unsigned u) { return __builtin_bit_cast(ps_bf16x2, u); };  // (by VALUE: __builtin_bit_cast of a vector-element lvalue reads element 0)
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) {
+    const unsigned w0 = wv[c].x, w1 = wv[c].y, w2 = wv[c].z, w3 = wv[c].w, x0 = xv[c].x, x1 = xv[c].y, x2 = xv[c].z, x3 = xv[c].w;
+    a0 = __builtin_amdgcn_fdot2_f32_bf16(bf2(w0), bf2(x0), a0, false);
+    a1 = __builtin_amdgcn_fdot2_f32_bf16(bf2(w1), bf2(x1), a1, false);
+    a2 = __builtin_amdgcn_fdot2_f32_bf16(bf2(w2), bf2(x2), a2, false);
+    a3 = __builtin_amdgcn_fdot2_f32_bf16(bf2(w3), bf2(x3), a3, false);
+  }
+  return (a0 + a1) + (a2 + a3);
+}
+// this lane's 8 bf16 activations of chunk c (elements c * 512 + lane * 8 ..) from the bf16 row at sxh
+template <int NCH>
+__device__ inline void ps_read_bf16(const float* sx, u32x4_t (&xv)[NCH]) {
+  const int lane = threadIdx.x & 63;
+#pragma unroll
+  for (int c = 0; c < NCH; ++c) xv[c] = *reinterpret_cast<const u32x4_t*>(reinterpret_cast<const unsigned char*>(sx) + (c * 512 + lane * 8) * 2);
+}
 
 // Spin state of a wave: `budget` polling passes left in this launch (0 = gave up: never waits again).
 struct PsSpin {
@@ -363,7 +398,9 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   int kvl = a.kv_len[0];            // slot of the new token; the old keys are [0, kvl)
   const int ctx_max = a.ctx_max;
   const int mode = a.mode;
-  constexpr bool hpack = (PK & 1) != 0, apack = (PK & 2) != 0, LF = (PK & 4) != 0;
+  constexpr bool hpack = (PK & 1) != 0, apack = (PK & 2) != 0, LF = (PK & 4) != 0, D2 = (PK & 8) != 0;
+  static_assert(!D2 || LF, "the bf16 activation rows carry x * gamma: folded LayerNorm only");
+  typedef unsigned u32x2v_t __attribute__((ext_vector_type(2)));
   const bool glocal = (mode & 16) != 0;
   // s_sleep(8) units ahead of the FIRST sweep of an all-to-all edge (attention output, x, x', hidden): a sweep that comes back
   // without the data costs a whole fabric round trip (~1.1 us) before the next one can see it -- waiting first is cheaper
@@ -499,7 +536,8 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     float xg[EPT];
 #pragma unroll
     for (int k = 0; k < EPT; ++k) xg[k] = xr[k] * gv[k];
-    store_ept_lds<EPT>(sx + tid * EPT, xg);
+    if constexpr (D2) *reinterpret_cast<u32x2v_t*>(reinterpret_cast<unsigned char*>(sx) + tid * 8) = u32x2v_t{pack_bf16x2(xg[0], xg[1]), pack_bf16x2(xg[2], xg[3])};
+    else store_ept_lds<EPT>(sx + tid * EPT, xg);
     float sw = 0.f;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) sw += xr[k];
@@ -567,13 +605,23 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     if constexpr (LF) fold_stats(xv, g1v, ln_mean, ln_rstd);
     else g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
     {
-      float x[NCH][VEC];
-      g1_read_shared<T, NCH>(sx, x);
       float mine = 0.f;
+      if constexpr (D2) {
+        u32x4_t xb[NCH];
+        ps_read_bf16<NCH>(sx, xb);
 #pragma unroll
-      for (int r = 0; r < RQ; ++r) {
-        const float t = wave_sum_dpp(g1_dot<T, NCH>(wq[r], x));
-        mine = lane == r ? t : mine;
+        for (int r = 0; r < RQ; ++r) {
+          const float t = wave_sum_dpp(ps_dot_bf16<NCH>(wq[r], xb));
+          mine = lane == r ? t : mine;
+        }
+      } else {
+        float x[NCH][VEC];
+        g1_read_shared<T, NCH>(sx, x);
+#pragma unroll
+        for (int r = 0; r < RQ; ++r) {
+          const float t = wave_sum_dpp(g1_dot<T, NCH>(wq[r], x));
+          mine = lane == r ? t : mine;
+        }
       }
       if (lane < RQ) {
         const int r = w * RQ + lane, which = r / QR, e = s * QR + (r % QR);  // e: element of the head
@@ -821,25 +869,40 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       nap(nap_att);
       if constexpr (PF == 1) ps_gather<NA>(GB, rs, G + G_ATT + tid * NA, epoch, raw, sp, [&]() { issue_w1(p); });
       else ps_gather<NA>(GB, rs, G + G_ATT + tid * NA, epoch, raw, sp, PsNoop());
-      if constexpr (apack) {
-#pragma unroll
-        for (int k = 0; k < EPT / 2; ++k) {
-          const unsigned u = __float_as_uint(raw[k]);
-          av[2 * k] = __uint_as_float(u << 16);
-          av[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
-        }
+      if constexpr (D2) {  // the row as bf16 in LDS (already bf16 pairs when the edge travels packed)
+        static_assert(EPT == 4, "two bf16 pairs per thread");
+        u32x2v_t pk;
+        if constexpr (apack) pk = u32x2v_t{__float_as_uint(raw[0]), __float_as_uint(raw[1])};
+        else pk = u32x2v_t{pack_bf16x2(raw[0], raw[1]), pack_bf16x2(raw[2], raw[3])};
+        *reinterpret_cast<u32x2v_t*>(reinterpret_cast<unsigned char*>(sx) + tid * 8) = pk;
       } else {
+        if constexpr (apack) {
 #pragma unroll
-        for (int k = 0; k < EPT; ++k) av[k] = raw[k];
+          for (int k = 0; k < EPT / 2; ++k) {
+            const unsigned u = __float_as_uint(raw[k]);
+            av[2 * k] = __uint_as_float(u << 16);
+            av[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < EPT; ++k) av[k] = raw[k];
+        }
+        store_ept_lds<EPT>(sx + tid * EPT, av);
       }
-      store_ept_lds<EPT>(sx + tid * EPT, av);
       g1_lds_barrier();
       pt_end<TR>(pt, sp.passes);
       if constexpr (PF == 2) issue_w1(p);
       __builtin_amdgcn_sched_barrier(0);
-      float x[NCH][VEC];
-      g1_read_shared<T, NCH>(sx, x);
-      const float mine = wave_sum_dpp(g1_dot<T, NCH>(wo, x));
+      float mine;
+      if constexpr (D2) {
+        u32x4_t xb[NCH];
+        ps_read_bf16<NCH>(sx, xb);
+        mine = wave_sum_dpp(ps_dot_bf16<NCH>(wo, xb));
+      } else {
+        float x[NCH][VEC];
+        g1_read_shared<T, NCH>(sx, x);
+        mine = wave_sum_dpp(g1_dot<T, NCH>(wo, x));
+      }
       if (lane == 0) {
         const float v = mine + bo_v;
         gran_store(G + G_X2 + 4 * c + w, epoch, sres[w] + v);
@@ -864,13 +927,23 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       float ln_mean = 0.f, ln_rstd = 1.f;
       if constexpr (LF) fold_stats(xv, g2v, ln_mean, ln_rstd);
       else g1_block_layernorm<D, PS_T>(xv, g2v, be2v, sx, red);
-      float x[NCH][VEC];
-      g1_read_shared<T, NCH>(sx, x);
       float mine = 0.f;
+      if constexpr (D2) {
+        u32x4_t xb[NCH];
+        ps_read_bf16<NCH>(sx, xb);
 #pragma unroll
-      for (int r = 0; r < R1; ++r) {
-        const float t = wave_sum_dpp(g1_dot<T, NCH>(w1[r], x));
-        mine = lane == r ? t : mine;
+        for (int r = 0; r < R1; ++r) {
+          const float t = wave_sum_dpp(ps_dot_bf16<NCH>(w1[r], xb));
+          mine = lane == r ? t : mine;
+        }
+      } else {
+        float x[NCH][VEC];
+        g1_read_shared<T, NCH>(sx, x);
+#pragma unroll
+        for (int r = 0; r < R1; ++r) {
+          const float t = wave_sum_dpp(g1_dot<T, NCH>(w1[r], x));
+          mine = lane == r ? t : mine;
+        }
       }
       const float hval = fmaxf(LF ? fmaf(ln_rstd, fmaf(-ln_mean, sg1_v, mine), b1_v) : mine + b1_v, 0.f);
       if constexpr (!hpack) {
@@ -891,25 +964,45 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       nap(nap_hid);
       if constexpr (PF == 1) ps_gather<NHG>(GB, rs, G + G_HID + tid * NHG, epoch, raw, sp, [&]() { issue_wqkv(pn, last); });
       else ps_gather<NHG>(GB, rs, G + G_HID + tid * NHG, epoch, raw, sp, PsNoop());
-      if constexpr (hpack) {
+      if constexpr (D2) {  // the 16 hidden values of this thread as 8 bf16 pairs: 32 bytes of the bf16 row
+        static_assert(EPT2 == 16, "eight bf16 pairs per thread");
+        unsigned pk[8];
 #pragma unroll
-        for (int k = 0; k < EPT2 / 2; ++k) {
-          const unsigned u = __float_as_uint(raw[k]);
-          hv[2 * k] = __uint_as_float(u << 16);
-          hv[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+        for (int k = 0; k < 8; ++k) {
+          if constexpr (hpack) pk[k] = __float_as_uint(raw[k]);
+          else pk[k] = pack_bf16x2(raw[2 * k], raw[2 * k + 1]);
         }
+        unsigned char* dst = reinterpret_cast<unsigned char*>(sx) + tid * 32;
+        *reinterpret_cast<u32x4_t*>(dst) = u32x4_t{pk[0], pk[1], pk[2], pk[3]};
+        *reinterpret_cast<u32x4_t*>(dst + 16) = u32x4_t{pk[4], pk[5], pk[6], pk[7]};
       } else {
+        if constexpr (hpack) {
 #pragma unroll
-        for (int k = 0; k < EPT2; ++k) hv[k] = raw[k];
+          for (int k = 0; k < EPT2 / 2; ++k) {
+            const unsigned u = __float_as_uint(raw[k]);
+            hv[2 * k] = __uint_as_float(u << 16);
+            hv[2 * k + 1] = __uint_as_float(u & 0xffff0000u);
+          }
+        } else {
+#pragma unroll
+          for (int k = 0; k < EPT2; ++k) hv[k] = raw[k];
+        }
+        store_ept_lds<EPT2>(sx + tid * EPT2, hv);
       }
-      store_ept_lds<EPT2>(sx + tid * EPT2, hv);
       g1_lds_barrier();
       pt_end<TR>(pt, sp.passes);
       if constexpr (PF == 2) issue_wqkv(pn, last);
       __builtin_amdgcn_sched_barrier(0);
-      float x[NCH2][VEC];
-      g1_read_shared<T, NCH2>(sx, x);
-      const float mine = wave_sum_dpp(g1_dot<T, NCH2>(w2, x));
+      float mine;
+      if constexpr (D2) {
+        u32x4_t xb[NCH2];
+        ps_read_bf16<NCH2>(sx, xb);
+        mine = wave_sum_dpp(ps_dot_bf16<NCH2>(w2, xb));
+      } else {
+        float x[NCH2][VEC];
+        g1_read_shared<T, NCH2>(sx, x);
+        mine = wave_sum_dpp(g1_dot<T, NCH2>(w2, x));
+      }
       if (lane == 0) {
         const float v = mine + b2_v;
         gran_store(G + GPL + G_X + 4 * c + w, epoch, sres[w] + v);  // the next layer's x edge (layer L: the final norm's)
@@ -928,9 +1021,16 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     float ln_mean = 0.f, ln_rstd = 1.f;
     if constexpr (LF) fold_stats(xv, g1v, ln_mean, ln_rstd);
     else g1_block_layernorm<D, PS_T>(xv, g1v, be1v, sx, red);
-    float x[NCH][VEC];
-    g1_read_shared<T, NCH>(sx, x);
-    const float t0 = wave_sum_dpp(g1_dot<T, NCH>(wq[0], x));
+    float x[D2 ? 1 : NCH][VEC];
+    u32x4_t xb[D2 ? NCH : 1];
+    float t0;
+    if constexpr (D2) {
+      ps_read_bf16<NCH>(sx, xb);
+      t0 = wave_sum_dpp(ps_dot_bf16<NCH>(wq[0], xb));
+    } else {
+      g1_read_shared<T, NCH>(sx, x);
+      t0 = wave_sum_dpp(g1_dot<T, NCH>(wq[0], x));
+    }
     constexpr int G_LOG = G_QKV;  // the final block's q/k/v slots carry the logits edge (V <= 3 D)
     if (lane == 0) {
       const float lg = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgq, t0), bq) : t0 + 0.f;
@@ -938,7 +1038,9 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if (own_sample) gran_store(G + G_LOG + 4 * c + w, epoch, lg);
     }
     if (extra_row) {
-      const float t1 = wave_sum_dpp(g1_dot<T, NCH>(wq[1], x));
+      float t1;
+      if constexpr (D2) t1 = wave_sum_dpp(ps_dot_bf16<NCH>(wq[1], xb));
+      else t1 = wave_sum_dpp(g1_dot<T, NCH>(wq[1], x));
       if (lane == 0) {
         const float lg = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgx, t1), tbx) : t1 + 0.f;
         a.logits[4 * NWG] = lg;
@@ -1101,9 +1203,14 @@ size_t pstep_gran_count(int d, int nhead, int L) { return (size_t)(L + 1) * ps_g
 
 // The timeline (option "persist_trace") exists for the shipped schedule (NK = 2, PF = 3), every packing mode; other schedules run
 // untraced (their trace buffer stays zero).
+static int ps_pk_of(int mode);
 static int ps_launch_traced(hipStream_t st, const PStepArgs& a) {
   const dim3 grid(256), block(PS_T);
-  switch (((a.mode >> 2) & 3) | ((a.mode >> 3) & 4)) {
+  switch (ps_pk_of(a.mode)) {
+    case 12: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 12, true>), grid, block, 0, st, a); break;
+    case 13: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 13, true>), grid, block, 0, st, a); break;
+    case 14: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 14, true>), grid, block, 0, st, a); break;
+    case 15: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 15, true>), grid, block, 0, st, a); break;
     case 0: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 0, true>), grid, block, 0, st, a); break;
     case 1: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 1, true>), grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 2, true>), grid, block, 0, st, a); break;
@@ -1111,7 +1218,25 @@ static int ps_launch_traced(hipStream_t st, const PStepArgs& a) {
     case 4: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 4, true>), grid, block, 0, st, a); break;
     case 5: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 5, true>), grid, block, 0, st, a); break;
     case 6: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 6, true>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 7, true>), grid, block, 0, st, a); break;
+    case 7: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 7, true>), grid, block, 0, st, a); break;
+    default: return -1;
+  }
+  return 0;
+}
+
+// PK of a mode: bits 4 / 8: hidden / attention rows as bf16 pairs; 32: folded LayerNorm; 64: bf16 activation rows + v_dot2c (D2)
+static int ps_pk_of(int mode) { return ((mode >> 2) & 3) | ((mode >> 3) & 4) | ((mode >> 3) & 8); }
+
+// D2 (mode bit 6) exists on the folded LayerNorm only, for the shipped key split (NK = 2) and the request schedules 0 and 3
+template <int PF>
+static int ps_launch_d2(hipStream_t st, const PStepArgs& a) {
+  const dim3 grid(256), block(PS_T);
+  switch (ps_pk_of(a.mode)) {
+    case 12: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, PF, 12>), grid, block, 0, st, a); break;
+    case 13: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, PF, 13>), grid, block, 0, st, a); break;
+    case 14: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, PF, 14>), grid, block, 0, st, a); break;
+    case 15: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, PF, 15>), grid, block, 0, st, a); break;
+    default: return -1;
   }
   return 0;
 }
@@ -1119,7 +1244,7 @@ static int ps_launch_traced(hipStream_t st, const PStepArgs& a) {
 template <int NK, int PF>
 static int ps_launch_pk(hipStream_t st, const PStepArgs& a) {
   const dim3 grid(256), block(PS_T);
-  switch (((a.mode >> 2) & 3) | ((a.mode >> 3) & 4)) {  // mode bits 4 / 8: hidden / attention rows as bf16 pairs; 32: folded LayerNorm
+  switch (ps_pk_of(a.mode) & 7) {
     case 0: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 0>), grid, block, 0, st, a); break;
     case 1: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 1>), grid, block, 0, st, a); break;
     case 2: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 2>), grid, block, 0, st, a); break;
@@ -1137,6 +1262,11 @@ int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
   if (!a.layers || !a.x_in || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
   if (a.nsteps < 0 || a.nsteps > 4096 || (a.nsteps > 0 && !a.smp)) return -1;
+  if (a.mode & 64) {  // D2
+    if (!(a.mode & 32) || a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
+    if (a.ptrace != nullptr && a.pf == 3) return ps_launch_traced(st, a);
+    return a.pf == 0 ? ps_launch_d2<0>(st, a) : ps_launch_d2<3>(st, a);
+  }
   if (a.ptrace != nullptr && a.nk != 4 && a.pf == 3) return ps_launch_traced(st, a);
   if (a.nk == 4) return a.pf == 0 ? ps_launch_pk<4, 0>(st, a) : a.pf == 1 ? ps_launch_pk<4, 1>(st, a) : a.pf == 2 ? ps_launch_pk<4, 2>(st, a) : ps_launch_pk<4, 3>(st, a);
   return a.pf == 0 ? ps_launch_pk<2, 0>(st, a) : a.pf == 1 ? ps_launch_pk<2, 1>(st, a) : a.pf == 2 ? ps_launch_pk<2, 2>(st, a) : ps_launch_pk<2, 3>(st, a);

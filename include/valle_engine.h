@@ -186,7 +186,8 @@ int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slo
  *          the persistent batch-1 AR launch (valle_amd/csrc/persist.hip): "persist" (default 1: bf16 d1024-h16 at one
  *          utterance runs it; 0 = the launch chain), "persist_sample" (default 1: topk_sampling, the stop rule and the next token's
  *          embedding inside the launch) with "persist_steps" (default 32 AR iterations per launch), "persist_mode" (bit field: 4 / 8
- *          hidden / attention rows as bf16 pairs, 16 XCD-local copies of the head-group edges, 32 folded LayerNorm; default 0x134),
+ *          hidden / attention rows as bf16 pairs, 16 XCD-local copies of the head-group edges, 32 folded LayerNorm, 64 bf16 activation
+ *          rows + v_dot2c_f32_bf16 dot products; default 0x174),
  *          "persist_pf" (0..3 operand request schedule), "persist_nk" (2 | 4 keys per lane), "persist_naps" (first-sweep waits, 4 bits
  *          per edge), "persist_trace" (in-kernel timeline), "act_bf16" (the chain's matching roundings).
  *          "persist_rearm" (any value: forget the back-off after VLE_EBUSY), "persist_inject_fail" (n: the next n persistent calls
@@ -248,9 +249,9 @@ int vle_op_linear_ws(void* stream, int dtype, const void* a, const void* w, cons
  * AdaptiveLayerNorm, followed by F.linear): LN(x) W^T + b = rstd * ((x * gamma) W^T - mean * sg) + tb with sg = W gamma,
  * tb = W beta + b.  The two halves as stand-alone operators, bf16 operands:
  *   producer: resid[M][N] (fp32) += a[M][K] @ w[N][K]^T + bias; xg[M][N] = bf16(resid * gamma);
- *             stats[M][N / 64][2] = (mean, sum of squared deviations) of every 64-column group of the completed row;
+ *             stats[N / 64][M][2] = (mean, sum of squared deviations) of every 64-column group of the completed row, group-major;
  *   consumer: out[M][N] = bf16(act(rstd_m * (xg[M][K] @ w[N][K]^T - mean_m * sg[n]) + tb[n])), the row's mean / rstd combined
- *             from stats[M][K / 64][2] (eps 1e-5, biased variance), act = ReLU when relu != 0.
+ *             from stats[K / 64][M][2] (eps 1e-5, biased variance), act = ReLU when relu != 0.
  * M >= 128; the normalised width (producer N, consumer K) a multiple of 256 and <= 1536; the other dimension a multiple of 256
  * (consumer N) / of 128 (producer K). */
 int vle_op_linear_ln_producer(void* stream, const void* a, const void* w, const float* bias, float* resid, const float* gamma,

@@ -492,8 +492,9 @@ def test_layernorm_folded_into_the_gemms_equals_layernorm_then_linear(M, d):
         xg64 = x.double().view(M, d // 64, 64)
         gm = xg64.mean(-1)
         gm2 = ((xg64 - gm[..., None]) ** 2).sum(-1)
-        assert (stats[..., 0].double() - gm).abs().max().item() < 1e-5 * max(1.0, gm.abs().max().item())
-        assert ((stats[..., 1].double() - gm2).abs() / gm2.clamp_min(1e-3)).max().item() < 1e-4
+        st = stats.permute(1, 0, 2)  # (M, groups, 2): the operator's layout is group-major
+        assert (st[..., 0].double() - gm).abs().max().item() < 1e-5 * max(1.0, gm.abs().max().item())
+        assert ((st[..., 1].double() - gm2).abs() / gm2.clamp_min(1e-3)).max().item() < 1e-4
         for N, relu in ((3 * d, False), (4 * d, True)):  # consumers: in-projection, linear1 + ReLU
             wc = (torch.randn(N, d, generator=g) / math.sqrt(d)).to(torch.bfloat16).to(DEV)
             bc = (torch.randn(N, generator=g) * 0.1).to(DEV)

@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 import valle_amd  # noqa: E402
 
 DEV = "cuda:0"
-CLASSIC, FOLDED = 0x114, 0x134  # persist_mode: three-barrier LayerNorm (bit-identical to the chain) / folded LayerNorm (the default)
+CLASSIC, FOLDED, DEFAULT = 0x114, 0x134, 0x174  # persist_mode: three-barrier LayerNorm (bit-identical to the chain) / folded LayerNorm / + bf16 rows and v_dot2c (the default)
 
 
 def _inputs(S, P, seed=0):

@@ -20,7 +20,7 @@ eng.set_option("ignore_eos", 1)
 x, y = synth_inputs(0)
 X, Y = x[None].to(dev), y[None].to(dev)
 steps = int(sys.argv[2]) if len(sys.argv) > 2 else 120
-MODE = 0x134
+MODE = 0x174
 variants = [(3, 0x335854), (0, 0x335854), (3, 0), (3, 0xFFFFFF), (1, 0x335854), (2, 0x335854), (3, 0x123456), (0, 0x0F0F0F)]
 ref = None
 t0 = time.time()

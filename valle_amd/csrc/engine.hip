@@ -125,7 +125,7 @@ struct vle_engine {
   hipEvent_t ev_chk = nullptr;
   float *X = nullptr, *yemb = nullptr, *nar_logits = nullptr;
   // LayerNorm folded into the packed-row GEMMs of the prefill / NAR passes (kernels.h GemmLn; option "ln_fold", default 1):
-  float* ln_rows_stats = nullptr;  // [max_rows][d / 64][2] (mean, M2) of every 64-column group of the residual rows (buffer)
+  float* ln_rows_stats = nullptr;  // [d / 64][max_rows][2] (mean, M2) of every 64-column group of the residual rows, group-major (buffer)
   float* nar_fold = nullptr;       // [Q - 1][L][14 d]: per (stage, layer) sg / tb of the in-projection (3 d each) and of linear1 (4 d each)
   bool opt_ln_fold = true;
   void *Xn = nullptr, *QKV = nullptr, *ATT = nullptr, *Hb = nullptr;
@@ -1166,7 +1166,7 @@ int enqueue_layer_rows(vle_engine* e, const LayerW& w, const float* g1, const fl
     // utterance 5 us + a launch boundary each) ride on the residual GEMMs' epilogues
     GemmLn ln;
     if (f->in_folded) {
-      ln.stats_in = e->ln_rows_stats; ln.sg = f->sg_qkv;
+      ln.stats_in = e->ln_rows_stats; ln.stats_ld = e->max_rows; ln.sg = f->sg_qkv;
       E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.wqkv, f->tb_qkv, e->QKV, nullptr, rows, 3 * d, d, EPI_STORE_LNC, &ln));
     } else {
       E_LAUNCH(e, launch_layernorm(st, e->dtype, e->X, nullptr, g1, b1, e->Xn, rows, d));
@@ -1175,14 +1175,14 @@ int enqueue_layer_rows(vle_engine* e, const LayerW& w, const float* g1, const fl
     if (kc) E_LAUNCH(e, launch_kv_scatter(st, e->dtype, e->QKV, kc, vc, row_seq, row_pos, rows, d, e->H, e->ctx_max));
     E_LAUNCH(e, launch_attention(st, e->dtype, e->QKV, e->ATT, seq_off, text_len, e->nseq > 0 ? e->nseq : e->B, max_len, d, e->H, causal));
     ln = GemmLn();
-    ln.gamma = g2; ln.xg = e->Xn; ln.stats_out = e->ln_rows_stats;
+    ln.gamma = g2; ln.xg = e->Xn; ln.stats_out = e->ln_rows_stats; ln.stats_ld = e->max_rows;
     E_LAUNCH(e, launch_gemm(st, e->dtype, e->ATT, w.wo, w.bo, nullptr, e->X, rows, d, d, EPI_RESID_LNP, &ln));
     ln = GemmLn();
-    ln.stats_in = e->ln_rows_stats; ln.sg = f->sg_1;
+    ln.stats_in = e->ln_rows_stats; ln.stats_ld = e->max_rows; ln.sg = f->sg_1;
     E_LAUNCH(e, launch_gemm(st, e->dtype, e->Xn, w.w1, f->tb_1, e->Hb, nullptr, rows, 4 * d, d, EPI_RELU_LNC, &ln));
     if (f->next_g1 != nullptr) {
       ln = GemmLn();
-      ln.gamma = f->next_g1; ln.xg = e->Xn; ln.stats_out = e->ln_rows_stats;
+      ln.gamma = f->next_g1; ln.xg = e->Xn; ln.stats_out = e->ln_rows_stats; ln.stats_ld = e->max_rows;
       E_LAUNCH(e, launch_gemm(st, e->dtype, e->Hb, w.w2, w.b2, nullptr, e->X, rows, d, 4 * d, EPI_RESID_LNP, &ln));
     } else {
       E_LAUNCH(e, launch_gemm(st, e->dtype, e->Hb, w.w2, w.b2, nullptr, e->X, rows, d, 4 * d, EPI_RESID));

@@ -65,7 +65,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
   // rstd * (acc - mean * sg) + tb in its epilogue
   constexpr bool LNP = EPI == EPI_RESID_LNP, LNC = EPI == EPI_STORE_LNC || EPI == EPI_RELU_LNC;
   constexpr bool RESID = EPI == EPI_RESID || LNP, RELU = EPI == EPI_RELU || EPI == EPI_RELU_LNC, BF16OUT = EPI == EPI_STORE || RELU || LNC;
-  constexpr int LN_LDS = LNC ? 256 * 16 : 0;  // (mean, M2) of the two halves of the tile's rows, behind the two buffers: never a DMA target
+  // LNC: behind the two buffers (never a K-tile target): (mean, M2) of the two halves of the tile's rows, then sg and tb of its columns
+  constexpr int LN_STATS = 256 * 16, LN_LDS = LNC ? LN_STATS + 2 * 256 * 4 : 0;
   __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G8_BUF + LN_LDS];  // the ONLY LDS object (a second one makes
                                                                                     // hipcc drain vmcnt before every ds_read)
   const int tid = threadIdx.x, lane = tid & 63;
@@ -120,14 +121,23 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
   };
 
   // bias of this lane's 4 consecutive output columns per n-fragment (requested ahead of the DMA queue)
-  g8_f32x4 bias4[2][2];
+  g8_f32x4 bias4[LNC ? 1 : 2][LNC ? 1 : 2];
+  if constexpr (LNC) {
+    // sg / tb of this tile's 256 columns into LDS, the first requests of the workgroup (a wave each: 64 lanes x 16 bytes): no
+    // registers through the main loop, no exposed load in the epilogue
+    bias4[0][0] = g8_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave < 2)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((wave == 0 ? ln.sg : bias) + n0 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(smem + 2 * G8_BUF + LN_STATS + wave * 1024), 16, 0, 0);
+  } else {
 #pragma unroll
-  for (int h = 0; h < 2; ++h)
+    for (int h = 0; h < 2; ++h)
 #pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const int n = n0 + h * 128 + wc * 32 + j * 16 + fg * 4;
-      bias4[h][j] = bias != nullptr ? *reinterpret_cast<const g8_f32x4*>(bias + n) : g8_f32x4{0.f, 0.f, 0.f, 0.f};
-    }
+      for (int j = 0; j < 2; ++j) {
+        const int n = n0 + h * 128 + wc * 32 + j * 16 + fg * 4;
+        bias4[h][j] = bias != nullptr ? *reinterpret_cast<const g8_f32x4*>(bias + n) : g8_f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+  }
 
   g8_f32x4 acc[2][2][4][2];  // [row half][col half][m-fragment][n-fragment]
 #pragma unroll
@@ -180,18 +190,19 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
   };
 
   const int KT = (dbg & 2) ? 2 : K / 64;  // diagnostic (g8_dbg bit 1): prologue + two K-tiles + epilogue only
-  // LNC: the row statistics, as in gemm_glds.hip: thread t owns HALF of row m0 + t % 256 (half t / 256 of its K / 64 group pairs); the
-  // pairs are requested AHEAD of the DMA queue (in-order return: the wait for them never drains the pipeline), on clamped addresses,
-  // and combined once the DMA prologue is on its way; the two halves meet in the epilogue
-  constexpr int LNV = 6;
-  g8_f32x4 lnp[LNC ? LNV : 1];
-  const int ln_np = K / 256;  // 16-byte loads (two groups each) per half row
+  // LNC: the row statistics, as in gemm_glds.hip: thread t owns HALF of row m0 + t % 256 (half t / 256 of its K / 64 groups); the
+  // (mean, M2) pairs are requested AHEAD of the K-tile queue (in-order return: the wait for them never drains the pipeline), one
+  // coalesced 8-byte load per group (group-major layout) on clamped addresses; the two halves meet in the epilogue
+  constexpr int LNV = 12;
+  typedef float g8_f32x2 __attribute__((ext_vector_type(2)));
+  g8_f32x2 lnp[LNC ? LNV : 1];
+  const int ln_ng = K / 128;  // groups per half row
   if constexpr (LNC) {
     int64_t m = m0 + (tid & 255);
     m = m < M ? m : M - 1;
-    const g8_f32x4* sp = reinterpret_cast<const g8_f32x4*>(ln.stats_in + m * (int64_t)(K / 32)) + (tid >> 8) * ln_np;
+    const g8_f32x2* sp = reinterpret_cast<const g8_f32x2*>(ln.stats_in) + (int64_t)(tid >> 8) * ln_ng * ln.stats_ld + m;
 #pragma unroll
-    for (int g = 0; g < LNV; ++g) lnp[g] = sp[g < ln_np ? g : ln_np - 1];
+    for (int g = 0; g < LNV; ++g) lnp[g] = sp[(int64_t)(g < ln_ng ? g : ln_ng - 1) * ln.stats_ld];
   }
   // Issue schedule (one half-tile per phase, in order of first use, into a half whose last read lies >= 2 phases back,
   // so it also holds when the two wave groups are half a phase apart):
@@ -207,13 +218,13 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
     float s1 = 0.f, s2 = 0.f, q = 0.f;
 #pragma unroll
     for (int g = 0; g < LNV; ++g) {
-      const bool on = g < ln_np;
-      const float d0 = on ? lnp[g][0] - ref : 0.f, d1 = on ? lnp[g][2] - ref : 0.f;
-      s1 += d0 + d1;
-      s2 = fmaf(d0, d0, fmaf(d1, d1, s2));
-      q += on ? lnp[g][1] + lnp[g][3] : 0.f;
+      const bool on = g < ln_ng;
+      const float d0 = on ? lnp[g][0] - ref : 0.f;
+      s1 += d0;
+      s2 = fmaf(d0, d0, s2);
+      q += on ? lnp[g][1] : 0.f;
     }
-    const float sm = s1 / (float)(2 * ln_np);  // mean_h - ref
+    const float sm = s1 / (float)ln_ng;  // mean_h - ref
     ln_mean = ref + sm;
     ln_m2 = q + (float)LN_GROUP * (s2 - s1 * sm);
   }
@@ -267,12 +278,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
   if (!(dbg & 4)) {
     unsigned char* const E = smem;
     if constexpr (BF16OUT) {
-      g8_f32x4 sg4[LNC ? 2 : 1][LNC ? 2 : 1];
       if constexpr (LNC) {
-#pragma unroll
-        for (int h = 0; h < 2; ++h)
-#pragma unroll
-          for (int j = 0; j < 2; ++j) sg4[h][j] = *reinterpret_cast<const g8_f32x4*>(ln.sg + n0 + h * 128 + wc * 32 + j * 16 + fg * 4);
         float* const S = reinterpret_cast<float*>(smem + 2 * G8_BUF);  // the rows' (mean, rstd): owner threads -> fragment layout
         S[4 * (tid & 255) + 2 * (tid >> 8)] = ln_mean;
         S[4 * (tid & 255) + 2 * (tid >> 8) + 1] = ln_m2;
@@ -297,10 +303,13 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
               const int c = b * 16 + wc * 4 + j * 2 + (fg >> 1);
               g8_f32x4 v;
               if constexpr (LNC) {
+                const int col = b * 128 + wc * 32 + j * 16 + fg * 4;
+                const g8_f32x4 sgv = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + LN_STATS + col * 4);
+                const g8_f32x4 tbv = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + LN_STATS + 1024 + col * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sg4[b][j][r], acc[a][b][i][j][r]), bias4[b][j][r]);
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sgv[r], acc[a][b][i][j][r]), tbv[r]);
               } else {
-                v = acc[a][b][i][j] + bias4[b][j];
+                v = acc[a][b][i][j] + bias4[LNC ? 0 : b][LNC ? 0 : j];
               }
               if constexpr (RELU) {
 #pragma unroll
@@ -338,7 +347,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
               const int c = b * 32 + wc * 8 + j * 4 + fg;
-              *reinterpret_cast<g8_f32x4*>(E + row * 1024 + ((c ^ (fr & 7)) << 4)) = acc[a][b][i][j] + bias4[b][j];
+              *reinterpret_cast<g8_f32x4*>(E + row * 1024 + ((c ^ (fr & 7)) << 4)) = acc[a][b][i][j] + bias4[LNC ? 0 : b][LNC ? 0 : j];
             }
         }
         float* const base = (RESID ? resid : reinterpret_cast<float*>(out_)) + n0 + lane * 4;
@@ -374,10 +383,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
 #pragma unroll
               for (int q = 0; q < 4; ++q) o4[q] = (__bf16)(v[q] * gamma4[q]);
               *reinterpret_cast<g8_bf16x4*>(reinterpret_cast<bf16_t*>(ln.xg) + m * N + n0 + lane * 4) = o4;
-              if ((lane & 15) == 0) {
-                typedef float g8_f32x2 __attribute__((ext_vector_type(2)));
-                *reinterpret_cast<g8_f32x2*>(ln.stats_out + (m * (int64_t)(N / LN_GROUP) + (n0 + lane * 4) / LN_GROUP) * 2) = g8_f32x2{gmean, gm2};
-              }
+              if ((lane & 15) == 0)
+                *reinterpret_cast<g8_f32x2*>(ln.stats_out + ((int64_t)((n0 + lane * 4) / LN_GROUP) * ln.stats_ld + m) * 2) = g8_f32x2{gmean, gm2};
             }
           }
         }
@@ -397,7 +404,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
 #pragma unroll
         for (int j = 0; j < 2; ++j) {
           const int n = n0 + b * 128 + wc * 32 + j * 16 + fg * 4;
-          g8_f32x4 v = acc[a][b][i][j] + bias4[b][j];
+          g8_f32x4 v = acc[a][b][i][j] + bias4[LNC ? 0 : b][LNC ? 0 : j];
           if ((dbg & 1) && v[0] != 1.2345e30f) continue;  // diagnostic (g8_dbg bit 0): no epilogue stores
           if constexpr (EPI == EPI_RELU) {
 #pragma unroll
@@ -435,9 +442,9 @@ int launch_gemm_8ph(hipStream_t st, const void* A, const void* W, const float* b
   if (epi >= EPI_RESID_LNP) {  // LayerNorm folded into the GEMM (kernels.h GemmLn): the default schedule only (staggered, row & 7 swizzle)
     if ((g_g8_dbg & 7) != 0) return -1;
     switch (epi) {
-      case EPI_RESID_LNP: if (!ln.gamma || !ln.xg || !ln.stats_out) return -1; VLE_G8(EPI_RESID_LNP, true, 0); break;
-      case EPI_STORE_LNC: if (!ln.stats_in || !ln.sg || K > 1536) return -1; VLE_G8(EPI_STORE_LNC, true, 0); break;
-      case EPI_RELU_LNC: if (!ln.stats_in || !ln.sg || K > 1536) return -1; VLE_G8(EPI_RELU_LNC, true, 0); break;
+      case EPI_RESID_LNP: if (!ln.gamma || !ln.xg || !ln.stats_out || ln.stats_ld < M) return -1; VLE_G8(EPI_RESID_LNP, true, 0); break;
+      case EPI_STORE_LNC: if (!ln.stats_in || !ln.sg || !bias || ln.stats_ld < M || K > 1536) return -1; VLE_G8(EPI_STORE_LNC, true, 0); break;
+      case EPI_RELU_LNC: if (!ln.stats_in || !ln.sg || !bias || ln.stats_ld < M || K > 1536) return -1; VLE_G8(EPI_RELU_LNC, true, 0); break;
       default: return -1;
     }
     return 0;

@@ -55,7 +55,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   constexpr int NI = NIA + NIB;
   constexpr int WMW = NW / 2;                   // waves along M (x 2 along N): 2 x 2, or 4 x 2 for the 8-wave 256-row tile
   constexpr int WM = BM / WMW, WN = BN / 2, FM = WM / 16, FN = WN / 16;
-  constexpr int LN_LDS = LNC ? BM * 16 : 0;  // (mean, M2) of the two halves of the tile's rows, behind the ring: never a DMA target
+  // LNC: behind the ring (never a K-tile target): (mean, M2) of the two halves of the tile's rows, then sg and tb of the tile's columns
+  constexpr int LN_STATS = BM * 16, LN_LDS = LNC ? LN_STATS + 2 * BN * 4 : 0;
   __shared__ __attribute__((aligned(16))) unsigned char smem[STAGES * STAGE_BYTES + LN_LDS];
 
   const int tid = threadIdx.x, lane = tid & 63;
@@ -110,11 +111,19 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   const int fr = lane & 15, fg = lane >> 4;
   // bias of this lane's 4 consecutive output columns per n-fragment: requested first (ahead of the
   // DMA queue, so its wait never drains the pipeline), clamped address, consumed in the epilogue
-  gg_f32x4 bias4[FN];
+  gg_f32x4 bias4[LNC ? 1 : FN];
+  if constexpr (LNC) {
+    // sg / tb of this tile's BN columns into LDS, the first requests of the workgroup (BN / 4 lanes x 16 bytes each, waves 0 and 1)
+    bias4[0] = gg_f32x4{0.f, 0.f, 0.f, 0.f};
+    if (wave < 2 && lane < BN / 4)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((wave == 0 ? ln.sg : bias) + n0 + lane * 4),
+                                       (__attribute__((address_space(3))) void*)(smem + STAGES * STAGE_BYTES + LN_STATS + wave * BN * 4), 16, 0, 0);
+  } else {
 #pragma unroll
-  for (int j = 0; j < FN; ++j) {
-    const int n = min(n0 + wn0 + j * 16 + fg * 4, N - 4);
-    bias4[j] = bias != nullptr ? *reinterpret_cast<const gg_f32x4*>(bias + n) : gg_f32x4{0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < FN; ++j) {
+      const int n = min(n0 + wn0 + j * 16 + fg * 4, N - 4);
+      bias4[j] = bias != nullptr ? *reinterpret_cast<const gg_f32x4*>(bias + n) : gg_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
   }
 
   gg_f32x4 acc[FM][FN];
@@ -127,22 +136,24 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   nlive = nlive < 0 ? 0 : (nlive > FM ? FM : nlive);
 
   const int KT = K / 64;
-  // LNC: the row statistics.  Thread t < 2 BM owns HALF of row m0 + t % BM (half t / BM of its K / 64 group pairs (mean, M2)): the
-  // pairs are requested AHEAD of the DMA queue (a wave's loads return in order: the wait for them never drains the pipeline),
-  // straight-line and on clamped addresses (no branch around a request), and combined after the DMA prologue is on its way:
+  // LNC: the row statistics.  Thread t < 2 BM owns HALF of row m0 + t % BM (half t / BM of its K / 64 groups): the (mean, M2) pairs are
+  // requested AHEAD of the K-tile queue (a wave's loads return in order: the wait for them never drains the pipeline), straight-line
+  // and on clamped addresses (no branch around a request), one coalesced 8-byte load per group (group-major layout), and combined
+  // after the main loop (the compiler sinks the arithmetic to its use):
   //   mean_h = avg(mean_g),  M2_h = sum(M2_g) + 64 * sum((mean_g - mean_h)^2)   (Chan; the squares taken around the half's first group)
-  // The two halves meet in the epilogue (LDS behind the ring).  Two threads per row keep the request at 6 registers x 4.
-  constexpr int LNV = 6;  // 16-byte loads (two groups each) per half row: K <= 1536
+  // The two halves meet in the epilogue (LDS behind the ring).
+  constexpr int LNV = 12;  // groups per half row: K <= 1536
+  typedef float gg_f32x2 __attribute__((ext_vector_type(2)));
   static_assert(!LNC || NW * 64 >= 2 * BM, "two threads per tile row");
-  gg_f32x4 lnp[LNC ? LNV : 1];
-  const int ln_np = K / 256;  // loads per half row
+  gg_f32x2 lnp[LNC ? LNV : 1];
+  const int ln_ng = K / 128;  // groups per half row
   if constexpr (LNC) {
     int64_t m = m0 + tid % BM;
     m = m < M ? m : M - 1;
     const int half = (tid / BM) & 1;
-    const gg_f32x4* sp = reinterpret_cast<const gg_f32x4*>(ln.stats_in + m * (int64_t)(KT * 2)) + half * ln_np;  // KT = K / 64 groups
+    const gg_f32x2* sp = reinterpret_cast<const gg_f32x2*>(ln.stats_in) + (int64_t)half * ln_ng * ln.stats_ld + m;
 #pragma unroll
-    for (int g = 0; g < LNV; ++g) lnp[g] = sp[g < ln_np ? g : ln_np - 1];
+    for (int g = 0; g < LNV; ++g) lnp[g] = sp[(int64_t)(g < ln_ng ? g : ln_ng - 1) * ln.stats_ld];
   }
 #pragma unroll
   for (int s = 0; s < D; ++s)
@@ -153,13 +164,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
     float s1 = 0.f, s2 = 0.f, q = 0.f;
 #pragma unroll
     for (int g = 0; g < LNV; ++g) {
-      const bool on = g < ln_np;
-      const float d0 = on ? lnp[g][0] - ref : 0.f, d1 = on ? lnp[g][2] - ref : 0.f;
-      s1 += d0 + d1;
-      s2 = fmaf(d0, d0, fmaf(d1, d1, s2));
-      q += on ? lnp[g][1] + lnp[g][3] : 0.f;
+      const bool on = g < ln_ng;
+      const float d0 = on ? lnp[g][0] - ref : 0.f;
+      s1 += d0;
+      s2 = fmaf(d0, d0, s2);
+      q += on ? lnp[g][1] : 0.f;
     }
-    const float sm = s1 / (float)(2 * ln_np);  // mean_h - ref
+    const float sm = s1 / (float)ln_ng;  // mean_h - ref
     ln_mean = ref + sm;
     ln_m2 = q + (float)LN_GROUP * (s2 - s1 * sm);
   }
@@ -235,12 +246,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
     constexpr int ES = F32OUT ? 4 : 2, RB = BN * ES, CPR = RB / 16, RPI = 64 / CPR, IT = BM / NW / RPI;
     static_assert(BM * RB <= STAGES * STAGE_BYTES && (BM / NW) % RPI == 0, "epilogue image must fit the LDS ring");
     static_assert(!LNP || CPR % 16 == 0, "a 16-lane row of the row-form pass covers one 64-column group");
-    gg_f32x4 sg4[LNC ? FN : 1];
-    if constexpr (LNC) {
-#pragma unroll
-      for (int j = 0; j < FN; ++j) sg4[j] = *reinterpret_cast<const gg_f32x4*>(ln.sg + min(n0 + wn0 + j * 16 + fg * 4, N - 4));
-    }
-    __syncthreads();  // every wave has consumed the last k-step
+    __syncthreads();  // every wave has consumed the last k-step (and its own requests have landed: the loop's last waits are vmcnt(0))
     unsigned char* const E = smem;
     if constexpr (LNC) {  // the rows' (mean, rstd) from their owner threads to the fragment layout
       float* const S = reinterpret_cast<float*>(smem + STAGES * STAGE_BYTES);
@@ -262,10 +268,12 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
           const float dm = hh[0] - hh[2];
           const float mean = 0.5f * (hh[0] + hh[2]);
           const float rstd = 1.0f / sqrtf((hh[1] + hh[3] + 0.25f * (float)K * dm * dm) / (float)K + LN_EPS);
+          const gg_f32x4 sgv = *reinterpret_cast<const gg_f32x4*>(smem + STAGES * STAGE_BYTES + LN_STATS + col * 4);
+          const gg_f32x4 tbv = *reinterpret_cast<const gg_f32x4*>(smem + STAGES * STAGE_BYTES + LN_STATS + BN * 4 + col * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sg4[j][r], acc[i][j][r]), bias4[j][r]);
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sgv[r], acc[i][j][r]), tbv[r]);
         } else {
-          v = acc[i][j] + bias4[j];
+          v = acc[i][j] + bias4[LNC ? 0 : j];
         }
         if constexpr (RELU) {
 #pragma unroll
@@ -314,8 +322,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
           for (int r = 0; r < 4; ++r) o4[r] = (__bf16)(x[r] * gamma4[r]);
           *reinterpret_cast<gg_bf16x4*>(reinterpret_cast<bf16_t*>(ln.xg) + m * N + n0 + l * 4) = o4;
           if ((l & 15) == 0) {
-            typedef float gg_f32x2 __attribute__((ext_vector_type(2)));
-            *reinterpret_cast<gg_f32x2*>(ln.stats_out + (m * (int64_t)(N / LN_GROUP) + (n0 + l * 4) / LN_GROUP) * 2) = gg_f32x2{gmean, gm2};
+            *reinterpret_cast<gg_f32x2*>(ln.stats_out + ((int64_t)((n0 + l * 4) / LN_GROUP) * ln.stats_ld + m) * 2) = gg_f32x2{gmean, gm2};
           }
         }
       } else if (m < M) {
@@ -350,13 +357,13 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
-      for (int j = 0; j < FN; ++j) acc[i][j] = old[i][j] + (acc[i][j] + bias4[j]);
+      for (int j = 0; j < FN; ++j) acc[i][j] = old[i][j] + (acc[i][j] + bias4[LNC ? 0 : j]);
   } else {
 #pragma unroll
     for (int i = 0; i < FM; ++i)
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
-        acc[i][j] += bias4[j];
+        acc[i][j] += bias4[LNC ? 0 : j];
         if constexpr (EPI == EPI_RELU) {
 #pragma unroll
           for (int r = 0; r < 4; ++r) acc[i][j][r] = fmaxf(acc[i][j][r], 0.f);
@@ -404,8 +411,8 @@ int g_glds_w8 = 1;  // "glds_w8": 8-wave workgroups on the 128-row tiles as well
 static GemmLn gg_ln_rows(const GemmLn* ln, int64_t rows, int N, int K) {
   GemmLn o = ln ? *ln : GemmLn();
   if (o.xg) o.xg = (bf16_t*)o.xg + rows * N;
-  if (o.stats_out) o.stats_out += rows * (N / LN_GROUP) * 2;
-  if (o.stats_in) o.stats_in += rows * (K / LN_GROUP) * 2;
+  if (o.stats_out) o.stats_out += rows * 2;  // group-major: the row index is the fast one
+  if (o.stats_in) o.stats_in += rows * 2;
   return o;
 }
 
@@ -430,9 +437,9 @@ static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const flo
     case EPI_RESID: VLE_GG(EPI_RESID); break;
     case EPI_F32: VLE_GG(EPI_F32); break;
     // LayerNorm folded into the GEMM (kernels.h GemmLn): the default body only (the swizzle / priority A-B variants stay un-folded)
-    case EPI_RESID_LNP: if (!ln.gamma || !ln.xg || !ln.stats_out || N % BN) return -1; VLE_GG_LN(EPI_RESID_LNP); break;
-    case EPI_STORE_LNC: if (!ln.stats_in || !ln.sg || N % BN || K > 1536 || K % 128) return -1; VLE_GG_LN(EPI_STORE_LNC); break;
-    case EPI_RELU_LNC: if (!ln.stats_in || !ln.sg || N % BN || K > 1536 || K % 128) return -1; VLE_GG_LN(EPI_RELU_LNC); break;
+    case EPI_RESID_LNP: if (!ln.gamma || !ln.xg || !ln.stats_out || ln.stats_ld < M || N % BN) return -1; VLE_GG_LN(EPI_RESID_LNP); break;
+    case EPI_STORE_LNC: if (!ln.stats_in || !ln.sg || !bias || ln.stats_ld < M || N % BN || K > 1536 || K % 128) return -1; VLE_GG_LN(EPI_STORE_LNC); break;
+    case EPI_RELU_LNC: if (!ln.stats_in || !ln.sg || !bias || ln.stats_ld < M || N % BN || K > 1536 || K % 128) return -1; VLE_GG_LN(EPI_RELU_LNC); break;
     default: return -1;
   }
 #undef VLE_GG_LN

@@ -42,13 +42,17 @@ enum { EPI_STORE = 0, EPI_RELU = 1, EPI_RESID = 2, EPI_F32 = 3,
 // The GEMM that completes the residual stream x (out-proj, linear2: EPI_RESID_LNP) also writes xg = bf16(x * gamma) of the NEXT
 // norm site and, per row and 64-column group, (mean, M2) of the group (exact two-pass over the 64 fp32 values); the GEMM that
 // reads the normalised row (in-proj, linear1: EPI_*_LNC) multiplies xg, combines the row's K / 64 group pairs (Chan) and applies
-// the affine in its epilogue -- `bias` must then be tb.  The layout of the statistics does not depend on tile sizes: any mix of
-// launches (tile policy, leftover-row launches) may produce and consume it.
+// the affine in its epilogue -- `bias` must then be tb; sg and tb reach the epilogue through LDS (an LDS-DMA issued first thing in
+// the prologue: no registers through the main loop, no exposed load in the epilogue).  The layout of the statistics does not depend
+// on tile sizes: any mix of launches (tile policy, leftover-row launches) may produce and consume it.
 struct GemmLn {
   const float* gamma = nullptr;   // producer: [N] of the next norm site
   void* xg = nullptr;             // producer: bf16 [M][N]
-  float* stats_out = nullptr;     // producer: [M][N / 64][2]
-  const float* stats_in = nullptr;  // consumer: [M][K / 64][2]
+  float* stats_out = nullptr;     // producer: [N / 64][stats_ld][2], GROUP-major: a consumer wave's lanes own consecutive rows, so its
+                                  //           request for one group is one contiguous 512 bytes (row-major cost it 64 lines per instruction:
+                                  //           1.3 us of address traffic in front of the first tile of every workgroup, measured)
+  const float* stats_in = nullptr;  // consumer: [K / 64][stats_ld][2]
+  int64_t stats_ld = 0;           // rows between two groups of the statistics (the buffer's row capacity)
   const float* sg = nullptr;      // consumer: [N]
 };
 constexpr int LN_GROUP = 64;
@@ -245,7 +249,7 @@ struct PLayer {  // one decoder layer's operands (device table, one entry per la
   const float *sgqkv = nullptr, *tbqkv = nullptr, *sg1 = nullptr, *tb1 = nullptr;
 };
 constexpr int PS_PT_SLOTS = 512;
-constexpr int PS_MODE_DEFAULT = 0x134;    // hidden vector as bf16 pairs, XCD-local group edges, folded LayerNorm, 1 sleep unit between sweeps
+constexpr int PS_MODE_DEFAULT = 0x174;    // hidden vector as bf16 pairs, XCD-local group edges, folded LayerNorm, bf16 activation rows + v_dot2c (D2), 1 sleep unit between sweeps
 constexpr int PS_NAPS_DEFAULT = 0x335854;  // units of s_sleep(4) ahead of the first sweep: att 4, x 5, x' 8, hidden 5, q/k/v 3, partials 3 (tools/persist_probe.py sweeps, persist_pf = 3)
 struct PStepArgs {
   const PLayer* layers = nullptr;  // device [L + 1]: the decoder layers, then the predict layer as a pseudo-layer (wqkv = ar_predict_layer.weight
@@ -263,8 +267,9 @@ struct PStepArgs {
   // "persist_mode": bit 2 (4) the FFN hidden vector, bit 3 (8) the attention output travel as bf16 pairs; bit 4 (16) the two
   // head-group edges also through XCD-local (default-policy) granules; bit 5 (32) folded LayerNorm: the dot products run on
   // x * gamma while the row statistics are still being combined, rstd * (dot - mean * sg) + tb afterwards -- one workgroup barrier
-  // per LayerNorm instead of three (not bit-identical to the launch chain: fp32 re-association); bits 8..11 s_sleep units between
-  // two sweeps of an edge
+  // per LayerNorm instead of three (not bit-identical to the launch chain: fp32 re-association); bit 6 (64) D2: the operators' input
+  // rows in LDS as bf16, dot products on v_dot2c_f32_bf16 (needs bit 5; keys per lane 2, request schedules 0 / 3); bits 8..11 s_sleep
+  // units between two sweeps of an edge
   int mode = PS_MODE_DEFAULT;
   // "persist_naps": s_sleep(4) units (~0.1 us each) ahead of the FIRST sweep of an edge, 4 bits each: attention output, x, x',
   // hidden, q/k/v, partials.  A sweep that comes back without the data costs a fabric round trip (~1.1 us) before the next one

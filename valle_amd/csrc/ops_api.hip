@@ -87,14 +87,14 @@ extern "C" int vle_op_linear_ws(void* stream, int dtype, const void* a, const vo
 }
 
 // LayerNorm folded into the packed-row GEMMs (kernels.h GemmLn), the two halves as stand-alone operators (bf16):
-//   producer: resid[M][N] += a @ w^T + bias; xg = bf16(resid * gamma); stats[M][N / 64][2] = (mean, M2) of every 64-column group
-//   consumer: out[M][N] = bf16(act(rstd * (xg @ w^T - mean * sg) + tb)) with the rows' mean / rstd combined from stats[M][K / 64][2]
+//   producer: resid[M][N] += a @ w^T + bias; xg = bf16(resid * gamma); stats[N / 64][M][2] = (mean, M2) of every 64-column group (group-major)
+//   consumer: out[M][N] = bf16(act(rstd * (xg @ w^T - mean * sg) + tb)) with the rows' mean / rstd combined from stats[K / 64][M][2]
 extern "C" int vle_op_linear_ln_producer(void* stream, const void* a, const void* w, const float* bias, float* resid, const float* gamma,
                                          void* xg, float* stats, int64_t M, int32_t N, int32_t K) {
   if (!a || !w || !resid || !gamma || !xg || !stats) return op_fail("vle_op_linear_ln_producer: null operand");
   if (!gemm_ln_supports(DT_BF16, M, N) || K % 128 != 0 || K < 256) return op_fail("vle_op_linear_ln_producer: shape not covered (M >= 128, N % 256 == 0, N <= 1536, K % 128 == 0)");
   GemmLn ln;
-  ln.gamma = gamma; ln.xg = xg; ln.stats_out = stats;
+  ln.gamma = gamma; ln.xg = xg; ln.stats_out = stats; ln.stats_ld = M;
   return op_done(launch_gemm((hipStream_t)stream, DT_BF16, a, w, bias, nullptr, resid, M, N, K, EPI_RESID_LNP, &ln), "vle_op_linear_ln_producer");
 }
 extern "C" int vle_op_linear_ln_consumer(void* stream, const void* xg, const void* w, const float* tb, const float* sg, const float* stats,
@@ -102,7 +102,7 @@ extern "C" int vle_op_linear_ln_consumer(void* stream, const void* xg, const voi
   if (!xg || !w || !tb || !sg || !stats || !out) return op_fail("vle_op_linear_ln_consumer: null operand");
   if (!gemm_ln_supports(DT_BF16, M, K) || N % 256 != 0) return op_fail("vle_op_linear_ln_consumer: shape not covered (M >= 128, K % 256 == 0, K <= 1536, N % 256 == 0)");
   GemmLn ln;
-  ln.stats_in = stats; ln.sg = sg;
+  ln.stats_in = stats; ln.stats_ld = M; ln.sg = sg;
   return op_done(launch_gemm((hipStream_t)stream, DT_BF16, xg, w, tb, out, nullptr, M, N, K, relu ? EPI_RELU_LNC : EPI_STORE_LNC, &ln), "vle_op_linear_ln_consumer");
 }
 

@@ -85,15 +85,15 @@ def linear(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor] = None
 
 
 def linear_ln_producer(a: torch.Tensor, w: torch.Tensor, bias: Optional[torch.Tensor], resid: torch.Tensor, gamma: torch.Tensor):
-    """resid (M,N) fp32 += a @ w.T + bias, in place; returns (xg bf16 (M,N) = resid * gamma, stats fp32 (M, N/64, 2) = (mean, M2) per
-    64-column group) -- the producer half of the LayerNorm folded into the packed-row GEMMs (vle_op_linear_ln_producer)."""
+    """resid (M,N) fp32 += a @ w.T + bias, in place; returns (xg bf16 (M,N) = resid * gamma, stats fp32 (N/64, M, 2) = (mean, M2) per
+    64-column group, group-major) -- the producer half of the LayerNorm folded into the packed-row GEMMs (vle_op_linear_ln_producer)."""
     lib = _lib.load()
     a, w = a.contiguous(), w.contiguous()
     assert a.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and resid.dtype == torch.float32 and resid.is_contiguous()
     M, K = a.shape
     N = w.shape[0]
     xg = torch.empty(M, N, dtype=torch.bfloat16, device=a.device)
-    stats = torch.empty(M, N // 64, 2, dtype=torch.float32, device=a.device)
+    stats = torch.empty(N // 64, M, 2, dtype=torch.float32, device=a.device)
     b = None if bias is None else bias.contiguous()
     _lib.check(lib.vle_op_linear_ln_producer(_st(a), _p(a), _p(w), _p(b), _p(resid), _p(gamma.contiguous()), _p(xg), _p(stats), M, N, K))
     return xg, stats
@@ -106,7 +106,7 @@ def linear_ln_consumer(xg: torch.Tensor, w: torch.Tensor, tb: torch.Tensor, sg: 
     assert xg.dtype == torch.bfloat16 and w.dtype == torch.bfloat16 and stats.dtype == torch.float32 and stats.is_contiguous()
     M, K = xg.shape
     N = w.shape[0]
-    assert stats.shape == (M, K // 64, 2)
+    assert stats.shape == (K // 64, M, 2)
     out = torch.empty(M, N, dtype=torch.bfloat16, device=xg.device)
     _lib.check(lib.vle_op_linear_ln_consumer(_st(xg), _p(xg), _p(w), _p(tb.contiguous()), _p(sg.contiguous()), _p(stats), _p(out), M, N, K, int(relu)))
     return out

@@ -129,6 +129,23 @@ __device__ inline float ps_dot_bf16(const u32x4_t (&wv)[NCH], const u32x4_t (&xv
   }
   return (a0 + a1) + (a2 + a3);
 }
+// Wave totals for the D2 forms (no bit-identity with the launch chain to keep: its wave_sum_dpp reads the four row totals back
+// through v_readlane -- 15 instructions per total).  One value: DPP row sums + the two permlane swaps (8).  R <= 4 values (the rows of
+// one operator): after the row sums, lane column c keeps value c & 3 and ONE pair of swaps finishes all of them -- lane r < R ends
+// up with total r, which is where the callers want it (R row sums + R - 1 selects + 4 instead of 15 R).
+__device__ inline float ps_wave_sum_fast(float v) { return rows4_sum(row16_sum_dpp(v)); }
+template <int R>
+__device__ inline float ps_wave_sums_fast(const float (&t)[R]) {
+  static_assert(R >= 1 && R <= 4, "one value per lane column modulo 4");
+  const int sel = threadIdx.x & 3;
+  float v = row16_sum_dpp(t[0]);
+#pragma unroll
+  for (int r = 1; r < R; ++r) {
+    const float u = row16_sum_dpp(t[r]);
+    v = sel == r ? u : v;
+  }
+  return rows4_sum(v);  // lanes with (lane & 3) == r < R: total r (other columns of R < 4: total 0's copy)
+}
 // this lane's 8 bf16 activations of chunk c (elements c * 512 + lane * 8 ..) from the bf16 row at sxh
 template <int NCH>
 __device__ inline void ps_read_bf16(const float* sx, u32x4_t (&xv)[NCH]) {
@@ -401,7 +418,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   constexpr bool hpack = (PK & 1) != 0, apack = (PK & 2) != 0, LF = (PK & 4) != 0, D2 = (PK & 8) != 0;
   static_assert(!D2 || LF, "the bf16 activation rows carry x * gamma: folded LayerNorm only");
   typedef unsigned u32x2v_t __attribute__((ext_vector_type(2)));
-  const bool glocal = (mode & 16) != 0;
+  const bool glocal = D2 ? true : (mode & 16) != 0;  // (D2 is instantiated with the XCD-local copies only: launch_pstep)
   // s_sleep(8) units ahead of the FIRST sweep of an all-to-all edge (attention output, x, x', hidden): a sweep that comes back
   // without the data costs a whole fabric round trip (~1.1 us) before the next one can see it -- waiting first is cheaper
   const int naps = a.naps;  // "persist_naps": s_sleep(4) units (~0.1 us), 4 bits per edge
@@ -541,14 +558,14 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     float sw = 0.f;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) sw += xr[k];
-    const float mw = wave_sum_dpp(sw) * (1.0f / (64.0f * EPT));
+    const float mw = (D2 ? ps_wave_sum_fast(sw) : wave_sum_dpp(sw)) * (1.0f / (64.0f * EPT));
     float qw = 0.f;
 #pragma unroll
     for (int k = 0; k < EPT; ++k) {
       const float t = xr[k] - mw;
       qw = fmaf(t, t, qw);
     }
-    qw = wave_sum_dpp(qw);
+    qw = D2 ? ps_wave_sum_fast(qw) : wave_sum_dpp(qw);
     if (lane == 0) {
       red[w] = mw;
       red[4 + w] = qw;
@@ -609,11 +626,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if constexpr (D2) {
         u32x4_t xb[NCH];
         ps_read_bf16<NCH>(sx, xb);
+        float t[RQ];
 #pragma unroll
-        for (int r = 0; r < RQ; ++r) {
-          const float t = wave_sum_dpp(ps_dot_bf16<NCH>(wq[r], xb));
-          mine = lane == r ? t : mine;
-        }
+        for (int r = 0; r < RQ; ++r) t[r] = ps_dot_bf16<NCH>(wq[r], xb);
+        mine = ps_wave_sums_fast<RQ>(t);  // lane r < RQ: row r
       } else {
         float x[NCH][VEC];
         g1_read_shared<T, NCH>(sx, x);
@@ -811,25 +827,41 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         for (int e = 0; e < QR; ++e) tq = fmaf(sq[(i * QR + e) % DH], sk[(i * QR + e) % DH], tq);
       }
       const float sself = head_group_sum64(tq, DH / QR) * (1.0f / sqrtf((float)DH));
-      float M = spm[0];
+      float M, Ls, acc[QR];
+      if constexpr (D2 && NS == 16 && QR == 4) {
+        // one split per lane of a 16-lane DPP row (every row of the wave computes the same): one exponential instruction for the 16
+        // splits instead of 16 in a row, the sums by row reductions -- ~50 instructions instead of ~150 on the merging wave's path
+        const int q = lane & 15;
+        const float mq = spm[q], lq = spl[q];
+        const f32x4v_t oq = *reinterpret_cast<const f32x4v_t*>(spo + q * QR);
+        M = fmaxf(row16_max_dpp(mq), sself);
+        const float f = __expf(mq - M), fs = __expf(sself - M);
+        Ls = row16_sum_dpp(lq * f) + fs;
+        acc[0] = fmaf(sv[s * QR + 0], fs, row16_sum_dpp(oq.x * f));
+        acc[1] = fmaf(sv[s * QR + 1], fs, row16_sum_dpp(oq.y * f));
+        acc[2] = fmaf(sv[s * QR + 2], fs, row16_sum_dpp(oq.z * f));
+        acc[3] = fmaf(sv[s * QR + 3], fs, row16_sum_dpp(oq.w * f));
+      } else {
+        M = spm[0];
 #pragma unroll
-      for (int q = 1; q < NS; ++q) M = fmaxf(M, spm[q]);
-      M = fmaxf(M, sself);
-      float Ls = 0.f, acc[QR];
+        for (int q = 1; q < NS; ++q) M = fmaxf(M, spm[q]);
+        M = fmaxf(M, sself);
+        Ls = 0.f;
 #pragma unroll
-      for (int e = 0; e < QR; ++e) acc[e] = 0.f;
+        for (int e = 0; e < QR; ++e) acc[e] = 0.f;
 #pragma unroll
-      for (int q = 0; q < NS; ++q) {
-        const float f = __expf(spm[q] - M);
-        Ls = fmaf(spl[q], f, Ls);
+        for (int q = 0; q < NS; ++q) {
+          const float f = __expf(spm[q] - M);
+          Ls = fmaf(spl[q], f, Ls);
 #pragma unroll
-        for (int e = 0; e < QR; ++e) acc[e] = fmaf(spo[q * QR + e], f, acc[e]);
-      }
-      {
-        const float f = __expf(sself - M);
-        Ls += f;
+          for (int e = 0; e < QR; ++e) acc[e] = fmaf(spo[q * QR + e], f, acc[e]);
+        }
+        {
+          const float f = __expf(sself - M);
+          Ls += f;
 #pragma unroll
-        for (int e = 0; e < QR; ++e) acc[e] = fmaf(sv[s * QR + e], f, acc[e]);
+          for (int e = 0; e < QR; ++e) acc[e] = fmaf(sv[s * QR + e], f, acc[e]);
+        }
       }
       const float inv = 1.0f / Ls;
 #pragma unroll
@@ -897,7 +929,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if constexpr (D2) {
         u32x4_t xb[NCH];
         ps_read_bf16<NCH>(sx, xb);
-        mine = wave_sum_dpp(ps_dot_bf16<NCH>(wo, xb));
+        mine = ps_wave_sum_fast(ps_dot_bf16<NCH>(wo, xb));
       } else {
         float x[NCH][VEC];
         g1_read_shared<T, NCH>(sx, x);
@@ -931,11 +963,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if constexpr (D2) {
         u32x4_t xb[NCH];
         ps_read_bf16<NCH>(sx, xb);
+        float t[R1];
 #pragma unroll
-        for (int r = 0; r < R1; ++r) {
-          const float t = wave_sum_dpp(ps_dot_bf16<NCH>(w1[r], xb));
-          mine = lane == r ? t : mine;
-        }
+        for (int r = 0; r < R1; ++r) t[r] = ps_dot_bf16<NCH>(w1[r], xb);
+        mine = ps_wave_sums_fast<R1>(t);  // lane r < R1: row r
       } else {
         float x[NCH][VEC];
         g1_read_shared<T, NCH>(sx, x);
@@ -997,7 +1028,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if constexpr (D2) {
         u32x4_t xb[NCH2];
         ps_read_bf16<NCH2>(sx, xb);
-        mine = wave_sum_dpp(ps_dot_bf16<NCH2>(w2, xb));
+        mine = ps_wave_sum_fast(ps_dot_bf16<NCH2>(w2, xb));
       } else {
         float x[NCH2][VEC];
         g1_read_shared<T, NCH2>(sx, x);
@@ -1026,7 +1057,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     float t0;
     if constexpr (D2) {
       ps_read_bf16<NCH>(sx, xb);
-      t0 = wave_sum_dpp(ps_dot_bf16<NCH>(wq[0], xb));
+      t0 = ps_wave_sum_fast(ps_dot_bf16<NCH>(wq[0], xb));
     } else {
       g1_read_shared<T, NCH>(sx, x);
       t0 = wave_sum_dpp(g1_dot<T, NCH>(wq[0], x));
@@ -1039,7 +1070,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     }
     if (extra_row) {
       float t1;
-      if constexpr (D2) t1 = wave_sum_dpp(ps_dot_bf16<NCH>(wq[1], xb));
+      if constexpr (D2) t1 = ps_wave_sum_fast(ps_dot_bf16<NCH>(wq[1], xb));
       else t1 = wave_sum_dpp(g1_dot<T, NCH>(wq[1], x));
       if (lane == 0) {
         const float lg = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgx, t1), tbx) : t1 + 0.f;
@@ -1263,7 +1294,7 @@ int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!a.layers || !a.x_in || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
   if (a.nsteps < 0 || a.nsteps > 4096 || (a.nsteps > 0 && !a.smp)) return -1;
   if (a.mode & 64) {  // D2
-    if (!(a.mode & 32) || a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
+    if (!(a.mode & 32) || !(a.mode & 16) || a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
     if (a.ptrace != nullptr && a.pf == 3) return ps_launch_traced(st, a);
     return a.pf == 0 ? ps_launch_d2<0>(st, a) : ps_launch_d2<3>(st, a);
   }

@@ -24,7 +24,7 @@ def reset(eng):
     for k in ("nsplit", "gemv1_rpw", "gemv1_rpw_qkv", "gemv1_rpw_ffn1", "no_gemv1", "attn_nk", "steps_per_graph"):
         eng.set_option(k, 0)
     for k, v in (("qkv_attn", 1), ("qa_nsplit", 8), ("g1_shared", 1), ("qa_waves", 4), ("qa_qtemporal", 1), ("qa_handoff", 1), ("qa_nk", 4),
-                 ("persist", 0), ("persist_pf", 3), ("persist_nk", 2), ("persist_mode", 0x174), ("persist_naps", 0x335854), ("persist_sample", 1), ("act_bf16", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
+                 ("persist", 0), ("persist_pf", 3), ("persist_nk", 2), ("persist_mode", 0x174), ("persist_naps", 0x325756), ("persist_sample", 1), ("act_bf16", 0), ("persist_trace", 0), ("trace_ar_logits", 0)):
         eng.set_option(k, v)
 
 

@@ -166,7 +166,10 @@ __global__ __launch_bounds__(256) void decode_attn_kernel(const float* __restric
   // the wave fetches anyway -- at 64 utterances the rows past the context were 10 % of the kernel's HBM traffic (r04 PMC: 186.8 MB
   // per launch against 170 MB of valid rows).  The batch-1 variant keeps the length in the same burst as the first keys (latency).
   int key_hi = ctx_max - 1;
-  if constexpr (NT) key_hi = kv_len[b];
+  if constexpr (NT) {  // (a free / finished slot's length is whatever it last held: keep the clamp inside the cache whatever it says)
+    const int kl = kv_len[b];
+    key_hi = kl < 0 ? 0 : (kl < ctx_max ? kl : ctx_max - 1);
+  }
   auto issue = [&](int base) {  // loads of the NK keys base + w*WCH + i*KPW + slot (clamped into the cache)
 #pragma unroll
     for (int i = 0; i < NK; ++i) {

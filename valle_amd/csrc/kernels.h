@@ -250,7 +250,7 @@ struct PLayer {  // one decoder layer's operands (device table, one entry per la
 };
 constexpr int PS_PT_SLOTS = 512;
 constexpr int PS_MODE_DEFAULT = 0x174;    // hidden vector as bf16 pairs, XCD-local group edges, folded LayerNorm, bf16 activation rows + v_dot2c (D2), 1 sleep unit between sweeps
-constexpr int PS_NAPS_DEFAULT = 0x335854;  // units of s_sleep(4) ahead of the first sweep: att 4, x 5, x' 8, hidden 5, q/k/v 3, partials 3 (tools/persist_probe.py sweeps, persist_pf = 3)
+constexpr int PS_NAPS_DEFAULT = 0x325756;  // re-timed for the D2 forms (round 5: 130.9 -> 129.6 us per step on the probe; round 4's 0x335854 was timed for the fp32-row forms)
 struct PStepArgs {
   const PLayer* layers = nullptr;  // device [L + 1]: the decoder layers, then the predict layer as a pseudo-layer (wqkv = ar_predict_layer.weight
                                    // bf16 [V][d], g1 / be1 = the final LayerNorm, sgqkv / tbqkv = its folded row constants [V], bqkv = any valid [3 d])

@@ -282,8 +282,10 @@ class Engine:
         return int(v.value)
 
     def fetch_persist_trace(self) -> torch.Tensor:
-        """(8 step slots, 256 workgroups, 96) int64 wall-clock stamps (10 ns ticks) of the persistent step's edges (option
-        "persist_trace"): slot 0 = workgroup entry, then one stamp after every completed hand-off; 0 where nothing was stamped."""
+        """(8 step slots, 256 workgroups, 512) int64 words of the persistent step's timeline (option "persist_trace"; the traced
+        instantiations exist for persist_nk = 2 / persist_pf = 3): triplets {wall clock (10 ns ticks) when the workgroup's thread 0
+        began to wait for a hand-off, polling passes it took, wall clock when the data was in LDS}, the first triplet = workgroup
+        entry; 0 where nothing was stamped."""
         raw = torch.zeros(8, 256, 512, dtype=torch.int64)
         n = self.lib.vle_debug_fetch(self.h, b"persist_trace", C.c_void_p(raw.data_ptr()), raw.numel() * 8)
         if n < 0:

@@ -224,7 +224,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
       s2 = fmaf(d0, d0, s2);
       q += on ? lnp[g][1] : 0.f;
     }
-    const float sm = s1 / (float)ln_ng;  // mean_h - ref
+    const float sm = s1 * __builtin_amdgcn_rcpf((float)ln_ng);  // mean_h - ref
     ln_mean = ref + sm;
     ln_m2 = q + (float)LN_GROUP * (s2 - s1 * sm);
   }
@@ -284,6 +284,17 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
         S[4 * (tid & 255) + 2 * (tid >> 8) + 1] = ln_m2;
         __syncthreads();
       }
+      g8_f32x4 sg4[LNC ? 2 : 1][LNC ? 2 : 1], tb4[LNC ? 2 : 1][LNC ? 2 : 1];  // this lane's columns of sg / tb, out of LDS once
+      if constexpr (LNC) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int col = b * 128 + wc * 32 + j * 16 + fg * 4;
+            sg4[b][j] = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + LN_STATS + col * 4);
+            tb4[b][j] = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + LN_STATS + 1024 + col * 4);
+          }
+      }
 #pragma unroll
       for (int a = 0; a < 2; ++a)
 #pragma unroll
@@ -294,7 +305,7 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
             const g8_f32x4 hh = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + row * 16);
             const float dm = hh[0] - hh[2];
             mean = 0.5f * (hh[0] + hh[2]);
-            rstd = 1.0f / sqrtf((hh[1] + hh[3] + 0.25f * (float)K * dm * dm) / (float)K + LN_EPS);
+            rstd = __builtin_amdgcn_rsqf(fmaf(hh[1] + hh[3] + 0.25f * (float)K * dm * dm, __builtin_amdgcn_rcpf((float)K), LN_EPS));  // v_rcp / v_rsq: no IEEE sequences
           }
 #pragma unroll
           for (int b = 0; b < 2; ++b)
@@ -303,11 +314,8 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
               const int c = b * 16 + wc * 4 + j * 2 + (fg >> 1);
               g8_f32x4 v;
               if constexpr (LNC) {
-                const int col = b * 128 + wc * 32 + j * 16 + fg * 4;
-                const g8_f32x4 sgv = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + LN_STATS + col * 4);
-                const g8_f32x4 tbv = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + LN_STATS + 1024 + col * 4);
 #pragma unroll
-                for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sgv[r], acc[a][b][i][j][r]), tbv[r]);
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sg4[b][j][r], acc[a][b][i][j][r]), tb4[b][j][r]);
               } else {
                 v = acc[a][b][i][j] + bias4[LNC ? 0 : b][LNC ? 0 : j];
               }

@@ -170,7 +170,8 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
       s2 = fmaf(d0, d0, s2);
       q += on ? lnp[g][1] : 0.f;
     }
-    const float sm = s1 / (float)ln_ng;  // mean_h - ref
+    const float sm = s1 * __builtin_amdgcn_rcpf((float)ln_ng);  // mean_h - ref (no IEEE division sequences in these epilogues: every
+                                                                // wave of the workgroup runs them at once, issue-bound)
     ln_mean = ref + sm;
     ln_m2 = q + (float)LN_GROUP * (s2 - s1 * sm);
   }
@@ -256,22 +257,34 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
       }
       __syncthreads();
     }
+    const float ln_invk = __builtin_amdgcn_rcpf((float)K);
+    gg_f32x4 sg4[LNC ? FN : 1], tb4[LNC ? FN : 1];  // this lane's columns of sg / tb, out of LDS once
+    if constexpr (LNC) {
 #pragma unroll
-    for (int i = 0; i < FM; ++i)
+      for (int j = 0; j < FN; ++j) {
+        sg4[j] = *reinterpret_cast<const gg_f32x4*>(smem + STAGES * STAGE_BYTES + LN_STATS + (wn0 + j * 16 + fg * 4) * 4);
+        tb4[j] = *reinterpret_cast<const gg_f32x4*>(smem + STAGES * STAGE_BYTES + LN_STATS + BN * 4 + (wn0 + j * 16 + fg * 4) * 4);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FM; ++i) {
+      float mean = 0.f, rstd = 1.f;
+      if constexpr (LNC) {
+        // the row's two halves (K / 2 elements each): mean = (m0 + m1) / 2, M2 = q0 + q1 + (K / 4) (m0 - m1)^2; once per row of the
+        // lane, v_rcp / v_rsq (1 ulp) instead of IEEE division + square root sequences (30 instructions each: the first build of this
+        // epilogue spent 600 instructions per wave on them, 1.2 us per tile with all eight waves in it)
+        const gg_f32x4 hh = *reinterpret_cast<const gg_f32x4*>(smem + STAGES * STAGE_BYTES + (wm0 + i * 16 + fr) * 16);
+        const float dm = hh[0] - hh[2];
+        mean = 0.5f * (hh[0] + hh[2]);
+        rstd = __builtin_amdgcn_rsqf(fmaf(hh[1] + hh[3] + 0.25f * (float)K * dm * dm, ln_invk, LN_EPS));
+      }
 #pragma unroll
       for (int j = 0; j < FN; ++j) {
         const int row = wm0 + i * 16 + fr, col = wn0 + j * 16 + fg * 4;
         gg_f32x4 v;
         if constexpr (LNC) {
-          // the row's two halves (K / 2 elements each): mean = (m0 + m1) / 2, M2 = q0 + q1 + (K / 4) (m0 - m1)^2
-          const gg_f32x4 hh = *reinterpret_cast<const gg_f32x4*>(smem + STAGES * STAGE_BYTES + row * 16);
-          const float dm = hh[0] - hh[2];
-          const float mean = 0.5f * (hh[0] + hh[2]);
-          const float rstd = 1.0f / sqrtf((hh[1] + hh[3] + 0.25f * (float)K * dm * dm) / (float)K + LN_EPS);
-          const gg_f32x4 sgv = *reinterpret_cast<const gg_f32x4*>(smem + STAGES * STAGE_BYTES + LN_STATS + col * 4);
-          const gg_f32x4 tbv = *reinterpret_cast<const gg_f32x4*>(smem + STAGES * STAGE_BYTES + LN_STATS + BN * 4 + col * 4);
 #pragma unroll
-          for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sgv[r], acc[i][j][r]), tbv[r]);
+          for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sg4[j][r], acc[i][j][r]), tb4[j][r]);
         } else {
           v = acc[i][j] + bias4[LNC ? 0 : j];
         }
@@ -288,6 +301,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
           *reinterpret_cast<gg_bf16x4*>(E + row * RB + (((col >> 3) ^ (fr & 7)) << 4) + ((((col >> 2) & 1) ^ (fr >> 3)) << 3)) = o4;
         }
       }
+    }
     const int l = lane % CPR, rsub = lane / CPR;
     gg_f32x4 old[RESID ? IT : 1];
     gg_f32x4 gamma4 = gg_f32x4{0.f, 0.f, 0.f, 0.f};

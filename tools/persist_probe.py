@@ -66,10 +66,12 @@ def main():
     # ---- 1. bit-identity with the chain --------------------------------------------------------------------------------------
     if not args.skip_check:
         checks = []
-        for nk, pf, md in ((2, 3, 0x134), (2, 0, 0x134), (4, 3, 0x13c), (2, 3, 0x114), (2, 0, 0x114), (2, 3, 0), (2, 3, 0x1c), (2, 3, 0x10), (4, 3, 0x114), (2, 1, 0x114), (2, 2, 0x118)):
+        for nk, pf, md in ((2, 3, 0x174), (2, 0, 0x174), (2, 3, 0x134), (2, 0, 0x134), (4, 3, 0x13c), (2, 3, 0x114), (2, 0, 0x114), (2, 3, 0), (2, 3, 0x1c), (2, 3, 0x10), (4, 3, 0x114), (2, 1, 0x114), (2, 2, 0x118)):
             if True:
                 ab = (2 if md & 4 else 0) | (1 if md & 8 else 0)
-                if md & 32:  # folded LayerNorm: against the three-barrier form of the same launch (fp32 re-association apart)
+                if md & 64:  # bf16 activation rows + v_dot2c: against the fp32-row form of the same launch (free-running: the record shows where they part)
+                    ref = decode(eng, X, Y, args.check_steps, {"persist": 1, "persist_nk": nk, "persist_pf": pf, "persist_mode": md & ~64}, trace=True)
+                elif md & 32:  # folded LayerNorm: against the three-barrier form of the same launch (fp32 re-association apart)
                     ref = decode(eng, X, Y, args.check_steps, {"persist": 1, "persist_nk": nk, "persist_pf": pf, "persist_mode": md & ~32}, trace=True)
                 else:
                     ref = decode(eng, X, Y, args.check_steps, {"qa_nsplit": 16, "qa_nk": nk, "act_bf16": ab}, trace=True)

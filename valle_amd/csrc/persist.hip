@@ -580,7 +580,9 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       dm = fmaf(t, t, dm);
     }
     m2 = fmaf(dm, 64.0f * EPT, m2);
-    rstd = 1.0f / sqrtf(m2 * (1.0f / (float)D) + LN_EPS);
+    // (D2: v_rsq_f32, 1 ulp -- the IEEE square root + division sequences are 25 instructions on every LayerNorm's critical path)
+    if constexpr (D2) rstd = __builtin_amdgcn_rsqf(fmaf(m2, 1.0f / (float)D, LN_EPS));
+    else rstd = 1.0f / sqrtf(m2 * (1.0f / (float)D) + LN_EPS);
   };
 
   // ---- sampling inside the launch: the utterance's state, carried in registers by every workgroup ------------------------------
@@ -863,7 +865,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
           for (int e = 0; e < QR; ++e) acc[e] = fmaf(sv[s * QR + e], f, acc[e]);
         }
       }
-      const float inv = 1.0f / Ls;
+      const float inv = D2 ? __builtin_amdgcn_rcpf(Ls) : 1.0f / Ls;
 #pragma unroll
       for (int e = 0; e < QR; ++e) acc[e] *= inv;
       if constexpr (!apack) {

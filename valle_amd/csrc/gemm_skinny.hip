@@ -330,7 +330,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
       if (j < ln_nq) msum += lst[j][0] + lst[j][2];
     msum = rows4_sum(msum);
     const float cnt = 16.f * (float)a.lnc.nslots;  // = K of the producer's rows
-    const float mean = msum / (float)a.lnc.nslots;
+    const float mean = msum * __builtin_amdgcn_rcpf((float)a.lnc.nslots);  // (v_rcp / v_rsq: the IEEE sequences are 45 of this epilogue's ~150 dependent instructions)
     float m2 = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXQ; ++j)
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(GemmSkinnyArgs a) {
       }
     m2 = rows4_sum(m2);
     ln_mean = mean;
-    ln_rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
+    ln_rstd = __builtin_amdgcn_rsqf(fmaf(m2, __builtin_amdgcn_rcpf(cnt), LN_EPS));
   };
   // Measured and rejected (MI355X, 64 utterances, tools/ktrace_dist.py): requesting the statistics AHEAD of the W / X burst and
   // merging them while the burst is in flight shrinks the epilogue after the MFMAs 1.2 -> 0.5 us, but the MFMAs start 0.7 us
@@ -793,7 +793,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs 
       if (j < ln_nq) msum += lst[j][0] + lst[j][2];
     msum = rows4_sum(msum);
     const float cnt = 16.f * (float)a.lnc.nslots;
-    const float mean = msum / (float)a.lnc.nslots;
+    const float mean = msum * __builtin_amdgcn_rcpf((float)a.lnc.nslots);  // (v_rcp / v_rsq: the IEEE sequences are 45 of this epilogue's ~150 dependent instructions)
     float m2 = 0.f;
 #pragma unroll
     for (int j = 0; j < LN_MAXQ; ++j)
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_skinny_ms_kernel(GemmSkinnyArgs 
         m2 += fmaf(16.f, fmaf(d1, d1, d0 * d0), lst[j][1] + lst[j][3]);
       }
     m2 = rows4_sum(m2);
-    const float rstd = 1.0f / sqrtf(m2 / cnt + LN_EPS);
+    const float rstd = __builtin_amdgcn_rsqf(fmaf(m2, __builtin_amdgcn_rcpf(cnt), LN_EPS));
     if constexpr (W8) v = v * scale4;
     // explicit fma's: left to -ffp-contract the compile-time-layout body fused the last step and the general body did not
     v = __builtin_elementwise_fma(__builtin_elementwise_fma(gs_f32x4{-mean, -mean, -mean, -mean}, wg4, v), gs_f32x4{rstd, rstd, rstd, rstd}, bias4);

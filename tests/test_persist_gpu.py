@@ -138,6 +138,47 @@ def test_bf16_activation_rows_with_dot2_match_the_fp32_rows(c2_model, mode):
     assert torch.equal(got, pf0)
 
 
+@pytest.fixture(scope="module")
+def c2_model_fp8w():
+    torch.manual_seed(13)
+    return valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="fp8w").to(DEV).eval()
+
+
+@pytest.mark.parametrize("pf", [3, 0])
+def test_fp8w_persistent_step_is_bit_identical_to_the_fp8w_launch_chain(c2_model_fp8w, pf):
+    """FP8W (e4m3fn weight rows + one power-of-two scale per row, BASELINE configs[4]'s weight format): the persistent launch widens
+    the codes with the chain's own device function and applies the scale as the chain does (fmaf(dot, scale, bias)), so in the
+    three-barrier LayerNorm form every logit of a decode equals the fp8w chain's (16 key splits, 2 keys per lane, bf16 hidden row)."""
+    S, P, steps = 20, 60, 40
+    eng = c2_model_fp8w.engine_for(1, S, P)
+    X, Y = _inputs(S, P)
+    ref_codes, ref = _decode(eng, X, Y, S, P, steps, {"qa_nsplit": 16, "qa_nk": 2, "act_bf16": 2})
+    assert eng.fetch_u32("persist_ran") == 0
+    got_codes, got = _decode(eng, X, Y, S, P, steps, {"persist": 1, "persist_nk": 2, "persist_pf": pf, "persist_mode": CLASSIC, "act_bf16": 2})
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+    assert torch.equal(ref_codes, got_codes)
+    assert ref.shape == got.shape and torch.equal(ref, got), f"max |dlogit| {(ref - got).abs().max().item():.3e} (must be 0)"
+
+
+def test_fp8w_persistent_step_default_form_matches_the_three_barrier_form(c2_model_fp8w):
+    """The fp8w engine's default form (folded LayerNorm; the v_dot2c forms need bf16 weights and are masked off) against the
+    three-barrier form, teacher-forced over 96 steps at the benchmark's prompt: within 5e-3 of the logits' spread; and it is what an
+    fp8w engine runs without any option."""
+    S, P, steps = 47, 225, 96
+    eng = c2_model_fp8w.engine_for(1, S, P)
+    X, Y = _inputs(S, P, seed=5)
+    ref_codes, ref = _decode(eng, X, Y, S, P, steps, {"persist": 1, "persist_mode": CLASSIC})
+    forced = dict(forced=ref_codes[None].to(DEV), forced_lens=[ref_codes.numel()])
+    _, got = _decode(eng, X, Y, S, P, 0, {"persist": 1, "persist_mode": DEFAULT}, **forced)  # bit 6 is masked for fp8 weights: = FOLDED
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+    _, got2 = _decode(eng, X, Y, S, P, 0, {"persist": 1, "persist_mode": FOLDED}, **forced)
+    assert torch.equal(got, got2)
+    n = min(ref.shape[0], got.shape[0])
+    sigma = ref[:n].std().item()
+    err = (ref[:n] - got[:n]).abs().max().item()
+    assert not torch.equal(ref[:n], got[:n]) and err <= 5e-3 * sigma, (err, sigma)
+
+
 def test_persistent_step_past_1024_keys_and_at_full_length(c2_model):
     """BASELINE configs[1]'s own lengths plus a longer text: the context passes 1024 keys, where a workgroup's attention share
     takes a second round of key chunks (16 splits x 64 keys per round at 2 keys per lane)."""
@@ -307,7 +348,15 @@ def test_persistent_step_is_the_default_where_covered_and_only_there():
     X, Y = _inputs(8, 10)
     eng.prefill(X, [8], Y, [10])
     assert eng.fetch_u32("persist_active") == 1
-    for dtype, d, h in (("fp32", 1024, 16), ("fp8w", 1024, 16), ("bf16", 512, 8)):
+    # fp8 weights (round 5): the same launch on e4m3fn rows + row scales; engine mode fp8 decodes its AR loop the same way
+    for dtype in ("fp8w", "fp8"):
+        m1 = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype=dtype).to(DEV).eval()
+        e1 = m1.engine_for(1, 8, 10)
+        e1.prefill(X, [8], Y, [10])
+        assert e1.fetch_u32("persist_active") == 1, dtype
+        codes, gl = e1.generate(top_k=1, max_new=6)
+        assert e1.fetch_u32("persist_ran") == 1 and e1.fetch_u32("persist_fail") == 0 and gl[0] >= 1
+    for dtype, d, h in (("fp32", 1024, 16), ("bf16", 512, 8)):
         m2 = valle_amd.VALLE(d, h, 2, prefix_mode=1, engine_dtype=dtype).to(DEV).eval()
         e2 = m2.engine_for(1, 8, 10)
         e2.prefill(X, [8], Y, [10])

@@ -1306,16 +1306,27 @@ int kv_stream_nt(const vle_engine* e) {
   return bytes > ((int64_t)192 << 20) ? 1 : 0;
 }
 
-// The persistent step (persist.hip) covers this call: batch 1, the covered shape, bf16 weights, its table built for this cache
+// FP8W engines run the persistent launch in the forms instantiated for fp8 weight rows: the hidden row as bf16 pairs, three-barrier or
+// folded LayerNorm, fp32 activation rows (the v_dot2c forms multiply bf16 weights), keys per lane 2, request schedules 0 / 3
+int ps_mode_of(const vle_engine* e) { return e->w8 ? (e->opt_ps_mode & ~(64 | 8)) : e->opt_ps_mode; }
+bool ps_w8_mode_ok(const vle_engine* e) {
+  const int m = ps_mode_of(e);
+  return (m & 4) != 0 && e->opt_ps_nk == 2 && (e->opt_ps_pf == 0 || e->opt_ps_pf == 3) && !e->opt_ps_trace && e->ar_predict8 != nullptr && e->ar_predict_s != nullptr &&
+         !e->ar.empty() && e->ar[0].wqkv8 != nullptr;
+}
+
+// The persistent step (persist.hip) covers this call: batch 1, the covered shape, bf16 or fp8 weights, its table built for this cache
 bool persist_ready(const vle_engine* e) {
-  return e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && e->B == 1 && !e->slot_mode && !e->w8 && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
+  return e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && e->B == 1 && !e->slot_mode && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
+         (!e->w8 || ps_w8_mode_ok(e)) &&
          e->ps_table_kc == e->kcache && e->ps_table_ctx == e->ctx_max && (int)e->ar.size() == e->L;
 }
 
 // (re)build the operand table for a batch-1 call and forget the granules' old tags (the iteration counter restarts at every
 // prefill).  Called from vle_ar_prefill: never inside a stream capture.
 int persist_prepare(vle_engine* e) {
-  if (!e->ps_table || !e->ps_gran || !e->ps_fold || !e->ps_sample || !e->ps_host || e->B != 1 || e->w8) return 0;
+  if (!e->ps_table || !e->ps_gran || !e->ps_fold || !e->ps_sample || !e->ps_host || e->B != 1) return 0;
+  if (e->w8 && (e->ar_predict8 == nullptr || e->ar.empty() || e->ar[0].wqkv8 == nullptr)) return 0;
   if (e->ps_table_kc != e->kcache || e->ps_table_ctx != e->ctx_max) {
     std::vector<PLayer> tab(e->L + 1);
     const int64_t d = e->d;
@@ -1327,6 +1338,10 @@ int persist_prepare(vle_engine* e) {
       E_LAUNCH(e, launch_ps_fold(e->st, w.wqkv, w.g1, w.be1, w.bqkv, f, f + 3 * d, (int)(3 * d), (int)d));
       E_LAUNCH(e, launch_ps_fold(e->st, w.w1, w.g2, w.be2, w.b1, f + 6 * d, f + 10 * d, (int)(4 * d), (int)d));
       t.wqkv = w.wqkv; t.wo = w.wo; t.w1 = w.w1; t.w2 = w.w2;
+      if (e->w8) {  // the e4m3fn codes + row scales (the folded-LayerNorm constants above come from bf16(W') = the same values)
+        t.wqkv = w.wqkv8; t.wo = w.wo8; t.w1 = w.w18; t.w2 = w.w28;
+        t.sqkv = w.sqkv; t.so = w.so; t.s1 = w.s1; t.s2 = w.s2;
+      }
       t.bqkv = w.bqkv; t.bo = w.bo; t.b1 = w.b1; t.b2 = w.b2;
       t.g1 = w.g1; t.be1 = w.be1; t.g2 = w.g2; t.be2 = w.be2;
       t.kc = cache_layer(e, e->kcache, l); t.vc = cache_layer(e, e->vcache, l);
@@ -1337,6 +1352,9 @@ int persist_prepare(vle_engine* e) {
       PLayer& t = tab[e->L];
       t = tab[e->L - 1];  // every pointer valid
       t.wqkv = e->ar_predict; t.g1 = e->ar_norm_g; t.be1 = e->ar_norm_b; t.sgqkv = f; t.tbqkv = f + V_AR + 3;
+      if (e->w8) {
+        t.wqkv = e->ar_predict8; t.sqkv = e->ar_predict_s;
+      }
     }
     // pinned staging + a copy ON THE ENGINE'S STREAM: the kernels that read the table through scalar loads are ordered behind it by
     // the stream itself (a synchronous copy from pageable memory may be a host write through the PCIe aperture)
@@ -1373,12 +1391,12 @@ int enqueue_persist_step(vle_engine* e, int nsteps = 1) {
   a.kv_len = e->S.kv_len; a.iter = e->S.iter; a.done = e->S.done; a.gran = e->ps_gran;
   a.fail = e->qa_spin_fail ? e->qa_spin_fail + 2 : nullptr;
   a.ptrace = e->opt_ps_trace ? e->ps_ptrace : nullptr;
-  a.mode = e->opt_ps_mode; a.nk = e->opt_ps_nk; a.pf = e->opt_ps_pf; a.naps = e->opt_ps_naps;
+  a.mode = ps_mode_of(e); a.nk = e->opt_ps_nk; a.pf = e->opt_ps_pf; a.naps = e->opt_ps_naps;
   if (e->opt_ps_sample) {
     a.nsteps = nsteps;
     a.smp = e->ps_sample;
   }
-  const int r = launch_pstep(e->st, e->dtype, a);
+  const int r = launch_pstep(e->st, e->w8 ? DT_FP8W : e->dtype, a);
   if (r != 0) return e->fail(VLE_EINVAL, "launch_pstep rejected the step");
   return 0;
 }

@@ -247,6 +247,8 @@ struct PLayer {  // one decoder layer's operands (device table, one entry per la
   // folded LayerNorm (persist_mode bit 5): per output row n of the in-projection / linear1, sg[n] = sum_k W[n][k] gamma[k] and
   // tb[n] = sum_k W[n][k] beta[k] + bias[n]  (launch_ps_fold)
   const float *sgqkv = nullptr, *tbqkv = nullptr, *sg1 = nullptr, *tb1 = nullptr;
+  // FP8W (the weights above are e4m3fn codes then): the rows' power-of-two scales; null in bf16 mode
+  const float *sqkv = nullptr, *so = nullptr, *s1 = nullptr, *s2 = nullptr;
 };
 constexpr int PS_PT_SLOTS = 512;
 constexpr int PS_MODE_DEFAULT = 0x174;    // hidden vector as bf16 pairs, XCD-local group edges, folded LayerNorm, bf16 activation rows + v_dot2c (D2), 1 sleep unit between sweeps

@@ -62,15 +62,16 @@ __device__ inline void ps_load4(const float PS_GLOBAL* p, float (&f)[4]) {
   f[0] = t.x; f[1] = t.y; f[2] = t.z; f[3] = t.w;
 }
 struct PsLayer {  // one entry of the table, as addresses
-  unsigned long long wqkv, wo, w1, w2, bqkv, bo, b1, b2, g1, be1, g2, be2, kc, vc, sgqkv, tbqkv, sg1, tb1;
+  unsigned long long wqkv, wo, w1, w2, bqkv, bo, b1, b2, g1, be1, g2, be2, kc, vc, sgqkv, tbqkv, sg1, tb1, sqkv, so, s1, s2;
 };
 __device__ inline PsLayer ps_layer(const PLayer* tab, int l) {
-  static_assert(sizeof(PLayer) == 18 * 8, "PLayer is 18 pointers");
-  const unsigned long long PS_CONST* t = (const unsigned long long PS_CONST*)tab + (size_t)l * 18;
+  static_assert(sizeof(PLayer) == 22 * 8, "PLayer is 22 pointers");
+  const unsigned long long PS_CONST* t = (const unsigned long long PS_CONST*)tab + (size_t)l * 22;
   PsLayer p;
   p.wqkv = t[0]; p.wo = t[1]; p.w1 = t[2]; p.w2 = t[3]; p.bqkv = t[4]; p.bo = t[5]; p.b1 = t[6]; p.b2 = t[7];
   p.g1 = t[8]; p.be1 = t[9]; p.g2 = t[10]; p.be2 = t[11]; p.kc = t[12]; p.vc = t[13];
   p.sgqkv = t[14]; p.tbqkv = t[15]; p.sg1 = t[16]; p.tb1 = t[17];
+  p.sqkv = t[18]; p.so = t[19]; p.s1 = t[20]; p.s2 = t[21];  // (the bf16 instantiations never use them: the loads are dropped)
   return p;
 }
 
@@ -367,7 +368,8 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   constexpr int CVEC = Elem<CT>::VEC;
   constexpr int LPK = DH / CVEC, KPW = 64 / LPK, WCH = NK * KPW, CHUNK = 4 * WCH;
   static_assert(DH % CVEC == 0 && (LPK & (LPK - 1)) == 0 && LPK <= 32, "head size");
-  static_assert(!G1W<T>::kScaled, "bf16 weights only");
+  // FP8W (T = bf16w8t_t): the weight rows are e4m3fn codes (8 bytes per lane and chunk, default cache policy: one utterance's fp8 AR
+  // weights fit the memory-side cache) with one power-of-two scale per row, applied as the launch chain does -- fmaf(dot, scale, bias)
 
   // ---- LDS: one array (> 80 KB: one workgroup per CU) -------------------------------------------------------------------------
   constexpr int SM_FLOATS = 21 * 1024;
@@ -415,7 +417,8 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   int kvl = a.kv_len[0];            // slot of the new token; the old keys are [0, kvl)
   const int ctx_max = a.ctx_max;
   const int mode = a.mode;
-  constexpr bool hpack = (PK & 1) != 0, apack = (PK & 2) != 0, LF = (PK & 4) != 0, D2 = (PK & 8) != 0;
+  constexpr bool hpack = (PK & 1) != 0, apack = (PK & 2) != 0, LF = (PK & 4) != 0, D2 = (PK & 8) != 0, W8 = G1W<T>::kScaled;
+  static_assert(!(W8 && D2), "the v_dot2c forms multiply bf16 weights");
   static_assert(!D2 || LF, "the bf16 activation rows carry x * gamma: folded LayerNorm only");
   typedef unsigned u32x2v_t __attribute__((ext_vector_type(2)));
   const bool glocal = D2 ? true : (mode & 16) != 0;  // (D2 is instantiated with the XCD-local copies only: launch_pstep)
@@ -440,6 +443,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
   // ---- register-resident operands, requested ahead -----------------------------------------------------------------------------
   u32x4_t wq[RQ][NCH], wo[NCH], w1[R1][NCH], w2[NCH2];
   float bq = 0.f, bo_v = 0.f, b1_v = 0.f, b2_v = 0.f;
+  float scq = 1.f, sco = 1.f, sc1 = 1.f, sc2 = 1.f, scx = 1.f;  // FP8W row scales, fetched beside the biases (scx: row 1024 of the predict layer)
   float sgq = 0.f, sg1_v = 0.f, sgx = 0.f, tbx = 0.f;  // folded LayerNorm: sg of the rows whose tb sits in bq / b1_v; row 1024's pair
   float g1v[EPT], be1v[EPT], g2v[EPT], be2v[EPT];
   u32x4_t kraw[NK], vraw[NK];
@@ -450,7 +454,12 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 
   // a row's 16-byte vectors of this lane: vector cc of row `row` of W[.][KK]
   auto wvec = [&](unsigned long long W, int64_t row, int KK, int cc) {
-    return ps_load_nt(reinterpret_cast<const u32x4_t PS_GLOBAL*>(as_g<T>(W) + row * KK + lane * VEC + cc * CH));
+    if constexpr (W8) {
+      const u32x2v_t t = *reinterpret_cast<const u32x2v_t PS_GLOBAL*>(as_g<T>(W) + row * KK + lane * VEC + cc * CH);
+      return u32x4_t{t.x, t.y, 0u, 0u};
+    } else {
+      return ps_load_nt(reinterpret_cast<const u32x4_t PS_GLOBAL*>(as_g<T>(W) + row * KK + lane * VEC + cc * CH));
+    }
   };
   // Every request below is STRAIGHT-LINE code on selected addresses: a load under a branch or an exec mask makes hipcc merge the
   // loaded registers with the other path's by v_mov after an s_waitcnt -- the "prefetch" then waits for its own HBM round trip
@@ -479,6 +488,11 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       sgx = as_g<float>(p.sgqkv)[pred ? 4 * NWG : 0];  // row 1024's pair (used by the one wave that owns the row)
       tbx = as_g<float>(p.tbqkv)[pred ? 4 * NWG : 0];
     }
+    if constexpr (W8) {
+      const int rq = qkv_row(w * RQ + (lane < RQ ? lane : RQ - 1));
+      scq = as_g<float>(p.sqkv)[pred ? 4 * c + w : rq];
+      scx = as_g<float>(p.sqkv)[pred ? 4 * NWG : 0];
+    }
     ps_load4(as_g<float>(p.g1) + tid * EPT, g1v);
     if constexpr (!LF) ps_load4(as_g<float>(p.be1) + tid * EPT, be1v);
   };
@@ -504,6 +518,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
 #pragma unroll
     for (int cc = 0; cc < NCH; ++cc) wo[cc] = wvec(p.wo, 4 * c + w, D, cc);
     bo_v = as_g<float>(p.bo)[4 * c + w];
+    if constexpr (W8) sco = as_g<float>(p.so)[4 * c + w];
   };
   // linear1's rows [r0, r1) of this wave (+ its bias and norm2's affine with the first part); linear2's chunks [c0, c1)
   auto issue_w1_rows = [&](const PsLayer& p, int r0, int r1) {
@@ -521,6 +536,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         sg1_v = as_g<float>(p.sg1)[r1i];
         b1_v = as_g<float>(p.tb1)[r1i];
       }
+      if constexpr (W8) sc1 = as_g<float>(p.s1)[r1i];
       ps_load4(as_g<float>(p.g2) + tid * EPT, g2v);
       if constexpr (!LF) ps_load4(as_g<float>(p.be2) + tid * EPT, be2v);
     }
@@ -532,7 +548,10 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if (cc < c0 || cc >= c1) continue;
       w2[cc] = wvec(p.w2, 4 * c + w, 4 * D, cc);
     }
-    if (c0 == 0) b2_v = as_g<float>(p.b2)[4 * c + w];
+    if (c0 == 0) {
+      b2_v = as_g<float>(p.b2)[4 * c + w];
+      if constexpr (W8) sc2 = as_g<float>(p.s2)[4 * c + w];
+    }
   };
   auto issue_w2 = [&](const PsLayer& p) { issue_w2_chunks(p, 0, NCH2); };
   // ---- x of the first layer: the sampling kernel's output (previous launch) ----------------------------------------------------
@@ -643,7 +662,8 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       }
       if (lane < RQ) {
         const int r = w * RQ + lane, which = r / QR, e = s * QR + (r % QR);  // e: element of the head
-        const float v = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgq, mine), bq) : mine + bq;
+        const float dq = W8 ? mine * scq : mine;  // (a power-of-two scale: exact)
+        const float v = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgq, dq), bq) : (W8 ? fmaf(mine, scq, bq) : mine + bq);
         gran_t* gq = G + G_QKV + h * (3 * DH) + which * DH + e;
         gran_t* gql = G + G_QKVL + h * (3 * DH) + which * DH + e;
         if (which == 0) {
@@ -938,7 +958,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         mine = wave_sum_dpp(g1_dot<T, NCH>(wo, x));
       }
       if (lane == 0) {
-        const float v = mine + bo_v;
+        const float v = W8 ? fmaf(mine, sco, bo_v) : mine + bo_v;
         gran_store(G + G_X2 + 4 * c + w, epoch, sres[w] + v);
       }
     }
@@ -978,7 +998,8 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
           mine = lane == r ? t : mine;
         }
       }
-      const float hval = fmaxf(LF ? fmaf(ln_rstd, fmaf(-ln_mean, sg1_v, mine), b1_v) : mine + b1_v, 0.f);
+      const float d1 = W8 ? mine * sc1 : mine;
+      const float hval = fmaxf(LF ? fmaf(ln_rstd, fmaf(-ln_mean, sg1_v, d1), b1_v) : (W8 ? fmaf(mine, sc1, b1_v) : mine + b1_v), 0.f);
       if constexpr (!hpack) {
         if (lane < R1) gran_store(G + G_HID + 4 * R1 * c + w * R1 + lane, epoch, hval);
       } else {  // two bf16 values per granule: half the bytes of the widest edge (the batched path keeps the hidden rows in bf16 too)
@@ -1037,7 +1058,7 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
         mine = wave_sum_dpp(g1_dot<T, NCH2>(w2, x));
       }
       if (lane == 0) {
-        const float v = mine + b2_v;
+        const float v = W8 ? fmaf(mine, sc2, b2_v) : mine + b2_v;
         gran_store(G + GPL + G_X + 4 * c + w, epoch, sres[w] + v);  // the next layer's x edge (layer L: the final norm's)
       }
     }
@@ -1066,7 +1087,8 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
     }
     constexpr int G_LOG = G_QKV;  // the final block's q/k/v slots carry the logits edge (V <= 3 D)
     if (lane == 0) {
-      const float lg = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgq, t0), bq) : t0 + 0.f;
+      const float d0 = W8 ? t0 * scq : t0;
+      const float lg = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgq, d0), bq) : d0 + 0.f;
       a.logits[4 * c + w] = lg;
       if (own_sample) gran_store(G + G_LOG + 4 * c + w, epoch, lg);
     }
@@ -1075,7 +1097,8 @@ __global__ __launch_bounds__(PS_T) void pstep_kernel(PStepArgs a) {
       if constexpr (D2) t1 = ps_wave_sum_fast(ps_dot_bf16<NCH>(wq[1], xb));
       else t1 = wave_sum_dpp(g1_dot<T, NCH>(wq[1], x));
       if (lane == 0) {
-        const float lg = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgx, t1), tbx) : t1 + 0.f;
+        const float dx = W8 ? t1 * scx : t1;
+        const float lg = LF ? fmaf(ln_rstd, fmaf(-ln_mean, sgx, dx), tbx) : dx + 0.f;
         a.logits[4 * NWG] = lg;
         if (own_sample) gran_store(G + G_LOG + 4 * NWG, epoch, lg);
       }
@@ -1229,7 +1252,7 @@ bool pstep_fits_one_per_cu() {
 }
 
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V) {
-  return dtype == DT_BF16 && d == 1024 && nhead == 16 && dh == 64 && V > 1024 && V <= 1025;
+  return (dtype == DT_BF16 || dtype == DT_FP8W) && d == 1024 && nhead == 16 && dh == 64 && V > 1024 && V <= 1025;
 }
 
 size_t pstep_gran_count(int d, int nhead, int L) { return (size_t)(L + 1) * ps_gran_per_layer(d, nhead, 256 / nhead); }
@@ -1290,11 +1313,28 @@ static int ps_launch_pk(hipStream_t st, const PStepArgs& a) {
   return 0;
 }
 
+// FP8W: fp8 weight rows + row scales (round 5): the shipped key split and request schedules 0 / 3, the hidden row as bf16 pairs, with
+// the three-barrier (bit-identical to the fp8w launch chain) or the folded LayerNorm; no timeline, no v_dot2c forms
+template <int PF>
+static int ps_launch_w8(hipStream_t st, const PStepArgs& a) {
+  const dim3 grid(256), block(PS_T);
+  switch (ps_pk_of(a.mode)) {
+    case 1: hipLaunchKernelGGL((pstep_kernel<bf16w8t_t, 1024, 16, 2, PF, 1>), grid, block, 0, st, a); break;
+    case 5: hipLaunchKernelGGL((pstep_kernel<bf16w8t_t, 1024, 16, 2, PF, 5>), grid, block, 0, st, a); break;
+    default: return -1;
+  }
+  return 0;
+}
+
 // returns 0 = launched, 1 = shape not covered, < 0 = error
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
   if (!a.layers || !a.x_in || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
   if (a.nsteps < 0 || a.nsteps > 4096 || (a.nsteps > 0 && !a.smp)) return -1;
+  if (dtype == DT_FP8W) {
+    if (a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
+    return a.pf == 0 ? ps_launch_w8<0>(st, a) : ps_launch_w8<3>(st, a);
+  }
   if (a.mode & 64) {  // D2
     if (!(a.mode & 32) || !(a.mode & 16) || a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
     if (a.ptrace != nullptr && a.pf == 3) return ps_launch_traced(st, a);

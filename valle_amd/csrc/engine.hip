@@ -1308,7 +1308,10 @@ int kv_stream_nt(const vle_engine* e) {
 
 // FP8W engines run the persistent launch in the forms instantiated for fp8 weight rows: the hidden row as bf16 pairs, three-barrier or
 // folded LayerNorm, fp32 activation rows (the v_dot2c forms multiply bf16 weights), keys per lane 2, request schedules 0 / 3
-int ps_mode_of(const vle_engine* e) { return e->w8 ? (e->opt_ps_mode & ~(64 | 8)) : e->opt_ps_mode; }
+int ps_mode_of(const vle_engine* e) {
+  if (e->dtype == DT_F32) return e->opt_ps_mode & ~(64 | 32 | 8 | 4);  // fp32 (token-exact) mode: nothing packed, three-barrier LayerNorm
+  return e->w8 ? (e->opt_ps_mode & ~(64 | 8)) : e->opt_ps_mode;
+}
 bool ps_w8_mode_ok(const vle_engine* e) {
   const int m = ps_mode_of(e);
   return (m & 4) != 0 && e->opt_ps_nk == 2 && (e->opt_ps_pf == 0 || e->opt_ps_pf == 3) && !e->opt_ps_trace && e->ar_predict8 != nullptr && e->ar_predict_s != nullptr &&
@@ -1318,7 +1321,7 @@ bool ps_w8_mode_ok(const vle_engine* e) {
 // The persistent step (persist.hip) covers this call: batch 1, the covered shape, bf16 or fp8 weights, its table built for this cache
 bool persist_ready(const vle_engine* e) {
   return e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && e->B == 1 && !e->slot_mode && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
-         (!e->w8 || ps_w8_mode_ok(e)) &&
+         (!e->w8 || ps_w8_mode_ok(e)) && (e->dtype != DT_F32 || (e->opt_ps_nk == 2 && (e->opt_ps_pf == 0 || e->opt_ps_pf == 3) && !e->opt_ps_trace)) &&
          e->ps_table_kc == e->kcache && e->ps_table_ctx == e->ctx_max && (int)e->ar.size() == e->L;
 }
 
@@ -1335,8 +1338,10 @@ int persist_prepare(vle_engine* e) {
       PLayer& t = tab[l];
       float* f = e->ps_fold + (size_t)l * 14 * d;
       t.sgqkv = f; t.tbqkv = f + 3 * d; t.sg1 = f + 6 * d; t.tb1 = f + 10 * d;
-      E_LAUNCH(e, launch_ps_fold(e->st, w.wqkv, w.g1, w.be1, w.bqkv, f, f + 3 * d, (int)(3 * d), (int)d));
-      E_LAUNCH(e, launch_ps_fold(e->st, w.w1, w.g2, w.be2, w.b1, f + 6 * d, f + 10 * d, (int)(4 * d), (int)d));
+      if (e->dtype == DT_BF16) {  // (fp32 mode runs the three-barrier form only: no row constants)
+        E_LAUNCH(e, launch_ps_fold(e->st, w.wqkv, w.g1, w.be1, w.bqkv, f, f + 3 * d, (int)(3 * d), (int)d));
+        E_LAUNCH(e, launch_ps_fold(e->st, w.w1, w.g2, w.be2, w.b1, f + 6 * d, f + 10 * d, (int)(4 * d), (int)d));
+      }
       t.wqkv = w.wqkv; t.wo = w.wo; t.w1 = w.w1; t.w2 = w.w2;
       if (e->w8) {  // the e4m3fn codes + row scales (the folded-LayerNorm constants above come from bf16(W') = the same values)
         t.wqkv = w.wqkv8; t.wo = w.wo8; t.w1 = w.w18; t.w2 = w.w28;
@@ -1348,7 +1353,7 @@ int persist_prepare(vle_engine* e) {
     }
     {  // entry L: the predict layer behind the final norm
       float* f = e->ps_fold + (size_t)e->L * 14 * d;
-      E_LAUNCH(e, launch_ps_fold(e->st, e->ar_predict, e->ar_norm_g, e->ar_norm_b, nullptr, f, f + V_AR + 3, V_AR, (int)d));
+      if (e->dtype == DT_BF16) E_LAUNCH(e, launch_ps_fold(e->st, e->ar_predict, e->ar_norm_g, e->ar_norm_b, nullptr, f, f + V_AR + 3, V_AR, (int)d));
       PLayer& t = tab[e->L];
       t = tab[e->L - 1];  // every pointer valid
       t.wqkv = e->ar_predict; t.g1 = e->ar_norm_g; t.be1 = e->ar_norm_b; t.sgqkv = f; t.tbqkv = f + V_AR + 3;

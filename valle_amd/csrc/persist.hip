@@ -29,6 +29,11 @@
 //     three-barrier LayerNorm (mode bit 5 off) the step is BIT-IDENTICAL to the chain run with qa_nsplit = 16, qa_nk = NK
 //     (tests/test_persist_gpu.py asserts equality of every logit and token of whole decodes); the folded LayerNorm (bit 5, default)
 //     is the same arithmetic up to fp32 re-association.
+// Round 5: between hand-offs the step is ISSUE-bound (one wave per SIMD: every instruction on a stage's critical path is time), so
+// the default form trades the chain's bit-identity for fewer instructions (template bit D2: bf16 activation rows in LDS + v_dot2c,
+// lane-parallel merge, DPP / permlane wave totals, v_rsq / v_rcp: layer loop 2873 -> 1998 instructions, 144.7 -> 127.8 us per step;
+// the fp32-row forms above are kept, instantiated and tested); the in-kernel timeline is a template parameter; and the launch is
+// instantiated for fp8 weight rows (FP8W: e4m3fn codes + row scales, bit-identical to the fp8w chain in the three-barrier form).
 // Spins are bounded: a wave that gives up marks the launch failed (PStepArgs::fail, reported by the engine as an error), stops
 // waiting for the rest of the launch and lets every other workgroup run through, so a lost granule cannot hang the device.
 // Co-residency: 256 workgroups of 256 threads with > 80 KB of LDS each = one per CU on an otherwise idle MI355X (the engine
@@ -1252,7 +1257,7 @@ bool pstep_fits_one_per_cu() {
 }
 
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V) {
-  return (dtype == DT_BF16 || dtype == DT_FP8W) && d == 1024 && nhead == 16 && dh == 64 && V > 1024 && V <= 1025;
+  return (dtype == DT_BF16 || dtype == DT_FP8W || dtype == DT_F32) && d == 1024 && nhead == 16 && dh == 64 && V > 1024 && V <= 1025;
 }
 
 size_t pstep_gran_count(int d, int nhead, int L) { return (size_t)(L + 1) * ps_gran_per_layer(d, nhead, 256 / nhead); }
@@ -1334,6 +1339,16 @@ int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (dtype == DT_FP8W) {
     if (a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
     return a.pf == 0 ? ps_launch_w8<0>(st, a) : ps_launch_w8<3>(st, a);
+  }
+  if (dtype == DT_F32) {
+    // fp32 weights, KV cache and edges (the token-exact mode): the three-barrier form with nothing packed -- every logit equals the
+    // fp32 launch chain's at 16 key splits.  192 KB of weights per layer and workgroup: the rows requested furthest ahead wait in
+    // accumulation registers (256 VGPRs + 10 AGPRs, no scratch)
+    if (ps_pk_of(a.mode) != 0 || a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
+    const dim3 grid(256), block(PS_T);
+    if (a.pf == 0) hipLaunchKernelGGL((pstep_kernel<float, 1024, 16, 2, 0, 0>), grid, block, 0, st, a);
+    else hipLaunchKernelGGL((pstep_kernel<float, 1024, 16, 2, 3, 0>), grid, block, 0, st, a);
+    return 0;
   }
   if (a.mode & 64) {  // D2
     if (!(a.mode & 32) || !(a.mode & 16) || a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;

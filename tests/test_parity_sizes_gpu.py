@@ -58,6 +58,7 @@ def test_c2_full_size_fp32_token_exact_vs_reference(c2_full):
     eng.set_option("trace_ar_logits", 1)
     eng.set_option("trace_nar_logits", 1)
     codes = m.inference(case["x"].to(DEV), case["x_lens"].to(DEV), case["y"].to(DEV), None, top_k=1).cpu()
+    assert_persistent_launch_ran(eng)  # round 5: the token-exact mode decodes through the persistent launch too (fp32 rows, nothing packed)
     ref = case["codes"]
     assert codes.shape == (1, 753, 8)
     assert torch.equal(codes[0, :, 0], ref[0, :, 0]), f"{(codes[0, :, 0] != ref[0, :, 0]).sum().item()} AR tokens differ from the reference"

@@ -179,6 +179,24 @@ def test_fp8w_persistent_step_default_form_matches_the_three_barrier_form(c2_mod
     assert not torch.equal(ref[:n], got[:n]) and err <= 5e-3 * sigma, (err, sigma)
 
 
+@pytest.mark.parametrize("pf", [3, 0])
+def test_fp32_persistent_step_is_bit_identical_to_the_fp32_launch_chain(pf):
+    """The token-exact mode (fp32 weights, fp32 KV cache, fp32 edges) through the persistent launch: three-barrier LayerNorm, nothing
+    packed -- every logit of a decode equals the fp32 launch chain's at the same key split (16 splits, 2 keys per lane), here past
+    512 keys so that the attention share runs more than one round of its fp32 cache rows."""
+    torch.manual_seed(14)
+    m = valle_amd.VALLE(1024, 16, 4, prefix_mode=1, engine_dtype="fp32").to(DEV).eval()
+    S, P, steps = 47, 225, 300
+    eng = m.engine_for(1, S, P)
+    X, Y = _inputs(S, P, seed=8)
+    ref_codes, ref = _decode(eng, X, Y, S, P, steps, {"qa_nsplit": 16, "qa_nk": 2})
+    assert eng.fetch_u32("persist_ran") == 0
+    got_codes, got = _decode(eng, X, Y, S, P, steps, {"persist": 1, "persist_nk": 2, "persist_pf": pf, "persist_mode": DEFAULT})  # masked to the fp32 form
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+    assert torch.equal(ref_codes, got_codes)
+    assert ref.shape == got.shape and torch.equal(ref, got), f"max |dlogit| {(ref - got).abs().max().item():.3e} (must be 0)"
+
+
 def test_persistent_step_past_1024_keys_and_at_full_length(c2_model):
     """BASELINE configs[1]'s own lengths plus a longer text: the context passes 1024 keys, where a workgroup's attention share
     takes a second round of key chunks (16 splits x 64 keys per round at 2 keys per lane)."""
@@ -356,7 +374,14 @@ def test_persistent_step_is_the_default_where_covered_and_only_there():
         assert e1.fetch_u32("persist_active") == 1, dtype
         codes, gl = e1.generate(top_k=1, max_new=6)
         assert e1.fetch_u32("persist_ran") == 1 and e1.fetch_u32("persist_fail") == 0 and gl[0] >= 1
-    for dtype, d, h in (("fp32", 1024, 16), ("bf16", 512, 8)):
+    # fp32 (round 5): the token-exact mode too, as the three-barrier form with nothing packed
+    m4 = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="fp32").to(DEV).eval()
+    e4 = m4.engine_for(1, 8, 10)
+    e4.prefill(X, [8], Y, [10])
+    assert e4.fetch_u32("persist_active") == 1
+    codes, gl = e4.generate(top_k=1, max_new=6)
+    assert e4.fetch_u32("persist_ran") == 1 and e4.fetch_u32("persist_fail") == 0 and gl[0] >= 1
+    for dtype, d, h in (("bf16", 512, 8), ("fp32", 512, 8)):
         m2 = valle_amd.VALLE(d, h, 2, prefix_mode=1, engine_dtype=dtype).to(DEV).eval()
         e2 = m2.engine_for(1, 8, 10)
         e2.prefill(X, [8], Y, [10])

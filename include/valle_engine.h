@@ -184,7 +184,7 @@ int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slo
  *          "gs_formal", "gs_gran" (split-K hand-off through granules, default 0),
  *          "gs_fuse_ln", "attn_oproj", "attn_nt", "attn_lds_pad" (batched step); "ktrace" (in-kernel timeline);
  *          the persistent batch-1 AR launch (valle_amd/csrc/persist.hip): "persist" (default 1: d1024-h16 at one
- *          utterance runs it in the bf16 / fp8w / fp8 modes; 0 = the launch chain), "persist_sample" (default 1: topk_sampling, the stop rule and the next token's
+ *          utterance runs it in every engine mode; 0 = the launch chain), "persist_sample" (default 1: topk_sampling, the stop rule and the next token's
  *          embedding inside the launch) with "persist_steps" (default 32 AR iterations per launch), "persist_mode" (bit field: 4 / 8
  *          hidden / attention rows as bf16 pairs, 16 XCD-local copies of the head-group edges, 32 folded LayerNorm, 64 bf16 activation
  *          rows + v_dot2c_f32_bf16 dot products; default 0x174),

@@ -104,3 +104,18 @@ def test_op_tune_knows_the_batched_gemm_knobs_and_rejects_the_rest():
     assert lib.vle_op_tune(b"gs_fast", 2) != 0
     assert lib.vle_op_tune(b"gs_nf", -1) != 0
     assert lib.vle_op_tune(b"no_such_knob", 1) != 0
+
+
+def test_error_codes_of_the_header_and_the_binding_agree():
+    """include/valle_engine.h #defines VLE_OK / VLE_E*: the ctypes binding must carry the same numbers (VLE_EBUSY, round 5, is what
+    VALLE.inference recognises a persistent launch that lost the GPU by -- a code, not a message text)."""
+    import re
+
+    from valle_amd import _lib
+
+    hdr = open(os.path.join(ROOT, "include", "valle_engine.h")).read()
+    codes = {m.group(1): int(m.group(2)) for m in re.finditer(r"#define\s+(VLE_(?:OK|E[A-Z]+))\s+\(?(-?\d+)\)?", hdr)}
+    assert {"VLE_OK", "VLE_EINVAL", "VLE_ESTATE", "VLE_EHIP", "VLE_EKEY", "VLE_ENOTOKEN", "VLE_EINDEX", "VLE_EBUSY"} <= set(codes), codes
+    for name, value in codes.items():
+        assert getattr(_lib, name) == value, (name, value)
+    assert codes["VLE_EBUSY"] == -7

@@ -52,11 +52,12 @@ def main():
     ap.add_argument("--variants", nargs="*", default=["pf=3", "pf=3,sample=0", "pf=3,steps=8", "pf=3,mode=0x114", "pf=0", "pf=3,naps=0"],
                     help="persistent variants to time: comma-separated persist_* options, e.g. pf=0,mode=3,nk=2")
     ap.add_argument("--trace", nargs="*", default=["pf=3"])
+    ap.add_argument("--dtype", default="bf16", help="engine mode of the probed model (bf16 | fp8w | fp32): the timing section only; --skip-check with the others")
     args = ap.parse_args()
     os.makedirs(args.out, exist_ok=True)
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    model = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16").to(dev).eval()
+    model = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype=args.dtype).to(dev).eval()
     eng = model.engine_for(1, S_TEXT, P_PROMPT)
     eng.set_option("ignore_eos", 1)
     x, y = synth_inputs(0)

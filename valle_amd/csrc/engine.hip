@@ -182,7 +182,7 @@ struct vle_engine {
   // ---- the batch-1 step as one persistent launch (persist.hip; option "persist") ----
   int opt_persist = 1;        // option "persist": 1 = batch-1 AR steps run pstep_kernel (+ the sampling launch) where the shape is covered
   int opt_ps_nk = 2, opt_ps_pf = 3;  // options "persist_nk", "persist_pf" (PStepArgs)
-  int opt_ps_naps = PS_NAPS_DEFAULT; // option "persist_naps"
+  int opt_ps_naps = -1;              // option "persist_naps" (-1: the engine mode's own timing, ps_naps_of)
   bool ps_device_ok = false;  // the device has the 256 CUs the persistent grid needs
   PLayer* ps_table = nullptr;               // device [L] operand table (rebuilt when the KV cache moves)
   PStepSample* ps_sample = nullptr;         // device copy of the in-launch sampling step's operands (PStepArgs::smp)
@@ -1308,6 +1308,12 @@ int kv_stream_nt(const vle_engine* e) {
 
 // FP8W engines run the persistent launch in the forms instantiated for fp8 weight rows: the hidden row as bf16 pairs, three-barrier or
 // folded LayerNorm, fp32 activation rows (the v_dot2c forms multiply bf16 weights), keys per lane 2, request schedules 0 / 3
+// first-sweep waits per engine mode (tools/persist_probe.py --dtype sweeps, round 5: the stages' lengths differ with the weight format):
+// bf16 D2 forms 0x325756 (126.9 us per step), fp8 weight rows 0x214645 (128.0 -> 125.7), fp32 0x217645 (191.7 -> 187.1)
+int ps_naps_of(const vle_engine* e) {
+  if (e->opt_ps_naps >= 0) return e->opt_ps_naps;
+  return e->dtype == DT_F32 ? 0x217645 : e->w8 ? 0x214645 : PS_NAPS_DEFAULT;
+}
 int ps_mode_of(const vle_engine* e) {
   if (e->dtype == DT_F32) return e->opt_ps_mode & ~(64 | 32 | 8 | 4);  // fp32 (token-exact) mode: nothing packed, three-barrier LayerNorm
   return e->w8 ? (e->opt_ps_mode & ~(64 | 8)) : e->opt_ps_mode;
@@ -1396,7 +1402,7 @@ int enqueue_persist_step(vle_engine* e, int nsteps = 1) {
   a.kv_len = e->S.kv_len; a.iter = e->S.iter; a.done = e->S.done; a.gran = e->ps_gran;
   a.fail = e->qa_spin_fail ? e->qa_spin_fail + 2 : nullptr;
   a.ptrace = e->opt_ps_trace ? e->ps_ptrace : nullptr;
-  a.mode = ps_mode_of(e); a.nk = e->opt_ps_nk; a.pf = e->opt_ps_pf; a.naps = e->opt_ps_naps;
+  a.mode = ps_mode_of(e); a.nk = e->opt_ps_nk; a.pf = e->opt_ps_pf; a.naps = ps_naps_of(e);
   if (e->opt_ps_sample) {
     a.nsteps = nsteps;
     a.smp = e->ps_sample;
@@ -2623,7 +2629,7 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     }
     else if (n == "act_bf16") e->opt_act_bf16 = (int)value & 3;
     else if (n == "persist_mode") e->opt_ps_mode = (int)value;
-    else if (n == "persist_naps") e->opt_ps_naps = (int)value;
+    else if (n == "persist_naps") e->opt_ps_naps = (int)value;  // (-1: back to the engine mode's default)
     else if (n == "persist_pf") {
       if (value < 0 || value > 3) return e->fail(VLE_EINVAL, "persist_pf must be 0 .. 3");
       e->opt_ps_pf = (int)value;

@@ -9,7 +9,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libvalle_engine.so")
+# VLE_LIB: another build of the same ABI (the `make asan` library); the default is the in-tree library
+LIB_PATH = os.environ.get("VLE_LIB") or os.path.join(_HERE, "libvalle_engine.so")
 
 VLE_OK = 0
 VLE_EINVAL, VLE_ESTATE, VLE_EHIP, VLE_EKEY, VLE_ENOTOKEN, VLE_EINDEX, VLE_EBUSY = -1, -2, -3, -4, -5, -6, -7

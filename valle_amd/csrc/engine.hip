@@ -1000,7 +1000,7 @@ static int alloc_buffers(vle_engine* e) {
   E_HIP(e, hipMemset(e->part_o, 0, (size_t)B * e->H * 16 * e->dh * sizeof(float)));
   E_HIP(e, hipMemset(e->part_ml, 0, (size_t)B * e->H * 16 * 2 * sizeof(float)));
   E_HIP(e, hipMemset(e->logits, 0, (size_t)B * V_AR * sizeof(float)));
-  if (B > SKINNY_MAX_B || true) {  // GEMM-path step buffers (also used when the GEMV path cannot hold B rows in LDS)
+  {  // GEMM-path step buffers (every batch size: the GEMV path also uses them when it cannot hold B rows in LDS)
     const size_t Bp = (size_t)(B + 15) / 16 * 16;  // the fragment-major layout (common.h xf_index) holds whole 16-row fragments
     if ((r = dev_alloc(e, &p, Bp * d * es))) return r;
     e->xn_step = p;

@@ -189,7 +189,7 @@ int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slo
  *          hidden / attention rows as bf16 pairs, 16 XCD-local copies of the head-group edges, 32 folded LayerNorm, 64 bf16 activation
  *          rows + v_dot2c_f32_bf16 dot products; default 0x174),
  *          "persist_pf" (0..3 operand request schedule), "persist_nk" (2 | 4 keys per lane), "persist_naps" (first-sweep waits, 4 bits
- *          per edge), "persist_trace" (in-kernel timeline), "act_bf16" (the chain's matching roundings).
+ *          per edge; -1 = the engine mode's measured default: bf16 0x325756, fp8 weight rows 0x214645, fp32 0x217645), "persist_trace" (in-kernel timeline), "act_bf16" (the chain's matching roundings).
  *          "persist_rearm" (any value: forget the back-off after VLE_EBUSY), "persist_inject_fail" (n: the next n persistent calls
  *          end as if a wave had given up -- the test hook of the VLE_EBUSY path).
  *   debug words of vle_debug_fetch for it: "persist_active" (the next batch-1 call would run it), "persist_ran" (the LAST

@@ -101,10 +101,11 @@ def synth_inputs(index: int, S: int = S_TEXT, P: int = P_PROMPT):
 def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
     """The CPU oracle (literal no-KV-cache restatement of valle/models/valle.py:961-1137), fp32, on
     the host cores, on a bounded sample: the first `frames` frames of utterance 0 (+ the 7 NAR
-    stages over them).  Only this leg of bench.py touches oracle/.  `full_length_estimate` extrapolates the
-    sample to the whole 753-frame utterance by the literal algorithm's row count (every AR step re-runs all
-    S+P+t rows; the NAR passes run S+P+G rows) -- attention's quadratic term is ignored, so the estimate is an
-    UPPER bound on the full-length rate."""
+    stages over them).  Only this leg of bench.py touches oracle/.  The sample's rate is NOT the full-length rate: the literal
+    algorithm re-runs all S+P+t rows every step and its attention grows quadratically, so the whole 753-frame utterance is far
+    slower per token -- `reference_full` carries the unmodified reference's measured full-length figure, and `port_vs_reference` the
+    calibration of this port against the unmodified reference on the same short decode (oracle/time_port_vs_reference.py, run in the
+    build container where /root/reference exists; profiles/cpu_port_vs_reference.json)."""
     from oracle import valle_oracle as vo
 
     # intra-op threads actually used: the reference's per-step ops are small (one utterance), more
@@ -124,9 +125,15 @@ def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
     n_tok = n_frames * codes.shape[2]
     G_full = 16 * S_TEXT + 1
     ctx0 = S_TEXT + P_PROMPT
-    rows_sample = sum(ctx0 + t for t in range(n_frames + 1))  # n_frames + 1 loop iterations (the last one stops)
-    rows_full = sum(ctx0 + t for t in range(G_full + 1))
-    est = t_ar * rows_full / rows_sample + t_nar * (ctx0 + G_full) / (ctx0 + n_frames)
+    try:
+        with open(os.path.join(ROOT, "profiles", "cpu_port_vs_reference.json")) as f:
+            cal = json.load(f)
+        pvr = dict(port_over_reference_speed=cal["port_over_reference_speed"], tokens_identical=cal["tokens_identical"],
+                   reference_tok_s=cal["reference_tok_s"], port_tok_s=cal["port_tok_s"], config=cal["config"],
+                   source="profiles/cpu_port_vs_reference.json (oracle/time_port_vs_reference.py: the unmodified reference and this port timed "
+                          "on the same decode in the build container -- the reference tree does not travel to the GPU box)")
+    except Exception as err:  # noqa: BLE001
+        pvr = {"error": repr(err)[:120]}
     return dict(
         value=round(n_tok / dt, 3), unit="audio-tokens/s", cores=cores, kind="port",
         sample=f"first {n_frames} of {G_full} frames of utterance 0 (ctx {ctx0}..{ctx0 + frames}) "
@@ -136,11 +143,7 @@ def cpu_baseline(sd_cpu, d_model, nhead, num_layers, frames: int):
             source="BASELINE.md section 2: the UNMODIFIED valle/models/valle.py::VALLE.inference at this workload's full length "
                    "(S=47, P=225 -> 753 frames), fp32, greedy, 8 threads of the survey container's Xeon (the reference tree does not "
                    "travel to the GPU box, so it cannot be re-timed there; the port above is what runs on this box's cores)"),
-        full_length_estimate=dict(
-            value=round(G_full * 8 / est, 3), unit="audio-tokens/s", seconds=round(est, 1),
-            method="row-count extrapolation of the sample (AR: sum over steps of S+P+t rows; NAR: S+P+G rows); "
-                   "ignores attention's quadratic growth => upper bound on the rate; SURVEY.md 6 measured 9.8 tok/s "
-                   "for the unmodified reference at full length on 8 threads"),
+        port_vs_reference=pvr,
     )
 
 
@@ -315,8 +318,11 @@ def decode_step(runner, X, s_lens, Y, p_lens, top_k, world, n_total, dev, temper
                                          temperature=temperature, seed=seed)
         gl = [int(o.shape[0]) for o in out]
     else:
-        runner.prefill(X, s_lens, Y, p_lens)
-        _, gl = runner.generate(top_k=top_k, temperature=temperature, seed=seed, allow_empty=B > 1)
+        if hasattr(runner, "prefill_generate"):  # the engine: one retry on VLE_EBUSY instead of an aborted timed run
+            _, gl = runner.prefill_generate(X, s_lens, Y, p_lens, top_k=top_k, temperature=temperature, seed=seed, allow_empty=B > 1)
+        else:
+            runner.prefill(X, s_lens, Y, p_lens)
+            _, gl = runner.generate(top_k=top_k, temperature=temperature, seed=seed, allow_empty=B > 1)
         codes = runner.nar(None)
         out = [codes[b, : gl[b]] for b in range(B)]
     if world > 1:

@@ -47,10 +47,13 @@ extern "C" {
 /* arithmetic mode of the whole path */
 #define VLE_DTYPE_F32 0  /* fp32 weights / KV / accumulate: token-id-exact vs the reference */
 #define VLE_DTYPE_BF16 1 /* bf16 weights + KV, fp32 residual stream and accumulators       */
-#define VLE_DTYPE_FP8 3  /* FP8W plus fp8 ACTIVATIONS on the MFMA-bound passes (prefill, NAR): every Linear there runs
-                            e4m3fn x e4m3fn on CDNA4's block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) with the
-                            activations quantised per row (power-of-two scale); the AR step is FP8W's (BASELINE configs[4]) */
-#define VLE_DTYPE_FP8W 2 /* BF16 mode on fp8-representable weights: every Linear weight row is replaced by
+#define VLE_DTYPE_FP8 3  /* EXPERIMENTAL -- not the mode BASELINE configs[4] is quoted on (that is VLE_DTYPE_FP8W below).  FP8W plus
+                            fp8 ACTIVATIONS on the MFMA-bound passes (prefill, NAR): every Linear there runs e4m3fn x e4m3fn on
+                            CDNA4's block-scaled fp8 MFMA (v_mfma_scale_f32_16x16x128_f8f6f4) with the activations quantised per
+                            ROW (one power-of-two scale, unit MX block scales).  Per-row activation scales hold only a 15 % sigma
+                            max / 3 % mean logit bar at d1536-L24 (the bf16 / FP8W bar is 5 %); per-32-column MX scales fused into
+                            the producers were not built.  The AR step is FP8W's. */
+#define VLE_DTYPE_FP8W 2 /* BASELINE configs[4]'s weight format, the mode that config is quoted on.  BF16 mode on fp8-representable weights: every Linear weight row is replaced by
                           * W' = e4m3fn(w / 2^e) * 2^e (one power-of-two scale per row, so W' is exact in bf16); the
                           * HBM-bound AR step streams the 1-byte codes, prefill / NAR run bf16 MFMA on bf16(W') */
 

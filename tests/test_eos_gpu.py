@@ -3,16 +3,14 @@ greedy decodes whose arg-max reaches EOS after 17 / 40 / 28 frames (prefix modes
 without appending EOS and runs its NAR stages on the shorter sequence (valle/models/valle.py:1044-1056, 1059-1137) -- and EOS at the
 very first step, its SyntaxError (:1049-1052).  fp32 engine mode: token ids bit-identical.
 
-Written after the round's GPU budget was spent, i.e. NOT yet run on hardware: marked xfail(strict=False) so that an untested test
-cannot take the suite down -- XPASS is the expected outcome (the stop rule itself is covered by test_engine_gpu.py and
-test_persist_gpu.py against the oracle and between the engine's own paths)."""
+First run on hardware by the round-5 driver (4 cases passed); a plain member of the GPU suite since round 6."""
 import os
 
 import numpy as np
 import pytest
 import torch
 
-pytestmark = [pytest.mark.gpu, pytest.mark.xfail(strict=False, reason="added after the last GPU session of round 5: first hardware run pending")]
+pytestmark = pytest.mark.gpu
 
 import valle_amd  # noqa: E402
 from oracle import valle_oracle as vo  # noqa: E402

@@ -62,7 +62,7 @@ def _mode_to_act(mode):
     return (2 if mode & 4 else 0) | (1 if mode & 8 else 0)
 
 
-@pytest.mark.parametrize("nk,pf,mode", [(2, 3, 0x114), (2, 0, 0x114), (2, 3, 0), (2, 3, 0x1c), (4, 3, 0x114), (2, 1, 0x114), (2, 2, 0x118)])
+@pytest.mark.parametrize("nk,pf,mode", [(2, 3, 0x114), (2, 0, 0x114), (2, 3, 0), (2, 0, 0)])
 def test_persistent_step_is_bit_identical_to_the_launch_chain(c2_model, nk, pf, mode):
     S, P, steps = 20, 60, 40
     eng = c2_model.engine_for(1, S, P)
@@ -77,7 +77,7 @@ def test_persistent_step_is_bit_identical_to_the_launch_chain(c2_model, nk, pf, 
     assert ref.shape == got.shape and torch.equal(ref, got), f"max |dlogit| {(ref - got).abs().max().item():.3e} (must be 0)"
 
 
-@pytest.mark.parametrize("nk,pf,mode", [(2, 3, 0x134), (2, 0, 0x134), (4, 3, 0x13c), (2, 3, 0x120)])
+@pytest.mark.parametrize("nk,pf,mode", [(2, 3, 0x134), (2, 0, 0x134)])
 def test_folded_layernorm_matches_the_three_barrier_form(c2_model, nk, pf, mode):
     """LN(x) . W[n] = rstd * (sum_k W[n][k] gamma[k] x[k] - mean * sg[n]) + tb[n]: the same numbers as LayerNorm followed by the
     linear layer (valle/modules/transformer.py:57-74, :296-302) up to fp32 re-association -- which the bf16 roundings of the K/V cache
@@ -105,7 +105,7 @@ def test_folded_layernorm_matches_the_three_barrier_form(c2_model, nk, pf, mode)
     assert torch.equal(own[:k][safe[:k]], ref[:k].argmax(-1)[safe[:k]])
 
 
-@pytest.mark.parametrize("mode", [0x174, 0x17c])
+@pytest.mark.parametrize("mode", [0x174])
 def test_bf16_activation_rows_with_dot2_match_the_fp32_rows(c2_model, mode):
     """persist_mode bit 6 (D2): the operators' input rows sit in LDS as bf16 and the dot products run on v_dot2c_f32_bf16.  For
     linear2 (and, with bit 3, out-proj) the row already travels as bf16 pairs -- the same products in another summation order; the
@@ -359,6 +359,24 @@ def test_decode_with_caller_buffers_at_the_edge_of_their_mappings():
         eng.set_option("persist", 1)
 
 
+def test_option_sets_without_an_instantiated_form_run_the_launch_chain(c2_model):
+    """Round 6 prune: 4 keys per lane, the request schedules 1 / 2 and the packing modes the ladder dropped are no longer compiled.
+    Setting such knobs on a default engine must not fail the call (launch_pstep used to reject the step with VLE_EINVAL):
+    the engine decodes on the launch chain, and is back on the persistent launch when the knob returns to a shipped value."""
+    S, P, steps = 12, 20, 10
+    eng = c2_model.engine_for(1, S, P)
+    X, Y = _inputs(S, P, seed=2)
+    base = {"persist": 1, "persist_mode": DEFAULT, "persist_naps": -1, "act_bf16": 0}
+    want, _ = _decode(eng, X, Y, S, P, steps, base)
+    assert eng.fetch_u32("persist_ran") == 1
+    for knob in ({"persist_nk": 4}, {"persist_pf": 1}, {"persist_pf": 2}, {"persist_mode": 0x17c}, {"persist_mode": 0x164}, {"persist_mode": 0x120}):
+        got, _ = _decode(eng, X, Y, S, P, steps, dict(base, **knob))
+        assert eng.fetch_u32("persist_active") == 0 and eng.fetch_u32("persist_ran") == 0, knob
+        assert got.numel() == steps
+    got, _ = _decode(eng, X, Y, S, P, steps, base)
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0 and torch.equal(got, want)
+
+
 def test_persistent_step_is_the_default_where_covered_and_only_there():
     torch.manual_seed(3)
     m = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()
@@ -412,8 +430,8 @@ def test_persistent_step_repeated_decodes_under_changing_timing_stay_identical(c
     for mode in (FOLDED, CLASSIC):
         ref_codes, ref = _decode(eng, X, Y, S, P, steps, {"persist": 1, "persist_mode": mode})
         for rep in range(3 if mode == FOLDED else 1):
-            for pf in (3, 0, 1, 2):
-                for naps in (0x335854, 0, 0xFFFFFF, 0x0F0F0F, 0x123456):
+            for pf in (3, 0):
+                for naps in (0x335854, 0, 0xFFFFFF, 0x0F0F0F, 0x123456, 0x325756, 0xF000F0, 0x00FF00, 0x111111, 0x654321):
                     codes, lg = _decode(eng, X, Y, S, P, steps, {"persist": 1, "persist_mode": mode, "persist_pf": pf, "persist_naps": naps})
                     assert eng.fetch_u32("persist_fail") == 0, (pf, hex(naps))
                     assert torch.equal(ref, lg) and torch.equal(ref_codes, codes), (hex(mode), rep, pf, hex(naps))

@@ -433,6 +433,373 @@ __global__ __launch_bounds__(512) void gemm_8ph_kernel(const bf16_t* __restrict_
     }
 }
 
+// =====================================================================================================================
+// Persistent tile loop (round 6; VERDICT r2-r5 "next": "a persistent tile loop whose epilogue shares the CU with the next tile's
+// first K-tiles").  One workgroup per CU walks tiles w, w + G, w + 2G ... of the same XCD-aware order; the main loop is the one
+// above, what changes is everything AROUND it:
+//   * the K-loop's DMA queue runs ACROSS tiles: the four half-tile requests the last two K-tiles of a tile have no use for
+//     (phases 3 / 4 of K-tile KT-2, phases 1 / 2 of K-tile KT-1) fetch K-tile 0 of the NEXT tile into buffer 0 (KT is even), so the
+//     next main loop starts on data that landed during this tile's epilogue -- no launch ramp, no kernarg fetch, no exposed first
+//     round trip (the one-tile kernel pays ~2.5 us of those per tile on a ~33 us K = 1024 tile);
+//   * the epilogue stages through buffer 1 ONLY (64 KB: a 128-row half of a bf16 tile, a 128 x 128 quarter of an fp32 tile per
+//     pass), because buffer 0 is already receiving; its barriers are raw s_barrier + lgkmcnt(0) -- a __syncthreads() would drain
+//     vmcnt and wait for every store of the previous pass to be acknowledged;
+//   * its global stores are never waited for: they drain while the next tile's MFMAs run (the one-tile kernel's workgroup cannot
+//     end, and the CU cannot take its next tile, before they have left);
+//   * the residual's old values are requested one pass AHEAD of the stores that precede them in program order (two register sets),
+//     so a pass waits for loads that were issued before the previous pass's stores (a wave's memory operations retire in order);
+//   * bias / sg / tb / row statistics of a tile are requested when the previous epilogue has issued its last store and are retired by
+//     the first counted wait of the main loop.
+// Per-element arithmetic, the group statistics' reduction order and every rounding are those of gemm_8ph_kernel: the two kernels
+// are bit-identical (tests/test_ops_gpu.py::test_gemm_8ph_persistent_tile_loop_is_bit_identical).
+template <int EPI>
+__global__ __launch_bounds__(512) void gemm_8ph_pl_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+                                                          const float* __restrict__ bias, void* __restrict__ out_,
+                                                          float* __restrict__ resid, int64_t M, int N, int K, int ntr, int ntc, GemmLn ln) {
+  constexpr int SWZ = 0;
+  constexpr bool LNP = EPI == EPI_RESID_LNP, LNC = EPI == EPI_STORE_LNC || EPI == EPI_RELU_LNC;
+  constexpr bool RESID = EPI == EPI_RESID || LNP, RELU = EPI == EPI_RELU || EPI == EPI_RELU_LNC, BF16OUT = EPI == EPI_STORE || RELU || LNC;
+  constexpr int LN_STATS = 256 * 16, LN_LDS = LNC ? LN_STATS + 2 * 256 * 4 : 0;
+  __shared__ __attribute__((aligned(16))) unsigned char smem[2 * G8_BUF + LN_LDS];  // the ONLY LDS object
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 2, wc = wave & 3;
+  const int fr = lane & 15, fg = lane >> 4;
+  const int ntiles = ntr * ntc, G = gridDim.x;
+  const int prow = lane >> 3;
+  const int KT = K / 64;  // even (K % 128 == 0)
+
+  // tile id -> (row, column) of the tile grid: the XCD-aware order of gemm_8ph_kernel (workgroup w runs on XCD w % 8, and with G a
+  // multiple of 8 so do all of its tiles)
+  auto tile_rc = [&](int t, int& tr, int& tc) {
+    const int q = ntiles / 8, r = ntiles % 8, xcd = t % 8, idx = t / 8;
+    const int b = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    tr = b / ntc;
+    tc = b - tr * ntc;
+  };
+
+  const unsigned char* src[4][2];  // [half][piece] of the tile the DMA queue is currently fetching for that half
+  auto set_src = [&](int half, int64_t m0, int n0) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int hr = (j * 8 + wave) * 8 + prow;
+      const int vec = (lane & 7) ^ g8_key<SWZ>(hr);
+      if (half == G8_ATOP || half == G8_ABOT) {
+        int64_t g = m0 + (half == G8_ABOT ? 128 : 0) + hr;
+        g = g < M ? g : M - 1;
+        src[half][j] = reinterpret_cast<const unsigned char*>(A + g * K) + vec * 16;
+      } else {
+        src[half][j] = reinterpret_cast<const unsigned char*>(W + (int64_t)(n0 + (half == G8_BRIGHT ? 128 : 0) + hr) * K) + vec * 16;
+      }
+    }
+  };
+  auto issue = [&](int half, int kt) {  // half-tile of K-tile kt (of the tile src[half] points at) into buffer kt & 1
+    unsigned char* dst = smem + (kt & 1) * G8_BUF + half * G8_HALF;
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src[half][j] + (int64_t)kt * 128),
+                                       (__attribute__((address_space(3))) void*)(dst + (j * 8 + wave) * 1024), 16, 0, 0);
+  };
+
+  g8_bf16x8 af[4][2], bl[2][2], brt[2][2];
+  auto read_a = [&](const unsigned char* half) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int row = wr * 64 + i * 16 + fr;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) af[i][ks] = *reinterpret_cast<const g8_bf16x8*>(half + row * 128 + (((ks * 4 + fg) ^ g8_key<SWZ>(row)) << 4));
+    }
+  };
+  auto read_b = [&](const unsigned char* half, g8_bf16x8 (&bf)[2][2]) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = wc * 32 + j * 16 + fr;
+#pragma unroll
+      for (int ks = 0; ks < 2; ++ks) bf[j][ks] = *reinterpret_cast<const g8_bf16x8*>(half + row * 128 + (((ks * 4 + fg) ^ g8_key<SWZ>(row)) << 4));
+    }
+  };
+  auto mma = [&](g8_f32x4 (&c)[4][2], const g8_bf16x8 (&bf)[2][2]) {
+    __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) c[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bf[j][ks], af[i][ks], c[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_setprio(0);
+  };
+  auto phase_sync = [&]() {
+    __builtin_amdgcn_s_barrier();
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto phase_end = [&]() {
+    __builtin_amdgcn_sched_barrier(0);
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+  auto lds_barrier = [&]() {  // the epilogue's barrier: LDS traffic of this wave retired, no vmcnt drain
+    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    __builtin_amdgcn_sched_barrier(0);
+  };
+
+  constexpr int LNV = 12;
+  typedef float g8_f32x2 __attribute__((ext_vector_type(2)));
+  const int ln_ng = K / 128;  // statistics groups per half row
+  // per-tile operands that ride through the main loop: bias of this lane's columns (non-LNC) / this thread's half-row statistics (LNC)
+  g8_f32x4 bias4[LNC ? 1 : 2][LNC ? 1 : 2];
+  float ln_mean = 0.f, ln_m2 = 0.f;
+  auto request_tile_operands = [&](int64_t m0, int n0) {
+    if constexpr (LNC) {
+      bias4[0][0] = g8_f32x4{0.f, 0.f, 0.f, 0.f};
+      if (wave < 2)  // sg / tb of the tile's 256 columns into LDS (read in the epilogue, 30 us from here)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)((wave == 0 ? ln.sg : bias) + n0 + lane * 4),
+                                         (__attribute__((address_space(3))) void*)(smem + 2 * G8_BUF + LN_STATS + wave * 1024), 16, 0, 0);
+      int64_t m = m0 + (tid & 255);
+      m = m < M ? m : M - 1;
+      const g8_f32x2* sp = reinterpret_cast<const g8_f32x2*>(ln.stats_in) + (int64_t)(tid >> 8) * ln_ng * ln.stats_ld + m;
+      g8_f32x2 lnp[LNV];
+#pragma unroll
+      for (int g = 0; g < LNV; ++g) lnp[g] = sp[(int64_t)(g < ln_ng ? g : ln_ng - 1) * ln.stats_ld];
+      const float ref = lnp[0][0];
+      float s1 = 0.f, s2 = 0.f, q = 0.f;
+#pragma unroll
+      for (int g = 0; g < LNV; ++g) {
+        const bool on = g < ln_ng;
+        const float d0 = on ? lnp[g][0] - ref : 0.f;
+        s1 += d0;
+        s2 = fmaf(d0, d0, s2);
+        q += on ? lnp[g][1] : 0.f;
+      }
+      const float sm = s1 * __builtin_amdgcn_rcpf((float)ln_ng);
+      ln_mean = ref + sm;
+      ln_m2 = q + (float)LN_GROUP * (s2 - s1 * sm);
+    } else {
+#pragma unroll
+      for (int h = 0; h < 2; ++h)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+          const int n = n0 + h * 128 + wc * 32 + j * 16 + fg * 4;
+          bias4[h][j] = bias != nullptr ? *reinterpret_cast<const g8_f32x4*>(bias + n) : g8_f32x4{0.f, 0.f, 0.f, 0.f};
+        }
+    }
+  };
+
+  int t = blockIdx.x;
+  if (t >= ntiles) return;
+  int tr, tc;
+  tile_rc(t, tr, tc);
+  int64_t m0 = (int64_t)tr * 256;
+  int n0 = tc * 256;
+  // ---- prologue of the workgroup's first tile (as gemm_8ph_kernel) ----
+  set_src(G8_ATOP, m0, n0); set_src(G8_ABOT, m0, n0); set_src(G8_BLEFT, m0, n0); set_src(G8_BRIGHT, m0, n0);
+  issue(G8_BLEFT, 0); issue(G8_ATOP, 0); issue(G8_BRIGHT, 0); issue(G8_ABOT, 0);
+  request_tile_operands(m0, n0);
+  issue(G8_BLEFT, 1); issue(G8_ATOP, 1);
+  g8_wait_vm<4>();
+  __builtin_amdgcn_s_barrier();
+
+  for (;;) {
+    const int tn = t + G;
+    const bool has_next = tn < ntiles;
+    int ntr_ = 0, ntc_ = 0;
+    if (has_next) tile_rc(tn, ntr_, ntc_);
+    const int64_t nm0 = (int64_t)ntr_ * 256;
+    const int nn0 = ntc_ * 256;
+
+    g8_f32x4 acc[2][2][4][2];
+#pragma unroll
+    for (int a = 0; a < 2; ++a)
+#pragma unroll
+      for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) acc[a][b][i][j] = g8_f32x4{0.f, 0.f, 0.f, 0.f};
+
+    if (wr == 1) __builtin_amdgcn_s_barrier();  // stagger: waves 4-7 half a phase behind (pairs with the first in-loop barrier of waves 0-3)
+    for (int kt = 0; kt < KT; ++kt) {
+      const unsigned char* buf = smem + (kt & 1) * G8_BUF;
+      // ---- phase 1 ----
+      read_b(buf + G8_BLEFT * G8_HALF, bl);
+      __builtin_amdgcn_sched_barrier(0);
+      read_a(buf + G8_ATOP * G8_HALF);
+      if (kt + 1 < KT) issue(G8_ABOT, kt + 1);
+      else if (has_next) { set_src(G8_ABOT, nm0, nn0); issue(G8_ABOT, 0); }
+      phase_sync();
+      mma(acc[0][0], bl);
+      phase_end();
+      // ---- phase 2 ----
+      read_b(buf + G8_BRIGHT * G8_HALF, brt);
+      if (kt + 1 < KT) issue(G8_BRIGHT, kt + 1);
+      else if (has_next) { set_src(G8_BRIGHT, nm0, nn0); issue(G8_BRIGHT, 0); }
+      phase_sync();
+      mma(acc[0][1], brt);
+      phase_end();
+      // ---- phase 3 ----
+      read_a(buf + G8_ABOT * G8_HALF);
+      if (kt + 2 < KT) issue(G8_BLEFT, kt + 2);
+      else if (kt + 2 == KT && has_next) { set_src(G8_BLEFT, nm0, nn0); issue(G8_BLEFT, 0); }
+      phase_sync();
+      mma(acc[1][1], brt);
+      phase_end();
+      // ---- phase 4: the one counted wait of the K-tile: everything but the two newest half-tiles (K-tile kt + 2, or the next
+      //      tile's K-tile 0) has landed, i.e. all of K-tile kt + 1 ----
+      if (kt + 2 < KT) {
+        issue(G8_ATOP, kt + 2);
+        g8_wait_vm<4>();
+      } else if (kt + 2 == KT) {
+        if (has_next) { set_src(G8_ATOP, nm0, nn0); issue(G8_ATOP, 0); g8_wait_vm<4>(); }
+        else g8_wait_vm<0>();
+      }  // (kt == KT - 1: K-tile KT - 1 landed one K-tile ago; what is in flight belongs to the next tile)
+      phase_sync();
+      mma(acc[1][0], bl);
+      phase_end();
+    }
+    if (wr == 0) __builtin_amdgcn_s_barrier();  // pairs with the last barrier of waves 4-7: everybody has read buffer 1 for the last time
+
+    // ---- epilogue through buffer 1 ----
+    unsigned char* const E = smem + G8_BUF;
+    if constexpr (BF16OUT) {
+      g8_f32x4 sg4[LNC ? 2 : 1][LNC ? 2 : 1], tb4[LNC ? 2 : 1][LNC ? 2 : 1];
+      if constexpr (LNC) {
+        float* const S = reinterpret_cast<float*>(smem + 2 * G8_BUF);
+        S[4 * (tid & 255) + 2 * (tid >> 8)] = ln_mean;
+        S[4 * (tid & 255) + 2 * (tid >> 8) + 1] = ln_m2;
+        lds_barrier();  // (sg / tb landed long ago: they are older than every K-tile the loop waited for)
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int col = b * 128 + wc * 32 + j * 16 + fg * 4;
+            sg4[b][j] = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + LN_STATS + col * 4);
+            tb4[b][j] = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + LN_STATS + 1024 + col * 4);
+          }
+      }
+      bf16_t* const outp = reinterpret_cast<bf16_t*>(out_);
+      const int l = lane & 31;
+#pragma unroll
+      for (int a = 0; a < 2; ++a) {
+        if (a == 1) lds_barrier();  // the rows of pass 0 have been read
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wr * 64 + i * 16 + fr;  // inside the 128-row half
+          float mean = 0.f, rstd = 1.f;
+          if constexpr (LNC) {
+            const g8_f32x4 hh = *reinterpret_cast<const g8_f32x4*>(smem + 2 * G8_BUF + (a * 128 + row) * 16);
+            const float dm = hh[0] - hh[2];
+            mean = 0.5f * (hh[0] + hh[2]);
+            rstd = __builtin_amdgcn_rsqf(fmaf(hh[1] + hh[3] + 0.25f * (float)K * dm * dm, __builtin_amdgcn_rcpf((float)K), LN_EPS));
+          }
+#pragma unroll
+          for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+              const int c = b * 16 + wc * 4 + j * 2 + (fg >> 1);
+              g8_f32x4 v;
+              if constexpr (LNC) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaf(rstd, fmaf(-mean, sg4[b][j][r], acc[a][b][i][j][r]), tb4[b][j][r]);
+              } else {
+                v = acc[a][b][i][j] + bias4[LNC ? 0 : b][LNC ? 0 : j];
+              }
+              if constexpr (RELU) {
+#pragma unroll
+                for (int r = 0; r < 4; ++r) v[r] = fmaxf(v[r], 0.f);
+              }
+              g8_bf16x4 o4;
+#pragma unroll
+              for (int r = 0; r < 4; ++r) o4[r] = (__bf16)v[r];
+              *reinterpret_cast<g8_bf16x4*>(E + row * 512 + ((c ^ (fr & 7)) << 4) + (((fg & 1) ^ (fr >> 3)) << 3)) = o4;
+            }
+        }
+        lds_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int r = wave * 16 + it * 2 + (lane >> 5);
+          g8_u32x4 v = *reinterpret_cast<const g8_u32x4*>(E + r * 512 + ((l ^ (r & 7)) << 4));
+          if ((r >> 3) & 1) v = g8_u32x4{v[2], v[3], v[0], v[1]};
+          const int64_t m = m0 + a * 128 + r;
+          if (m < M) *reinterpret_cast<g8_u32x4*>(outp + m * N + n0 + l * 8) = v;
+        }
+      }
+    } else {
+      // fp32 output: four 128 x 128 quarters (row half a, column half b), 64 KB each.  Lane l = lane & 31 owns 4 consecutive columns
+      // of a quarter row (16 lanes = one 64-column statistics group), a wave-instruction covers two rows.
+      const int l = lane & 31, rsub = lane >> 5;
+      float* const base = (RESID ? resid : reinterpret_cast<float*>(out_)) + n0 + l * 4;
+      g8_f32x4 gamma4[2] = {g8_f32x4{0.f, 0.f, 0.f, 0.f}, g8_f32x4{0.f, 0.f, 0.f, 0.f}};
+      if constexpr (LNP) {
+        gamma4[0] = *reinterpret_cast<const g8_f32x4*>(ln.gamma + n0 + l * 4);
+        gamma4[1] = *reinterpret_cast<const g8_f32x4*>(ln.gamma + n0 + 128 + l * 4);
+      }
+      g8_f32x4 old[2][RESID ? 8 : 1];
+      auto request_old = [&](int p) {  // pass p = 2 a + b
+        if constexpr (RESID) {
+#pragma unroll
+          for (int it = 0; it < 8; ++it) {
+            const int64_t m = m0 + (p >> 1) * 128 + wave * 16 + it * 2 + rsub;
+            old[p & 1][it] = *reinterpret_cast<const g8_f32x4*>(base + (p & 1) * 128 + (m < M ? m : M - 1) * N);
+          }
+        }
+      };
+      request_old(0);
+#pragma unroll
+      for (int p = 0; p < 4; ++p) {
+        const int a = p >> 1, b = p & 1;
+        if (p > 0) lds_barrier();  // the rows of the previous pass have been read
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          const int row = wr * 64 + i * 16 + fr;
+#pragma unroll
+          for (int j = 0; j < 2; ++j) {
+            const int c = wc * 8 + j * 4 + fg;
+            *reinterpret_cast<g8_f32x4*>(E + row * 512 + ((c ^ (fr & 7)) << 4)) = acc[a][b][i][j] + bias4[LNC ? 0 : b][LNC ? 0 : j];
+          }
+        }
+        if (p < 3) request_old(p + 1);  // ahead of this pass's stores in the wave's memory queue
+        lds_barrier();
+#pragma unroll
+        for (int it = 0; it < 8; ++it) {
+          const int r = wave * 16 + it * 2 + rsub;
+          g8_f32x4 v = *reinterpret_cast<const g8_f32x4*>(E + r * 512 + ((l ^ (r & 7)) << 4));
+          if constexpr (RESID) v = old[p & 1][it] + v;
+          const int64_t m = m0 + a * 128 + r;
+          float gmean = 0.f, gm2 = 0.f;
+          if constexpr (LNP) {
+            gmean = row16_sum_dpp((v[0] + v[1]) + (v[2] + v[3])) * (1.0f / (float)LN_GROUP);
+            const float d0 = v[0] - gmean, d1 = v[1] - gmean, d2 = v[2] - gmean, d3 = v[3] - gmean;
+            gm2 = row16_sum_dpp(fmaf(d3, d3, fmaf(d2, d2, fmaf(d1, d1, d0 * d0))));
+          }
+          if (m < M) {
+            *reinterpret_cast<g8_f32x4*>(base + b * 128 + m * N) = v;
+            if constexpr (LNP) {
+              g8_bf16x4 o4;
+#pragma unroll
+              for (int q = 0; q < 4; ++q) o4[q] = (__bf16)(v[q] * gamma4[b][q]);
+              *reinterpret_cast<g8_bf16x4*>(reinterpret_cast<bf16_t*>(ln.xg) + m * N + n0 + b * 128 + l * 4) = o4;
+              if ((lane & 15) == 0)
+                *reinterpret_cast<g8_f32x2*>(ln.stats_out + ((int64_t)((n0 + b * 128 + l * 4) / LN_GROUP) * ln.stats_ld + m) * 2) = g8_f32x2{gmean, gm2};
+            }
+          }
+        }
+      }
+    }
+    if (!has_next) return;
+    // ---- next tile: its K-tile 0 is in buffer 0 (requested during the last two K-tiles, landed during the epilogue) ----
+    t = tn; m0 = nm0; n0 = nn0;
+    lds_barrier();  // every wave has read its rows out of buffer 1 (and S): K-tile 1 may land there, sg / tb may be replaced
+    request_tile_operands(m0, n0);
+    issue(G8_BLEFT, 1); issue(G8_ATOP, 1);
+    // K-tile 0: this wave's pieces are older than everything the epilogue issued and waited for (RESID) -- or are waited for here
+    if constexpr (!RESID) g8_wait_vm<4>();
+    else g8_wait_vm<4>();
+    __builtin_amdgcn_s_barrier();
+  }
+}
+
+int g_g8_persist = 1;   // "g8_persist": 1 = the persistent tile loop (gemm_8ph_pl_kernel) for the default schedule; 0 = one tile per workgroup (A/B)
 int g_g8_nt = 0;        // "g8_nt": non-temporal epilogue traffic -- 1 the bf16 output tiles, 2 the fp32 residual read-modify-write, 3 both
 int g_g8_dbg = 0;       // "g8_dbg": diagnostics -- 1 no epilogue stores, 2 two K-tiles only (what do prologue / epilogue cost?), 4 legacy epilogue
 int g_g8_colgroup = 0;  // "g8_colgroup": column tiles per group of the tile order (0 / 1 = row-major)

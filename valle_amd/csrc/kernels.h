@@ -286,8 +286,9 @@ struct PStepArgs {
                                    // before the sweep that precedes the operator, 3 = linear1 / linear2 spread over three sweeps (default)
 };
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V);
-// the persistent grid needs one workgroup per CU: the occupancy calculator must place (at least) one pstep_kernel workgroup on a CU
-bool pstep_fits_one_per_cu();
+// 1 = (weight type, persist_mode, keys per lane, request schedule, timeline) is an instantiated form of pstep_kernel and the occupancy
+// calculator places one of ITS workgroups per CU (the persistent grid needs all 256 resident); 0 = no such form; -1 = does not fit
+int pstep_form_ok(int dtype, int mode, int nk, int pf, bool traced);
 size_t pstep_gran_count(int d, int nhead, int L);
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched, 1 shape not covered, < 0 error
 // sg[n] = sum_k W[n][k] gamma[k], tb[n] = sum_k W[n][k] beta[k] + (bias ? bias[n] : 0) for the N rows of bf16 W[N][K] (fp64 sums)

@@ -1246,89 +1246,51 @@ int launch_ps_fold(hipStream_t st, const void* W, const float* gamma, const floa
   return 0;
 }
 
-bool pstep_fits_one_per_cu() {
-  int per_cu = 0;
-  const hipError_t r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, (pstep_kernel<bf16_t, 1024, 16, 2, 3, 5>), PS_T, 0);
-  if (r != hipSuccess) {
-    (void)hipGetLastError();
-    return false;
-  }
-  return per_cu >= 1;
-}
-
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V) {
   return (dtype == DT_BF16 || dtype == DT_FP8W || dtype == DT_F32) && d == 1024 && nhead == 16 && dh == 64 && V > 1024 && V <= 1025;
 }
 
 size_t pstep_gran_count(int d, int nhead, int L) { return (size_t)(L + 1) * ps_gran_per_layer(d, nhead, 256 / nhead); }
 
-// The timeline (option "persist_trace") exists for the shipped schedule (NK = 2, PF = 3), every packing mode; other schedules run
-// untraced (their trace buffer stays zero).
-static int ps_pk_of(int mode);
-static int ps_launch_traced(hipStream_t st, const PStepArgs& a) {
-  const dim3 grid(256), block(PS_T);
-  switch (ps_pk_of(a.mode)) {
-    case 12: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 12, true>), grid, block, 0, st, a); break;
-    case 13: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 13, true>), grid, block, 0, st, a); break;
-    case 14: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 14, true>), grid, block, 0, st, a); break;
-    case 15: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 15, true>), grid, block, 0, st, a); break;
-    case 0: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 0, true>), grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 1, true>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 2, true>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 3, true>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 4, true>), grid, block, 0, st, a); break;
-    case 5: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 5, true>), grid, block, 0, st, a); break;
-    case 6: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 6, true>), grid, block, 0, st, a); break;
-    case 7: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, 3, 7, true>), grid, block, 0, st, a); break;
-    default: return -1;
-  }
-  return 0;
-}
-
 // PK of a mode: bits 4 / 8: hidden / attention rows as bf16 pairs; 32: folded LayerNorm; 64: bf16 activation rows + v_dot2c (D2)
 static int ps_pk_of(int mode) { return ((mode >> 2) & 3) | ((mode >> 3) & 4) | ((mode >> 3) & 8); }
 
-// D2 (mode bit 6) exists on the folded LayerNorm only, for the shipped key split (NK = 2) and the request schedules 0 and 3
-template <int PF>
-static int ps_launch_d2(hipStream_t st, const PStepArgs& a) {
-  const dim3 grid(256), block(PS_T);
-  switch (ps_pk_of(a.mode)) {
-    case 12: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, PF, 12>), grid, block, 0, st, a); break;
-    case 13: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, PF, 13>), grid, block, 0, st, a); break;
-    case 14: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, PF, 14>), grid, block, 0, st, a); break;
-    case 15: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, 2, PF, 15>), grid, block, 0, st, a); break;
-    default: return -1;
-  }
-  return 0;
+// The instantiations that ship (round 6: the forms the measurement ladder of DESIGN.md 4.1 dropped -- 4 keys per lane, request
+// schedules 1 / 2, the attention row as bf16 pairs, D2 / folded forms without the packed hidden row -- are no longer compiled):
+//   bf16 weights   PK 0  fp32 rows, nothing packed, three-barrier LayerNorm   } bit-identical to the launch chain at the same
+//                  PK 1  + hidden row as bf16 pairs                           } decomposition (tests/test_persist_gpu.py)
+//                  PK 5  + folded LayerNorm
+//                  PK 13 + bf16 activation rows on v_dot2c (the default; also with the in-kernel timeline)
+//   fp8 weights    PK 1, PK 5 (the default)          fp32: PK 0
+// each for 2 keys per lane and the request schedules 0 (all at once) and 3 (spread over three sweeps, the default).
+typedef void (*PsKernel)(PStepArgs);
+template <typename WT, int PK, bool TR = false>
+static PsKernel ps_pf(int pf) {
+  return pf == 3 ? (PsKernel)pstep_kernel<WT, 1024, 16, 2, 3, PK, TR> : pf == 0 && !TR ? (PsKernel)pstep_kernel<WT, 1024, 16, 2, 0, PK, false> : nullptr;
+}
+static PsKernel ps_select(int dtype, int mode, int nk, int pf, bool traced) {
+  if (nk != 2) return nullptr;
+  const int pk = ps_pk_of(mode);
+  if (dtype == DT_FP8W) return traced ? nullptr : pk == 1 ? ps_pf<bf16w8t_t, 1>(pf) : pk == 5 ? ps_pf<bf16w8t_t, 5>(pf) : nullptr;
+  if (dtype == DT_F32) return traced || pk != 0 ? nullptr : ps_pf<float, 0>(pf);
+  if (dtype != DT_BF16) return nullptr;
+  if (pk == 13 && !(mode & 16)) return nullptr;  // (the D2 forms were built on the XCD-local group edges only)
+  if (traced) return pk == 13 ? ps_pf<bf16_t, 13, true>(pf) : nullptr;
+  return pk == 0 ? ps_pf<bf16_t, 0>(pf) : pk == 1 ? ps_pf<bf16_t, 1>(pf) : pk == 5 ? ps_pf<bf16_t, 5>(pf) : pk == 13 ? ps_pf<bf16_t, 13>(pf) : nullptr;
 }
 
-template <int NK, int PF>
-static int ps_launch_pk(hipStream_t st, const PStepArgs& a) {
-  const dim3 grid(256), block(PS_T);
-  switch (ps_pk_of(a.mode) & 7) {
-    case 0: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 0>), grid, block, 0, st, a); break;
-    case 1: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 1>), grid, block, 0, st, a); break;
-    case 2: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 2>), grid, block, 0, st, a); break;
-    case 3: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 3>), grid, block, 0, st, a); break;
-    case 4: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 4>), grid, block, 0, st, a); break;
-    case 5: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 5>), grid, block, 0, st, a); break;
-    case 6: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 6>), grid, block, 0, st, a); break;
-    default: hipLaunchKernelGGL((pstep_kernel<bf16_t, 1024, 16, NK, PF, 7>), grid, block, 0, st, a); break;
+// 1 = this (weight type, mode, schedule) is an instantiated form AND the occupancy calculator places (at least) one of ITS workgroups
+// on a CU -- asked about the kernel that would be launched, not about a stand-in; 0 = no such form; -1 = it does not fit
+int pstep_form_ok(int dtype, int mode, int nk, int pf, bool traced) {
+  const PsKernel k = ps_select(dtype, mode, nk, pf, traced);
+  if (k == nullptr) return 0;
+  int per_cu = 0;
+  const hipError_t r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, PS_T, 0);
+  if (r != hipSuccess) {
+    (void)hipGetLastError();
+    return -1;
   }
-  return 0;
-}
-
-// FP8W: fp8 weight rows + row scales (round 5): the shipped key split and request schedules 0 / 3, the hidden row as bf16 pairs, with
-// the three-barrier (bit-identical to the fp8w launch chain) or the folded LayerNorm; no timeline, no v_dot2c forms
-template <int PF>
-static int ps_launch_w8(hipStream_t st, const PStepArgs& a) {
-  const dim3 grid(256), block(PS_T);
-  switch (ps_pk_of(a.mode)) {
-    case 1: hipLaunchKernelGGL((pstep_kernel<bf16w8t_t, 1024, 16, 2, PF, 1>), grid, block, 0, st, a); break;
-    case 5: hipLaunchKernelGGL((pstep_kernel<bf16w8t_t, 1024, 16, 2, PF, 5>), grid, block, 0, st, a); break;
-    default: return -1;
-  }
-  return 0;
+  return per_cu >= 1 ? 1 : -1;
 }
 
 // returns 0 = launched, 1 = shape not covered, < 0 = error
@@ -1336,28 +1298,10 @@ int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstep_supports(dtype, a.d, a.nhead, a.dh, a.V)) return 1;
   if (!a.layers || !a.x_in || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
   if (a.nsteps < 0 || a.nsteps > 4096 || (a.nsteps > 0 && !a.smp)) return -1;
-  if (dtype == DT_FP8W) {
-    if (a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
-    return a.pf == 0 ? ps_launch_w8<0>(st, a) : ps_launch_w8<3>(st, a);
-  }
-  if (dtype == DT_F32) {
-    // fp32 weights, KV cache and edges (the token-exact mode): the three-barrier form with nothing packed -- every logit equals the
-    // fp32 launch chain's at 16 key splits.  192 KB of weights per layer and workgroup: the rows requested furthest ahead wait in
-    // accumulation registers (256 VGPRs + 10 AGPRs, no scratch)
-    if (ps_pk_of(a.mode) != 0 || a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
-    const dim3 grid(256), block(PS_T);
-    if (a.pf == 0) hipLaunchKernelGGL((pstep_kernel<float, 1024, 16, 2, 0, 0>), grid, block, 0, st, a);
-    else hipLaunchKernelGGL((pstep_kernel<float, 1024, 16, 2, 3, 0>), grid, block, 0, st, a);
-    return 0;
-  }
-  if (a.mode & 64) {  // D2
-    if (!(a.mode & 32) || !(a.mode & 16) || a.nk == 4 || !(a.pf == 0 || a.pf == 3)) return -1;
-    if (a.ptrace != nullptr && a.pf == 3) return ps_launch_traced(st, a);
-    return a.pf == 0 ? ps_launch_d2<0>(st, a) : ps_launch_d2<3>(st, a);
-  }
-  if (a.ptrace != nullptr && a.nk != 4 && a.pf == 3) return ps_launch_traced(st, a);
-  if (a.nk == 4) return a.pf == 0 ? ps_launch_pk<4, 0>(st, a) : a.pf == 1 ? ps_launch_pk<4, 1>(st, a) : a.pf == 2 ? ps_launch_pk<4, 2>(st, a) : ps_launch_pk<4, 3>(st, a);
-  return a.pf == 0 ? ps_launch_pk<2, 0>(st, a) : a.pf == 1 ? ps_launch_pk<2, 1>(st, a) : a.pf == 2 ? ps_launch_pk<2, 2>(st, a) : ps_launch_pk<2, 3>(st, a);
+  const PsKernel k = ps_select(dtype, a.mode, a.nk, a.pf, a.ptrace != nullptr);
+  if (k == nullptr) return -1;
+  hipLaunchKernelGGL(k, dim3(256), dim3(PS_T), 0, st, a);
+  return 0;
 }
 
 }  // namespace vle

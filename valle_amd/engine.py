@@ -155,6 +155,27 @@ class Engine:
             _lib.check(rc, self.h)
         return codes0, self._gen_lens
 
+    def prefill_generate(self, text: torch.Tensor, text_lens: Sequence[int], prompts: torch.Tensor, prompt_lens: Sequence[int], **gen):
+        """prefill() + generate(**gen) with the ONE retry the persistent batch-1 launch asks of its callers: that launch needs every
+        CU of the GPU; when another workload holds some for > 0.1 s a wave gives up, vle_ar_generate ends with VLE_EBUSY and the
+        call's state is void.  The decode is repeated from the prefill -- the engine itself keeps its next batch-1 calls on the launch
+        chain (same sampling stream; same tokens up to the fp32 re-association of the folded LayerNorm) and re-arms the persistent
+        launch after a back-off (2, 4 ... 64 calls): a busy neighbour costs speed for a while, not the request.  Every caller that
+        wants a decode rather than the raw ABI answer goes through here (VALLE.inference_batch, bench.py, smoke)."""
+        self.prefill(text, text_lens, prompts, prompt_lens)
+        try:
+            return self.generate(**gen)
+        except _lib.VleError as err:
+            if err.code != _lib.VLE_EBUSY:
+                raise
+            import sys
+
+            print("valle_amd: the persistent AR launch could not hold the whole GPU; this decode is repeated on the launch chain "
+                  f"(fallback #{self.fetch_u32('persist_fallbacks')}, persistent launch re-armed after {self.fetch_u32('persist_backoff')} calls)",
+                  file=sys.stderr)
+            self.prefill(text, text_lens, prompts, prompt_lens)
+            return self.generate(**gen)
+
     def nar(self, enroll_lens: Optional[Sequence[int]] = None, forced: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The 7 NAR stages; ``forced`` int64 (B, >=G, Q) teacher-forces the stage history (parity hook, vle_nar_force)."""
         B, Q = self._B, self.cfg.num_quantizers

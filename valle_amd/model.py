@@ -261,26 +261,10 @@ class VALLE(nn.Module):
             # from it, so torch.manual_seed() makes sampled decodes reproducible and successive calls differ
             seed = 0 if top_k == 1 else int(torch.randint(0, 2**62, (1,)).item())
         xd, yd = x.to(dev, torch.int64), y.to(dev, torch.int64)[..., : self.num_quantizers]
-        eng.prefill(xd, xl, yd, yl)
         try:
-            # batch 1 keeps the reference's SyntaxError; in a batch an utterance that hits EOS at step 0 returns 0 frames
-            try:
-                _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
-            except _lib.VleError as err:
-                # The persistent batch-1 launch needs every CU of the GPU; when another workload holds some for > 0.1 s a wave gives up
-                # and the call ends with VLE_EBUSY.  The decode is repeated from the prefill: the engine itself keeps its next batch-1
-                # calls on the launch chain (same sampling stream, same tokens up to the fp32 re-association of the folded LayerNorm)
-                # and re-arms the persistent launch after a back-off (2, 4 ... 64 calls) -- a busy neighbour costs speed for a
-                # while, not the request and not the engine's fast path for good.
-                if err.code != _lib.VLE_EBUSY:
-                    raise
-                import sys
-
-                print("valle_amd: the persistent AR launch could not hold the whole GPU; this decode is repeated on the launch chain "
-                      f"(fallback #{eng.fetch_u32('persist_fallbacks')}, persistent launch re-armed after {eng.fetch_u32('persist_backoff')} calls)",
-                      file=sys.stderr)
-                eng.prefill(xd, xl, yd, yl)
-                _, gl = eng.generate(top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
+            # batch 1 keeps the reference's SyntaxError; in a batch an utterance that hits EOS at step 0 returns 0 frames.
+            # (Engine.prefill_generate repeats the decode once on VLE_EBUSY -- the persistent launch could not hold the GPU.)
+            _, gl = eng.prefill_generate(xd, xl, yd, yl, top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
         except _lib.VleError as err:
             if err.code == _lib.VLE_ENOTOKEN:
                 raise SyntaxError("well trained model shouldn't reach here.") from None  # valle.py:1049-1052

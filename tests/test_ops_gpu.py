@@ -465,6 +465,54 @@ def test_linear_gemm_leftover_rows_as_a_second_launch(M, N, K):
     assert (split[1][tail].double() - ref[tail]).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(64 * 256, 1024, 1024), (65600, 1024, 4096), (65600, 3072, 1024), (40 * 256 + 37, 4096, 1024), (33 * 256, 1024, 256),
+                                   (150 * 256 + 255, 512, 1536)])
+def test_gemm_8ph_persistent_tile_loop_is_bit_identical(M, N, K):
+    """Knob "g8_persist" (gemm_8ph.hip, round 6): one workgroup per CU walks several 256 x 256 tiles -- the DMA queue runs across
+    tiles, the epilogue stages through one LDS buffer while the other receives the next tile's first K-tile, its stores are never
+    waited for.  Arithmetic, reduction orders and roundings are the one-tile kernel's: every epilogue (fp32, bf16, ReLU, residual
+    read-modify-write, and the LayerNorm-folded producer / consumer pair) must give the SAME BITS with the knob on and off -- with
+    1 / 2 / 4+ tiles per workgroup, ragged last tile rows (with glds_tail = 0 they stay inside the launch), K = 256 (four K-tiles: the
+    cross-tile requests start in the first trip) -- and repeated runs must agree (race screen)."""
+    assert (M // 256) * (N // 256) >= 128, "a shape the 256 x 256 tiles take"
+    a = _rand(M, K, seed=170).to(torch.bfloat16)
+    w = (_rand(N, K, seed=171) / math.sqrt(K)).to(torch.bfloat16)
+    bias = _rand(N, seed=172) * 0.1
+    r0 = _rand(M, N, seed=173)
+    d = N
+    gamma = 1.0 + 0.3 * _rand(d, seed=174)
+    ln_ok = d % 256 == 0 and d <= 1536
+
+    def run():
+        outs = [ops.linear(a, w, bias, ops.EPI_F32, ksplit=None), ops.linear(a, w, bias, ops.EPI_STORE, ksplit=None),
+                ops.linear(a, w, bias, ops.EPI_RELU, ksplit=None), ops.linear(a, w, bias, ops.EPI_RESID, resid=r0.clone(), ksplit=None)]
+        if ln_ok:  # producer (this GEMM completes the residual stream of width N), then a consumer of its xg / statistics
+            x = r0.clone()
+            xg, stats = ops.linear_ln_producer(a, w, bias, x, gamma)
+            wc = (_rand(2 * d, d, seed=175) / math.sqrt(d)).to(torch.bfloat16)
+            sg, tb = _rand(2 * d, seed=176), _rand(2 * d, seed=177)
+            outs += [x, xg, stats, ops.linear_ln_consumer(xg, wc, tb, sg, stats, relu=False), ops.linear_ln_consumer(xg, wc, tb, sg, stats, relu=True)]
+        torch.cuda.synchronize()
+        return outs
+
+    for tail in (1, 0):  # 0: a ragged last tile row stays inside the 256 x 256 launch (rows clamped on load, dropped on store)
+        ops.tune("glds_tail", tail)
+        try:
+            ops.tune("g8_persist", 0)
+            one = run()
+            ops.tune("g8_persist", 7)  # every epilogue class on the persistent loop (the engine's default policy is a subset)
+            loop = run()
+            again = run()
+        finally:
+            ops.tune("g8_persist", 1)
+            ops.tune("glds_tail", 1)
+        for i, (x, y, z) in enumerate(zip(one, loop, again)):
+            assert torch.equal(x, y), (tail, i, (x.double() - y.double()).abs().max().item())
+            assert torch.equal(y, z), (tail, i, "run-to-run")
+    ref = a.double() @ w.double().t() + bias.double()
+    assert (loop[0].double() - ref).abs().max().item() < 3e-5 * math.sqrt(K / 64) * max(1.0, ref.abs().max().item())
+
+
 # (M, d): every tile policy of gemm_glds.hip / gemm_8ph.hip the prefill / NAR rows meet -- 64 x 64 (few rows), 128 x 64 / 128 x 128 with the
 # 64 x 64 leftover launch (one utterance, M = 1025), 256 x 128, 256 x 256 phase-split + leftover rows (batched NAR rows), d 1536 (24 groups)
 @pytest.mark.parametrize("M,d", [(128, 256), (272, 1024), (1025, 1024), (2 * 1025, 1024), (8 * 1025, 1024), (33 * 1025, 1024), (1025, 1536), (12 * 1025, 1536)])

@@ -35,6 +35,15 @@ def main():
     shapes = [("qkv", 3072, 1024, ops.EPI_STORE), ("oproj", 1024, 1024, ops.EPI_RESID), ("ffn1", 4096, 1024, ops.EPI_RELU),
               ("ffn2", 1024, 4096, ops.EPI_RESID)]
     quick = "--quick" in sys.argv
+    if "--persist" in sys.argv:  # round 6: the persistent tile loop of gemm_8ph.hip against the one-tile kernel, alternating
+        for M in (65600, 32800, 16400):
+            for rep in range(2):
+                for v in (0, 7):
+                    ops.tune("g8_persist", v)
+                    row = [f"{name} {tflops(M, N, K, epi):7.1f}" for name, N, K, epi in shapes]
+                    print(f"M={M:6d} g8_persist={v} TF/s: " + "  ".join(row), flush=True)
+        ops.tune("g8_persist", 1)
+        return
     for M in ((65600,) if quick else (65600, 8200, 1025)):
         for knobs in (({}, {"g8_nt": 1}, {"g8_nt": 2}, {"g8_nt": 3}, {"g8_dbg": 1}, {}) if quick else
                       ({}, {"g8_nt": 1}, {"g8_nt": 2}, {"g8_nt": 3}, {"g8_dbg": 4}, {"g8_dbg": 1}, {"g8_colgroup": 4}, {"glds_8ph": 0}, {"glds_8ph": 0, "glds_epi": 0}, {})):

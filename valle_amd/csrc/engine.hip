@@ -2647,6 +2647,10 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     g_g8_nt = (int)value & 3;
     return VLE_OK;
   }
+  if (n == "g8_persist") {  // process-global: gemm_8ph.hip's persistent tile loop (A/B)
+    g_g8_persist = (int)value & 7;
+    return VLE_OK;
+  }
   if (n == "glds_swz" || n == "glds_8ph" || n == "g8_stagger" || n == "g8_colgroup" || n == "glds_tail" || n == "glds_t64") {
     (n == "glds_swz" ? g_glds_swz : n == "glds_8ph" ? g_glds_8ph : n == "g8_stagger" ? g_g8_stagger : n == "glds_tail" ? g_glds_tail : n == "glds_t64" ? g_glds_t64 : g_g8_colgroup) = (int)value;
     return VLE_OK;

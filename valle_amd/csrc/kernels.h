@@ -73,6 +73,7 @@ int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* 
 extern int g_attn_qw;
 extern int g_g8_colgroup;
 extern int g_g8_stagger;
+extern int g_g8_persist;  // gemm_8ph.hip: 1 = persistent tile loop (one workgroup per CU walks several tiles), 0 = one tile per workgroup
 extern int g_glds_8ph;
 extern int g_glds_t64;
 extern int g_glds_tail;  // gemm_glds.hip: 1 = the rows past the last full 256-row tile of a gemm_8ph launch as a second small launch when that saves a round

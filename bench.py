@@ -475,12 +475,19 @@ def main():
         acc["gl"], acc["n_out"] = gl, len(out)
         acc["out"] = out
         acc["tokens"] += sum(gl) * 8
-        tm = eng.timings()
+        seq = getattr(model, "sequential_timings", None)  # two utterances decoded one after the other on the batch-1 path (model.py)
+        tm = seq if seq is not None else eng.timings()
+        acc["sequential"] = seq is not None
         acc["pre"] += tm["prefill_ms"]; acc["ar"] += tm["ar_ms"]; acc["nar"] += tm["nar_ms"]; acc["ar_steps"] += int(tm["ar_steps"])
         # algorithmic bytes of this utterance batch's AR loop: per step W_AR*w + sum_b 2*L*d*a*(c_b + 1)
-        for t in range(1, max(gl) + 1):
-            live = sum(1 for b in range(B) if gl[b] >= t)
-            acc["ar_bytes"] += eng.ar_step_bytes(live, live * (S_TEXT + P_PROMPT + t))
+        if seq is not None:  # every utterance streams the weights for itself
+            for b in range(B):
+                for t in range(1, gl[b] + 1):
+                    acc["ar_bytes"] += eng.ar_step_bytes(1, S_TEXT + P_PROMPT + t)
+        else:
+            for t in range(1, max(gl) + 1):
+                live = sum(1 for b in range(B) if gl[b] >= t)
+                acc["ar_bytes"] += eng.ar_step_bytes(live, live * (S_TEXT + P_PROMPT + t))
 
     elapsed = timed_loop(step, args.steps, args.warmup, world, dev, on_step)
     tokens, gl = acc["tokens"], acc["gl"]
@@ -541,6 +548,7 @@ def main():
                             f"{'greedy (top_k=1)' if args.top_k == 1 else f'top_k={args.top_k}'}, random-init weights",
                 "parallelism": f"batch-sharded x{args.gpus} (independent utterances, gather of codes only)",
                 "batch_per_gpu": B,
+                "sequential": bool(acc.get("sequential")),  # two utterances decoded one after the other on the persistent batch-1 launch (model.py)
                 "world_size": world_seen,
                 "backend": "nccl (RCCL)" if world > 1 else "none (single process)",
                 "hip_graph": not args.no_graph,

@@ -377,6 +377,55 @@ def test_option_sets_without_an_instantiated_form_run_the_launch_chain(c2_model)
     assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0 and torch.equal(got, want)
 
 
+def test_two_utterances_are_decoded_one_after_the_other_on_the_persistent_launch(c2_model):
+    """Round 6 (profiles/r06_small_batch.json): at two utterances the batched launch chain (369 us per AR step, 41 k tokens/s) is slower
+    than ONE utterance on the persistent launch (128 us, 56.7 k), so VALLE.inference_batch decodes a batch of two one after the other
+    where that launch is available.  Ragged lengths; every utterance must equal its own batch-1 decode -- greedy, and sampled: utterance b
+    draws from the stream of request b (what the batched call gives it), not from request 0's."""
+    import valle_amd as va
+
+    torch.manual_seed(21)
+    m = va.VALLE(1024, 16, 3, prefix_mode=1, engine_dtype="bf16", max_batch=4).to(DEV).eval()
+    S, P = [9, 14], [20, 31]
+    g = torch.Generator().manual_seed(5)
+    X = torch.zeros(2, max(S), dtype=torch.int64)
+    Y = torch.zeros(2, max(P), 8, dtype=torch.int64)
+    for b in range(2):
+        X[b, : S[b]] = torch.randint(3, 100, (S[b],), generator=g)
+        X[b, 0], X[b, S[b] - 1] = 1, 2
+        Y[b, : P[b]] = torch.randint(0, 1024, (P[b], 8), generator=g)
+    X, Y = X.to(DEV), Y.to(DEV)
+    lens = torch.tensor(S, dtype=torch.int32)
+    eng = m.engine_for(2, max(S), max(P))
+    eng.set_option("ignore_eos", 1)
+    assert eng.fetch_u32("persist_capable") == 1
+    for kw in (dict(top_k=1), dict(top_k=20, temperature=0.9, seed=1234)):
+        got = m.inference_batch(X, lens, Y, P, None, max_new=40, **kw)
+        assert m.sequential_timings is not None and eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+        assert m.sequential_timings["ar_steps"] >= 2 * 39
+        for b in range(2):
+            kb = dict(kw)
+            if "seed" in kb:
+                kb["seed"] = (kb["seed"] + b * 0x9E3779B97F4A7C15) & (2**64 - 1)  # request b's stream as request 0 of a one-utterance call
+            one = m.inference_batch(X[b : b + 1, : S[b]], lens[b : b + 1], Y[b : b + 1, : P[b]], [P[b]], None, max_new=40, **kb)[0]
+            assert torch.equal(got[b], one), (kw, b)
+        # ... and the batched launch chain (forced: persist = 0) gives utterance b the same sampling stream: the decodes START alike (two
+        # free-running bf16 paths part at their first sub-noise tie, so only the first tokens are compared)
+        eng.set_option("persist", 0)
+        try:
+            chain = m.inference_batch(X, lens, Y, P, None, max_new=40, **kw)
+            assert m.sequential_timings is None
+        finally:
+            eng.set_option("persist", 1)
+        for b in range(2):
+            assert chain[b].shape == got[b].shape
+            assert torch.equal(chain[b][:3, 0], got[b][:3, 0]), (kw, b)
+    # three utterances: the chain (ahead from there on)
+    X3, Y3 = torch.cat([X, X[:1]]), torch.cat([Y, Y[:1]])
+    m.inference_batch(X3, torch.tensor(S + S[:1], dtype=torch.int32), Y3, P + P[:1], None, top_k=1, max_new=8)
+    assert m.sequential_timings is None and eng.fetch_u32("persist_ran") == 0
+
+
 def test_persistent_step_is_the_default_where_covered_and_only_there():
     torch.manual_seed(3)
     m = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16").to(DEV).eval()

@@ -2801,6 +2801,15 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
     const size_t nb = std::min(bytes, sizeof(v));
     memcpy(host_dst, &v, nb);
     return (int64_t)nb;
+  } else if (w == "persist_capable") {
+    // 1 when a ONE-utterance call on this engine would run the persistent launch (shape, device, options, tables, not backed off) whatever
+    // the batch of the last prefill was: what VALLE.inference_batch asks before it decodes two utterances one after the other
+    const bool v1 = e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && !e->slot_mode && !e->opt_profile && e->ps_table != nullptr &&
+                    e->ps_gran != nullptr && (!e->w8 || ps_w8_mode_ok(e)) && ps_form_ok(e) && (int)e->ar.size() == e->L;
+    const int32_t v = v1 ? 1 : 0;
+    const size_t nb = std::min(bytes, sizeof(v));
+    memcpy(host_dst, &v, nb);
+    return (int64_t)nb;
   } else if (w == "persist_active") {  // 1 when the next batch-1 step would run the persistent launch
     const int32_t v = persist_ready(e) ? 1 : 0;
     const size_t nb = std::min(bytes, sizeof(v));

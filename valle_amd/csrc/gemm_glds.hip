@@ -40,14 +40,37 @@ __device__ inline int gg_key(int row) {
   return SWZ ? ((row >> 1) & 7) : (row & 7);
 }
 
-template <int BM, int BN, int EPI, int NW, bool PRIO = false, int SWZ = 0>
-__global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
+// one 16-byte fragment pair -> accumulator: bf16: 8 k per lane, one MFMA; fp32: 4 k per lane, four exact-fp32 MFMAs (x, y, z, w)
+template <typename T>
+__device__ inline gg_f32x4 gg_mma(const gg_bf16x8& w, const gg_bf16x8& a, gg_f32x4 c) {
+  if constexpr (sizeof(T) == 2) {
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, a, c, 0, 0, 0);
+  } else {
+    const gg_f32x4 wf = __builtin_bit_cast(gg_f32x4, w), af = __builtin_bit_cast(gg_f32x4, a);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[0], af[0], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[1], af[1], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[2], af[2], c, 0, 0, 0);
+    c = __builtin_amdgcn_mfma_f32_16x16x4f32(wf[3], af[3], c, 0, 0, 0);
+    return c;
+  }
+}
+
+// T: bf16_t, or float (round 6) -- the token-exact engine mode's packed-row GEMMs on the same pipeline: a stage row is still 128 bytes
+// (32 fp32 of K), a fragment read is still one 16-byte vector per lane (4 consecutive k), fed to four v_mfma_f32_16x16x4_f32 (components
+// x, y, z, w) exactly as gemm.hip's register-staged kernel does, in the same stage / half / component order: every output element is
+// the same chain of exact fp32 FMAs, so the two kernels are BIT-IDENTICAL (tests/test_ops_gpu.py) and the token-exact mode's ids cannot
+// move.  fp32 MFMA runs at the vector rate (157 TF/s), so what the ring buys is latency hiding: gemm.hip keeps one k-step in flight.
+template <typename T, int BM, int BN, int EPI, int NW, bool PRIO = false, int SWZ = 0>
+__global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const T* __restrict__ A, const T* __restrict__ W,
                                                         const float* __restrict__ bias, void* __restrict__ out_,
                                                         float* __restrict__ resid, int64_t M, int N, int K, int glds_legacy_epilogue, GemmLn ln) {
   // LayerNorm folded into the GEMMs (kernels.h GemmLn): LNP = this launch completes the residual stream and leaves bf16(x * gamma) +
   // group statistics for the next norm site; LNC = this launch reads x * gamma and applies rstd * (acc - mean * sg) + tb
   constexpr bool LNP = EPI == EPI_RESID_LNP, LNC = EPI == EPI_STORE_LNC || EPI == EPI_RELU_LNC;
   constexpr bool RESID = EPI == EPI_RESID || LNP, RELU = EPI == EPI_RELU || EPI == EPI_RELU_LNC;
+  constexpr bool F32IN = sizeof(T) == 4;
+  static_assert(!F32IN || !(LNP || LNC), "the LayerNorm-folded epilogues are bf16 only");
+  constexpr int KE = 128 / (int)sizeof(T);  // K elements per stage row
   constexpr int STAGE_BYTES = (BM + BN) * 128;
   constexpr int STAGES = (4 * STAGE_BYTES <= 144 * 1024) ? 4 : 3;
   constexpr int D = STAGES - 1;                 // k-steps in flight
@@ -135,7 +158,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   int nlive = (int)((M - (m0 + wm0) + 15) / 16);
   nlive = nlive < 0 ? 0 : (nlive > FM ? FM : nlive);
 
-  const int KT = K / 64;
+  const int KT = K / KE;
   // LNC: the row statistics.  Thread t < 2 BM owns HALF of row m0 + t % BM (half t / BM of its K / 64 groups): the (mean, M2) pairs are
   // requested AHEAD of the K-tile queue (a wave's loads return in order: the wait for them never drains the pipeline), straight-line
   // and on clamped addresses (no branch around a request), one coalesced 8-byte load per group (group-major layout), and combined
@@ -207,7 +230,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
         for (int i = 0; i < FM; ++i)
 #pragma unroll
           for (int j = 0; j < FN; ++j)  // W fragment as the A operand: C^T, see the epilogue
-            acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], af[i], acc[i][j], 0, 0, 0);
+            acc[i][j] = gg_mma<T>(bfr[j], af[i], acc[i][j]);
         if constexpr (PRIO) __builtin_amdgcn_s_setprio(0);
       }
     } else if (nlive > 0) {  // tail tile (rows beyond M): only fragment rows that exist
@@ -226,7 +249,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
             const int row = wm0 + i * 16 + fr;
             const gg_bf16x8 a = *reinterpret_cast<const gg_bf16x8*>(As + row * 128 + ((c ^ gg_key<SWZ>(row)) << 4));
 #pragma unroll
-            for (int j = 0; j < FN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(bfr[j], a, acc[i][j], 0, 0, 0);
+            for (int j = 0; j < FN; ++j) acc[i][j] = gg_mma<T>(bfr[j], a, acc[i][j]);
           }
         }
       }
@@ -243,7 +266,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
   // as whole rows: every global access is BN x element-size contiguous bytes of one output row, 16 bytes per lane; the
   // residual's old values are loaded in that row form too (requested before the barrier).
   if ((n0 + BN <= N && !glds_legacy_epilogue) || LNP || LNC) {  // (the LN epilogues exist in this form only: gemm_ln_supports)
-    constexpr bool F32OUT = RESID || EPI == EPI_F32;
+    constexpr bool F32OUT = RESID || EPI == EPI_F32 || F32IN;  // (fp32 activations: every epilogue writes floats)
     constexpr int ES = F32OUT ? 4 : 2, RB = BN * ES, CPR = RB / 16, RPI = 64 / CPR, IT = BM / NW / RPI;
     static_assert(BM * RB <= STAGES * STAGE_BYTES && (BM / NW) % RPI == 0, "epilogue image must fit the LDS ring");
     static_assert(!LNP || CPR % 16 == 0, "a 16-lane row of the row-form pass covers one 64-column group");
@@ -343,7 +366,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
         if constexpr (EPI == EPI_RESID) {
           const gg_f32x4 f = gg_f32x4{__uint_as_float(v[0]), __uint_as_float(v[1]), __uint_as_float(v[2]), __uint_as_float(v[3])};
           *reinterpret_cast<gg_f32x4*>(resid + m * N + n0 + l * 4) = old[it] + f;
-        } else if constexpr (EPI == EPI_F32) {
+        } else if constexpr (F32OUT) {
           *reinterpret_cast<gg_u32x4*>(reinterpret_cast<float*>(out_) + m * N + n0 + l * 4) = v;
         } else {
           *reinterpret_cast<gg_u32x4*>(reinterpret_cast<bf16_t*>(out_) + m * N + n0 + l * 8) = v;
@@ -399,7 +422,7 @@ __global__ __launch_bounds__(NW * 64) void gemm_glds_kernel(const bf16_t* __rest
       if (full || (m < M && n < N)) {
         if constexpr (EPI == EPI_RESID) {
           *reinterpret_cast<gg_f32x4*>(resid + m * N + n) = acc[i][j];
-        } else if constexpr (EPI == EPI_F32) {
+        } else if constexpr (EPI == EPI_F32 || F32IN) {
           *reinterpret_cast<gg_f32x4*>(reinterpret_cast<float*>(out_) + m * N + n) = acc[i][j];
         } else {
           gg_bf16x4 o4;

@@ -246,6 +246,7 @@ class VALLE(nn.Module):
         temperature: float = 1.0,
         seed: Optional[int] = None,
         max_new: int = 0,
+        _allow_empty: Optional[bool] = None,
     ) -> List[torch.Tensor]:
         """B independent utterances (the reference is batch-1, valle.py:989): returns a list of
         (G_b, Q) int64 tensors on the model's device."""
@@ -254,17 +255,37 @@ class VALLE(nn.Module):
         yl = [int(v) for v in y_lens]
         if not self.fused:
             return self._inference_blocks(x, xl, y, yl, enroll_x_lens, top_k, temperature, seed, max_new)
-        eng = self.engine_for(B, max(xl), max(yl))
-        dev = eng.device
         if seed is None:
             # the reference samples from torch's global generator (valle.py:1301): draw the engine's RNG seed
             # from it, so torch.manual_seed() makes sampled decodes reproducible and successive calls differ
             seed = 0 if top_k == 1 else int(torch.randint(0, 2**62, (1,)).item())
+        if B == 2 and _allow_empty is None:
+            # Two utterances: measured on MI355X (profiles/r06_small_batch.json), the batched launch chain decodes them at 369 us per AR
+            # step -- 41 k tokens/s, LESS than one utterance on the persistent batch-1 launch (128 us per step, 56.7 k) -- so where that
+            # launch is available they are decoded one after the other.  Same results as the batched call: utterances never interact,
+            # and utterance b draws from the sampling stream of request b (common.h request_seed: the stream of request b under `seed` is
+            # the stream of request 0 under seed + b * 0x9E3779B97F4A7C15).  From 3 utterances on the chain is ahead (60.7 k).
+            eng = self.engine_for(B, max(xl), max(yl))
+            if eng.fetch_u32("persist_capable") == 1:
+                outs, tsum = [], dict(prefill_ms=0.0, ar_ms=0.0, nar_ms=0.0, ar_steps=0.0)
+                for b in range(B):
+                    en_b = None if enroll_x_lens is None else (enroll_x_lens if enroll_x_lens.numel() == 1 else enroll_x_lens[b : b + 1])
+                    outs += self.inference_batch(x[b : b + 1, : xl[b]], x_lens[b : b + 1], y[b : b + 1, : yl[b]], [yl[b]], en_b, top_k, temperature,
+                                                 (seed + b * 0x9E3779B97F4A7C15) & (2**64 - 1), max_new, _allow_empty=True)
+                    for k, v in eng.timings().items():
+                        tsum[k] += v
+                self.sequential_timings = tsum  # (bench.py: the phase times of the whole call, not of its last utterance)
+                return outs
+        if _allow_empty is None:
+            self.sequential_timings = None
+        eng = self.engine_for(B, max(xl), max(yl))
+        dev = eng.device
+        allow_empty = B > 1 if _allow_empty is None else _allow_empty
         xd, yd = x.to(dev, torch.int64), y.to(dev, torch.int64)[..., : self.num_quantizers]
         try:
             # batch 1 keeps the reference's SyntaxError; in a batch an utterance that hits EOS at step 0 returns 0 frames.
             # (Engine.prefill_generate repeats the decode once on VLE_EBUSY -- the persistent launch could not hold the GPU.)
-            _, gl = eng.prefill_generate(xd, xl, yd, yl, top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=B > 1)
+            _, gl = eng.prefill_generate(xd, xl, yd, yl, top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=allow_empty)
         except _lib.VleError as err:
             if err.code == _lib.VLE_ENOTOKEN:
                 raise SyntaxError("well trained model shouldn't reach here.") from None  # valle.py:1049-1052

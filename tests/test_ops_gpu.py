@@ -465,6 +465,35 @@ def test_linear_gemm_leftover_rows_as_a_second_launch(M, N, K):
     assert (split[1][tail].double() - ref[tail]).abs().max().item() < 0.02 * max(1.0, ref.abs().max().item())
 
 
+@pytest.mark.parametrize("M,N,K", [(1025, 3072, 1024), (1025, 1024, 4096), (1025, 4096, 1024), (272, 1024, 1024), (128, 64, 32), (2050, 1536, 1536), (131, 260, 96)])
+def test_fp32_gemm_on_the_lds_dma_ring_is_bit_identical_to_the_register_staged_kernel(M, N, K):
+    """Round 6 ("f32_glds"): the token-exact mode's packed-row GEMMs (M >= 128) run gemm_glds.hip's LDS-DMA ring instantiated for fp32
+    operands -- 64 x 64 tiles, v_mfma_f32_16x16x4_f32 fed the same 16-byte fragments in the same stage / half / component order as
+    gemm.hip, i.e. the same chain of exact fp32 FMAs per output element.  Every epilogue must give the SAME BITS as gemm.hip (knob off), so
+    the reference's greedy ids (tests/test_parity_sizes_gpu.py) cannot move; also against the fp64 product, ragged M, N not a tile multiple."""
+    a = _rand(M, K, seed=180)
+    w = _rand(N, K, seed=181) / math.sqrt(K)
+    bias = _rand(N, seed=182) * 0.1
+    r0 = _rand(M, N, seed=183)
+
+    def run():
+        return [ops.linear(a, w, bias, ops.EPI_F32, ksplit=None), ops.linear(a, w, bias, ops.EPI_STORE, ksplit=None),
+                ops.linear(a, w, bias, ops.EPI_RELU, ksplit=None), ops.linear(a, w, bias, ops.EPI_RESID, resid=r0.clone(), ksplit=None),
+                ops.linear(a, w, None, ops.EPI_STORE, ksplit=None)]
+
+    ops.tune("f32_glds", 0)
+    try:
+        old = run()
+    finally:
+        ops.tune("f32_glds", 1)
+    new, again = run(), run()
+    for i, (x, y, z) in enumerate(zip(old, new, again)):
+        assert x.dtype == torch.float32 and torch.equal(x, y), (i, (x - y).abs().max().item())
+        assert torch.equal(y, z), (i, "run-to-run")
+    ref = a.double() @ w.double().t() + bias.double()
+    assert (new[0].double() - ref).abs().max().item() < 3e-5 * math.sqrt(K / 64) * max(1.0, ref.abs().max().item())
+
+
 @pytest.mark.parametrize("M,N,K", [(64 * 256, 1024, 1024), (65600, 1024, 4096), (65600, 3072, 1024), (40 * 256 + 37, 4096, 1024), (33 * 256, 1024, 256),
                                    (150 * 256 + 255, 512, 1536)])
 def test_gemm_8ph_persistent_tile_loop_is_bit_identical(M, N, K):

@@ -17,11 +17,13 @@ namespace vle {
 // ------------------------------------------------------------------------------------------------
 // (1) prefill / NAR attention
 // ------------------------------------------------------------------------------------------------
-constexpr int AT_QB = 64;  // query rows per block
 constexpr int AT_KB = 32;  // keys per LDS tile
 
-template <typename T, int DPT>
-__global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+// QB: query rows per block (4 lanes each).  64 until round 6; 32 (128 threads) puts two blocks on a CU at one utterance (M = 1025: 33 x 16
+// blocks instead of 17 x 16), so one block's staging / barriers run under the other's arithmetic -- per-row arithmetic is unchanged (same
+// bits): knob "attn_f32_qb".
+template <typename T, int DPT, int QB>
+__global__ __launch_bounds__(QB * 4) void attention_rows_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                              const int32_t* __restrict__ seq_off,
                                                              const int32_t* __restrict__ text_len, int d, int nhead,
                                                              int causal) {
@@ -29,6 +31,7 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
   __shared__ __attribute__((aligned(16))) float Ks[AT_KB * DH];
   __shared__ __attribute__((aligned(16))) float Vs[AT_KB * DH];
 
+  constexpr int AT_QB = QB, NT = QB * 4;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AT_QB;
   const int off = seq_off[b], len = seq_off[b + 1] - off;
   if (q0 >= len) return;
@@ -53,7 +56,7 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
 
   for (int kt0 = 0; kt0 < kmax; kt0 += AT_KB) {
     __syncthreads();
-    for (int idx = tid; idx < AT_KB * DH; idx += 256) {
+    for (int idx = tid; idx < AT_KB * DH; idx += NT) {
       const int kk = idx / DH, e = idx - kk * DH;
       const int key = kt0 + kk;
       float kv = 0.f, vv = 0.f;
@@ -99,14 +102,19 @@ __global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict
   }
 }
 
+int g_attn_f32_qb = 64;  // "attn_f32_qb": query rows per block of attention_rows_kernel (64 / 32)
+
 template <typename T>
 static int attention_dispatch(hipStream_t st, const void* qkv, void* out, const int32_t* seq_off, const int32_t* text_len,
                               int B, int max_len, int d, int nhead, int causal) {
   const int dh = d / nhead;
-  const dim3 grid((max_len + AT_QB - 1) / AT_QB, nhead, B), block(256);
-#define VLE_AT(DPT)                                                                                                 \
-  hipLaunchKernelGGL((attention_rows_kernel<T, DPT>), grid, block, 0, st, (const T*)qkv, (T*)out, seq_off, text_len, d, \
-                     nhead, causal)
+  const int qb = g_attn_f32_qb == 32 ? 32 : 64;
+  const dim3 grid((max_len + qb - 1) / qb, nhead, B), block(qb * 4);
+#define VLE_AT(DPT)                                                                                                     \
+  do {                                                                                                                  \
+    if (qb == 32) hipLaunchKernelGGL((attention_rows_kernel<T, DPT, 32>), grid, block, 0, st, (const T*)qkv, (T*)out, seq_off, text_len, d, nhead, causal); \
+    else hipLaunchKernelGGL((attention_rows_kernel<T, DPT, 64>), grid, block, 0, st, (const T*)qkv, (T*)out, seq_off, text_len, d, nhead, causal); \
+  } while (0)
   switch (dh) {
     case 4: VLE_AT(1); break;
     case 8: VLE_AT(2); break;

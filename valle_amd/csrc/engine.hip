@@ -2651,6 +2651,15 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     g_g8_persist = (int)value & 7;
     return VLE_OK;
   }
+  if (n == "attn_f32_qb") {  // process-global: query rows per block of the fp32 attention kernel
+    if (!(value == 32 || value == 64)) return e->fail(VLE_EINVAL, "attn_f32_qb must be 32 or 64");
+    g_attn_f32_qb = (int)value;
+    return VLE_OK;
+  }
+  if (n == "f32_glds") {  // process-global: fp32 packed-row GEMMs on gemm_glds.hip's ring (1) or gemm.hip (0)
+    g_f32_glds = value != 0;
+    return VLE_OK;
+  }
   if (n == "glds_swz" || n == "glds_8ph" || n == "g8_stagger" || n == "g8_colgroup" || n == "glds_tail" || n == "glds_t64") {
     (n == "glds_swz" ? g_glds_swz : n == "glds_8ph" ? g_glds_8ph : n == "g8_stagger" ? g_g8_stagger : n == "glds_tail" ? g_glds_tail : n == "glds_t64" ? g_glds_t64 : g_g8_colgroup) = (int)value;
     return VLE_OK;

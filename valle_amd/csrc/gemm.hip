@@ -187,7 +187,10 @@ int launch_gemm(hipStream_t st, int dtype, const void* A, const void* W, const f
     if (dtype != DT_BF16 || ln == nullptr) return -1;
     return launch_gemm_glds(st, A, W, bias, out, resid, M, N, K, epi, ln) == 0 ? 0 : -1;
   }
-  if (dtype == DT_F32) return gemm_dispatch<float>(st, A, W, bias, out, resid, M, N, K, epi);
+  if (dtype == DT_F32) {  // packed rows: the LDS-DMA ring of gemm_glds.hip on fp32 operands (bit-identical to the kernel above); else this file's
+    if (launch_gemm_glds_f32(st, (const float*)A, (const float*)W, bias, out, resid, M, N, K, epi) == 0) return 0;
+    return gemm_dispatch<float>(st, A, W, bias, out, resid, M, N, K, epi);
+  }
   // bf16: the LDS-DMA pipelined kernel (gemm_glds.hip) when it has the shape
   if (launch_gemm_glds(st, A, W, bias, out, resid, M, N, K, epi) == 0) return 0;
   return gemm_dispatch<bf16_t>(st, A, W, bias, out, resid, M, N, K, epi);

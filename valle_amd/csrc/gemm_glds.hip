@@ -461,13 +461,13 @@ static int gg_launch(hipStream_t st, const bf16_t* A, const bf16_t* W, const flo
 #define VLE_GG(E)                                                                                                       \
   do {                                                                                                                  \
     if (NW == 8 && g_glds_swz)                                                                                          \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, (NW == 8) ? 1 : 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0, ln); \
+      hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, BM, BN, E, NW, false, (NW == 8) ? 1 : 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0, ln); \
     else if (NW == 8 && g_glds_prio)                                                                                    \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, (NW == 8), 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0, ln); \
+      hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, BM, BN, E, NW, (NW == 8), 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0, ln); \
     else                                                                                                                \
-      hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0, ln);  \
+      hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, g_glds_epi == 0, ln);  \
   } while (0)
-#define VLE_GG_LN(E) hipLaunchKernelGGL((gemm_glds_kernel<BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, 0, ln)
+#define VLE_GG_LN(E) hipLaunchKernelGGL((gemm_glds_kernel<bf16_t, BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, 0, ln)
   switch (epi) {
     case EPI_STORE: VLE_GG(EPI_STORE); break;
     case EPI_RELU: VLE_GG(EPI_RELU); break;
@@ -494,6 +494,28 @@ int g_glds_tail = 1;
 // "glds_t64": 128 x 64 tiles from this many of them, 64 x 64 tiles below.  96 until round 4; at 144 tiles of 128 x 64 (the N = 1024
 // GEMMs of one utterance's NAR rows, M = 1025: 56 % of the CUs) the 272 tiles of 64 x 64 are faster -- NAR 8.52 -> 8.21 ms.
 int g_glds_t64 = 160;
+
+// fp32 operands (the token-exact engine mode, M >= 128 packed rows): 64 x 64 tiles, 4 waves, a 4-stage ring of 16 KB = 64 KB of LDS, so two
+// workgroups share a CU (one's epilogue and barriers under the other's MFMAs) and the 17th tile row of M = 1025 costs no round of its
+// own.  fp32 MFMA is 16x slower than bf16: the launch is MFMA-bound at any tile size, and the ring exists to keep that pipe fed.
+// Bit-identical to gemm.hip's fp32 kernel (same per-element FMA chain).  "f32_glds" = 0: gemm.hip (A/B).
+int g_f32_glds = 1;
+int launch_gemm_glds_f32(hipStream_t st, const float* A, const float* W, const float* bias, void* out, float* resid, int64_t M, int N, int K, int epi) {
+  if (!g_f32_glds || K % 32 != 0 || K < 32 || M < 128 || N < 4 || N % 4 != 0) return 1;
+  constexpr int BM = 64, BN = 64, NW = 4;
+  const dim3 grid((N + BN - 1) / BN, (unsigned)((M + BM - 1) / BM)), block(NW * 64);
+  const GemmLn ln;
+#define VLE_GGF(E) hipLaunchKernelGGL((gemm_glds_kernel<float, BM, BN, E, NW, false, 0>), grid, block, 0, st, A, W, bias, out, resid, M, N, K, 0, ln)
+  switch (epi) {
+    case EPI_STORE: VLE_GGF(EPI_STORE); break;
+    case EPI_RELU: VLE_GGF(EPI_RELU); break;
+    case EPI_RESID: VLE_GGF(EPI_RESID); break;
+    case EPI_F32: VLE_GGF(EPI_F32); break;
+    default: return 1;
+  }
+#undef VLE_GGF
+  return 0;
+}
 
 bool gemm_ln_supports(int dtype, int64_t M, int d) {
   return dtype == DT_BF16 && M >= 128 && d % 256 == 0 && d >= 256 && d <= 1536 && g_glds_epi != 0;

@@ -134,6 +134,28 @@ def test_attention_rows(nhead, dh, causal, dt):
     assert err < (2e-5 if dt == torch.float32 else 0.02), err
 
 
+@pytest.mark.parametrize("nhead,dh", [(16, 64), (2, 96), (4, 16), (8, 128)])
+@pytest.mark.parametrize("causal", [True, False])
+def test_fp32_attention_vector_staging_is_bit_identical(nhead, dh, causal):
+    """attention.hip, the token-exact mode's attention (round 6 knob "attn_f32_vec"): 16-byte, register-double-buffered K / V staging
+    changes how tiles reach LDS -- not what a row computes: the same bits as round 1's element-wise staging, on ragged packed sequences
+    incl. M = 1025 (fp32 NAR 55.2 -> 49.1 ms, profiles/r06_fp32_glds.json)."""
+    d = nhead * dh
+    lens, text_lens = [1025, 70, 1, 133], [47, 9, 1, 20]
+    qkv = _rand(sum(lens), 3 * d, seed=15)
+    so = torch.tensor([0] + list(torch.tensor(lens).cumsum(0)), dtype=torch.int32, device=DEV)
+    tl = torch.tensor(text_lens, dtype=torch.int32, device=DEV)
+    try:
+        ops.tune("attn_f32_vec", 0)
+        old = ops.attention(qkv, so, tl, nhead, causal).clone()
+    finally:
+        ops.tune("attn_f32_vec", 1)
+    new = ops.attention(qkv, so, tl, nhead, causal)
+    assert torch.equal(old, new)
+    ref = _ref_attention(qkv, lens, text_lens, nhead, causal)
+    assert (new.double() - ref).abs().max().item() < 2e-5
+
+
 @pytest.mark.parametrize("nhead,dh,lens,text_lens", [
     (16, 64, [1025], [47]), (16, 64, [272, 300, 65], [47, 100, 64]), (8, 128, [200, 129], [30, 129]), (4, 32, [513], [1]),
     (2, 96, [1100], [64]),

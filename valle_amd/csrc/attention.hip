@@ -19,11 +19,10 @@ namespace vle {
 // ------------------------------------------------------------------------------------------------
 constexpr int AT_KB = 32;  // keys per LDS tile
 
-// QB: query rows per block (4 lanes each).  64 until round 6; 32 (128 threads) puts two blocks on a CU at one utterance (M = 1025: 33 x 16
-// blocks instead of 17 x 16), so one block's staging / barriers run under the other's arithmetic -- per-row arithmetic is unchanged (same
-// bits): knob "attn_f32_qb".
-template <typename T, int DPT, int QB>
-__global__ __launch_bounds__(QB * 4) void attention_rows_kernel(const T* __restrict__ qkv, T* __restrict__ out,
+// 64 query rows per block, 4 lanes each.  (Measured and dropped, round 6: 32 rows per block -- two blocks per CU at one utterance -- fp32 NAR
+// 49.1 -> 51.5 ms with the vector staging, 55.2 -> 59.9 without: every block stages all keys, twice the K / V traffic.)
+template <typename T, int DPT, bool VS = true>  // VS: vector staging (below; fp32 only)
+__global__ __launch_bounds__(256) void attention_rows_kernel(const T* __restrict__ qkv, T* __restrict__ out,
                                                              const int32_t* __restrict__ seq_off,
                                                              const int32_t* __restrict__ text_len, int d, int nhead,
                                                              int causal) {
@@ -31,7 +30,7 @@ __global__ __launch_bounds__(QB * 4) void attention_rows_kernel(const T* __restr
   __shared__ __attribute__((aligned(16))) float Ks[AT_KB * DH];
   __shared__ __attribute__((aligned(16))) float Vs[AT_KB * DH];
 
-  constexpr int AT_QB = QB, NT = QB * 4;
+  constexpr int AT_QB = 64, NT = 256;
   const int b = blockIdx.z, h = blockIdx.y, q0 = blockIdx.x * AT_QB;
   const int off = seq_off[b], len = seq_off[b + 1] - off;
   if (q0 >= len) return;
@@ -54,8 +53,41 @@ __global__ __launch_bounds__(QB * 4) void attention_rows_kernel(const T* __restr
   }
   float m = -1e30f, l = 0.f;
 
+  // Staging (round 6): fp32 tiles are fetched as 16-byte vectors, the NEXT tile's vectors are requested before this tile's arithmetic
+  // and written to LDS after it (register double buffer): the kernel used to fetch 4-byte elements through an integer division and wait
+  // for them between two barriers, once per 32 keys.  What a row computes, and in which order, is untouched (same bits).
+  constexpr bool VEC = VS && sizeof(T) == 4 && (AT_KB * DH / 4) % NT == 0;
+  constexpr int NV = VEC ? AT_KB * DH / 4 / NT : 1;  // float4 of K (and of V) per thread and tile
+  typedef float at_f32x4 __attribute__((ext_vector_type(4)));
+  at_f32x4 pk[NV], pv[NV];
+  auto fetch = [&](int kt0) {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx4 = tid + v * NT, kk = idx4 / (DH / 4), e = (idx4 - kk * (DH / 4)) * 4;
+      const int key = kt0 + kk;
+      const float* base = reinterpret_cast<const float*>(qkv) + (int64_t)(off + (key < len ? key : len - 1)) * d3 + h * DH + e;
+      const at_f32x4 k4 = *reinterpret_cast<const at_f32x4*>(base + d), v4 = *reinterpret_cast<const at_f32x4*>(base + 2 * d);
+      pk[v] = key < len ? k4 : at_f32x4{0.f, 0.f, 0.f, 0.f};
+      pv[v] = key < len ? v4 : at_f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  };
+  auto stash = [&]() {
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      const int idx4 = tid + v * NT;
+      *reinterpret_cast<at_f32x4*>(&Ks[idx4 * 4]) = pk[v];
+      *reinterpret_cast<at_f32x4*>(&Vs[idx4 * 4]) = pv[v];
+    }
+  };
+  if constexpr (VEC) {
+    if (kmax > 0) fetch(0);
+  }
   for (int kt0 = 0; kt0 < kmax; kt0 += AT_KB) {
     __syncthreads();
+    if constexpr (VEC) {
+      stash();
+      if (kt0 + AT_KB < kmax) fetch(kt0 + AT_KB);
+    } else {
     for (int idx = tid; idx < AT_KB * DH; idx += NT) {
       const int kk = idx / DH, e = idx - kk * DH;
       const int key = kt0 + kk;
@@ -67,6 +99,7 @@ __global__ __launch_bounds__(QB * 4) void attention_rows_kernel(const T* __restr
       }
       Ks[idx] = kv;
       Vs[idx] = vv;
+    }
     }
     __syncthreads();
     float sc[AT_KB];
@@ -102,18 +135,17 @@ __global__ __launch_bounds__(QB * 4) void attention_rows_kernel(const T* __restr
   }
 }
 
-int g_attn_f32_qb = 64;  // "attn_f32_qb": query rows per block of attention_rows_kernel (64 / 32)
+int g_attn_f32_vec = 1;  // "attn_f32_vec": 16-byte, register-double-buffered K / V staging of the fp32 instantiations (0: round 1's element-wise staging)
 
 template <typename T>
 static int attention_dispatch(hipStream_t st, const void* qkv, void* out, const int32_t* seq_off, const int32_t* text_len,
                               int B, int max_len, int d, int nhead, int causal) {
   const int dh = d / nhead;
-  const int qb = g_attn_f32_qb == 32 ? 32 : 64;
-  const dim3 grid((max_len + qb - 1) / qb, nhead, B), block(qb * 4);
+  const dim3 grid((max_len + 63) / 64, nhead, B), block(256);
 #define VLE_AT(DPT)                                                                                                     \
   do {                                                                                                                  \
-    if (qb == 32) hipLaunchKernelGGL((attention_rows_kernel<T, DPT, 32>), grid, block, 0, st, (const T*)qkv, (T*)out, seq_off, text_len, d, nhead, causal); \
-    else hipLaunchKernelGGL((attention_rows_kernel<T, DPT, 64>), grid, block, 0, st, (const T*)qkv, (T*)out, seq_off, text_len, d, nhead, causal); \
+    if (g_attn_f32_vec) hipLaunchKernelGGL((attention_rows_kernel<T, DPT, true>), grid, block, 0, st, (const T*)qkv, (T*)out, seq_off, text_len, d, nhead, causal); \
+    else hipLaunchKernelGGL((attention_rows_kernel<T, DPT, false>), grid, block, 0, st, (const T*)qkv, (T*)out, seq_off, text_len, d, nhead, causal); \
   } while (0)
   switch (dh) {
     case 4: VLE_AT(1); break;

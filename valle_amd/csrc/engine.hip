@@ -2651,9 +2651,8 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     g_g8_persist = (int)value & 7;
     return VLE_OK;
   }
-  if (n == "attn_f32_qb") {  // process-global: query rows per block of the fp32 attention kernel
-    if (!(value == 32 || value == 64)) return e->fail(VLE_EINVAL, "attn_f32_qb must be 32 or 64");
-    g_attn_f32_qb = (int)value;
+  if (n == "attn_f32_vec") {
+    g_attn_f32_vec = value != 0;
     return VLE_OK;
   }
   if (n == "f32_glds") {  // process-global: fp32 packed-row GEMMs on gemm_glds.hip's ring (1) or gemm.hip (0)

@@ -73,7 +73,7 @@ int launch_gemm_glds(hipStream_t st, const void* A, const void* W, const float* 
 // gemm_glds.hip on fp32 operands (token-exact mode, M >= 128): 0 launched, 1 shape not covered / switched off ("f32_glds")
 int launch_gemm_glds_f32(hipStream_t st, const float* A, const float* W, const float* bias, void* out, float* resid, int64_t M, int N, int K, int epi);
 extern int g_f32_glds;
-extern int g_attn_f32_qb;  // attention.hip: query rows per block of the fp32 / generic attention kernel
+extern int g_attn_f32_vec;  // attention.hip: 16-byte register-double-buffered K / V staging of the fp32 attention (0: element-wise, A/B)
 extern int g_attn_qw;
 extern int g_g8_colgroup;
 extern int g_g8_stagger;

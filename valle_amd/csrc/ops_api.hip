@@ -42,7 +42,7 @@ extern "C" int vle_op_tune(const char* name, int64_t value) {
   else if (n == "g8_colgroup" && value >= 0 && value <= 16) vle::g_g8_colgroup = (int)value;
   else if (n == "g8_persist" && value >= 0 && value <= 7) vle::g_g8_persist = (int)value;
   else if (n == "f32_glds" && value >= 0 && value <= 1) vle::g_f32_glds = (int)value;
-  else if (n == "attn_f32_qb" && (value == 32 || value == 64)) vle::g_attn_f32_qb = (int)value;
+  else if (n == "attn_f32_vec" && value >= 0 && value <= 1) vle::g_attn_f32_vec = (int)value;
   else if (n == "attn_qw" && value >= 0 && value <= 2) vle::g_attn_qw = (int)value;
   else if (n == "attn_v2" && value >= 0 && value <= 2) vle::g_attn_v2 = (int)value;
   else if (n == "attn_xcd" && value >= 0 && value <= 1) vle::g_attn_xcd = (int)value;

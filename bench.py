@@ -85,7 +85,7 @@ def measured_traffic(args, B):
     except OSError:
         return None, "profiles/ar_step_traffic.json missing"
     if t.get("kernel_set") != kernel_set_hash():
-        return None, f"stale: measured on kernel set {t.get('kernel_set')}, the kernels have changed since (re-run tools/gpu_r4_collect.sh + tools/make_traffic.py)"
+        return None, f"stale: measured on kernel set {t.get('kernel_set')}, the kernels have changed since (re-run tools/gpu_r6_collect.sh + tools/make_traffic.py)"
     return int(t["bytes_per_step"]), t.get("source", "profiles/")
 
 

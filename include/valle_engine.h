@@ -191,11 +191,13 @@ int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slo
  *          embedding inside the launch) with "persist_steps" (default 32 AR iterations per launch), "persist_mode" (bit field: 4 / 8
  *          hidden / attention rows as bf16 pairs, 16 XCD-local copies of the head-group edges, 32 folded LayerNorm, 64 bf16 activation
  *          rows + v_dot2c_f32_bf16 dot products; default 0x174),
- *          "persist_pf" (0..3 operand request schedule), "persist_nk" (2 | 4 keys per lane), "persist_naps" (first-sweep waits, 4 bits
+ *          "persist_pf" (0 | 3 operand request schedule), "persist_nk" (2 keys per lane) -- since round 6 only the shipped forms are compiled:
+ *          other values (pf 1 / 2, nk 4, packing modes the measurements dropped) make the call run the launch chain --, "persist_naps" (first-sweep waits, 4 bits
  *          per edge; -1 = the engine mode's measured default: bf16 0x325756, fp8 weight rows 0x214645, fp32 0x217645), "persist_trace" (in-kernel timeline), "act_bf16" (the chain's matching roundings).
  *          "persist_rearm" (any value: forget the back-off after VLE_EBUSY), "persist_inject_fail" (n: the next n persistent calls
  *          end as if a wave had given up -- the test hook of the VLE_EBUSY path).
- *   debug words of vle_debug_fetch for it: "persist_active" (the next batch-1 call would run it), "persist_ran" (the LAST
+ *   debug words of vle_debug_fetch for it: "persist_active" (the next batch-1 call would run it), "persist_capable" (a ONE-utterance call on this engine
+ *   would, whatever the batch of the last prefill: valle_amd.VALLE.inference_batch decodes two utterances one after the other then), "persist_ran" (the LAST
  *   vle_ar_generate did), "persist_fail" (waves that gave up in the last call; 0 in a healthy run), "persist_fallbacks" (calls that
  *   ended with VLE_EBUSY since vle_create), "persist_backoff" (batch-1 calls left on the launch chain before it is re-armed),
  *   "persist_sample_active", "ar_launches", "persist_trace".
@@ -274,7 +276,10 @@ int vle_op_linear_fp8w(void* stream, const void* a, const void* w8, const float*
  * "glds_big" -1 default | 0 never | n: full-tile count from which the bf16 GEMM uses its 8-wave 256 x 128 tile;
  * "glds_8ph" 0 never | -1 | n: tile count from which it uses the phase-split 256 x 256 kernel; "glds_t64" n: 128 x 64 tiles from n of them, 64 x 64 below (default 160); "glds_tail" 1 | 0: the rows past
  * its last full 256-row tile as a second small launch when that saves a round of tiles; "glds_w8", "glds_swz",
- * "glds_prio" 0 | 1: A/B switches of the tile kernels. */
+ * "glds_prio" 0 | 1: A/B switches of the tile kernels; "g8_persist" bits 1 | 2 | 4: which launches of the 256 x 256 kernel take its
+ * persistent tile loop (bf16-output forms | residual forms K < 2048 | K >= 2048; default 1); "f32_glds" 1 | 0: fp32 packed-row GEMMs on the
+ * LDS-DMA ring | the register-staged kernel (bit-identical); "attn_f32_vec" 1 | 0: 16-byte double-buffered K / V staging of the fp32 attention
+ * (bit-identical).  The three are also engine options (vle_set_option), process-global. */
 int vle_op_tune(const char* name, int64_t value);
 /* Same contract on the skinny (M <= 8, fp32 activations) weight-streaming path of the AR step:
  * x[f32, M x K]; optional fused LayerNorm prologue when gamma != NULL;

@@ -1,6 +1,6 @@
-# round 5 collection: instrumented first process, whole GPU suite, smoke, default bench line, the side benches, rocprofv3 kernel stats
+# round 6 collection: instrumented first process, whole GPU suite, smoke, default bench line, the side benches, rocprofv3 kernel stats
 # (B = 1 / 64), PMC passes (HBM traffic of the AR step at B = 1; MFMA utilisation at B = 64), persistent-step probe (bit-identity ladder,
-# timing, timeline) and stress.   gpurun --timeout 2700 -- 'bash tools/gpu_r5_collect.sh <tag>'   (judged copies go to profiles/r05_*)
+# timing, timeline) and stress.   gpurun --timeout 2700 -- 'bash tools/gpu_r6_collect.sh <tag>'   (judged copies go to profiles/r06_*)
 cd $GRAFT_REPO_ROOT
 D=gpurun_out/$1; mkdir -p $D
 export TMPDIR=/tmp
@@ -10,6 +10,8 @@ python -c "import __graft_entry__ as g; g.smoke()" > $D/smoke.log 2>&1; echo "sm
 timeout 900 python bench.py > $D/bench_default.log 2> $D/bench_default.err; echo "default bench rc=$?"; tail -n 1 $D/bench_default.log | cut -c1-300
 timeout 300 python bench.py --steps 5 --warmup 2 --cpu-frames 0 --no-side --dtype fp8w > $D/bench_b1_fp8w.log 2>/dev/null; tail -n 1 $D/bench_b1_fp8w.log | cut -c1-200
 timeout 300 python bench.py --batch 8 --steps 3 --warmup 1 --cpu-frames 0 --no-side > $D/bench_b8.log 2>/dev/null; tail -n 1 $D/bench_b8.log | cut -c1-200
+timeout 300 python bench.py --batch 2 --steps 3 --warmup 1 --cpu-frames 0 --no-side > $D/bench_b2.log 2>/dev/null; tail -n 1 $D/bench_b2.log | cut -c1-200
+timeout 300 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-side --dtype fp32 > $D/bench_b1_fp32.log 2>/dev/null; tail -n 1 $D/bench_b1_fp32.log | cut -c1-200
 timeout 300 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-side --opt persist=0 > $D/bench_b1_chain.log 2>/dev/null; tail -n 1 $D/bench_b1_chain.log | cut -c1-200
 (cd /tmp && rm -rf /tmp/prof1 && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o b1 --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-side > $GRAFT_REPO_ROOT/$D/prof1.log 2>&1); echo "prof1 rc=$?"
 cp $(find /tmp/prof1 -name "*kernel_stats.csv" | head -1) $D/b1_kernel_stats.csv 2>/dev/null

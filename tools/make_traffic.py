@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""profiles/ar_step_traffic.json -- HBM bytes per batch-1 AR step from the rocprofv3 PMC passes (tools/gpu_r4_collect.sh: FETCH_SIZE and
+"""profiles/ar_step_traffic.json -- HBM bytes per batch-1 AR step from the rocprofv3 PMC passes (tools/gpu_r6_collect.sh: FETCH_SIZE and
 WRITE_SIZE in SEPARATE runs over `bench.py --steps 1 --warmup 1 --cpu-frames 0 --no-graph --no-c3 --no-fp32`), keyed by the hash of
 the step's kernel sources (bench.kernel_set_hash) so that bench.py stops reporting it once the kernels change.
 

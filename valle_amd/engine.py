@@ -17,6 +17,28 @@ from . import _lib
 NUM_AUDIO_TOKENS = 1024  # valle/models/macros.py:5
 
 
+def prefill_generate(eng, text, text_lens, prompts, prompt_lens, **gen):
+    """prefill() + generate(**gen) with the ONE retry the persistent batch-1 launch asks of its callers: that launch needs every
+    CU of the GPU; when another workload holds some for > 0.1 s a wave gives up, vle_ar_generate ends with VLE_EBUSY and the
+    call's state is void.  The decode is repeated from the prefill -- the engine itself keeps its next batch-1 calls on the launch
+    chain (same sampling stream; same tokens up to the fp32 re-association of the folded LayerNorm) and re-arms the persistent
+    launch after a back-off (2, 4 ... 64 calls): a busy neighbour costs speed for a while, not the request.  Every caller that
+    wants a decode rather than the raw ABI answer goes through here (VALLE.inference_batch, bench.py, smoke)."""
+    eng.prefill(text, text_lens, prompts, prompt_lens)
+    try:
+        return eng.generate(**gen)
+    except _lib.VleError as err:
+        if err.code != _lib.VLE_EBUSY:
+            raise
+        import sys
+
+        print("valle_amd: the persistent AR launch could not hold the whole GPU; this decode is repeated on the launch chain "
+              f"(fallback #{eng.fetch_u32('persist_fallbacks')}, persistent launch re-armed after {eng.fetch_u32('persist_backoff')} calls)",
+              file=sys.stderr)
+        eng.prefill(text, text_lens, prompts, prompt_lens)
+        return eng.generate(**gen)
+
+
 @dataclass
 class EngineConfig:
     d_model: int
@@ -156,25 +178,8 @@ class Engine:
         return codes0, self._gen_lens
 
     def prefill_generate(self, text: torch.Tensor, text_lens: Sequence[int], prompts: torch.Tensor, prompt_lens: Sequence[int], **gen):
-        """prefill() + generate(**gen) with the ONE retry the persistent batch-1 launch asks of its callers: that launch needs every
-        CU of the GPU; when another workload holds some for > 0.1 s a wave gives up, vle_ar_generate ends with VLE_EBUSY and the
-        call's state is void.  The decode is repeated from the prefill -- the engine itself keeps its next batch-1 calls on the launch
-        chain (same sampling stream; same tokens up to the fp32 re-association of the folded LayerNorm) and re-arms the persistent
-        launch after a back-off (2, 4 ... 64 calls): a busy neighbour costs speed for a while, not the request.  Every caller that
-        wants a decode rather than the raw ABI answer goes through here (VALLE.inference_batch, bench.py, smoke)."""
-        self.prefill(text, text_lens, prompts, prompt_lens)
-        try:
-            return self.generate(**gen)
-        except _lib.VleError as err:
-            if err.code != _lib.VLE_EBUSY:
-                raise
-            import sys
-
-            print("valle_amd: the persistent AR launch could not hold the whole GPU; this decode is repeated on the launch chain "
-                  f"(fallback #{self.fetch_u32('persist_fallbacks')}, persistent launch re-armed after {self.fetch_u32('persist_backoff')} calls)",
-                  file=sys.stderr)
-            self.prefill(text, text_lens, prompts, prompt_lens)
-            return self.generate(**gen)
+        """prefill() + generate(**gen) with the one repeat VLE_EBUSY asks for: the module-level `prefill_generate` on this engine."""
+        return prefill_generate(self, text, text_lens, prompts, prompt_lens, **gen)
 
     def nar(self, enroll_lens: Optional[Sequence[int]] = None, forced: Optional[torch.Tensor] = None) -> torch.Tensor:
         """The 7 NAR stages; ``forced`` int64 (B, >=G, Q) teacher-forces the stage history (parity hook, vle_nar_force)."""

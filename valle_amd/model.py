@@ -24,6 +24,7 @@ import torch.nn as nn
 
 from .engine import Engine, EngineConfig
 from . import _lib
+from . import engine as _engine
 
 NUM_TEXT_TOKENS = 512  # valle/models/macros.py:2
 NUM_AUDIO_TOKENS = 1024  # valle/models/macros.py:5
@@ -285,7 +286,7 @@ class VALLE(nn.Module):
         try:
             # batch 1 keeps the reference's SyntaxError; in a batch an utterance that hits EOS at step 0 returns 0 frames.
             # (Engine.prefill_generate repeats the decode once on VLE_EBUSY -- the persistent launch could not hold the GPU.)
-            _, gl = eng.prefill_generate(xd, xl, yd, yl, top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=allow_empty)
+            _, gl = _engine.prefill_generate(eng, xd, xl, yd, yl, top_k=top_k, temperature=temperature, seed=seed, max_new=max_new, allow_empty=allow_empty)
         except _lib.VleError as err:
             if err.code == _lib.VLE_ENOTOKEN:
                 raise SyntaxError("well trained model shouldn't reach here.") from None  # valle.py:1049-1052

@@ -175,6 +175,16 @@ def test_bf16_batch_path_teacher_forced_against_batch1(B):
         assert d <= 0.03 * sigma, (b, d, sigma)
     codes = eng.nar(None)
     assert codes.shape[0] == B and torch.equal(codes[: len(toks), :nsteps, 0].cpu(), F[: len(toks)])
+    if B <= 5:
+        # since round 6 the batched step never splits the KV stream by itself (choose_nsplit); the split + combine launches stay
+        # reachable through option "nsplit" and must give the same logits up to the merge's fp32 re-association
+        for ns in (2, 4):
+            eng.set_option("nsplit", ns)
+            eng.prefill(X, S, Y, P)
+            eng.generate(top_k=1, forced=F.to(DEV), forced_lens=[nsteps] * B)
+            lgS = eng.fetch_ar_logits()
+            assert (lgS[:nsteps] - lgB[:nsteps]).abs().max().item() <= 2e-2 * lgB[:nsteps].std().item(), ns
+        eng.set_option("nsplit", 0)
 
 
 def _bench_inputs(i, S=47, P=225):

@@ -461,6 +461,12 @@ def test_persistent_step_is_the_default_where_covered_and_only_there():
     X2, Y2 = torch.cat([X, X]), torch.cat([Y, Y])
     e3.prefill(X2, [8, 8], Y2, [10, 10])
     assert e3.fetch_u32("persist_active") == 0
+    # slot mode (continuous batching): every live slot advances on the batched launch chain, one slot included
+    e3.slots_begin()
+    e3.slots_prefill([0], X, [8], Y, [10])
+    assert e3.fetch_u32("persist_active") == 0 and e3.fetch_u32("persist_capable") == 0
+    e3.slots_step(4, top_k=1)
+    assert e3.fetch_u32("persist_ran") == 0
     # ... and one utterance on the same engine: persistent again (the operand table is rebuilt for the one-utterance cache layout)
     e3.prefill(X, [8], Y, [10])
     assert e3.fetch_u32("persist_active") == 1

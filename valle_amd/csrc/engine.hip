@@ -556,6 +556,10 @@ void build_pe(std::vector<float>& pe, int max_pos, int d) {
 int choose_nsplit(const vle_engine* e, int B) {
   // spread the KV stream of a small batch over >= ~128-256 blocks, but never over more blocks than
   // the context has key chunks (decode_attn.hip: a block owns fixed chunks of 16 wave-loads)
+  // Batched bf16 step: never split -- one block per (utterance, head) writes the normalised row itself, a split needs the combine launch
+  // behind it, and the step is launch-count-bound at small batches.  Measured (round 6, profiles/r06_small_batch.json): 2 utterances
+  // 368.7 -> 328.9 us per step, 3 utterances 378.1 -> 330.0 (two splits were chosen below 64 (utterance, head) blocks).
+  if (B >= 2 && e->dtype == DT_BF16 && !e->opt_no_gemm_skinny) return 1;
   int ns = 1;
   while (ns < 16 && (int64_t)B * e->H * ns < 64) ns *= 2;  // measured at B=1, H=16: 4 splits best (op_chain_bench)
   const int vec = e->dtype == DT_F32 ? 4 : 8;

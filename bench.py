@@ -26,8 +26,9 @@ asserts, length conversions, engine lookup and EOS prints inside the number (pri
 valle/models/valle.py:967-968); `s200` (N = 1) a realistic text length (S = 200 -> 3201 frames = 42.7 s of audio).
 `frames_per_s` / `rtf` (wall seconds per second of generated audio at 75 frames/s) accompany every tokens/s figure.
 `fp32_exact` (N = 1) is the same decode in engine mode fp32 -- the mode whose greedy token ids are bit-identical to the
-reference (tests/test_parity_sizes_gpu.py) -- timed in the same process; `c5_share_fp8` (N = 1) is the per-GPU share of BASELINE
-configs[4] (d1536-L24-h16, fp8 weights, fp8 MFMA in prefill / NAR, 32 utterances).
+reference (tests/test_parity_sizes_gpu.py) -- timed in the same process; `c5_share_fp8w` (N = 1) is the per-GPU share of BASELINE
+configs[4] (d1536-L24-h16, 32 utterances) in the config's weight format: fp8 (e4m3) weights, bf16 activations on the bf16 MFMA -- the
+mode that holds the 5 % sigma parity bar; the experimental fp8-MFMA mode only with --c5-fp8.
 """
 from __future__ import annotations
 
@@ -290,6 +291,9 @@ def c5_leg(args, dev, dtype="fp8", B=32, steps=2, warmup=1):
     res = {
         "workload": f"dim{d}-L{L}-h{H} engine mode {dtype} ({what}), batch={B}, S={S_TEXT}, P={P_PROMPT} -> G={G}, greedy, ignore_eos, "
                     f"random-init weights (the reference's init distributions, torch.manual_seed(0))",
+        "quoted_on": ("BASELINE configs[4] is quoted on THIS mode: the config's weight format (e4m3 weights) with bf16 activations on the bf16 MFMA; "
+                      "the fp8-MFMA mode (engine mode fp8: per-row e4m3 activations, 15 % sigma bar) is experimental and measured only with --c5-fp8")
+                     if dtype == "fp8w" else "experimental mode (fp8 activations, looser parity bar): not the mode configs[4] is quoted on",
         "value": round(tokens / elapsed, 1), "unit": "audio-tokens/s", "steps": steps, "warmup": warmup,
         "phase_ms": {"prefill": round(pre / steps, 3), "ar": round(ar / steps, 3), "nar": round(nar / steps, 3)},
         "roofline_ar": {"bound": "hbm", "achieved": round(hbm, 1), "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": round(hbm / HBM_PEAK_GBS, 4),

@@ -214,11 +214,10 @@ def side_leg(sd, args, dev, rank, world, B, dtype, steps=2, warmup=1, label="", 
         acc["tokens"] += sum(gl) * 8
         tm = eng.timings()
         acc["pre"] += tm["prefill_ms"]; acc["ar"] += tm["ar_ms"]; acc["nar"] += tm["nar_ms"]; acc["ar_steps"] += int(tm["ar_steps"])
-        for t in range(1, max(gl) + 1):
-            live = sum(1 for b in range(B) if gl[b] >= t)
-            acc["ar_bytes"] += eng.ar_step_bytes(live, live * (S + P_PROMPT + t))
+        acc.setdefault("gls", []).append(list(gl))
 
     elapsed = timed_loop(step, steps, warmup, world, dev, on_step)
+    acc["ar_bytes"] = sum(ar_bytes_of(eng, g, S) for g in acc.get("gls", []))
     tokens = acc["tokens"]
     if world > 1:
         tk = torch.tensor([tokens], dtype=torch.float64, device=dev)
@@ -271,16 +270,16 @@ def c5_leg(args, dev, dtype="fp8", B=32, steps=2, warmup=1):
         step()
     torch.cuda.synchronize(dev)
     t0 = time.perf_counter()
-    tokens, pre, ar, nar, ar_steps, ar_bytes = 0, 0.0, 0.0, 0.0, 0, 0
+    tokens, pre, ar, nar, ar_steps, ar_bytes, gls = 0, 0.0, 0.0, 0.0, 0, 0, []
     for _ in range(steps):
         gl = step()
         tokens += sum(gl) * 8
         tm = eng.timings()
         pre += tm["prefill_ms"]; ar += tm["ar_ms"]; nar += tm["nar_ms"]; ar_steps += int(tm["ar_steps"])
-        for t in range(1, max(gl) + 1):
-            ar_bytes += eng.ar_step_bytes(B, B * (S_TEXT + P_PROMPT + t))
+        gls.append(list(gl))
     torch.cuda.synchronize(dev)
     elapsed = time.perf_counter() - t0
+    ar_bytes = sum(ar_bytes_of(eng, g, S_TEXT) for g in gls)
     N, G = S_TEXT + P_PROMPT + gl[0], gl[0]
     nar_flops = B * (7 * (2 * N * 12 * L * d * d + 4 * L * N * N * d) + 14 * G * d * 1024)
     hbm = (ar_bytes / 1e9) / (ar / 1e3)
@@ -332,6 +331,22 @@ def decode_step(runner, X, s_lens, Y, p_lens, top_k, world, n_total, dev, temper
     if world > 1:
         out = vdist.gather_codes(out, n_total, 8, dev)
     return gl, out
+
+
+def ar_bytes_of(eng, gl, S, sequential=False):
+    """Algorithmic bytes of one decode's AR loop: per iteration W_AR*w + sum_b 2*L*d*a*(c_b + 1) over the utterances still
+    generating; `sequential`: each utterance streams the weights for itself (two utterances on the batch-1 path).  753 calls into the
+    library per decode: bookkeeping of the BENCHMARK, so it runs after the timed region (until round 6 it sat inside it: ~0.5 ms per step)."""
+    B, tot = len(gl), 0
+    if sequential:
+        for b in range(B):
+            for t in range(1, gl[b] + 1):
+                tot += eng.ar_step_bytes(1, S + P_PROMPT + t)
+    else:
+        for t in range(1, max(gl) + 1):
+            live = sum(1 for b in range(B) if gl[b] >= t)
+            tot += eng.ar_step_bytes(live, live * (S + P_PROMPT + t))
+    return tot
 
 
 def rates(tokens, elapsed, n_utt_steps, frames_per_utt):
@@ -483,17 +498,10 @@ def main():
         tm = seq if seq is not None else eng.timings()
         acc["sequential"] = seq is not None
         acc["pre"] += tm["prefill_ms"]; acc["ar"] += tm["ar_ms"]; acc["nar"] += tm["nar_ms"]; acc["ar_steps"] += int(tm["ar_steps"])
-        # algorithmic bytes of this utterance batch's AR loop: per step W_AR*w + sum_b 2*L*d*a*(c_b + 1)
-        if seq is not None:  # every utterance streams the weights for itself
-            for b in range(B):
-                for t in range(1, gl[b] + 1):
-                    acc["ar_bytes"] += eng.ar_step_bytes(1, S_TEXT + P_PROMPT + t)
-        else:
-            for t in range(1, max(gl) + 1):
-                live = sum(1 for b in range(B) if gl[b] >= t)
-                acc["ar_bytes"] += eng.ar_step_bytes(live, live * (S_TEXT + P_PROMPT + t))
+        acc.setdefault("gls", []).append(list(gl))
 
     elapsed = timed_loop(step, args.steps, args.warmup, world, dev, on_step)
+    acc["ar_bytes"] = sum(ar_bytes_of(eng, g, S_TEXT, bool(acc.get("sequential"))) for g in acc.get("gls", []))
     tokens, gl = acc["tokens"], acc["gl"]
     pre_ms, ar_ms, nar_ms, ar_steps, ar_bytes = acc["pre"], acc["ar"], acc["nar"], acc["ar_steps"], acc["ar_bytes"]
     assert acc["n_out"] == world * B, "the gather did not return every rank's utterances"

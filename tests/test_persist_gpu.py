@@ -377,53 +377,128 @@ def test_option_sets_without_an_instantiated_form_run_the_launch_chain(c2_model)
     assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0 and torch.equal(got, want)
 
 
-def test_two_utterances_are_decoded_one_after_the_other_on_the_persistent_launch(c2_model):
-    """Round 6 (profiles/r06_small_batch.json): at two utterances the batched launch chain (369 us per AR step, 41 k tokens/s) is slower
-    than ONE utterance on the persistent launch (128 us, 56.7 k), so VALLE.inference_batch decodes a batch of two one after the other
-    where that launch is available.  Ragged lengths; every utterance must equal its own batch-1 decode -- greedy, and sampled: utterance b
-    draws from the stream of request b (what the batched call gives it), not from request 0's."""
-    import valle_amd as va
-
-    torch.manual_seed(21)
-    m = va.VALLE(1024, 16, 3, prefix_mode=1, engine_dtype="bf16", max_batch=4).to(DEV).eval()
-    S, P = [9, 14], [20, 31]
-    g = torch.Generator().manual_seed(5)
-    X = torch.zeros(2, max(S), dtype=torch.int64)
-    Y = torch.zeros(2, max(P), 8, dtype=torch.int64)
-    for b in range(2):
+def _ragged_batch(B, seed=5):
+    # (the packed prefill of all four stays below 128 rows: from there on the engine picks another GEMM tiling, whose summation order --
+    #  hence the cached keys -- differs in the last bf16 bit from the one-utterance prefill the bit-identity tests compare with)
+    S, P = [9, 14, 11, 17][:B], [12, 20, 16, 14][:B]
+    g = torch.Generator().manual_seed(seed)
+    X = torch.zeros(B, max(S), dtype=torch.int64)
+    Y = torch.zeros(B, max(P), 8, dtype=torch.int64)
+    for b in range(B):
         X[b, : S[b]] = torch.randint(3, 100, (S[b],), generator=g)
         X[b, 0], X[b, S[b] - 1] = 1, 2
         Y[b, : P[b]] = torch.randint(0, 1024, (P[b], 8), generator=g)
-    X, Y = X.to(DEV), Y.to(DEV)
-    lens = torch.tensor(S, dtype=torch.int32)
-    eng = m.engine_for(2, max(S), max(P))
+    return X.to(DEV), Y.to(DEV), S, P
+
+
+def _batch_decode(eng, X, Y, S, P, steps, **kw):
+    """prefill + AR loop of the whole batch with the logits trace: (first-codebook tokens per utterance, logits [steps][B][V])"""
+    eng.set_option("trace_ar_logits", 1)
+    eng.prefill(X, S, Y, P)
+    codes, gl = eng.generate(max_new=steps, **kw)
+    return [codes[b, : gl[b]].cpu() for b in range(len(S))], eng.fetch_ar_logits().clone()
+
+
+@pytest.fixture(scope="module")
+def small_batch_model():
+    torch.manual_seed(21)
+    return valle_amd.VALLE(1024, 16, 3, prefix_mode=1, engine_dtype="bf16", max_batch=4).to(DEV).eval()
+
+
+@pytest.mark.parametrize("B", [2, 3, 4])
+def test_batched_persistent_launch_is_bit_identical_to_one_utterance_launches(small_batch_model, B):
+    """Round 6: 2 .. 4 utterances share ONE persistent launch (csrc/persist_nb.hip: the weights are requested once per step and
+    multiplied with every utterance's row; every edge carries B rows).  Per utterance the arithmetic is the one-utterance launch's
+    default form on the same lane <-> element mapping, so every logit and token of utterance b must be BIT-IDENTICAL to a
+    one-utterance decode of utterance b alone -- ragged lengths, greedy and sampled (utterance b draws from request b's stream)."""
+    m = small_batch_model
+    X, Y, S, P = _ragged_batch(B)
+    eng = m.engine_for(4, max(S), max(P))
     eng.set_option("ignore_eos", 1)
-    assert eng.fetch_u32("persist_capable") == 1
+    assert eng.fetch_u32("persist_batch_capable") == 4
+    steps = 40
     for kw in (dict(top_k=1), dict(top_k=20, temperature=0.9, seed=1234)):
-        got = m.inference_batch(X, lens, Y, P, None, max_new=40, **kw)
-        assert m.sequential_timings is not None and eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
-        assert m.sequential_timings["ar_steps"] >= 2 * 39
-        for b in range(2):
+        got, lg = _batch_decode(eng, X, Y, S, P, steps, **kw)
+        assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0, "the batched persistent launch did not run"
+        assert eng.fetch_u32("persist_sample_active") == 1
+        for b in range(B):
             kb = dict(kw)
             if "seed" in kb:
                 kb["seed"] = (kb["seed"] + b * 0x9E3779B97F4A7C15) & (2**64 - 1)  # request b's stream as request 0 of a one-utterance call
-            one = m.inference_batch(X[b : b + 1, : S[b]], lens[b : b + 1], Y[b : b + 1, : P[b]], [P[b]], None, max_new=40, **kb)[0]
-            assert torch.equal(got[b], one), (kw, b)
-        # ... and the batched launch chain (forced: persist = 0) gives utterance b the same sampling stream: the decodes START alike (two
-        # free-running bf16 paths part at their first sub-noise tie, so only the first tokens are compared)
-        eng.set_option("persist", 0)
-        try:
-            chain = m.inference_batch(X, lens, Y, P, None, max_new=40, **kw)
-            assert m.sequential_timings is None
-        finally:
-            eng.set_option("persist", 1)
-        for b in range(2):
-            assert chain[b].shape == got[b].shape
-            assert torch.equal(chain[b][:3, 0], got[b][:3, 0]), (kw, b)
-    # three utterances: the chain (ahead from there on)
-    X3, Y3 = torch.cat([X, X[:1]]), torch.cat([Y, Y[:1]])
-    m.inference_batch(X3, torch.tensor(S + S[:1], dtype=torch.int32), Y3, P + P[:1], None, top_k=1, max_new=8)
-    assert m.sequential_timings is None and eng.fetch_u32("persist_ran") == 0
+            one, lg1 = _batch_decode(eng, X[b : b + 1, : S[b]], Y[b : b + 1, : P[b]], S[b : b + 1], P[b : b + 1], steps, **kb)
+            assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+            assert torch.equal(got[b], one[0]), (kw, b)
+            # row 0 is the PREFILL's logits row (a different predict-layer kernel for one and for several rows: bf16 rounding of its
+            # operand, 5 % sigma bar of tests/test_engine_gpu.py); every row after it comes out of the persistent launches
+            n = min(lg.shape[0], lg1.shape[0])
+            assert (lg[0, b] - lg1[0, 0]).abs().max().item() <= 0.02 * lg1[0, 0].std().item()
+            assert n >= steps and torch.equal(lg[1:n, b], lg1[1:n, 0]), f"utterance {b}: max |dlogit| {(lg[1:n, b] - lg1[1:n, 0]).abs().max().item():.3e} (must be 0)"
+    # ... and the launch chain (persist_batch = 0 for 3 / 4 utterances) gives the same first tokens from the same sampling streams (two
+    # free-running bf16 paths part at their first sub-noise tie, so only the first tokens are compared)
+    eng.set_option("persist", 0)
+    try:
+        chain, _ = _batch_decode(eng, X, Y, S, P, steps, top_k=20, temperature=0.9, seed=1234)
+        assert eng.fetch_u32("persist_ran") == 0
+    finally:
+        eng.set_option("persist", 1)
+    for b in range(B):
+        assert chain[b].shape == got[b].shape and torch.equal(chain[b][:3], got[b][:3]), b
+
+
+def test_batched_persistent_launch_utterances_stop_on_eos_at_their_own_steps(eos_model):
+    """Utterances of a batch hit EOS (arg-max or draw, valle.py:1044-1046) at different iterations: a stopped utterance stays in the
+    launch with a frozen cache slot and nothing of it is stored any more; the launch ends when the last one has stopped.  Lengths and
+    tokens of every utterance equal its own one-utterance decode."""
+    m = eos_model
+    X, Y, S, P = _ragged_batch(4, seed=9)
+    eng = m.engine_for(4, max(S), max(P))
+    eng.set_option("ignore_eos", 0)
+    lens = torch.tensor(S, dtype=torch.int32)
+    for kw in (dict(top_k=1), dict(top_k=-100, temperature=1.3, seed=77)):
+        for B in (2, 3, 4):
+            got = m.inference_batch(X[:B], lens[:B], Y[:B], P[:B], None, max_new=64, **kw)
+            assert m.sequential_timings is None and eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+            for b in range(B):
+                kb = dict(kw)
+                if "seed" in kb:
+                    kb["seed"] = (kb["seed"] + b * 0x9E3779B97F4A7C15) & (2**64 - 1)
+                one = m.inference_batch(X[b : b + 1, : S[b]], lens[b : b + 1], Y[b : b + 1, : P[b]], [P[b]], None, max_new=64, _allow_empty=True, **kb)[0]
+                assert got[b].shape == one.shape and torch.equal(got[b][:, 0], one[:, 0]), (kw, B, b, got[b].shape, one.shape)
+        lens_seen = {int(t.shape[0]) for t in got}
+    assert len(lens_seen) > 1, f"every utterance stopped at the same step ({lens_seen}): the test did not exercise the staggered stop"
+
+
+def test_two_utterances_are_decoded_one_after_the_other_where_the_batched_launch_is_off(small_batch_model):
+    """Round 6 (profiles/r06_small_batch.json): at two utterances the batched launch chain (369 us per AR step, 41 k tokens/s) is slower
+    than ONE utterance on the persistent launch (128 us, 56.7 k), so where the batched persistent launch is not available (here:
+    persist_batch = 0; fp32 / fp8-weight engines) VALLE.inference_batch decodes a batch of two one after the other.  Ragged lengths;
+    every utterance must equal its own batch-1 decode -- greedy, and sampled: utterance b draws from the stream of request b."""
+    m = small_batch_model
+    X, Y, S, P = _ragged_batch(2)
+    lens = torch.tensor(S, dtype=torch.int32)
+    eng = m.engine_for(4, max(S), max(P))
+    eng.set_option("ignore_eos", 1)
+    eng.set_option("persist_batch", 0)
+    try:
+        assert eng.fetch_u32("persist_capable") == 1 and eng.fetch_u32("persist_batch_capable") == 0
+        for kw in (dict(top_k=1), dict(top_k=20, temperature=0.9, seed=1234)):
+            got = m.inference_batch(X, lens, Y, P, None, max_new=40, **kw)
+            assert m.sequential_timings is not None and eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+            assert m.sequential_timings["ar_steps"] >= 2 * 39
+            for b in range(2):
+                kb = dict(kw)
+                if "seed" in kb:
+                    kb["seed"] = (kb["seed"] + b * 0x9E3779B97F4A7C15) & (2**64 - 1)
+                one = m.inference_batch(X[b : b + 1, : S[b]], lens[b : b + 1], Y[b : b + 1, : P[b]], [P[b]], None, max_new=40, **kb)[0]
+                assert torch.equal(got[b], one), (kw, b)
+        # three utterances with the batched launch off: the chain
+        X3, Y3 = torch.cat([X, X[:1]]), torch.cat([Y, Y[:1]])
+        m.inference_batch(X3, torch.tensor(S + S[:1], dtype=torch.int32), Y3, P + P[:1], None, top_k=1, max_new=8)
+        assert m.sequential_timings is None and eng.fetch_u32("persist_ran") == 0
+    finally:
+        eng.set_option("persist_batch", 1)
+    m.inference_batch(X, lens, Y, P, None, top_k=1, max_new=8)
+    assert m.sequential_timings is None and eng.fetch_u32("persist_ran") == 1
 
 
 def test_persistent_step_is_the_default_where_covered_and_only_there():
@@ -455,12 +530,21 @@ def test_persistent_step_is_the_default_where_covered_and_only_there():
         assert e2.fetch_u32("persist_active") == 0, (dtype, d)
         codes, gl = e2.generate(top_k=1, max_new=4)
         assert gl[0] >= 1
-    # two utterances: the batched path
-    m3 = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16", max_batch=2).to(DEV).eval()
-    e3 = m3.engine_for(2, 8, 10)
+    # two utterances (bf16, round 6): the batched persistent launch (persist_nb.hip); five: the launch chain; fp32 engines: the chain
+    m3 = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16", max_batch=5).to(DEV).eval()
+    e3 = m3.engine_for(5, 8, 10)
     X2, Y2 = torch.cat([X, X]), torch.cat([Y, Y])
     e3.prefill(X2, [8, 8], Y2, [10, 10])
+    assert e3.fetch_u32("persist_active") == 1
+    codes, gl = e3.generate(top_k=1, max_new=6)
+    assert e3.fetch_u32("persist_ran") == 1 and e3.fetch_u32("persist_fail") == 0 and min(gl) >= 1
+    e3.prefill(torch.cat([X] * 5), [8] * 5, torch.cat([Y] * 5), [10] * 5)
     assert e3.fetch_u32("persist_active") == 0
+    codes, gl = e3.generate(top_k=1, max_new=4)
+    assert e3.fetch_u32("persist_ran") == 0 and min(gl) >= 1
+    e4.reserve(2, 8, 10, 16 * 8 + 1)
+    e4.prefill(X2, [8, 8], Y2, [10, 10])
+    assert e4.fetch_u32("persist_active") == 0 and e4.fetch_u32("persist_batch_capable") == 0
     # slot mode (continuous batching): every live slot advances on the batched launch chain, one slot included
     e3.slots_begin()
     e3.slots_prefill([0], X, [8], Y, [10])

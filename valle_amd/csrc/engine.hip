@@ -184,6 +184,10 @@ struct vle_engine {
   int opt_qa_qtemporal = 1;   // option "qa_qtemporal": its query-row loads with the default cache policy (shared by a head's splits through L2)
   // ---- the batch-1 step as one persistent launch (persist.hip; option "persist") ----
   int opt_persist = 1;        // option "persist": 1 = batch-1 AR steps run pstep_kernel (+ the sampling launch) where the shape is covered
+  int opt_persist_batch = 1;  // option "persist_batch": 1 = calls of 2 .. PSB_MAX utterances run pstepb_kernel (persist_nb.hip) where the shape is covered
+  int ps_gran_B = 1;          // utterances the granule buffer was sized for
+  int ps_table_B = 0;         // batch the operand table was built for (the caches' layer stride depends on it)
+  mutable int psb_form_key = -1, psb_form_res = 0;  // pstepb_form_ok(B), cached
   int opt_ps_nk = 2, opt_ps_pf = 3;  // options "persist_nk", "persist_pf" (PStepArgs)
   int opt_ps_naps = -1;              // option "persist_naps" (-1: the engine mode's own timing, ps_naps_of)
   bool ps_device_ok = false;  // the device has the 256 CUs the persistent grid needs
@@ -685,7 +689,7 @@ static void release_buffers(vle_engine* e) {
   e->x_step = e->q_step = e->h_step = e->part_o = e->part_ml = e->logits = nullptr;
   e->k_new = e->v_new = nullptr; e->qgran = nullptr; e->qa_spin_fail = nullptr;
   e->ps_sample_valid = false;
-  e->ps_table = nullptr; e->ps_sample = nullptr; e->ps_fold = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0;
+  e->ps_table = nullptr; e->ps_sample = nullptr; e->ps_fold = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0; e->ps_table_B = 0;
   e->xn_step = e->qkv_step = e->att_step = e->hT_step = nullptr;
   e->gs_ws = nullptr; e->ln_stats = nullptr; e->ao_part = nullptr; e->ao_cnt = nullptr;
   e->state_dev = nullptr; e->S = ArState{}; e->dyn_dev = nullptr;
@@ -1010,7 +1014,8 @@ static int alloc_buffers(vle_engine* e) {
   if ((r = dev_alloc(e, &e->qa_spin_fail, 4))) return r;
   E_HIP(e, hipMemset(e->qa_spin_fail, 0, 4 * sizeof(unsigned)));
   if (pstep_supports(e->w8 ? DT_FP8W : e->dtype, e->d, e->H, e->dh, V_AR)) {
-    e->ps_gran_n = pstep_gran_count(e->d, e->H, e->L);
+    e->ps_gran_B = (e->dtype == DT_BF16 && !e->w8) ? std::max(1, std::min(e->max_B, PSB_MAX)) : 1;  // the batched persistent launch: [B] rows per edge
+    e->ps_gran_n = (size_t)e->ps_gran_B * pstep_gran_count(e->d, e->H, e->L);
     if ((r = dev_alloc(e, &e->ps_gran, e->ps_gran_n))) return r;
     E_HIP(e, hipMemset(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long)));
     if ((r = dev_alloc(e, &e->ps_table, (size_t)e->L + 1))) return r;
@@ -1365,18 +1370,31 @@ bool ps_form_ok(const vle_engine* e) {
 }
 
 // The persistent step (persist.hip) covers this call: batch 1, the covered shape, bf16 or fp8 weights, its table built for this cache
+// ... or 2 .. PSB_MAX utterances on pstepb_kernel (persist_nb.hip): bf16 weights, the default form only (PS_MODE_DEFAULT's packing /
+// LayerNorm / v_dot2c bits, 2 keys per lane, request schedule 3, no timeline), sampling inside the launch
+bool psb_covers(const vle_engine* e, int B) {
+  if (!e->opt_persist_batch || B < 2 || B > PSB_MAX || B > e->ps_gran_B) return false;
+  if (e->dtype != DT_BF16 || e->w8 || !e->opt_ps_sample || e->opt_ps_trace || e->opt_ps_nk != 2 || e->opt_ps_pf != 3) return false;
+  if ((e->opt_ps_mode & 0xfc) != (PS_MODE_DEFAULT & 0xfc)) return false;
+  if (!pstepb_supports(e->dtype, e->d, e->H, e->dh, V_AR, B)) return false;
+  if (e->psb_form_key != B) {
+    e->psb_form_key = B;
+    e->psb_form_res = pstepb_form_ok(B);
+  }
+  return e->psb_form_res == 1;
+}
 bool persist_ready(const vle_engine* e) {
-  return e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && e->B == 1 && !e->slot_mode && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
-         (!e->w8 || ps_w8_mode_ok(e)) && ps_form_ok(e) &&
-         e->ps_table_kc == e->kcache && e->ps_table_ctx == e->ctx_max && (int)e->ar.size() == e->L;
+  return e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && (e->B == 1 || psb_covers(e, e->B)) && !e->slot_mode && !e->opt_profile && e->ps_table != nullptr &&
+         e->ps_gran != nullptr && (!e->w8 || ps_w8_mode_ok(e)) && ps_form_ok(e) &&
+         e->ps_table_kc == e->kcache && e->ps_table_ctx == e->ctx_max && e->ps_table_B == e->B && (int)e->ar.size() == e->L;
 }
 
 // (re)build the operand table for a batch-1 call and forget the granules' old tags (the iteration counter restarts at every
 // prefill).  Called from vle_ar_prefill: never inside a stream capture.
 int persist_prepare(vle_engine* e) {
-  if (!e->ps_table || !e->ps_gran || !e->ps_fold || !e->ps_sample || !e->ps_host || e->B != 1) return 0;
+  if (!e->ps_table || !e->ps_gran || !e->ps_fold || !e->ps_sample || !e->ps_host || !(e->B == 1 || psb_covers(e, e->B))) return 0;
   if (e->w8 && (e->ar_predict8 == nullptr || e->ar.empty() || e->ar[0].wqkv8 == nullptr)) return 0;
-  if (e->ps_table_kc != e->kcache || e->ps_table_ctx != e->ctx_max) {
+  if (e->ps_table_kc != e->kcache || e->ps_table_ctx != e->ctx_max || e->ps_table_B != e->B) {
     std::vector<PLayer> tab(e->L + 1);
     const int64_t d = e->d;
     for (int l = 0; l < e->L; ++l) {
@@ -1412,7 +1430,7 @@ int persist_prepare(vle_engine* e) {
     E_HIP(e, hipStreamSynchronize(e->st));  // no earlier copy still reads the staging area
     memcpy(e->ps_host, tab.data(), tab.size() * sizeof(PLayer));
     E_HIP(e, hipMemcpyAsync(e->ps_table, e->ps_host, tab.size() * sizeof(PLayer), hipMemcpyHostToDevice, e->st));
-    e->ps_table_kc = e->kcache; e->ps_table_ctx = e->ctx_max;
+    e->ps_table_kc = e->kcache; e->ps_table_ctx = e->ctx_max; e->ps_table_B = e->B;
   }
   {
     PStepSample q;
@@ -1431,7 +1449,7 @@ int persist_prepare(vle_engine* e) {
       e->ps_sample_valid = true;
     }
   }
-  E_HIP(e, hipMemsetAsync(e->ps_gran, 0, e->ps_gran_n * sizeof(unsigned long long), e->st));
+  E_HIP(e, hipMemsetAsync(e->ps_gran, 0, (e->ps_gran_n / e->ps_gran_B) * e->B * sizeof(unsigned long long), e->st));
   return 0;
 }
 
@@ -1447,7 +1465,8 @@ int enqueue_persist_step(vle_engine* e, int nsteps = 1) {
     a.nsteps = nsteps;
     a.smp = e->ps_sample;
   }
-  const int r = launch_pstep(e->st, e->w8 ? DT_FP8W : e->dtype, a);
+  a.B = e->B;
+  const int r = e->B > 1 ? launch_pstepb(e->st, e->dtype, a) : launch_pstep(e->st, e->w8 ? DT_FP8W : e->dtype, a);
   if (r != 0) return e->fail(VLE_EINVAL, "launch_pstep rejected the step");
   return 0;
 }
@@ -1980,7 +1999,7 @@ extern "C" int vle_ar_generate(vle_engine* e, void* stream, int32_t top_k, float
     e->ps_backoff_next = 2;
   }
   if (not_done) return e->fail(VLE_ESTATE, "AR loop ended with unfinished utterances (capacity too small?)");
-  if (!ps_call && B == 1 && !e->slot_mode && e->ps_backoff > 0) --e->ps_backoff;  // one more batch-1 call on the chain after VLE_EBUSY; at 0 the persistent launch is re-armed
+  if (!ps_call && B <= PSB_MAX && !e->slot_mode && e->ps_backoff > 0) --e->ps_backoff;  // one more batch-1 call on the chain after VLE_EBUSY; at 0 the persistent launch is re-armed
   if (no_token) return e->fail(VLE_ENOTOKEN, "well trained model shouldn't reach here.");
   return VLE_OK;
 }
@@ -2672,8 +2691,9 @@ extern "C" int vle_set_option(vle_engine* e, const char* name, int64_t value) {
     return VLE_OK;
   }
   if (n == "persist" || n == "persist_pf" || n == "persist_nk" || n == "persist_trace" || n == "persist_mode" || n == "persist_naps" || n == "act_bf16" ||
-      n == "persist_sample" || n == "persist_steps") {  // change the captured graphs: drop them
+      n == "persist_sample" || n == "persist_steps" || n == "persist_batch") {  // change the captured graphs: drop them
     if (n == "persist") e->opt_persist = value != 0;
+    else if (n == "persist_batch") e->opt_persist_batch = value != 0;  // 2 .. PSB_MAX utterances on the persistent launch (0: the launch chain)
     else if (n == "persist_sample") e->opt_ps_sample = value != 0;
     else if (n == "persist_steps") {
       if (value < 1 || value > 4096) return e->fail(VLE_EINVAL, "persist_steps must be 1 .. 4096");
@@ -2819,6 +2839,17 @@ extern "C" int64_t vle_debug_fetch(vle_engine* e, const char* what, void* host_d
     const bool v1 = e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && !e->slot_mode && !e->opt_profile && e->ps_table != nullptr &&
                     e->ps_gran != nullptr && (!e->w8 || ps_w8_mode_ok(e)) && ps_form_ok(e) && (int)e->ar.size() == e->L;
     const int32_t v = v1 ? 1 : 0;
+    const size_t nb = std::min(bytes, sizeof(v));
+    memcpy(host_dst, &v, nb);
+    return (int64_t)nb;
+  } else if (w == "persist_batch_capable") {
+    // the largest batch (0, or 2 .. PSB_MAX) a call on this engine would run on the batched persistent launch (persist_nb.hip) whatever
+    // the batch of the last prefill was: VALLE.inference_batch decodes two utterances one after the other only where this says 0
+    int32_t v = 0;
+    if (e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && !e->slot_mode && !e->opt_profile && e->ps_table != nullptr && e->ps_gran != nullptr &&
+        ps_form_ok(e) && (int)e->ar.size() == e->L)
+      for (int b = 2; b <= PSB_MAX; ++b)
+        if (psb_covers(e, b)) v = b;
     const size_t nb = std::min(bytes, sizeof(v));
     memcpy(host_dst, &v, nb);
     return (int64_t)nb;

@@ -289,6 +289,8 @@ struct PStepArgs {
   int nk = 2;                      // "persist_nk": keys per lane per round of the attention share (2: 1024 keys in one round; 4)
   int pf = 3;                      // "persist_pf": when the compute waves request an operator's operands (persist.hip): 0 = in one burst right
                                    // before the sweep that precedes the operator, 3 = linear1 / linear2 spread over three sweeps (default)
+  int B = 1;                       // utterances in the launch: 1 = pstep_kernel (persist.hip); 2 .. PSB_MAX = pstepb_kernel (persist_nb.hip: x_in
+                                   // [B][d], logits [B][V], kv_len / iter / done [B], gran sized by pstepb_gran_count, the caches [B][H][ctx_max][dh])
 };
 bool pstep_supports(int dtype, int d, int nhead, int dh, int V);
 // 1 = (weight type, persist_mode, keys per lane, request schedule, timeline) is an instantiated form of pstep_kernel and the occupancy
@@ -296,6 +298,13 @@ bool pstep_supports(int dtype, int d, int nhead, int dh, int V);
 int pstep_form_ok(int dtype, int mode, int nk, int pf, bool traced);
 size_t pstep_gran_count(int d, int nhead, int L);
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched, 1 shape not covered, < 0 error
+// persist_nb.hip: the same launch for 2 .. PSB_MAX utterances (bf16 weights, the default form only: PS_MODE_DEFAULT, 2 keys per lane,
+// request schedule 3, sampling inside the launch); per utterance bit-identical to pstep_kernel's default form
+constexpr int PSB_MAX = 4;
+bool pstepb_supports(int dtype, int d, int nhead, int dh, int V, int B);
+int pstepb_form_ok(int B);  // 1 = one workgroup of the B-utterance form fits a CU; 0 = no such form; -1 = does not fit
+size_t pstepb_gran_count(int d, int nhead, int L, int B);
+int launch_pstepb(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched, 1 shape not covered, < 0 error
 // sg[n] = sum_k W[n][k] gamma[k], tb[n] = sum_k W[n][k] beta[k] + (bias ? bias[n] : 0) for the N rows of bf16 W[N][K] (fp64 sums)
 int launch_ps_fold(hipStream_t st, const void* W, const float* gamma, const float* beta, const float* bias, float* sg, float* tb, int N, int K);
 

@@ -391,6 +391,13 @@ def _ragged_batch(B, seed=5):
     return X.to(DEV), Y.to(DEV), S, P
 
 
+def _engine_defaults(eng):
+    """the options other tests of this module leave on a shared engine, back to the engine's defaults"""
+    for k, v in {"persist": 1, "persist_batch": 1, "persist_pf": 3, "persist_nk": 2, "persist_mode": DEFAULT, "persist_naps": -1, "persist_sample": 1, "persist_steps": 32,
+                 "act_bf16": 2, "qa_nsplit": 8, "qa_nk": 4, "steps_per_graph": 0, "persist_trace": 0}.items():
+        eng.set_option(k, v)
+
+
 def _batch_decode(eng, X, Y, S, P, steps, **kw):
     """prefill + AR loop of the whole batch with the logits trace: (first-codebook tokens per utterance, logits [steps][B][V])"""
     eng.set_option("trace_ar_logits", 1)
@@ -414,6 +421,7 @@ def test_batched_persistent_launch_is_bit_identical_to_one_utterance_launches(sm
     m = small_batch_model
     X, Y, S, P = _ragged_batch(B)
     eng = m.engine_for(4, max(S), max(P))
+    _engine_defaults(eng)
     eng.set_option("ignore_eos", 1)
     assert eng.fetch_u32("persist_batch_capable") == 4
     steps = 40
@@ -452,6 +460,7 @@ def test_batched_persistent_launch_utterances_stop_on_eos_at_their_own_steps(eos
     m = eos_model
     X, Y, S, P = _ragged_batch(4, seed=9)
     eng = m.engine_for(4, max(S), max(P))
+    _engine_defaults(eng)
     eng.set_option("ignore_eos", 0)
     lens = torch.tensor(S, dtype=torch.int32)
     for kw in (dict(top_k=1), dict(top_k=-100, temperature=1.3, seed=77)):
@@ -477,6 +486,7 @@ def test_two_utterances_are_decoded_one_after_the_other_where_the_batched_launch
     X, Y, S, P = _ragged_batch(2)
     lens = torch.tensor(S, dtype=torch.int32)
     eng = m.engine_for(4, max(S), max(P))
+    _engine_defaults(eng)
     eng.set_option("ignore_eos", 1)
     eng.set_option("persist_batch", 0)
     try:

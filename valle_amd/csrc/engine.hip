@@ -1346,8 +1346,12 @@ int kv_stream_nt(const vle_engine* e) {
 // folded LayerNorm, fp32 activation rows (the v_dot2c forms multiply bf16 weights), keys per lane 2, request schedules 0 / 3
 // first-sweep waits per engine mode (tools/persist_probe.py --dtype sweeps, round 5: the stages' lengths differ with the weight format):
 // bf16 D2 forms 0x325756 (126.9 us per step), fp8 weight rows 0x214645 (128.0 -> 125.7), fp32 0x217645 (191.7 -> 187.1)
+// the batched launch (persist_nb.hip): the stages between two hand-offs grow with the number of rows, so the first sweeps are
+// timed per batch (tools/persist_nb_probe.py, coordinate descent over the six edges)
+constexpr int PSB_NAPS_DEFAULT[PSB_MAX + 1] = {0, 0, 0x405745, 0x305752, 0x317780};  // profiles/r06_persist_nb_probe.json: 157.1 / 187.6 / 221.4 us per step
 int ps_naps_of(const vle_engine* e) {
   if (e->opt_ps_naps >= 0) return e->opt_ps_naps;
+  if (e->B > 1 && e->B <= PSB_MAX) return PSB_NAPS_DEFAULT[e->B];
   return e->dtype == DT_F32 ? 0x217645 : e->w8 ? 0x214645 : PS_NAPS_DEFAULT;
 }
 int ps_mode_of(const vle_engine* e) {
@@ -1371,15 +1375,15 @@ bool ps_form_ok(const vle_engine* e) {
 
 // The persistent step (persist.hip) covers this call: batch 1, the covered shape, bf16 or fp8 weights, its table built for this cache
 // ... or 2 .. PSB_MAX utterances on pstepb_kernel (persist_nb.hip): bf16 weights, the default form only (PS_MODE_DEFAULT's packing /
-// LayerNorm / v_dot2c bits, 2 keys per lane, request schedule 3, no timeline), sampling inside the launch
+// LayerNorm / v_dot2c bits, 2 keys per lane, request schedule 3), sampling inside the launch
 bool psb_covers(const vle_engine* e, int B) {
   if (!e->opt_persist_batch || B < 2 || B > PSB_MAX || B > e->ps_gran_B) return false;
-  if (e->dtype != DT_BF16 || e->w8 || !e->opt_ps_sample || e->opt_ps_trace || e->opt_ps_nk != 2 || e->opt_ps_pf != 3) return false;
+  if (e->dtype != DT_BF16 || e->w8 || !e->opt_ps_sample || e->opt_ps_nk != 2 || e->opt_ps_pf != 3) return false;
   if ((e->opt_ps_mode & 0xfc) != (PS_MODE_DEFAULT & 0xfc)) return false;
   if (!pstepb_supports(e->dtype, e->d, e->H, e->dh, V_AR, B)) return false;
-  if (e->psb_form_key != B) {
-    e->psb_form_key = B;
-    e->psb_form_res = pstepb_form_ok(B);
+  if (e->psb_form_key != B * 2 + (e->opt_ps_trace ? 1 : 0)) {
+    e->psb_form_key = B * 2 + (e->opt_ps_trace ? 1 : 0);
+    e->psb_form_res = pstepb_form_ok(B, e->opt_ps_trace);
   }
   return e->psb_form_res == 1;
 }

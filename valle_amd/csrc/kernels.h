@@ -302,7 +302,7 @@ int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched,
 // request schedule 3, sampling inside the launch); per utterance bit-identical to pstep_kernel's default form
 constexpr int PSB_MAX = 4;
 bool pstepb_supports(int dtype, int d, int nhead, int dh, int V, int B);
-int pstepb_form_ok(int B);  // 1 = one workgroup of the B-utterance form fits a CU; 0 = no such form; -1 = does not fit
+int pstepb_form_ok(int B, bool traced);  // 1 = one workgroup of the B-utterance form fits a CU; 0 = no such form; -1 = does not fit
 size_t pstepb_gran_count(int d, int nhead, int L, int B);
 int launch_pstepb(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched, 1 shape not covered, < 0 error
 // sg[n] = sum_k W[n][k] gamma[k], tb[n] = sum_k W[n][k] beta[k] + (bias ? bias[n] : 0) for the N rows of bf16 W[N][K] (fp64 sums)

@@ -120,6 +120,50 @@ __device__ inline void for_each_utt(F&& body) {
   }
 }
 
+// The wave totals of persist_dev.h for N independent values IN LOCKSTEP: between two hand-offs a workgroup runs one wave per SIMD, so
+// every DPP / permlane step of a reduction waits out its own latency -- N reductions written one after the other cost N times that.
+// Step k of all N values is issued before step k + 1 of any; per value the arithmetic is row16_sum_dpp's / rows4_sum's.
+template <int N>
+__device__ inline void row16_sums_lockstep(float (&v)[N]) {
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_f32<0xB1>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_f32<0x4E>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_f32<0x141>(v[i]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] += dpp_f32<0x140>(v[i]);
+}
+template <int N>
+__device__ inline void rows4_sums_lockstep(float (&v)[N]) {
+  permlane_u32x2 r[N];
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = __builtin_amdgcn_permlane16_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __uint_as_float(r[i][0]) + __uint_as_float(r[i][1]);
+#pragma unroll
+  for (int i = 0; i < N; ++i) r[i] = __builtin_amdgcn_permlane32_swap(__float_as_uint(v[i]), __float_as_uint(v[i]), false, false);
+#pragma unroll
+  for (int i = 0; i < N; ++i) v[i] = __uint_as_float(r[i][0]) + __uint_as_float(r[i][1]);
+}
+// (lane & 15) == c, on an opaque copy of the lane id (see sel_by_lane)
+__device__ inline bool lane_col_is(int c) {
+  int x = threadIdx.x & 15;
+  asm volatile("" : "+v"(x));
+  return x == c;
+}
+// N <= 16 wave totals at once: value i's 16-lane row sums are kept in lane column i of every row, ONE pair of permlane swaps finishes all
+// of them -- lanes i, i + 16, i + 32, i + 48 end up with total i (per value: rows4_sum(row16_sum_dpp(v)), persist_dev.h's arithmetic)
+template <int N>
+__device__ inline float wave_sums_by_column(float (&v)[N]) {
+  static_assert(N <= 16, "one lane column per value");
+  row16_sums_lockstep<N>(v);
+  float r = v[0];
+#pragma unroll
+  for (int i = 1; i < N; ++i) r = lane_col_is(i) ? v[i] : r;
+  return rows4_sum(r);
+}
+
 // value of utterance (lane >> 2) out of per-utterance values (lanes >= 4 NB: utterance 0's)
 template <int NB, typename X>
 __device__ inline X sel_by_lane(const X (&v)[NB]) {
@@ -137,7 +181,7 @@ __device__ inline X sel_by_lane(const X (&v)[NB]) {
 
 }  // namespace
 
-template <int NB>
+template <int NB, bool TR = false>
 __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
   typedef bf16_t T;
   constexpr int D = 1024, H = 16, NK = 2;
@@ -210,6 +254,10 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
   const int nap_att = naps & 15, nap_x = (naps >> 4) & 15, nap_x2 = (naps >> 8) & 15, nap_hid = (naps >> 12) & 15, nap_qkv = (naps >> 16) & 15,
             nap_part = (naps >> 20) & 15;
   PsSpin sp{PS_SPINS, a.fail, (a.mode >> 8) & 15, 0u};
+  PsTrace pt{nullptr, 0, 0ull};  // in-kernel timeline (option "persist_trace"; persist_dev.h): the same stamps as pstep_kernel's
+  if constexpr (TR) pt.p = (a.ptrace && tid == 0) ? a.ptrace + ((size_t)(it & 7) * NWG + c) * PS_PT_SLOTS : nullptr;
+  pt_begin<TR>(pt);
+  pt_end<TR>(pt, 0u);
 
   const int GPL1 = ps_gran_per_layer(D, H, NS);  // per utterance
   const int GPL = NB * GPL1;
@@ -312,27 +360,37 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
   };
   // folded LayerNorm, the row side, for the NB rows (persist.hip fold_stats per row; ONE barrier for all of them)
   auto fold_stats = [&](const float (&xr)[NB][EPT], const float (&gv)[EPT], float (&mean)[NB], float (&rstd)[NB]) {
+    float sw[NB], qw[NB];
 #pragma unroll
     for (int b = 0; b < NB; ++b) {
       float xg[EPT];
 #pragma unroll
       for (int k = 0; k < EPT; ++k) xg[k] = xr[b][k] * gv[k];
       *reinterpret_cast<u32x2v_t*>(reinterpret_cast<unsigned char*>(sxrow(b)) + tid * 8) = u32x2v_t{pack_bf16x2(xg[0], xg[1]), pack_bf16x2(xg[2], xg[3])};
-      float sw = 0.f;
+      sw[b] = 0.f;
 #pragma unroll
-      for (int k = 0; k < EPT; ++k) sw += xr[b][k];
-      const float mw = ps_wave_sum_fast(sw) * (1.0f / (64.0f * EPT));
-      float qw = 0.f;
+      for (int k = 0; k < EPT; ++k) sw[b] += xr[b][k];
+    }
+    row16_sums_lockstep<NB>(sw);
+    rows4_sums_lockstep<NB>(sw);
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      sw[b] *= (1.0f / (64.0f * EPT));  // the wave's mean
+      qw[b] = 0.f;
 #pragma unroll
       for (int k = 0; k < EPT; ++k) {
-        const float t = xr[b][k] - mw;
-        qw = fmaf(t, t, qw);
+        const float t = xr[b][k] - sw[b];
+        qw[b] = fmaf(t, t, qw[b]);
       }
-      qw = ps_wave_sum_fast(qw);
-      if (lane == 0) {
+    }
+    row16_sums_lockstep<NB>(qw);
+    rows4_sums_lockstep<NB>(qw);
+    if (lane == 0) {
+#pragma unroll
+      for (int b = 0; b < NB; ++b) {
         float* red = ub(b) + O_RED;
-        red[w] = mw;
-        red[4 + w] = qw;
+        red[w] = sw[b];
+        red[4 + w] = qw[b];
       }
     }
     g1_lds_barrier();
@@ -368,7 +426,12 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
   const int nsteps = a.nsteps;
 
   for (int step = 0; step < nsteps; ++step) {
-  if (step > 0) sp.budget = sp.budget ? PS_SPINS : 0u;
+  if (step > 0) {
+    sp.budget = sp.budget ? PS_SPINS : 0u;
+    if constexpr (TR) pt = PsTrace{(a.ptrace && tid == 0) ? a.ptrace + ((size_t)(it & 7) * NWG + c) * PS_PT_SLOTS : nullptr, 0, 0ull};
+    pt_begin<TR>(pt);
+    pt_end<TR>(pt, 0u);
+  }
   for (int l = 0; l < a.L; ++l) {
     const PsLayer p = ps_layer(a.layers, l);
     const PsLayer pn = ps_layer(a.layers, l + 1);
@@ -377,8 +440,10 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
 
     // ======== (1) LN1 + in-projection of this head's 3 QR rows, NB input rows ====================================================
     if (l > 0) {
+      pt_begin<TR>(pt);
       nap(nap_x);
       gather_rows16<NB, EPT>(rs, goff(G + G_X + tid * EPT), D * 8u, epoch, xv, sp);
+      pt_end<TR>(pt, sp.passes);
     }
     if (tid == c) {
 #pragma unroll
@@ -388,17 +453,16 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
     {
       float ln_mean[NB], ln_rstd[NB];
       fold_stats(xv, g1v, ln_mean, ln_rstd);
-      float mine = 0.f;
+      float t[4 * NB];  // value 4 b + r: row r of utterance b (r = 3: unused)
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         u32x4_t xb[NCH];
         ps_read_bf16<NCH>(sxrow(b), xb);
-        float t[RQ];
 #pragma unroll
-        for (int r = 0; r < RQ; ++r) t[r] = ps_dot_bf16<NCH>(wq[r], xb);
-        const float tb = ps_wave_sums_fast<RQ>(t);  // lanes with (lane & 3) == r < RQ: row r
-        mine = lb == b ? tb : mine;
+        for (int r = 0; r < RQ; ++r) t[4 * b + r] = ps_dot_bf16<NCH>(wq[r], xb);
+        t[4 * b + 3] = 0.f;
       }
+      const float mine = wave_sums_by_column<4 * NB>(t);  // lane 4 b + r: row r of utterance b
       const float mean_l = sel_by_lane<NB>(ln_mean), rstd_l = sel_by_lane<NB>(ln_rstd);
       if (lane < 4 * NB && lr < RQ) {
         const int r = w * RQ + lr, which = r / QR, e = s * QR + (r % QR);  // e: element of the head
@@ -419,6 +483,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
     issue_kv_all(p);
 
     // ======== (2) q, k_new, v_new of the head; attention over this workgroup's share of each utterance's cached keys ==============
+    pt_begin<TR>(pt);
     {
       nap(nap_qkv);
       const int wq_i = w < 3 ? w : 0;
@@ -431,6 +496,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
       }
     }
     g1_lds_barrier();
+    pt_end<TR>(pt, sp.passes);
     __builtin_amdgcn_sched_barrier(0);
     {
       auto widen = [&](const u32x4_t& r, float (&f)[CVEC]) {
@@ -440,68 +506,135 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
         f[6] = __uint_as_float(r.w << 16); f[7] = __uint_as_float(r.w & 0xffff0000u);
       };
       const float scale = 1.0f / sqrtf((float)DH);
-      for_each_utt<NB>([&](auto bc) {
-        constexpr int b = decltype(bc)::value;
-        float* const u = ub(b);
-        float qv[CVEC];
+      // The NB attention shares IN LOCKSTEP (see row16_sums_lockstep): step k of every utterance's chain -- scores, head sums, running
+      // maximum, exponentials, weighted values -- is issued before step k + 1 of any.  Per utterance: pstep_kernel's arithmetic.
+      float qv[NB][CVEC], m[NB], lsum[NB], oacc[NB][CVEC];
 #pragma unroll
-        for (int j = 0; j < CVEC; ++j) qv[j] = u[O_SQ + part * CVEC + j];
-        const int ctx = kvl[b];
-        int base = s * CHUNK;
-        float m = G1_NEG, lsum = 0.f, oacc[CVEC];
+      for (int b = 0; b < NB; ++b) {
+        const float* const u = ub(b);
 #pragma unroll
-        for (int j = 0; j < CVEC; ++j) oacc[j] = 0.f;
-        while (true) {
-          float sc[NK];
-          float mx = G1_NEG;
+        for (int j = 0; j < CVEC; ++j) qv[b][j] = u[O_SQ + part * CVEC + j];
+        m[b] = G1_NEG;
+        lsum[b] = 0.f;
+#pragma unroll
+        for (int j = 0; j < CVEC; ++j) oacc[b][j] = 0.f;
+      }
+      // one round = this workgroup's CHUNK keys at `base` of the utterances B0 .. B0 + NU - 1 (their K / V rows are in kraw / vraw)
+      auto attn_round = [&](auto b0c, auto nuc, int base) {
+        constexpr int B0 = decltype(b0c)::value, NU = decltype(nuc)::value;
+        float sc[NU][NK], mx[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
 #pragma unroll
           for (int i = 0; i < NK; ++i) {
             float kf[CVEC];
-            widen(kraw[b][i], kf);
+            widen(kraw[B0 + u][i], kf);
             float t = 0.f;
 #pragma unroll
-            for (int j = 0; j < CVEC; ++j) t = fmaf(qv[j], kf[j], t);
-            t = head_group_sum(t, LPK) * scale;
-            const int key = base + w * WCH + i * KPW + slot;
-            sc[i] = key < ctx ? t : G1_NEG;
-            mx = fmaxf(mx, sc[i]);
+            for (int j = 0; j < CVEC; ++j) t = fmaf(qv[B0 + u][j], kf[j], t);
+            sc[u][i] = t;
           }
-          const float mn = fmaxf(m, wave_max_dpp(mx));  // wave-uniform running max
-          const float f = __expf(m - mn);
-          lsum *= f;
+        static_assert(LPK == 8, "head_group_sum's three steps");
 #pragma unroll
-          for (int j = 0; j < CVEC; ++j) oacc[j] *= f;
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int i = 0; i < NK; ++i) sc[u][i] += dpp_f32<0xB1>(sc[u][i]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int i = 0; i < NK; ++i) sc[u][i] += dpp_f32<0x4E>(sc[u][i]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int i = 0; i < NK; ++i) sc[u][i] += dpp_f32<0x141>(sc[u][i]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          mx[u] = G1_NEG;
 #pragma unroll
           for (int i = 0; i < NK; ++i) {
             const int key = base + w * WCH + i * KPW + slot;
-            const float pr = key < ctx ? __expf(sc[i] - mn) : 0.f;
-            lsum += pr;
-            float vf[CVEC];
-            widen(vraw[b][i], vf);
-#pragma unroll
-            for (int j = 0; j < CVEC; ++j) oacc[j] = fmaf(pr, vf[j], oacc[j]);
+            sc[u][i] = key < kvl[B0 + u] ? sc[u][i] * scale : G1_NEG;
+            mx[u] = fmaxf(mx[u], sc[u][i]);
           }
-          m = mn;
-          base += NS * CHUNK;
-          if (base >= ctx) break;  // block-uniform
-          issue_kv(p, b, base, kvl[b]);
         }
-        // merge the KPW key slots of the wave, then the 4 waves through LDS (persist.hip's order)
-        lsum += dpp_f32<0x128>(lsum);
+        // wave_max_dpp of every utterance, step by step
 #pragma unroll
-        for (int j = 0; j < CVEC; ++j) oacc[j] += dpp_f32<0x128>(oacc[j]);
-        lsum = rows4_sum(lsum);
+        for (int u = 0; u < NU; ++u) mx[u] = fmaxf(mx[u], dpp_f32<0xB1>(mx[u]));
 #pragma unroll
-        for (int j = 0; j < CVEC; ++j) oacc[j] = rows4_sum(oacc[j]);
-        if (slot == 0) {
-          if (part == 0) {
-            u[O_SMM + w] = m;
-            u[O_SML + w] = lsum;
+        for (int u = 0; u < NU; ++u) mx[u] = fmaxf(mx[u], dpp_f32<0x4E>(mx[u]));
+#pragma unroll
+        for (int u = 0; u < NU; ++u) mx[u] = fmaxf(mx[u], dpp_f32<0x141>(mx[u]));
+#pragma unroll
+        for (int u = 0; u < NU; ++u) mx[u] = fmaxf(mx[u], dpp_f32<0x140>(mx[u]));
+        float mn[NU], f[NU];
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          const float wm = fmaxf(fmaxf(readlane_f32(mx[u], 0), readlane_f32(mx[u], 16)), fmaxf(readlane_f32(mx[u], 32), readlane_f32(mx[u], 48)));
+          mn[u] = fmaxf(m[B0 + u], wm);  // wave-uniform running max
+        }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) f[u] = __expf(m[B0 + u] - mn[u]);
+#pragma unroll
+        for (int u = 0; u < NU; ++u) {
+          lsum[B0 + u] *= f[u];
+#pragma unroll
+          for (int j = 0; j < CVEC; ++j) oacc[B0 + u][j] *= f[u];
+        }
+        float pr[NU][NK];
+#pragma unroll
+        for (int u = 0; u < NU; ++u)
+#pragma unroll
+          for (int i = 0; i < NK; ++i) {
+            const int key = base + w * WCH + i * KPW + slot;
+            pr[u][i] = key < kvl[B0 + u] ? __expf(sc[u][i] - mn[u]) : 0.f;
           }
 #pragma unroll
-          for (int j = 0; j < CVEC; ++j) u[O_SMO + w * DH + part * CVEC + j] = oacc[j];
+        for (int i = 0; i < NK; ++i)
+#pragma unroll
+          for (int u = 0; u < NU; ++u) {
+            lsum[B0 + u] += pr[u][i];
+            float vf[CVEC];
+            widen(vraw[B0 + u][i], vf);
+#pragma unroll
+            for (int j = 0; j < CVEC; ++j) oacc[B0 + u][j] = fmaf(pr[u][i], vf[j], oacc[B0 + u][j]);
+          }
+#pragma unroll
+        for (int u = 0; u < NU; ++u) m[B0 + u] = mn[u];
+      };
+      attn_round(std::integral_constant<int, 0>{}, std::integral_constant<int, NB>{}, s * CHUNK);
+      // contexts beyond NS * CHUNK = 1024 keys: the further rounds per utterance (block-uniform)
+      for_each_utt<NB>([&](auto bc) {
+        constexpr int b = decltype(bc)::value;
+        for (int base = s * CHUNK + NS * CHUNK; base < kvl[b]; base += NS * CHUNK) {
+          issue_kv(p, b, base, kvl[b]);
+          attn_round(bc, std::integral_constant<int, 1>{}, base);
         }
       });
+      // merge the KPW key slots of the wave, then the 4 waves through LDS (persist.hip's order)
+      {
+        float red9[NB * (CVEC + 1)];
+#pragma unroll
+        for (int b = 0; b < NB; ++b) {
+          red9[b * (CVEC + 1)] = lsum[b];
+#pragma unroll
+          for (int j = 0; j < CVEC; ++j) red9[b * (CVEC + 1) + 1 + j] = oacc[b][j];
+        }
+#pragma unroll
+        for (int i = 0; i < NB * (CVEC + 1); ++i) red9[i] += dpp_f32<0x128>(red9[i]);
+        rows4_sums_lockstep<NB * (CVEC + 1)>(red9);
+        if (slot == 0) {
+#pragma unroll
+          for (int b = 0; b < NB; ++b) {
+            float* const u = ub(b);
+            if (part == 0) {
+              u[O_SMM + w] = m[b];
+              u[O_SML + w] = red9[b * (CVEC + 1)];
+            }
+#pragma unroll
+            for (int j = 0; j < CVEC; ++j) u[O_SMO + w * DH + part * CVEC + j] = red9[b * (CVEC + 1) + 1 + j];
+          }
+        }
+      }
       g1_lds_barrier();
       if (w < NB) {  // wave b: the workgroup's partial of utterance b (DH lanes: the output; lane 0 also the (max, sum) pair)
         const int b = w;
@@ -548,6 +681,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
         off = 0;
       }
       float t2[2];
+      pt_begin<TR>(pt);
       nap(nap_part);
       {
         const unsigned bo = goff(gp + (size_t)j * (2 + DH) + off);
@@ -562,6 +696,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
         u[O_SPO + j * QR + 2 * (t % (QR / 2)) + 1] = t2[1];
       }
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      pt_end<TR>(pt, sp.passes);
       float tq = 0.f;
       {
         const int i = lane & 15;
@@ -605,6 +740,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
     g1_lds_barrier();  // (persist.hip: the other waves do not sweep the attention edge while the merging waves still load)
     {
       float raw[NB][EPT];
+      pt_begin<TR>(pt);
       issue_w1_rows(p, 0, R1 - 1);
       nap(nap_att);
       gather_rows16<NB, EPT>(rs, goff(G + G_ATT + tid * EPT), D * 8u, epoch, raw, sp);
@@ -613,15 +749,16 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
         *reinterpret_cast<u32x2v_t*>(reinterpret_cast<unsigned char*>(sxrow(b)) + tid * 8) =
             u32x2v_t{pack_bf16x2(raw[b][0], raw[b][1]), pack_bf16x2(raw[b][2], raw[b][3])};
       g1_lds_barrier();
+      pt_end<TR>(pt, sp.passes);
       __builtin_amdgcn_sched_barrier(0);
-      float mine = 0.f;
+      float t[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         u32x4_t xb[NCH];
         ps_read_bf16<NCH>(sxrow(b), xb);
-        const float tb = ps_wave_sum_fast(ps_dot_bf16<NCH>(wo, xb));
-        mine = lane == b ? tb : mine;
+        t[b] = ps_dot_bf16<NCH>(wo, xb);
       }
+      const float mine = wave_sums_by_column<NB>(t);  // lane b: utterance b
       if (lane < NB) {
         const float v = mine + bo_v;
         gran_store(G + G_X2 + lane * D + 4 * c + w, epoch, ub(lane)[O_SRES + w] + v);
@@ -632,8 +769,10 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
 
     // ======== (5) LN2 + linear1 + ReLU of rows 16c .. 16c+15, NB rows =============================================================
     {
+      pt_begin<TR>(pt);
       nap(nap_x2);
       gather_rows16<NB, EPT>(rs, goff(G + G_X2 + tid * EPT), D * 8u, epoch, xv, sp);
+      pt_end<TR>(pt, sp.passes);
       __builtin_amdgcn_sched_barrier(0);
       if (tid == c) {
 #pragma unroll
@@ -641,17 +780,15 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
       }
       float ln_mean[NB], ln_rstd[NB];
       fold_stats(xv, g2v, ln_mean, ln_rstd);
-      float mine = 0.f;
+      float t[4 * NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         u32x4_t xb[NCH];
         ps_read_bf16<NCH>(sxrow(b), xb);
-        float t[R1];
 #pragma unroll
-        for (int r = 0; r < R1; ++r) t[r] = ps_dot_bf16<NCH>(w1[r], xb);
-        const float tb = ps_wave_sums_fast<R1>(t);  // lanes with (lane & 3) == r: row r
-        mine = lb == b ? tb : mine;
+        for (int r = 0; r < R1; ++r) t[4 * b + r] = ps_dot_bf16<NCH>(w1[r], xb);
       }
+      const float mine = wave_sums_by_column<4 * NB>(t);  // lane 4 b + r: row r of utterance b
       const float mean_l = sel_by_lane<NB>(ln_mean), rstd_l = sel_by_lane<NB>(ln_rstd);
       const float hval = fmaxf(fmaf(rstd_l, fmaf(-mean_l, sg1_v, mine), b1_v), 0.f);
       const float nbv = dpp_f32<0xB1>(hval);  // lane ^ 1
@@ -664,6 +801,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
     {
       constexpr int NHG = EPT2 / 2;
       float raw[NB][NHG];
+      pt_begin<TR>(pt);
       nap(nap_hid);
       gather_rows16<NB, NHG>(rs, goff(G + G_HID + tid * NHG), 4 * D * 8u, epoch, raw, sp);
 #pragma unroll
@@ -675,15 +813,16 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
             u32x4_t{__float_as_uint(raw[b][4]), __float_as_uint(raw[b][5]), __float_as_uint(raw[b][6]), __float_as_uint(raw[b][7])};
       }
       g1_lds_barrier();
+      pt_end<TR>(pt, sp.passes);
       __builtin_amdgcn_sched_barrier(0);
-      float mine = 0.f;
+      float t[NB];
 #pragma unroll
       for (int b = 0; b < NB; ++b) {
         u32x4_t xb[NCH2];
         ps_read_bf16<NCH2>(sxrow(b), xb);
-        const float tb = ps_wave_sum_fast(ps_dot_bf16<NCH2>(w2, xb));
-        mine = lane == b ? tb : mine;
+        t[b] = ps_dot_bf16<NCH2>(w2, xb);
       }
+      const float mine = wave_sums_by_column<NB>(t);  // lane b: utterance b
       if (lane < NB) {
         const float v = mine + b2_v;
         gran_store(G + GPL + G_X + lane * D + 4 * c + w, epoch, ub(lane)[O_SRES + w] + v);  // the next layer's x edge (layer L: the final norm's)
@@ -695,22 +834,25 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
   // ======== final norm + predict layer: rows 4c .. 4c+3 (+ row 1024), NB rows =======================================================
   {
     gran_t* const G = a.gran + (size_t)a.L * GPL;
+    pt_begin<TR>(pt);
     nap(nap_x);
     gather_rows16<NB, EPT>(rs, goff(G + G_X + tid * EPT), D * 8u, epoch, xv, sp);
+    pt_end<TR>(pt, sp.passes);
     float ln_mean[NB], ln_rstd[NB];
     fold_stats(xv, g1v, ln_mean, ln_rstd);
     constexpr int G_LOG = G_QKV;  // the final block's q/k/v slots carry the logits edges (V <= 3 D)
     float t0 = 0.f, t1 = 0.f;
+    {
+      float ta[NB], tx[NB];
 #pragma unroll
-    for (int b = 0; b < NB; ++b) {
-      u32x4_t xb[NCH];
-      ps_read_bf16<NCH>(sxrow(b), xb);
-      const float tb = ps_wave_sum_fast(ps_dot_bf16<NCH>(wq[0], xb));
-      t0 = lane == b ? tb : t0;
-      if (extra_row) {
-        const float tx = ps_wave_sum_fast(ps_dot_bf16<NCH>(wq[1], xb));
-        t1 = lane == b ? tx : t1;
+      for (int b = 0; b < NB; ++b) {
+        u32x4_t xb[NCH];
+        ps_read_bf16<NCH>(sxrow(b), xb);
+        ta[b] = ps_dot_bf16<NCH>(wq[0], xb);
+        tx[b] = extra_row ? ps_dot_bf16<NCH>(wq[1], xb) : 0.f;
       }
+      t0 = wave_sums_by_column<NB>(ta);  // lane b: utterance b
+      if (extra_row) t1 = wave_sums_by_column<NB>(tx);
     }
     {
       float mean_l = ln_mean[0], rstd_l = ln_rstd[0];  // of utterance `lane`
@@ -752,8 +894,10 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
       }
       const float alpha = *q.alpha_audio;
       float lg4[NB][EPT], lgx[NB];
+      pt_begin<TR>(pt);
       nap(nap_x);
       gather_rows16_plus1<NB, EPT>(rs, goff(G + G_LOG + tid * EPT), goff(G + G_LOG + 4 * NWG), 3 * D * 8u, epoch, lg4, lgx, sp);
+      pt_end<TR>(pt, sp.passes);
       const int V = a.V;
       int next[NB];
       unsigned stopped = 0u;  // utterances that stop in THIS step
@@ -852,6 +996,8 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
       it += 1;
       epoch = (unsigned)(it + 1);
     }
+    pt_begin<TR>(pt);
+    pt_end<TR>(pt, 0u);
   }
   }  // step
 }
@@ -863,13 +1009,14 @@ bool pstepb_supports(int dtype, int d, int nhead, int dh, int V, int B) {
 size_t pstepb_gran_count(int d, int nhead, int L, int B) { return (size_t)B * (L + 1) * ps_gran_per_layer(d, nhead, 256 / nhead); }
 
 typedef void (*PsbKernel)(PStepArgs);
-static PsbKernel psb_select(int B) {
+static PsbKernel psb_select(int B, bool traced) {
+  if (traced) return B == 2 ? (PsbKernel)pstepb_kernel<2, true> : B == 3 ? (PsbKernel)pstepb_kernel<3, true> : B == 4 ? (PsbKernel)pstepb_kernel<4, true> : nullptr;
   return B == 2 ? (PsbKernel)pstepb_kernel<2> : B == 3 ? (PsbKernel)pstepb_kernel<3> : B == 4 ? (PsbKernel)pstepb_kernel<4> : nullptr;
 }
 
 // 1 = the occupancy calculator places one workgroup of the B-utterance form on a CU; -1 = it does not fit; 0 = no such form
-int pstepb_form_ok(int B) {
-  const PsbKernel k = psb_select(B);
+int pstepb_form_ok(int B, bool traced) {
+  const PsbKernel k = psb_select(B, traced);
   if (k == nullptr) return 0;
   int per_cu = 0;
   const hipError_t r = hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, k, PS_T, 0);
@@ -885,7 +1032,7 @@ int launch_pstepb(hipStream_t st, int dtype, const PStepArgs& a) {
   if (!pstepb_supports(dtype, a.d, a.nhead, a.dh, a.V, a.B)) return 1;
   if (!a.layers || !a.x_in || !a.logits || !a.kv_len || !a.iter || !a.done || !a.gran || a.L < 1) return -1;
   if (a.nsteps < 1 || a.nsteps > 4096 || !a.smp) return -1;  // (the sampling step is always inside this launch)
-  const PsbKernel k = psb_select(a.B);
+  const PsbKernel k = psb_select(a.B, a.ptrace != nullptr);
   if (k == nullptr) return -1;
   hipLaunchKernelGGL(k, dim3(256), dim3(PS_T), 0, st, a);
   return 0;

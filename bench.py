@@ -22,6 +22,7 @@ Scaling efficiency of either workload = its value at N / (N x its value at N = 1
 Timed region = the reference's own seam (SURVEY.md 8d "wall-time from inference() entry"): every decode goes through
 `model.inference_batch()` -- the method `VALLE.inference()` is a batch-1 wrapper of (valle/models/valle.py:961) -- with its
 asserts, length conversions, engine lookup and EOS prints inside the number (prints redirected to stderr).
+`batch4` (N = 1) is 4 utterances per GPU on the batched persistent launch (csrc/persist_nb.hip);
 `sampled` (N = 1) is the headline workload at the reference's own default sampling (top_k = -100, temperature = 1.0,
 valle/models/valle.py:967-968); `s200` (N = 1) a realistic text length (S = 200 -> 3201 frames = 42.7 s of audio).
 `frames_per_s` / `rtf` (wall seconds per second of generated audio at 75 frames/s) accompany every tokens/s figure.
@@ -652,6 +653,10 @@ def main():
         leg("s200", lambda: side_leg(sd_all, args, dev, rank, world, 1, args.dtype, steps=2, warmup=1, S=200, model=model,
                                      label="; SURVEY.md 8(d) 'realistic text' row"), False)
     model._invalidate()
+    if plain and world == 1 and not args.no_side:
+        # 4 utterances share ONE persistent launch (csrc/persist_nb.hip, round 6): the small-batch serving point between the headline and c3
+        leg("batch4", lambda: side_leg(sd_all, args, dev, rank, world, 4, args.dtype, steps=3, warmup=1,
+                                       label="; 2 .. 4 utterances run the batched persistent AR launch (weights streamed once per step for all of them)"), False)
     if plain and not args.no_c3:
         c3 = leg("c3_batch64", lambda: side_leg(sd_all, args, dev, rank, world, 64, args.dtype), True)
         if out is not None and isinstance(c3, dict) and "value" in c3:

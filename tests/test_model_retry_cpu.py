@@ -78,3 +78,42 @@ def test_no_token_is_the_references_syntax_error(model, monkeypatch, codes):
     with pytest.raises(SyntaxError, match="well trained model shouldn't reach here"):  # valle.py:1049-1052
         _decode(model, eng, monkeypatch)
     assert "nar" not in eng.calls
+
+
+class TwoUtteranceEngine(ScriptedEngine):
+    """answers the model's questions about the persistent launches; records the batch of every prefill"""
+
+    def __init__(self, batch_capable, capable=1):
+        super().__init__([])
+        self.words = {"persist_batch_capable": batch_capable, "persist_capable": capable, "persist_fallbacks": 0, "persist_backoff": 0}
+        self.batches = []
+
+    def prefill(self, x, xl, y, yl):
+        self.batches.append(len(xl))
+
+    def generate(self, **kw):
+        return None, [self.G] * self.batches[-1]
+
+    def fetch_u32(self, what):
+        return self.words[what]
+
+    def timings(self):
+        return dict(prefill_ms=1.0, ar_ms=2.0, nar_ms=3.0, ar_steps=4.0)
+
+    def nar(self, enroll):
+        B = self.batches[-1]
+        return torch.arange(B * self.G * self.Q, dtype=torch.int64).reshape(B, self.G, self.Q)
+
+
+@pytest.mark.parametrize("batch_capable,capable,want", [(4, 1, [2]), (2, 1, [2]), (0, 1, [1, 1]), (0, 0, [2])])
+def test_two_utterances_take_the_batched_persistent_launch_where_the_engine_offers_it(model, monkeypatch, batch_capable, capable, want):
+    """Round 6 policy of VALLE.inference_batch at two utterances (valle_amd/model.py): ONE call where the engine runs 2 .. 4 utterances on
+    the batched persistent launch (csrc/persist_nb.hip); one after the other where only the one-utterance launch exists (the batched
+    launch chain is slower than that, profiles/r06_small_batch.json); the batched chain where neither does."""
+    eng = TwoUtteranceEngine(batch_capable, capable)
+    monkeypatch.setattr(model, "engine_for", lambda *a, **k: eng)
+    x = torch.ones(2, 6, dtype=torch.int64)
+    y = torch.ones(2, 9, 8, dtype=torch.int64)
+    out = model.inference_batch(x, torch.tensor([6, 6]), y, [9, 9], top_k=1)
+    assert eng.batches == want and len(out) == 2 and all(o.shape == (5, 8) for o in out)
+    assert (model.sequential_timings is not None) == (want == [1, 1])

@@ -586,3 +586,29 @@ def test_persistent_step_repeated_decodes_under_changing_timing_stay_identical(c
                     assert torch.equal(ref, lg) and torch.equal(ref_codes, codes), (hex(mode), rep, pf, hex(naps))
                     n += 1
     assert n == 80
+
+
+def test_batched_persistent_launch_under_changing_timing_stays_identical(c2_model):
+    """The batched launch's hand-offs are correct by protocol too (every granule of every utterance's row carries the step's epoch):
+    12 layers, 4 utterances, the first sweeps timed well, not at all, very late and unevenly, eager single steps and graph replays of
+    32-step launches -- the same bits every time, no give-up."""
+    B, S, P, steps = 4, 24, 70, 48
+    eng = c2_model.engine_for(4, S, P)
+    _engine_defaults(eng)
+    eng.set_option("ignore_eos", 1)
+    xs, ys = zip(*[_inputs(S, P, seed=40 + b) for b in range(B)])
+    X, Y = torch.cat(xs), torch.cat(ys)
+    ref_codes, ref = _batch_decode(eng, X, Y, [S] * B, [P] * B, steps, top_k=1)
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+    n = 0
+    for spg, psteps in ((0, 32), (0, 5), (1, 32)):  # (steps_per_graph = 1: one-step launches)
+        eng.set_option("steps_per_graph", spg)
+        eng.set_option("persist_steps", psteps)
+        for naps in (-1, 0, 0xFFFFFF, 0x0F0F0F, 0x123456, 0xF000F0, 0x00FF00, 0x654321):
+            eng.set_option("persist_naps", naps)
+            codes, lg = _batch_decode(eng, X, Y, [S] * B, [P] * B, steps, top_k=1)
+            assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0, (spg, psteps, hex(naps & 0xFFFFFF))
+            assert torch.equal(ref, lg) and all(torch.equal(a, b) for a, b in zip(ref_codes, codes)), (spg, psteps, hex(naps & 0xFFFFFF))
+            n += 1
+    _engine_defaults(eng)
+    assert n == 24

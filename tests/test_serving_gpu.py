@@ -124,3 +124,41 @@ def test_single_slot_serving_on_the_fused_batch1_step():
     # and the dense API afterwards (vle_ar_prefill clears them too)
     for (x, xl, y), w in zip(ins[:2], want[:2]):
         assert torch.equal(m.inference(x.to(DEV), xl.to(DEV), y.to(DEV), None, top_k=1).cpu()[0], w)
+
+
+def test_small_slot_engines_step_on_the_batched_persistent_launch():
+    """Round 6: on engines of 2 .. 4 slots (bf16, d1024-h16) vle_slots_step advances the live slots on the batched persistent launch
+    (csrc/persist_nb.hip) -- the slots are its utterances, a free or finished slot is a stopped one, every slot keeps its own
+    iteration counter (Philox counter) while the hand-off epochs follow a counter of the session.  More requests than slots, ragged
+    lengths, utterances stopping on EOS at their own steps, admissions while the other slots are mid-decode: every request's AR tokens
+    equal its own one-utterance decode (the one-utterance persistent launch: the same arithmetic per utterance), greedy and sampled."""
+    torch.manual_seed(31)
+    m = valle_amd.VALLE(1024, 16, 3, prefix_mode=1, engine_dtype="bf16", max_batch=3)
+    with torch.no_grad():
+        m.ar_predict_layer.weight[1024] *= -1.5  # EOS tops the row every few steps: ragged G
+    m = m.to(DEV).eval()
+    ins = _requests(8, 7, smin=4, smax=8, pmin=6, pmax=18)
+    reqs = [Request(x[0], y[0]) for x, _, y in ins]
+    for max_batch, spr in ((3, 8), (2, 5)):
+        cb = ContinuousBatcher(m, max_batch, max_text=8, max_prompt=18, steps_per_round=spr, harvest_min=1)
+        eng = cb.eng  # (the second batcher uses 2 of the same engine's 3 slots: the third stays a stopped utterance of the launch)
+        for kw in (dict(top_k=1), dict(top_k=30, temperature=1.1, seed=99)):
+            got = cb.decode(reqs, **kw)
+            assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0, "the slots did not step on the batched persistent launch"
+            lens = set()
+            for i, (x, xl, y) in enumerate(ins):
+                kb = dict(kw)
+                if "seed" in kb:
+                    kb["seed"] = (kb["seed"] + i * 0x9E3779B97F4A7C15) & (2**64 - 1)  # request i's stream as request 0 of a one-utterance call
+                one = m.inference_batch(x.to(DEV), xl, y.to(DEV), [int(y.shape[1])], None, _allow_empty=True, **kb)[0]
+                assert got[i].shape == one.shape and torch.equal(got[i][:, 0], one[:, 0]), (kw, i, got[i].shape, one.shape)
+                lens.add(int(one.shape[0]))
+            assert len(lens) > 2, f"the workload must be ragged in G ({lens})"
+        # the launch chain on the same slots (persist = 0) starts every request alike (two free-running bf16 paths part at their first tie)
+        eng.set_option("persist", 0)
+        try:
+            chain = cb.decode(reqs, top_k=1)
+            assert eng.fetch_u32("persist_ran") == 0
+        finally:
+            eng.set_option("persist", 1)
+        assert all(torch.equal(c[:2, 0], g[:2, 0]) for c, g in zip(chain, cb.decode(reqs, top_k=1)))

@@ -187,6 +187,8 @@ struct vle_engine {
   int opt_persist_batch = 1;  // option "persist_batch": 1 = calls of 2 .. PSB_MAX utterances run pstepb_kernel (persist_nb.hip) where the shape is covered
   int ps_gran_B = 1;          // utterances the granule buffer was sized for
   int ps_table_B = 0;         // batch the operand table was built for (the caches' layer stride depends on it)
+  int32_t* ps_epoch = nullptr; // [1] device: epoch counter of the batched launch in slot mode (PStepArgs::epoch_ctr)
+  bool ps_fold_valid = false; // ps_fold holds the row constants (they depend on the weights only: not recomputed when the table is rebuilt for another batch)
   mutable int psb_form_key = -1, psb_form_res = 0;  // pstepb_form_ok(B), cached
   int opt_ps_nk = 2, opt_ps_pf = 3;  // options "persist_nk", "persist_pf" (PStepArgs)
   int opt_ps_naps = -1;              // option "persist_naps" (-1: the engine mode's own timing, ps_naps_of)
@@ -689,7 +691,7 @@ static void release_buffers(vle_engine* e) {
   e->x_step = e->q_step = e->h_step = e->part_o = e->part_ml = e->logits = nullptr;
   e->k_new = e->v_new = nullptr; e->qgran = nullptr; e->qa_spin_fail = nullptr;
   e->ps_sample_valid = false;
-  e->ps_table = nullptr; e->ps_sample = nullptr; e->ps_fold = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0; e->ps_table_B = 0;
+  e->ps_table = nullptr; e->ps_sample = nullptr; e->ps_fold = nullptr; e->ps_gran = nullptr; e->ps_gran_n = 0; e->ps_ptrace = nullptr; e->ps_table_kc = nullptr; e->ps_table_ctx = 0; e->ps_table_B = 0; e->ps_fold_valid = false; e->ps_epoch = nullptr;
   e->xn_step = e->qkv_step = e->att_step = e->hT_step = nullptr;
   e->gs_ws = nullptr; e->ln_stats = nullptr; e->ao_part = nullptr; e->ao_cnt = nullptr;
   e->state_dev = nullptr; e->S = ArState{}; e->dyn_dev = nullptr;
@@ -1021,6 +1023,7 @@ static int alloc_buffers(vle_engine* e) {
     if ((r = dev_alloc(e, &e->ps_table, (size_t)e->L + 1))) return r;
     if ((r = dev_alloc(e, &e->ps_fold, (size_t)e->L * 14 * d + 2 * (V_AR + 3)))) return r;
     if ((r = dev_alloc(e, &e->ps_sample, (size_t)1))) return r;
+    if ((r = dev_alloc(e, &e->ps_epoch, (size_t)4))) return r;
     e->ps_host_bytes = ((size_t)e->L + 1) * sizeof(PLayer) + sizeof(PStepSample);
     E_HIP(e, hipHostMalloc((void**)&e->ps_host, e->ps_host_bytes, hipHostMallocDefault));
     debug_host_note(e->ps_host, e->ps_host_bytes, "pinned ps_host");
@@ -1406,7 +1409,7 @@ int persist_prepare(vle_engine* e) {
       PLayer& t = tab[l];
       float* f = e->ps_fold + (size_t)l * 14 * d;
       t.sgqkv = f; t.tbqkv = f + 3 * d; t.sg1 = f + 6 * d; t.tb1 = f + 10 * d;
-      if (e->dtype == DT_BF16) {  // (fp32 mode runs the three-barrier form only: no row constants)
+      if (e->dtype == DT_BF16 && !e->ps_fold_valid) {  // (fp32 mode runs the three-barrier form only: no row constants)
         E_LAUNCH(e, launch_ps_fold(e->st, w.wqkv, w.g1, w.be1, w.bqkv, f, f + 3 * d, (int)(3 * d), (int)d));
         E_LAUNCH(e, launch_ps_fold(e->st, w.w1, w.g2, w.be2, w.b1, f + 6 * d, f + 10 * d, (int)(4 * d), (int)d));
       }
@@ -1421,7 +1424,8 @@ int persist_prepare(vle_engine* e) {
     }
     {  // entry L: the predict layer behind the final norm
       float* f = e->ps_fold + (size_t)e->L * 14 * d;
-      if (e->dtype == DT_BF16) E_LAUNCH(e, launch_ps_fold(e->st, e->ar_predict, e->ar_norm_g, e->ar_norm_b, nullptr, f, f + V_AR + 3, V_AR, (int)d));
+      if (e->dtype == DT_BF16 && !e->ps_fold_valid) E_LAUNCH(e, launch_ps_fold(e->st, e->ar_predict, e->ar_norm_g, e->ar_norm_b, nullptr, f, f + V_AR + 3, V_AR, (int)d));
+      e->ps_fold_valid = true;
       PLayer& t = tab[e->L];
       t = tab[e->L - 1];  // every pointer valid
       t.wqkv = e->ar_predict; t.g1 = e->ar_norm_g; t.be1 = e->ar_norm_b; t.sgqkv = f; t.tbqkv = f + V_AR + 3;
@@ -1443,7 +1447,7 @@ int persist_prepare(vle_engine* e) {
     q.tokens = e->tokens; q.sampled = e->sampled; q.g_stride = e->max_G;
     q.audio_emb = e->ar_audio_emb; q.pe = e->pe; q.alpha_audio = e->alphas + 1; q.x = e->x_step;
     q.id_err = e->id_err_dev;
-    q.host_prog = e->opt_host_prog ? e->prog_dev : nullptr;
+    q.host_prog = (e->opt_host_prog && !e->slot_mode) ? e->prog_dev : nullptr;  // (vle_slots_step runs a fixed number of steps: nobody polls)
     if (!e->ps_sample_valid || memcmp(&q, &e->ps_sample_sent, sizeof(q)) != 0) {  // unchanged between prefills: no stall of the stream
       unsigned char* hq = e->ps_host + ((size_t)e->L + 1) * sizeof(PLayer);
       E_HIP(e, hipStreamSynchronize(e->st));
@@ -1454,7 +1458,16 @@ int persist_prepare(vle_engine* e) {
     }
   }
   E_HIP(e, hipMemsetAsync(e->ps_gran, 0, (e->ps_gran_n / e->ps_gran_B) * e->B * sizeof(unsigned long long), e->st));
+  if (e->ps_epoch) E_HIP(e, hipMemsetAsync(e->ps_epoch, 0, 4 * sizeof(int32_t), e->st));
   return 0;
+}
+
+// Slot mode (continuous batching) on engines of 2 .. PSB_MAX slots: vle_slots_step advances every live slot on the batched persistent
+// launch -- the slots are its utterances, a free slot is a stopped one (tables and granules prepared by vle_slots_begin)
+bool slot_persist_ready(const vle_engine* e) {
+  return e->slot_mode && e->opt_persist && e->ps_backoff == 0 && e->ps_device_ok && !e->opt_profile && psb_covers(e, e->max_B) && e->B == e->max_B &&
+         e->ps_table != nullptr && e->ps_gran != nullptr && e->ps_epoch != nullptr && ps_form_ok(e) && e->ps_table_kc == e->kcache &&
+         e->ps_table_ctx == e->ctx_max && e->ps_table_B == e->B && (int)e->ar.size() == e->L;
 }
 
 int enqueue_persist_step(vle_engine* e, int nsteps = 1) {
@@ -1470,6 +1483,10 @@ int enqueue_persist_step(vle_engine* e, int nsteps = 1) {
     a.smp = e->ps_sample;
   }
   a.B = e->B;
+  if (e->slot_mode) {
+    a.epoch_ctr = e->ps_epoch;
+    a.slot_seed = e->slot_seed_dev;
+  }
   const int r = e->B > 1 ? launch_pstepb(e->st, e->dtype, a) : launch_pstep(e->st, e->w8 ? DT_FP8W : e->dtype, a);
   if (r != 0) return e->fail(VLE_EINVAL, "launch_pstep rejected the step");
   return 0;
@@ -2301,6 +2318,7 @@ extern "C" int vle_slots_begin(vle_engine* e, void* stream) {
   E_HIP(e, hipMemcpyAsync(e->state_dev, e->tables_host, e->slot_state.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->st));
   // free slots run through the (row-independent) GEMMs of every step: give them finite inputs
   E_HIP(e, hipMemsetAsync(e->x_step, 0, (size_t)e->max_B * e->d * sizeof(float), e->st));
+  if ((r = persist_prepare(e))) return r;  // 2 .. PSB_MAX slots: the steps run the batched persistent launch (slot_persist_ready)
   return leave(e, stream);
 }
 
@@ -2433,8 +2451,23 @@ extern "C" int vle_slots_step(vle_engine* e, void* stream, int32_t nsteps, int32
   const int spg = e->opt_spg > 0 ? e->opt_spg : (e->cfg.steps_per_graph > 0 ? e->cfg.steps_per_graph : 8);
   const bool use_graph = e->cfg.use_graph != 0 && !e->opt_profile;
   int steps_done = 0;
+  const bool ps_call = slot_persist_ready(e) && nsteps > 0;
+  e->ps_last_call = ps_call;
+  if (ps_call) {
+    // ONE launch per call runs the nsteps iterations of every live slot, sampling and stop rule included (persist_nb.hip); a slot
+    // that stops inside the launch stays in it with a frozen cache position
+    if (e->qa_spin_fail) E_HIP(e, hipMemsetAsync(e->qa_spin_fail + 2, 0, sizeof(unsigned), st));
+    e->kt_idx = 0;
+    while (steps_done < nsteps) {
+      const int n = std::min(nsteps - steps_done, 4096);
+      if ((r = enqueue_persist_step(e, n))) return r;
+      steps_done += n;
+    }
+    e->poll_host[POLL_PSFAIL] = 0;
+    if (e->qa_spin_fail) E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_PSFAIL, e->qa_spin_fail + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
+  }
   hipGraphExec_t g_multi = nullptr, g_single = nullptr;
-  if (use_graph && nsteps > 0) {
+  if (use_graph && nsteps > 0 && !ps_call) {
     auto it = e->graphs.find(B * 64 + e->nsplit);
     if (it == e->graphs.end()) {
       if ((r = enqueue_ar_step(e))) return r;  // first step eagerly (kernel attributes are set outside capture)
@@ -2466,6 +2499,19 @@ extern "C" int vle_slots_step(vle_engine* e, void* stream, int32_t nsteps, int32
     e->G_len[b] = e->slot_state[2 * e->max_B + b];
     if (done_out) done_out[b] = e->slot_state[3 * e->max_B + b];
     if (gen_lens_out) gen_lens_out[b] = e->G_len[b];
+  }
+  if (ps_call) {
+    e->ps_last_fail = (unsigned)e->poll_host[POLL_PSFAIL];
+    if (e->ps_last_fail != 0) {  // the launch could not keep the whole GPU: the slots' state is void
+      ++e->ps_fallbacks;
+      e->ps_backoff = e->ps_backoff_next;
+      e->ps_backoff_next = std::min(64, 2 * e->ps_backoff_next);
+      e->slot_mode = false;
+      (void)leave(e, stream);
+      return e->fail(VLE_EBUSY, "the persistent AR launch could not keep the whole GPU (a wave gave up waiting for an in-launch hand-off: GPU shared "
+                                "with another workload?): the slots' utterances are lost; call vle_slots_begin and admit them again -- the engine "
+                                "runs the launch chain for its next calls and re-arms the persistent launch by itself");
+    }
   }
   return leave(e, stream);
 }

@@ -289,6 +289,11 @@ struct PStepArgs {
   int nk = 2;                      // "persist_nk": keys per lane per round of the attention share (2: 1024 keys in one round; 4)
   int pf = 3;                      // "persist_pf": when the compute waves request an operator's operands (persist.hip): 0 = in one burst right
                                    // before the sweep that precedes the operator, 3 = linear1 / linear2 spread over three sweeps (default)
+  // slot mode of the batched launch (vle_slots_step on engines of 2 .. PSB_MAX slots): the slots' iteration counters differ (each restarts
+  // at its admission), so the granules' epoch comes from a counter of its own that only ever grows between two vle_slots_begin calls
+  // (null: epoch = iteration + 1), and slot b draws from the RNG stream of the request it holds (null: request_seed(dyn.seed, b))
+  int32_t* epoch_ctr = nullptr;
+  const unsigned long long* slot_seed = nullptr;
   int B = 1;                       // utterances in the launch: 1 = pstep_kernel (persist.hip); 2 .. PSB_MAX = pstepb_kernel (persist_nb.hip: x_in
                                    // [B][d], logits [B][V], kv_len / iter / done [B], gran sized by pstepb_gran_count, the caches [B][H][ctx_max][dh])
 };

@@ -223,13 +223,17 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
   const int h = (c & 7) * (H / 8) + jj / NS, s = jj % NS;
 
   unsigned live = 0u;  // bit b: utterance b has not stopped
-  int it = 0;
+  int itb[NB];         // AR iteration of utterance b: its Philox counter and its row of the logits trace
+  int it = 0;          // the launch's step counter: epoch of the granules = it + 1
 #pragma unroll
-  for (int b = 0; b < NB; ++b)
+  for (int b = 0; b < NB; ++b) {
+    itb[b] = a.iter[b];
     if (!a.done[b]) {
       live |= 1u << b;
-      it = a.iter[b];  // (the same for every utterance still running: they step together from the prefill)
+      it = itb[b];  // (batch calls: the same for every utterance still running -- they step together from the prefill)
     }
+  }
+  if (a.epoch_ctr != nullptr) it = a.epoch_ctr[0];  // slot mode: the slots' iteration counters differ, the epochs follow a counter of their own
   if (live == 0u) {  // every utterance has stopped: the remaining launches of the host's queue are no-ops that still report
     if (a.nsteps > 0 && c == 0 && tid == 0) {
       const PStepSample q = ps_sample_load(a.smp);
@@ -914,8 +918,8 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
           const int idx = tid * SAMP_PER + j;
           raw[j] = idx < V ? slog[idx] : -INFINITY;
         }
-        if (c == 0 && dyn.trace != nullptr && it < dyn.trace_cap) {
-          float* tr = dyn.trace + ((int64_t)it * a.B + b) * V;
+        if (c == 0 && dyn.trace != nullptr && itb[b] < dyn.trace_cap) {
+          float* tr = dyn.trace + ((int64_t)itb[b] * a.B + b) * V;
 #pragma unroll
           for (int j = 0; j < SAMP_PER; ++j) {
             const int idx = tid * SAMP_PER + j;
@@ -923,8 +927,8 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
           }
         }
         const int argmax = argmax_row(raw, V, red64);
-        const int sample = sample_row(raw, V, dyn.top_k, dyn.temperature, request_seed(dyn.seed, (unsigned long long)b), (uint32_t)it, argmax,
-                                      SampScratch{red64, redi, redf, wave_tot});
+        const unsigned long long rseed = a.slot_seed != nullptr ? a.slot_seed[b] : request_seed(dyn.seed, (unsigned long long)b);
+        const int sample = sample_row(raw, V, dyn.top_k, dyn.temperature, rseed, (uint32_t)itb[b], argmax, SampScratch{red64, redi, redf, wave_tot});
         __syncthreads();  // the row and the scratch words are free for the next utterance
         // stop rule (valle.py:1044-1048) and bookkeeping: the same integers in every workgroup; workgroup 0 stores them
         const int kvl1 = kvl[b] + 1;
@@ -954,8 +958,9 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
             if (n_gen[b] < (int)q.g_stride) q.sampled[(int64_t)b * q.g_stride + n_gen[b]] = sample;  // the stopping iteration's own draw
             q.s.done[b] = 1;
           }
-          q.s.iter[b] = it + 1;
+          q.s.iter[b] = itb[b] + 1;
         }
+        itb[b] += 1;
         if (stop) {
           stopped |= 1u << b;
         } else {
@@ -975,6 +980,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
           __hip_atomic_store(q.host_prog + 1, sc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         }
         if (nd) q.s.done_count[0] = dcount + nd;
+        if (a.epoch_ctr != nullptr) a.epoch_ctr[0] = it + 1;  // (read again only by the next launch)
       }
       dcount += __builtin_popcount(stopped);
       live = live_after;

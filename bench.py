@@ -49,7 +49,7 @@ HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (/opt/skills/guides/MI355X_MICRO
 S_TEXT, P_PROMPT = 47, 225  # 47 phonemes, 3 s x 75 Hz prompt
 TRAFFIC_FILE = os.path.join(ROOT, "profiles", "ar_step_traffic.json")    # tools/make_traffic.py from the PMC passes
 CPU_CACHE_FILE = os.path.join(ROOT, "profiles", "cpu_baseline_n1.json")  # the N = 1 line's cpu_baseline, committed
-AR_STEP_KERNEL_SOURCES = ("persist.hip", "gemv1_dev.h", "sampling_dev.h", "gemv1.hip", "sampling.hip", "common.h")  # the batch-1 AR step's kernels
+AR_STEP_KERNEL_SOURCES = ("persist.hip", "persist_dev.h", "gemv1_dev.h", "sampling_dev.h", "gemv1.hip", "sampling.hip", "common.h")  # the batch-1 AR step's kernels
 N1_REF_FILE = os.path.join(ROOT, "profiles", "bench_n1_reference.json")  # value / c3_batch64.value of the committed N = 1 line (scale_ref)
 FRAME_RATE = 75.0  # EnCodec frames per second of audio (valle/data/tokenizer.py: 24 kHz / 320)
 

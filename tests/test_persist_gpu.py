@@ -325,6 +325,42 @@ def test_model_falls_back_to_the_launch_chain_when_the_persistent_launch_gives_u
     assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0 and torch.equal(got, want)
 
 
+def test_batched_persistent_launch_gives_up_falls_back_and_rearms(small_batch_model, capfd):
+    """The same contract for a call of three utterances on the batched persistent launch: a give-up ends the call with VLE_EBUSY, the
+    model API repeats the decode from the prefill on the launch chain, the engine backs off (batches of 2 .. 4 count its back-off down)
+    and re-arms the batched launch by itself -- the request survives."""
+    m = small_batch_model
+    X, Y, S, P = _ragged_batch(3)
+    lens = torch.tensor(S, dtype=torch.int32)
+    eng = m.engine_for(4, max(S), max(P))
+    _engine_defaults(eng)
+    eng.set_option("ignore_eos", 1)
+    eng.set_option("persist_rearm", 1)
+    want = m.inference_batch(X, lens, Y, P, None, top_k=1, max_new=24)
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+    f0 = eng.fetch_u32("persist_fallbacks")
+    eng.set_option("persist_inject_fail", 1)
+    eng.prefill(X, S, Y, P)
+    with pytest.raises(valle_amd._lib.VleError) as ei:
+        eng.generate(top_k=1, max_new=24)
+    assert ei.value.code == valle_amd._lib.VLE_EBUSY
+    assert eng.fetch_u32("persist_fallbacks") == f0 + 1 and eng.fetch_u32("persist_backoff") == 2 and eng.fetch_u32("persist_batch_capable") == 0
+    for left in (1, 0):  # two calls on the chain (the first tokens of two free-running bf16 paths agree), then the batched launch is back
+        got = m.inference_batch(X, lens, Y, P, None, top_k=1, max_new=24)
+        assert eng.fetch_u32("persist_ran") == 0 and eng.fetch_u32("persist_backoff") == left
+        assert all(torch.equal(g[:3, 0], w[:3, 0]) for g, w in zip(got, want))
+    got = m.inference_batch(X, lens, Y, P, None, top_k=1, max_new=24)
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0 and all(torch.equal(g, w) for g, w in zip(got, want))
+    capfd.readouterr()
+    eng.set_option("persist_inject_fail", 1)
+    got = m.inference_batch(X, lens, Y, P, None, top_k=1, max_new=24)  # through the model API: repeated on the chain
+    assert "launch chain" in capfd.readouterr().err and eng.fetch_u32("persist_ran") == 0
+    assert all(g.shape == w.shape and torch.equal(g[:3, 0], w[:3, 0]) for g, w in zip(got, want))
+    eng.set_option("persist_rearm", 1)
+    got = m.inference_batch(X, lens, Y, P, None, top_k=1, max_new=24)
+    assert eng.fetch_u32("persist_ran") == 1 and all(torch.equal(g, w) for g, w in zip(got, want))
+
+
 def test_decode_with_caller_buffers_at_the_edge_of_their_mappings():
     """Every caller-owned input of the decode path (text, prompt codes, forced tokens, forced NAR history) in a virtual-memory
     mapping of its own that ENDS (then: starts) at the buffer's last (first) byte, an unmapped page behind (in front): a kernel of
@@ -451,6 +487,35 @@ def test_batched_persistent_launch_is_bit_identical_to_one_utterance_launches(sm
         eng.set_option("persist", 1)
     for b in range(B):
         assert chain[b].shape == got[b].shape and torch.equal(chain[b][:3], got[b][:3]), b
+
+
+def test_batched_persistent_launch_past_1024_keys(small_batch_model):
+    """Contexts beyond 1024 keys: a workgroup's attention share of an utterance takes further rounds of key chunks (per utterance, after
+    the first round all utterances run in lockstep) -- two utterances of different lengths, one crossing 1024 keys 200 steps before the
+    other and both ending near 1 350; every logit and token equal to the one-utterance launch."""
+    m = small_batch_model
+    S, P = [70, 68], [100, 60]  # (each prefill, alone and packed, is >= 128 rows: the same GEMM family rounds the cached keys)
+    g = torch.Generator().manual_seed(77)
+    X = torch.zeros(2, max(S), dtype=torch.int64)
+    Y = torch.zeros(2, max(P), 8, dtype=torch.int64)
+    for b in range(2):
+        X[b, : S[b]] = torch.randint(3, 100, (S[b],), generator=g)
+        X[b, 0], X[b, S[b] - 1] = 1, 2
+        Y[b, : P[b]] = torch.randint(0, 1024, (P[b], 8), generator=g)
+    X, Y = X.to(DEV), Y.to(DEV)
+    eng = m.engine_for(4, max(S), max(P))
+    _engine_defaults(eng)
+    eng.set_option("ignore_eos", 1)
+    got, lg = _batch_decode(eng, X, Y, S, P, 0, top_k=1)  # to the reference's own caps: 16 S + 1 = 1121 / 1025 frames
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+    assert [int(t.numel()) for t in got] == [16 * S[0] + 1, 16 * S[1] + 1]
+    for b in range(2):
+        one, lg1 = _batch_decode(eng, X[b : b + 1, : S[b]], Y[b : b + 1, : P[b]], S[b : b + 1], P[b : b + 1], 0, top_k=1)
+        assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
+        assert torch.equal(got[b], one[0]), b
+        n = one[0].numel()
+        assert S[b] + P[b] + n > 1024 + 64
+        assert torch.equal(lg[1:n, b], lg1[1:n, 0]), f"utterance {b}: first differing step {int((lg[1:n, b] != lg1[1:n, 0]).any(-1).nonzero()[0]) + 1}"
 
 
 def test_batched_persistent_launch_utterances_stop_on_eos_at_their_own_steps(eos_model):

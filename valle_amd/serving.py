@@ -8,6 +8,9 @@ prefilled into the free slot while the other slots keep decoding.  Every arithme
 What an utterance decodes to is independent of its batch mates: greedy decodes are token-identical to ``VALLE.inference``,
 and sampled decodes draw from an RNG stream keyed on (seed, request index, iteration) -- not on the slot -- so they do not
 depend on ``max_batch`` / scheduling either and equal ``VALLE.inference_batch`` with the same seed.
+Engines of 2 .. 4 slots (bf16, d1024-h16) advance their live slots on the batched persistent launch (csrc/persist_nb.hip): one launch per
+``slots_step`` call; if that launch cannot keep the whole GPU the call raises ``VleError(VLE_EBUSY)`` and the session's utterances have to
+be admitted again (the engine then runs the launch chain for its next calls).
 """
 from __future__ import annotations
 

@@ -134,3 +134,40 @@ def test_malformed_requests_are_rejected_before_anything_is_scheduled():
     with pytest.raises(AssertionError):
         cb.decode([Request(torch.zeros(2, dtype=torch.int64), torch.zeros(1, 4, dtype=torch.int64))])  # fewer codebooks than the model's
     assert eng.began == 0 and not eng.log
+
+
+def test_a_busy_gpu_costs_the_session_not_the_requests():
+    """Engines of 2 .. 4 slots step on the batched persistent launch (csrc/persist_nb.hip); when that launch cannot keep the whole GPU
+    vle_slots_step answers VLE_EBUSY and the slots' utterances are void.  The batcher puts the utterances in flight back at the front of
+    the queue, opens a new session and decodes them again: every request still comes back, in request order; other errors and an
+    endless series of busy answers are passed on."""
+    from valle_amd import _lib
+
+    class BusyEngine(ScriptedEngine):
+        def __init__(self, *a, busy_at=(), code=_lib.VLE_EBUSY):
+            super().__init__(*a)
+            self.busy_at, self.code, self.steps = set(busy_at), code, 0
+
+        def slots_step(self, n, top_k, temperature, seed):
+            self.steps += 1
+            if self.steps in self.busy_at:
+                raise _lib.VleError(self.code, "scripted")
+            return super().slots_step(n, top_k, temperature, seed)
+
+    lengths = [5, 17, 9, 30, 3, 12, 8]
+    eng = BusyEngine(3, lengths, 8, busy_at={2, 5})
+    cb = ContinuousBatcher(ScriptedModel(eng), 3, max_text=8, max_prompt=4, steps_per_round=4, harvest_min=1)
+    out = cb.decode(make_requests(len(lengths)), top_k=1)
+    assert [int(o.shape[0]) for o in out] == lengths and all(int(o[0, 0]) == i for i, o in enumerate(out))
+    assert cb.stats["busy_restarts"] == 2 and eng.began == 3
+    # the first prefill after a restart holds the utterances that were in flight, in request order
+    prefills = [e[1] for e in eng.log if e[0] == "prefill"]
+    assert prefills[0] == (0, 1, 2) and prefills[1] == (0, 1, 2)
+    eng2 = BusyEngine(3, lengths, 8, busy_at={1}, code=_lib.VLE_EHIP)
+    with pytest.raises(_lib.VleError):
+        ContinuousBatcher(ScriptedModel(eng2), 3, max_text=8, max_prompt=4).decode(make_requests(len(lengths)), top_k=1)
+    eng3 = BusyEngine(3, lengths, 8, busy_at=set(range(1, 100)))
+    cb3 = ContinuousBatcher(ScriptedModel(eng3), 3, max_text=8, max_prompt=4)
+    with pytest.raises(_lib.VleError) as ei:
+        cb3.decode(make_requests(len(lengths)), top_k=1)
+    assert ei.value.code == _lib.VLE_EBUSY and cb3.stats["busy_restarts"] == cb3.max_busy_restarts

@@ -162,3 +162,25 @@ def test_small_slot_engines_step_on_the_batched_persistent_launch():
         finally:
             eng.set_option("persist", 1)
         assert all(torch.equal(c[:2, 0], g[:2, 0]) for c, g in zip(chain, cb.decode(reqs, top_k=1)))
+
+
+def test_small_slot_engine_survives_a_busy_gpu():
+    """The batched persistent launch gives up (option persist_inject_fail: the DEVICE counter, as a wave that gives up sets it): the slot
+    session ends with VLE_EBUSY, the batcher re-admits the utterances in flight in a new session, which the engine runs on the launch chain
+    (its back-off counts slot sessions); the session after that is on the persistent launch again.  Every request comes back."""
+    torch.manual_seed(33)
+    m = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16", max_batch=3).to(DEV).eval()
+    ins = _requests(5, 11, smin=4, smax=6, pmin=6, pmax=12)
+    reqs = [Request(x[0], y[0]) for x, _, y in ins]
+    cb = ContinuousBatcher(m, 3, max_text=8, max_prompt=18, steps_per_round=8, harvest_min=1)
+    eng = cb.eng
+    eng.set_option("ignore_eos", 1)
+    want = cb.decode(reqs, top_k=1)
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0 and cb.stats["busy_restarts"] == 0
+    eng.set_option("persist_inject_fail", 1)
+    got = cb.decode(reqs, top_k=1)
+    assert cb.stats["busy_restarts"] == 1 and eng.fetch_u32("persist_ran") == 0, "the re-admitted session runs the launch chain"
+    assert all(g.shape == w.shape and torch.equal(g[:2, 0], w[:2, 0]) for g, w in zip(got, want))
+    again = cb.decode(reqs, top_k=1)  # the next session: back on the persistent launch, the same bits as the undisturbed run
+    assert eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0 and cb.stats["busy_restarts"] == 1
+    assert all(torch.equal(g, w) for g, w in zip(again, want))

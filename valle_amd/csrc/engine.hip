@@ -2318,6 +2318,9 @@ extern "C" int vle_slots_begin(vle_engine* e, void* stream) {
   E_HIP(e, hipMemcpyAsync(e->state_dev, e->tables_host, e->slot_state.size() * sizeof(int32_t), hipMemcpyHostToDevice, e->st));
   // free slots run through the (row-independent) GEMMs of every step: give them finite inputs
   E_HIP(e, hipMemsetAsync(e->x_step, 0, (size_t)e->max_B * e->d * sizeof(float), e->st));
+  // after VLE_EBUSY the engine stays on the launch chain for `ps_backoff` calls: a slot session counts as one (the session that follows
+  // the failed one runs the chain, the one after it the persistent launch again; doubling while it keeps happening)
+  if (e->ps_backoff > 0 && e->max_B >= 2 && e->max_B <= PSB_MAX) --e->ps_backoff;
   if ((r = persist_prepare(e))) return r;  // 2 .. PSB_MAX slots: the steps run the batched persistent launch (slot_persist_ready)
   return leave(e, stream);
 }
@@ -2464,6 +2467,10 @@ extern "C" int vle_slots_step(vle_engine* e, void* stream, int32_t nsteps, int32
       steps_done += n;
     }
     e->poll_host[POLL_PSFAIL] = 0;
+    if (e->dbg_inject_psfail > 0 && e->qa_spin_fail) {  // test hook: as if one wave had given up
+      --e->dbg_inject_psfail;
+      E_HIP(e, hipMemsetAsync(e->qa_spin_fail + 2, 1, 1, st));
+    }
     if (e->qa_spin_fail) E_HIP(e, hipMemcpyAsync(e->poll_host + POLL_PSFAIL, e->qa_spin_fail + 2, sizeof(int32_t), hipMemcpyDeviceToHost, st));
   }
   hipGraphExec_t g_multi = nullptr, g_single = nullptr;
@@ -2512,6 +2519,7 @@ extern "C" int vle_slots_step(vle_engine* e, void* stream, int32_t nsteps, int32
                                 "with another workload?): the slots' utterances are lost; call vle_slots_begin and admit them again -- the engine "
                                 "runs the launch chain for its next calls and re-arms the persistent launch by itself");
     }
+    e->ps_backoff_next = 2;
   }
   return leave(e, stream);
 }

@@ -20,6 +20,7 @@ from typing import List, Optional, Sequence
 
 import torch
 
+from . import _lib
 from .model import VALLE
 
 
@@ -46,7 +47,8 @@ class ContinuousBatcher:
         self.model, self.max_batch, self.steps_per_round = model, max_batch, steps_per_round
         self.harvest_min = max(1, max_batch // 8) if harvest_min is None else max(1, int(harvest_min))
         self.eng = model.engine_for(max_batch, max_text, max_prompt)
-        self.stats = dict(rounds=0, admitted=0, ar_steps=0, harvests=0)
+        self.stats = dict(rounds=0, admitted=0, ar_steps=0, harvests=0, busy_restarts=0)
+        self.max_busy_restarts = 8  # sessions restarted after VLE_EBUSY before the error is passed on
 
     @torch.no_grad()
     def decode(self, requests: Sequence[Request], top_k: int = 1, temperature: float = 1.0, seed: int = 0) -> List[torch.Tensor]:
@@ -78,7 +80,22 @@ class ContinuousBatcher:
                 for s, i in zip(slots, take):
                     live[s] = i
                 self.stats["admitted"] += len(take)
-            done, gl = eng.slots_step(self.steps_per_round, top_k, temperature, seed)
+            try:
+                done, gl = eng.slots_step(self.steps_per_round, top_k, temperature, seed)
+            except _lib.VleError as err:
+                # engines of 2 .. 4 slots step on the batched persistent launch, which needs the whole GPU: when it could not keep it
+                # (VLE_EBUSY) the session's slots are void.  The requests are not: the utterances in flight go back to the FRONT of the
+                # queue (request order is kept) and are decoded again in a new session -- the engine runs the launch chain for its next
+                # calls and re-arms the persistent launch by itself.  A shared GPU costs time, not a request.
+                if err.code != _lib.VLE_EBUSY or self.stats["busy_restarts"] >= self.max_busy_restarts:
+                    raise
+                self.stats["busy_restarts"] += 1
+                for i in sorted(live.values(), reverse=True):
+                    pending.appendleft(i)
+                live.clear()
+                free = list(range(B))
+                eng.slots_begin()
+                continue
             self.stats["rounds"] += 1
             self.stats["ar_steps"] += self.steps_per_round
             fin = [s for s in live if done[s]]

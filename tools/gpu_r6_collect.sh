@@ -34,3 +34,4 @@ for SET in "FETCH_SIZE" "WRITE_SIZE"; do
   python tools/pmc_summary.py $(find /tmp/pmc_run -name "*counter_collection.csv" | head -1) $D/pmc_b4_${SET}_by_kernel.csv
 done
 timeout 600 python tools/persist_nb_probe.py --out $D --trace > $D/persist_nb_probe.log 2>&1; echo "persist nb probe rc=$?"; grep "\[time\]" $D/persist_nb_probe.log | cut -c1-300
+timeout 300 python tools/persist_nb_stress.py 150 > $D/persist_nb_stress.log 2>&1; echo "persist nb stress rc=$?"; tail -n 1 $D/persist_nb_stress.log

@@ -656,7 +656,7 @@ def main():
     if plain and world == 1 and not args.no_side:
         # 4 utterances share ONE persistent launch (csrc/persist_nb.hip, round 6): the small-batch serving point between the headline and c3
         leg("batch4", lambda: side_leg(sd_all, args, dev, rank, world, 4, args.dtype, steps=3, warmup=1,
-                                       label="; 2 .. 4 utterances run the batched persistent AR launch (weights streamed once per step for all of them)"), False)
+                                       label="; 2 .. 6 utterances run the batched persistent AR launch (weights streamed once per step for all of them)"), False)
     if plain and not args.no_c3:
         c3 = leg("c3_batch64", lambda: side_leg(sd_all, args, dev, rank, world, 64, args.dtype), True)
         if out is not None and isinstance(c3, dict) and "value" in c3:

@@ -39,7 +39,7 @@ extern "C" {
                              >= 1024, or negative): the reference's nn.Embedding raises IndexError
                              (valle/modules/embedding.py:34,44).  The engine replaced the id by 0 before using it. */
 #define VLE_EBUSY (-7)    /* vle_ar_generate / vle_slots_step: the persistent AR launch (one workgroup per CU for the whole AR loop;
-                             1 .. 4 utterances) could not keep the whole GPU -- another workload held CUs for > 0.1 s and a wave
+                             1 .. 6 utterances) could not keep the whole GPU -- another workload held CUs for > 0.1 s and a wave
                              gave up waiting.  This call's tokens are invalid.  Repeat vle_ar_prefill + vle_ar_generate (slot mode:
                              vle_slots_begin and admit the utterances again): the engine runs its next such calls on the launch
                              chain (2, then 4 ... 64 calls while it keeps happening) and re-arms the persistent launch by itself.
@@ -195,13 +195,13 @@ int vle_slots_harvest(vle_engine* e, void* stream, int32_t n, const int32_t* slo
  *          "persist_pf" (0 | 3 operand request schedule), "persist_nk" (2 keys per lane) -- since round 6 only the shipped forms are compiled:
  *          other values (pf 1 / 2, nk 4, packing modes the measurements dropped) make the call run the launch chain --, "persist_naps" (first-sweep waits, 4 bits
  *          per edge; -1 = the engine mode's measured default: bf16 0x325756, fp8 weight rows 0x214645, fp32 0x217645), "persist_trace" (in-kernel timeline), "act_bf16" (the chain's matching roundings).
- *          "persist_batch" (default 1: calls of 2 .. 4 utterances on bf16 engines -- vle_ar_generate and, on engines of 2 .. 4 slots,
+ *          "persist_batch" (default 1: calls of 2 .. 6 utterances on bf16 engines -- vle_ar_generate and, on engines of 2 .. 6 slots,
  *          vle_slots_step -- run the batched persistent launch, valle_amd/csrc/persist_nb.hip, DESIGN.md 4.2: the default form only; per utterance
- *          bit-identical to the one-utterance launch; 0 = the launch chain; first-sweep waits per batch 0x405745 / 0x305752 / 0x317780),
+ *          bit-identical to the one-utterance launch; 0 = the launch chain; first-sweep waits per batch 0x405745 / 0x305752 / 0x317780 / 0x006876 / 0x007860),
  *          "persist_rearm" (any value: forget the back-off after VLE_EBUSY), "persist_inject_fail" (n: the next n persistent calls
  *          end as if a wave had given up -- the test hook of the VLE_EBUSY path).
  *   debug words of vle_debug_fetch for it: "persist_active" (the next batch-1 call would run it), "persist_capable" (a ONE-utterance call on this engine
- *   would, whatever the batch of the last prefill), "persist_batch_capable" (the largest batch, 0 or 2 .. 4, a call on this engine would run on the
+ *   would, whatever the batch of the last prefill), "persist_batch_capable" (the largest batch, 0 or 2 .. 6, a call on this engine would run on the
  *   batched persistent launch: valle_amd.VALLE.inference_batch decodes two utterances one after the other only where this says 0), "persist_ran" (the LAST
  *   vle_ar_generate / vle_slots_step did), "persist_fail" (waves that gave up in the last call; 0 in a healthy run), "persist_fallbacks" (calls that
  *   ended with VLE_EBUSY since vle_create), "persist_backoff" (batch-1 calls left on the launch chain before it is re-armed),

@@ -107,7 +107,7 @@ class TwoUtteranceEngine(ScriptedEngine):
 
 @pytest.mark.parametrize("batch_capable,capable,want", [(4, 1, [2]), (2, 1, [2]), (0, 1, [1, 1]), (0, 0, [2])])
 def test_two_utterances_take_the_batched_persistent_launch_where_the_engine_offers_it(model, monkeypatch, batch_capable, capable, want):
-    """Round 6 policy of VALLE.inference_batch at two utterances (valle_amd/model.py): ONE call where the engine runs 2 .. 4 utterances on
+    """Round 6 policy of VALLE.inference_batch at two utterances (valle_amd/model.py): ONE call where the engine runs 2 .. 6 utterances on
     the batched persistent launch (csrc/persist_nb.hip); one after the other where only the one-utterance launch exists (the batched
     launch chain is slower than that, profiles/r06_small_batch.json); the batched chain where neither does."""
     eng = TwoUtteranceEngine(batch_capable, capable)

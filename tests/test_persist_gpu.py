@@ -327,12 +327,12 @@ def test_model_falls_back_to_the_launch_chain_when_the_persistent_launch_gives_u
 
 def test_batched_persistent_launch_gives_up_falls_back_and_rearms(small_batch_model, capfd):
     """The same contract for a call of three utterances on the batched persistent launch: a give-up ends the call with VLE_EBUSY, the
-    model API repeats the decode from the prefill on the launch chain, the engine backs off (batches of 2 .. 4 count its back-off down)
+    model API repeats the decode from the prefill on the launch chain, the engine backs off (batches of 2 .. 6 count its back-off down)
     and re-arms the batched launch by itself -- the request survives."""
     m = small_batch_model
     X, Y, S, P = _ragged_batch(3)
     lens = torch.tensor(S, dtype=torch.int32)
-    eng = m.engine_for(4, max(S), max(P))
+    eng = m.engine_for(6, max(S), max(P))
     _engine_defaults(eng)
     eng.set_option("ignore_eos", 1)
     eng.set_option("persist_rearm", 1)
@@ -415,8 +415,9 @@ def test_option_sets_without_an_instantiated_form_run_the_launch_chain(c2_model)
 
 def _ragged_batch(B, seed=5):
     # (the packed prefill of all four stays below 128 rows: from there on the engine picks another GEMM tiling, whose summation order --
-    #  hence the cached keys -- differs in the last bf16 bit from the one-utterance prefill the bit-identity tests compare with)
-    S, P = [9, 14, 11, 17][:B], [12, 20, 16, 14][:B]
+    #  hence the cached keys -- differs in the last bf16 bit from the one-utterance prefill the bit-identity tests compare with:
+    #  21 + 34 + 20 + 20 + 13 + 17 = 125 rows at six utterances)
+    S, P = [9, 14, 11, 12, 8, 10][:B], [12, 20, 9, 8, 5, 7][:B]
     g = torch.Generator().manual_seed(seed)
     X = torch.zeros(B, max(S), dtype=torch.int64)
     Y = torch.zeros(B, max(P), 8, dtype=torch.int64)
@@ -445,21 +446,21 @@ def _batch_decode(eng, X, Y, S, P, steps, **kw):
 @pytest.fixture(scope="module")
 def small_batch_model():
     torch.manual_seed(21)
-    return valle_amd.VALLE(1024, 16, 3, prefix_mode=1, engine_dtype="bf16", max_batch=4).to(DEV).eval()
+    return valle_amd.VALLE(1024, 16, 3, prefix_mode=1, engine_dtype="bf16", max_batch=6).to(DEV).eval()
 
 
-@pytest.mark.parametrize("B", [2, 3, 4])
+@pytest.mark.parametrize("B", [2, 3, 4, 5, 6])
 def test_batched_persistent_launch_is_bit_identical_to_one_utterance_launches(small_batch_model, B):
-    """Round 6: 2 .. 4 utterances share ONE persistent launch (csrc/persist_nb.hip: the weights are requested once per step and
+    """Round 6: 2 .. 6 utterances share ONE persistent launch (csrc/persist_nb.hip: the weights are requested once per step and
     multiplied with every utterance's row; every edge carries B rows).  Per utterance the arithmetic is the one-utterance launch's
     default form on the same lane <-> element mapping, so every logit and token of utterance b must be BIT-IDENTICAL to a
     one-utterance decode of utterance b alone -- ragged lengths, greedy and sampled (utterance b draws from request b's stream)."""
     m = small_batch_model
     X, Y, S, P = _ragged_batch(B)
-    eng = m.engine_for(4, max(S), max(P))
+    eng = m.engine_for(6, max(S), max(P))
     _engine_defaults(eng)
     eng.set_option("ignore_eos", 1)
-    assert eng.fetch_u32("persist_batch_capable") == 4
+    assert eng.fetch_u32("persist_batch_capable") == 6
     steps = 40
     for kw in (dict(top_k=1), dict(top_k=20, temperature=0.9, seed=1234)):
         got, lg = _batch_decode(eng, X, Y, S, P, steps, **kw)
@@ -503,7 +504,7 @@ def test_batched_persistent_launch_past_1024_keys(small_batch_model):
         X[b, 0], X[b, S[b] - 1] = 1, 2
         Y[b, : P[b]] = torch.randint(0, 1024, (P[b], 8), generator=g)
     X, Y = X.to(DEV), Y.to(DEV)
-    eng = m.engine_for(4, max(S), max(P))
+    eng = m.engine_for(6, max(S), max(P))
     _engine_defaults(eng)
     eng.set_option("ignore_eos", 1)
     got, lg = _batch_decode(eng, X, Y, S, P, 0, top_k=1)  # to the reference's own caps: 16 S + 1 = 1121 / 1025 frames
@@ -523,13 +524,13 @@ def test_batched_persistent_launch_utterances_stop_on_eos_at_their_own_steps(eos
     launch with a frozen cache slot and nothing of it is stored any more; the launch ends when the last one has stopped.  Lengths and
     tokens of every utterance equal its own one-utterance decode."""
     m = eos_model
-    X, Y, S, P = _ragged_batch(4, seed=9)
-    eng = m.engine_for(4, max(S), max(P))
+    X, Y, S, P = _ragged_batch(6, seed=9)
+    eng = m.engine_for(6, max(S), max(P))
     _engine_defaults(eng)
     eng.set_option("ignore_eos", 0)
     lens = torch.tensor(S, dtype=torch.int32)
     for kw in (dict(top_k=1), dict(top_k=-100, temperature=1.3, seed=77)):
-        for B in (2, 3, 4):
+        for B in (2, 3, 4, 6):
             got = m.inference_batch(X[:B], lens[:B], Y[:B], P[:B], None, max_new=64, **kw)
             assert m.sequential_timings is None and eng.fetch_u32("persist_ran") == 1 and eng.fetch_u32("persist_fail") == 0
             for b in range(B):
@@ -550,7 +551,7 @@ def test_two_utterances_are_decoded_one_after_the_other_where_the_batched_launch
     m = small_batch_model
     X, Y, S, P = _ragged_batch(2)
     lens = torch.tensor(S, dtype=torch.int32)
-    eng = m.engine_for(4, max(S), max(P))
+    eng = m.engine_for(6, max(S), max(P))
     _engine_defaults(eng)
     eng.set_option("ignore_eos", 1)
     eng.set_option("persist_batch", 0)
@@ -605,15 +606,15 @@ def test_persistent_step_is_the_default_where_covered_and_only_there():
         assert e2.fetch_u32("persist_active") == 0, (dtype, d)
         codes, gl = e2.generate(top_k=1, max_new=4)
         assert gl[0] >= 1
-    # two utterances (bf16, round 6): the batched persistent launch (persist_nb.hip); five: the launch chain; fp32 engines: the chain
-    m3 = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16", max_batch=5).to(DEV).eval()
-    e3 = m3.engine_for(5, 8, 10)
+    # two utterances (bf16, round 6): the batched persistent launch (persist_nb.hip, 2 .. 6 utterances); seven: the launch chain; fp32 engines: the chain
+    m3 = valle_amd.VALLE(1024, 16, 2, prefix_mode=1, engine_dtype="bf16", max_batch=7).to(DEV).eval()
+    e3 = m3.engine_for(7, 8, 10)
     X2, Y2 = torch.cat([X, X]), torch.cat([Y, Y])
     e3.prefill(X2, [8, 8], Y2, [10, 10])
     assert e3.fetch_u32("persist_active") == 1
     codes, gl = e3.generate(top_k=1, max_new=6)
     assert e3.fetch_u32("persist_ran") == 1 and e3.fetch_u32("persist_fail") == 0 and min(gl) >= 1
-    e3.prefill(torch.cat([X] * 5), [8] * 5, torch.cat([Y] * 5), [10] * 5)
+    e3.prefill(torch.cat([X] * 7), [8] * 7, torch.cat([Y] * 7), [10] * 7)
     assert e3.fetch_u32("persist_active") == 0
     codes, gl = e3.generate(top_k=1, max_new=4)
     assert e3.fetch_u32("persist_ran") == 0 and min(gl) >= 1

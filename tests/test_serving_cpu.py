@@ -137,7 +137,7 @@ def test_malformed_requests_are_rejected_before_anything_is_scheduled():
 
 
 def test_a_busy_gpu_costs_the_session_not_the_requests():
-    """Engines of 2 .. 4 slots step on the batched persistent launch (csrc/persist_nb.hip); when that launch cannot keep the whole GPU
+    """Engines of 2 .. 6 slots step on the batched persistent launch (csrc/persist_nb.hip); when that launch cannot keep the whole GPU
     vle_slots_step answers VLE_EBUSY and the slots' utterances are void.  The batcher puts the utterances in flight back at the front of
     the queue, opens a new session and decodes them again: every request still comes back, in request order; other errors and an
     endless series of busy answers are passed on."""

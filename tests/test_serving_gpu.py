@@ -127,7 +127,7 @@ def test_single_slot_serving_on_the_fused_batch1_step():
 
 
 def test_small_slot_engines_step_on_the_batched_persistent_launch():
-    """Round 6: on engines of 2 .. 4 slots (bf16, d1024-h16) vle_slots_step advances the live slots on the batched persistent launch
+    """Round 6: on engines of 2 .. 6 slots (bf16, d1024-h16) vle_slots_step advances the live slots on the batched persistent launch
     (csrc/persist_nb.hip) -- the slots are its utterances, a free or finished slot is a stopped one, every slot keeps its own
     iteration counter (Philox counter) while the hand-off epochs follow a counter of the session.  More requests than slots, ragged
     lengths, utterances stopping on EOS at their own steps, admissions while the other slots are mid-decode: every request's AR tokens

@@ -1,5 +1,5 @@
 #!/usr/bin/env python
-"""The batched persistent AR launch (valle_amd/csrc/persist_nb.hip, 2 .. 4 utterances per launch) on one GPU:
+"""The batched persistent AR launch (valle_amd/csrc/persist_nb.hip, 2 .. 6 utterances per launch) on one GPU:
    python tools/persist_nb_probe.py --out gpurun_out/r6n [--batches 2 3 4] [--steps 300] [--tune] [--trace]
  1. microseconds per AR step of the launch chain, of the one-utterance launch and of the batched launch at BASELINE configs[1]'s shape;
  2. --tune: coordinate descent over the six first-sweep waits ("persist_naps", 4 bits per edge) per batch;
@@ -36,7 +36,7 @@ def timed(eng, X, Y, B, steps, opts, reps=2):
 
 def main():
     ap = argparse.ArgumentParser()
-    ap.add_argument("--batches", type=int, nargs="*", default=[2, 3, 4])
+    ap.add_argument("--batches", type=int, nargs="*", default=[2, 3, 4, 5, 6])
     ap.add_argument("--steps", type=int, default=300)
     ap.add_argument("--out", default="gpurun_out/persist_nb_probe")
     ap.add_argument("--tune", action="store_true")
@@ -46,10 +46,10 @@ def main():
     os.makedirs(args.out, exist_ok=True)
     dev = torch.device("cuda", 0)
     torch.manual_seed(0)
-    model = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16", max_batch=4).to(dev).eval()
-    eng = model.engine_for(4, S_TEXT, P_PROMPT)
+    model = valle_amd.VALLE(1024, 16, 12, prefix_mode=1, engine_dtype="bf16", max_batch=6).to(dev).eval()
+    eng = model.engine_for(6, S_TEXT, P_PROMPT)
     eng.set_option("ignore_eos", 1)
-    xs, ys = zip(*[synth_inputs(b) for b in range(4)])
+    xs, ys = zip(*[synth_inputs(b) for b in range(6)])
     X, Y = torch.stack(xs).to(dev), torch.stack(ys).to(dev)
     report = {"shape": "d1024-L12-h16 bf16, S=%d, P=%d, %d AR steps, greedy" % (S_TEXT, P_PROMPT, args.steps), "rows": []}
     one = timed(eng, X, Y, 1, args.steps, {"persist": 1, "persist_naps": -1})

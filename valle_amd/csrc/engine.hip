@@ -1351,7 +1351,7 @@ int kv_stream_nt(const vle_engine* e) {
 // bf16 D2 forms 0x325756 (126.9 us per step), fp8 weight rows 0x214645 (128.0 -> 125.7), fp32 0x217645 (191.7 -> 187.1)
 // the batched launch (persist_nb.hip): the stages between two hand-offs grow with the number of rows, so the first sweeps are
 // timed per batch (tools/persist_nb_probe.py, coordinate descent over the six edges)
-constexpr int PSB_NAPS_DEFAULT[PSB_MAX + 1] = {0, 0, 0x405745, 0x305752, 0x317780};  // profiles/r06_persist_nb_probe.json: 157.1 / 187.6 / 221.4 us per step
+constexpr int PSB_NAPS_DEFAULT[PSB_MAX + 1] = {0, 0, 0x405745, 0x305752, 0x317780, 0x006876, 0x007860};  // profiles/r06_persist_nb_probe*.json: 157 / 188 / 221 / 265 / 298 us per step
 int ps_naps_of(const vle_engine* e) {
   if (e->opt_ps_naps >= 0) return e->opt_ps_naps;
   if (e->B > 1 && e->B <= PSB_MAX) return PSB_NAPS_DEFAULT[e->B];

@@ -305,7 +305,7 @@ size_t pstep_gran_count(int d, int nhead, int L);
 int launch_pstep(hipStream_t st, int dtype, const PStepArgs& a);  // 0 launched, 1 shape not covered, < 0 error
 // persist_nb.hip: the same launch for 2 .. PSB_MAX utterances (bf16 weights, the default form only: PS_MODE_DEFAULT, 2 keys per lane,
 // request schedule 3, sampling inside the launch); per utterance bit-identical to pstep_kernel's default form
-constexpr int PSB_MAX = 4;
+constexpr int PSB_MAX = 6;
 bool pstepb_supports(int dtype, int d, int nhead, int dh, int V, int B);
 int pstepb_form_ok(int B, bool traced);  // 1 = one workgroup of the B-utterance form fits a CU; 0 = no such form; -1 = does not fit
 size_t pstepb_gran_count(int d, int nhead, int L, int B);

@@ -1,4 +1,4 @@
-// Device helpers of the persistent AR launches (persist.hip: one utterance; persist_nb.hip: 2-4 utterances per launch): granule
+// Device helpers of the persistent AR launches (persist.hip: one utterance; persist_nb.hip: 2-6 utterances per launch): granule
 // loads / stores, the bounded sweeps, the bf16-row dot product and the wave totals of the D2 forms, the in-kernel timeline.
 // (Moved out of persist.hip unchanged in round 6 so that both kernels run the SAME functions.)
 #pragma once

@@ -1,4 +1,4 @@
-// The AR decode loop of 2 .. 4 utterances as ONE persistent launch (round 6; option "persist_batch").
+// The AR decode loop of 2 .. 6 utterances as ONE persistent launch (round 6; option "persist_batch").
 //   reference: the AR loop of VALLE.inference (valle/models/valle.py:1012-1057) for every utterance of the batch -- the L pre-norm
 //   decoder layers (valle/modules/transformer.py:296-302, 332-334; attention valle/modules/activation.py:408-427), the final norm
 //   and ar_predict_layer (valle.py:1035-1039), topk_sampling (:1287-1302), the stop rule (:1044-1048) and the next token's
@@ -164,6 +164,26 @@ __device__ inline float wave_sums_by_column(float (&v)[N]) {
   return rows4_sum(r);
 }
 
+// 4 rows of NB <= 8 utterances (value 4 b + r): lane 4 b + r ends up with its total -- utterances 0 .. 3 through the 16 lane columns of
+// one reduction, utterances 4 .. through a second one whose totals the lanes 16 .. 31 keep
+template <int NB>
+__device__ inline float wave_sums_rows4(float (&v)[4 * NB]) {
+  if constexpr (NB <= 4) {
+    return wave_sums_by_column<4 * NB>(v);
+  } else {
+    float a[16], b[4 * NB - 16];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) a[i] = v[i];
+#pragma unroll
+    for (int i = 16; i < 4 * NB; ++i) b[i - 16] = v[i];
+    const float ra = wave_sums_by_column<16>(a);
+    const float rb = wave_sums_by_column<4 * NB - 16>(b);
+    int hi = (threadIdx.x & 63) >> 4;
+    asm volatile("" : "+v"(hi));
+    return hi == 1 ? rb : ra;
+  }
+}
+
 // value of utterance (lane >> 2) out of per-utterance values (lanes >= 4 NB: utterance 0's)
 template <int NB, typename X>
 __device__ inline X sel_by_lane(const X (&v)[NB]) {
@@ -197,7 +217,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
   constexpr int R1 = 4 * D / NWG / 4;  // linear1 rows per wave
   constexpr int EPT = D / PS_T;      // elements of a d-vector per thread
   constexpr int EPT2 = 4 * D / PS_T; // ... of the hidden vector
-  static_assert(NB >= 2 && NB <= 4, "lane 4 b + r carries row r of utterance b; wave b merges utterance b's attention partials");
+  static_assert(NB >= 2 && NB <= 6, "lane 4 b + r carries row r of utterance b (lanes 0 .. 4 NB - 1); wave w merges the attention partials of utterances w and w + 4");
   static_assert(VEC == 8 && NCH == 2 && NCH2 == 8 && DH == 64 && NS == 16 && QR == 4 && RQ == 3 && R1 == 4 && EPT == 4 && EPT2 == 16, "shape");
   typedef bf16_t CT;
   constexpr int CVEC = 8;
@@ -210,10 +230,11 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
   constexpr int SXF = 2 * 1024;   // floats per utterance's input row (4 d bf16 values)
   constexpr int UBF = 576;        // floats of an utterance's small arrays
   auto sxrow = [&](int b) { return smem + b * SXF; };                  // the operator's input row of utterance b (bf16)
-  auto ub = [&](int b) { return smem + 11 * 1024 + b * UBF; };         // small arrays of utterance b:
+  constexpr int SAMP0 = NB * SXF;  // the sampling step's row [V] and scratch words (3 K floats), then the utterances' small arrays
+  auto ub = [&](int b) { return smem + SAMP0 + 3 * 1024 + b * UBF; };  // small arrays of utterance b:
   constexpr int O_RED = 0, O_SQ = 8, O_SK = O_SQ + DH, O_SV = O_SK + DH, O_SMM = O_SV + DH, O_SML = O_SMM + 4, O_SMO = O_SML + 4, O_SPM = O_SMO + 4 * DH,
                 O_SPL = O_SPM + NS, O_SPO = O_SPL + NS, O_SRES = O_SPO + NS * QR;
-  static_assert(O_SRES + 4 <= UBF && NB * SXF <= 8 * 1024 && 11 * 1024 + NB * UBF <= SM_FLOATS, "LDS carve");
+  static_assert(O_SRES + 4 <= UBF && SAMP0 + 3 * 1024 + NB * UBF <= SM_FLOATS, "LDS carve");
 
   const int tid = threadIdx.x, lane = tid & 63, w = tid >> 6;
   const int c = (int)blockIdx.x;
@@ -466,7 +487,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
         for (int r = 0; r < RQ; ++r) t[4 * b + r] = ps_dot_bf16<NCH>(wq[r], xb);
         t[4 * b + 3] = 0.f;
       }
-      const float mine = wave_sums_by_column<4 * NB>(t);  // lane 4 b + r: row r of utterance b
+      const float mine = wave_sums_rows4<NB>(t);  // lane 4 b + r: row r of utterance b
       const float mean_l = sel_by_lane<NB>(ln_mean), rstd_l = sel_by_lane<NB>(ln_rstd);
       if (lane < 4 * NB && lr < RQ) {
         const int r = w * RQ + lr, which = r / QR, e = s * QR + (r % QR);  // e: element of the head
@@ -640,8 +661,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
         }
       }
       g1_lds_barrier();
-      if (w < NB) {  // wave b: the workgroup's partial of utterance b (DH lanes: the output; lane 0 also the (max, sum) pair)
-        const int b = w;
+      auto publish_partial = [&](int b) {  // wave w: the workgroup's partials of utterances w, w + 4 (DH lanes: the output; lane 0 also the (max, sum) pair)
         const float* const u = ub(b);
         const float M = fmaxf(fmaxf(u[O_SMM + 0], u[O_SMM + 1]), fmaxf(u[O_SMM + 2], u[O_SMM + 3]));
         float f[4];
@@ -664,13 +684,17 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
           gran_store_local(gp + (G_PARTL - G_PART) + 0, epoch, __float_as_uint(M));
           gran_store_local(gp + (G_PARTL - G_PART) + 1, epoch, __float_as_uint(Ls));
         }
+      };
+      if constexpr (NB <= 4) {
+        if (w < NB) publish_partial(w);  // wave b: utterance b
+      } else {
+        for (int b = w; b < NB; b += 4) publish_partial(b);  // wave w: utterances w, w + 4
       }
     }
     issue_wo(p);
 
     // ======== (3) merge of the head's NS partials + the new token's own key: wave b for utterance b ===============================
-    if (w < NB) {
-      const int b = w;
+    auto merge_partials = [&](int b) {
       float* const u = ub(b);
       const gran_t* gp = G + G_PART + b * L_PART + (size_t)h * NS * (2 + DH);
       constexpr int NL = NS + NS * QR / 2;
@@ -728,6 +752,11 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
 #pragma unroll
       for (int e = 0; e < QR; ++e) outv = lane == e ? acc[e] : outv;
       if (lane < QR) gran_store(G + G_ATT + b * D + h * DH + s * QR + lane, epoch, outv);
+    };
+    if constexpr (NB <= 4) {
+      if (w < NB) merge_partials(w);  // wave b: utterance b
+    } else {
+      for (int b = w; b < NB; b += 4) merge_partials(b);  // wave w: utterances w, w + 4
     }
 
     // the new tokens' K / V elements go into the caches HERE, write-through (persist.hip: behind the merge, in front of an all-to-all edge)
@@ -792,7 +821,7 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
 #pragma unroll
         for (int r = 0; r < R1; ++r) t[4 * b + r] = ps_dot_bf16<NCH>(w1[r], xb);
       }
-      const float mine = wave_sums_by_column<4 * NB>(t);  // lane 4 b + r: row r of utterance b
+      const float mine = wave_sums_rows4<NB>(t);  // lane 4 b + r: row r of utterance b
       const float mean_l = sel_by_lane<NB>(ln_mean), rstd_l = sel_by_lane<NB>(ln_rstd);
       const float hval = fmaxf(fmaf(rstd_l, fmaf(-mean_l, sg1_v, mine), b1_v), 0.f);
       const float nbv = dpp_f32<0xB1>(hval);  // lane ^ 1
@@ -879,11 +908,11 @@ __global__ __launch_bounds__(PS_T) void pstepb_kernel(PStepArgs a) {
     {
       // ======== sampling, stop rule, next input rows (ar_sample_kernel, sampling.hip; valle/models/valle.py:1039-1057) ==============
       // Every workgroup gathers the logits of every utterance and draws the SAME tokens (persist.hip).
-      float* const slog = smem + 8 * 1024;   // [V] one utterance's row at a time
-      unsigned long long* const red64 = reinterpret_cast<unsigned long long*>(smem + 10 * 1024);
-      int* const redi = reinterpret_cast<int*>(smem + 10 * 1024 + 16);
-      float* const redf = smem + 10 * 1024 + 32;
-      float* const wave_tot = smem + 10 * 1024 + 48;
+      float* const slog = smem + SAMP0;   // [V] one utterance's row at a time
+      unsigned long long* const red64 = reinterpret_cast<unsigned long long*>(smem + SAMP0 + 2 * 1024);
+      int* const redi = reinterpret_cast<int*>(smem + SAMP0 + 2 * 1024 + 16);
+      float* const redf = smem + SAMP0 + 2 * 1024 + 32;
+      float* const wave_tot = smem + SAMP0 + 2 * 1024 + 48;
       static_assert(SAMP_T == PS_T && SAMP_T * SAMP_PER >= 4 * NWG + 1, "the sampling code's block shape");
       const PStepSample q = ps_sample_load(a.smp);
       const ArDyn dyn = *q.dyn;
@@ -1017,7 +1046,8 @@ size_t pstepb_gran_count(int d, int nhead, int L, int B) { return (size_t)B * (L
 typedef void (*PsbKernel)(PStepArgs);
 static PsbKernel psb_select(int B, bool traced) {
   if (traced) return B == 2 ? (PsbKernel)pstepb_kernel<2, true> : B == 3 ? (PsbKernel)pstepb_kernel<3, true> : B == 4 ? (PsbKernel)pstepb_kernel<4, true> : nullptr;
-  return B == 2 ? (PsbKernel)pstepb_kernel<2> : B == 3 ? (PsbKernel)pstepb_kernel<3> : B == 4 ? (PsbKernel)pstepb_kernel<4> : nullptr;
+  return B == 2 ? (PsbKernel)pstepb_kernel<2> : B == 3 ? (PsbKernel)pstepb_kernel<3> : B == 4 ? (PsbKernel)pstepb_kernel<4> :
+         B == 5 ? (PsbKernel)pstepb_kernel<5> : B == 6 ? (PsbKernel)pstepb_kernel<6> : nullptr;
 }
 
 // 1 = the occupancy calculator places one workgroup of the B-utterance form on a CU; -1 = it does not fit; 0 = no such form

@@ -266,7 +266,7 @@ class VALLE(nn.Module):
             # launch is available they are decoded one after the other.  Same results as the batched call: utterances never interact,
             # and utterance b draws from the sampling stream of request b (common.h request_seed: the stream of request b under `seed` is
             # the stream of request 0 under seed + b * 0x9E3779B97F4A7C15).  From 3 utterances on the chain is ahead (60.7 k).
-            # Since the batched persistent launch (csrc/persist_nb.hip: 2 .. 4 utterances share ONE launch, the weights are streamed once
+            # Since the batched persistent launch (csrc/persist_nb.hip: 2 .. 6 utterances share ONE launch, the weights are streamed once
             # per step for all of them) this is the path only where that launch is not available (fp32 / fp8-weight engines, options).
             eng = self.engine_for(B, max(xl), max(yl))
             if eng.fetch_u32("persist_batch_capable") < B and eng.fetch_u32("persist_capable") == 1:

@@ -8,7 +8,7 @@ prefilled into the free slot while the other slots keep decoding.  Every arithme
 What an utterance decodes to is independent of its batch mates: greedy decodes are token-identical to ``VALLE.inference``,
 and sampled decodes draw from an RNG stream keyed on (seed, request index, iteration) -- not on the slot -- so they do not
 depend on ``max_batch`` / scheduling either and equal ``VALLE.inference_batch`` with the same seed.
-Engines of 2 .. 4 slots (bf16, d1024-h16) advance their live slots on the batched persistent launch (csrc/persist_nb.hip): one launch per
+Engines of 2 .. 6 slots (bf16, d1024-h16) advance their live slots on the batched persistent launch (csrc/persist_nb.hip): one launch per
 ``slots_step`` call; if that launch cannot keep the whole GPU the call raises ``VleError(VLE_EBUSY)`` and the session's utterances have to
 be admitted again (the engine then runs the launch chain for its next calls).
 """
@@ -83,7 +83,7 @@ class ContinuousBatcher:
             try:
                 done, gl = eng.slots_step(self.steps_per_round, top_k, temperature, seed)
             except _lib.VleError as err:
-                # engines of 2 .. 4 slots step on the batched persistent launch, which needs the whole GPU: when it could not keep it
+                # engines of 2 .. 6 slots step on the batched persistent launch, which needs the whole GPU: when it could not keep it
                 # (VLE_EBUSY) the session's slots are void.  The requests are not: the utterances in flight go back to the FRONT of the
                 # queue (request order is kept) and are decoded again in a new session -- the engine runs the launch chain for its next
                 # calls and re-arms the persistent launch by itself.  A shared GPU costs time, not a request.

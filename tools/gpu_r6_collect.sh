@@ -10,7 +10,7 @@ python -c "import __graft_entry__ as g; g.smoke()" > $D/smoke.log 2>&1; echo "sm
 timeout 900 python bench.py > $D/bench_default.log 2> $D/bench_default.err; echo "default bench rc=$?"; tail -n 1 $D/bench_default.log | cut -c1-300
 timeout 300 python bench.py --steps 5 --warmup 2 --cpu-frames 0 --no-side --dtype fp8w > $D/bench_b1_fp8w.log 2>/dev/null; tail -n 1 $D/bench_b1_fp8w.log | cut -c1-200
 timeout 300 python bench.py --batch 8 --steps 3 --warmup 1 --cpu-frames 0 --no-side > $D/bench_b8.log 2>/dev/null; tail -n 1 $D/bench_b8.log | cut -c1-200
-for b in 2 3 4; do timeout 300 python bench.py --batch $b --steps 3 --warmup 1 --cpu-frames 0 --no-side > $D/bench_b$b.log 2>/dev/null; tail -n 1 $D/bench_b$b.log | cut -c1-200; done
+for b in 2 3 4 5 6; do timeout 300 python bench.py --batch $b --steps 3 --warmup 1 --cpu-frames 0 --no-side > $D/bench_b$b.log 2>/dev/null; tail -n 1 $D/bench_b$b.log | cut -c1-200; done
 timeout 300 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-side --dtype fp32 > $D/bench_b1_fp32.log 2>/dev/null; tail -n 1 $D/bench_b1_fp32.log | cut -c1-200
 timeout 300 python bench.py --steps 3 --warmup 1 --cpu-frames 0 --no-side --opt persist=0 > $D/bench_b1_chain.log 2>/dev/null; tail -n 1 $D/bench_b1_chain.log | cut -c1-200
 (cd /tmp && rm -rf /tmp/prof1 && timeout 400 rocprofv3 --kernel-trace --stats -d /tmp/prof1 -o b1 --output-format csv -- python $GRAFT_REPO_ROOT/bench.py --steps 2 --warmup 1 --cpu-frames 0 --no-side > $GRAFT_REPO_ROOT/$D/prof1.log 2>&1); echo "prof1 rc=$?"
